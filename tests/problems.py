@@ -1,0 +1,143 @@
+"""Deterministic problem instances taken from the reference's own test-suite and
+docs (inputs are formulaic, so no data file is needed).  Each builder returns
+(Q, c, A, b, cone_dims, G, d, expect) with ``expect`` = the analytic answer the
+reference asserts.  Citations: /root/reference/test/runtests.jl and docs."""
+import numpy as np
+import scipy.sparse as sp
+
+
+def sphere(n=2):
+    """test/runtests.jl:137-166 -- projection of ones(n) onto the unit sphere."""
+    H = sp.identity(n, format="csr")
+    a = np.ones(n)
+    A = sp.vstack([sp.csr_matrix((1, n)), sp.identity(n)]).tocsr()
+    b = np.concatenate([[-1.0], np.zeros(n)])
+    return H, H @ a, A, b, [("Q", n + 1)], None, None, a / np.linalg.norm(a)
+
+
+def combined(n=10):
+    """test/runtests.jl:168-206 -- R + Q cones."""
+    H = sp.identity(n, format="csr")
+    c = np.arange(1.0, n + 1)
+    A = sp.vstack([sp.identity(n), sp.csr_matrix((1, n)), sp.identity(n)]).tocsr()
+    b = np.concatenate([np.zeros(n), [-1.0], np.zeros(n)])
+    y = np.maximum(0, c)
+    return H, H @ c, A, b, [("R", n), ("Q", n + 1)], None, None, y / np.linalg.norm(y)
+
+
+def simplex(n=10):
+    """test/runtests.jl:208-244 -- projection onto the simplex (R + equality)."""
+    H = np.eye(n)
+    c = np.arange(1.0, n + 1)
+    A = sp.identity(n, format="csr")
+    b = np.zeros(n)
+    G = np.ones((1, n))
+    d = np.array([1.0])
+    y = np.zeros(n)
+    y[-1] = 1
+    return H, H @ c, A, b, [("R", n)], G, d, y
+
+
+def psd_projection():
+    """test/runtests.jl:527-552 -- projection of diag(1,1,1,-1,-1,-1) onto PSD."""
+    from oracle.cones import vecm
+    n = 21
+    H = np.eye(n)
+    c = vecm(np.diag([1.0, 1, 1, -1, -1, -1]))
+    A = sp.identity(n, format="csr")
+    b = np.zeros(n)
+    return H, c, A, b, [("S", n)], None, None, vecm(np.diag([1.0, 1, 1, 0, 0, 0]))
+
+
+def soc_direct():
+    """test/runtests.jl:554-590 -- min 1/2||x||^2 + 1'x, ||x[1:3]||<=1, x>=0 -> 0."""
+    n = 4
+    Q = sp.identity(n, format="csr")
+    c = -np.ones(n)
+    A_soc = sp.vstack([sp.csr_matrix((1, n)), sp.identity(n, format="csr")[:3, :]])
+    A = sp.vstack([A_soc, sp.identity(n)]).tocsr()
+    b = np.concatenate([[-1.0], np.zeros(3), np.zeros(n)])
+    return Q, c, A, b, [("Q", 4), ("R", n)], None, None, np.zeros(n)
+
+
+def box_qp(n=1000):
+    """test/runtests.jl:90-131 -- box-constrained QP, H = I/2, c = 1:n."""
+    H = 0.5 * sp.identity(n, format="csr")
+    c = np.arange(1.0, n + 1)
+    A = sp.vstack([sp.identity(n), -sp.identity(n)]).tocsr()
+    b = -np.ones(2 * n)
+    return H, H @ c, A, b, [("R", 2 * n)], None, None, np.ones(n)
+
+
+def unbounded(n=10):
+    """test/runtests.jl:487-505."""
+    H = np.zeros((n, n))
+    c = np.arange(1.0, n + 1)
+    A = sp.identity(n, format="csr")
+    b = np.zeros(n)
+    return H, c, A, b, [("R", n)], None, None, None
+
+
+def infeasible_box(n=10, seed=0):
+    """test/runtests.jl:441-460 (status is data-independent: y>=1 and y<=-1)."""
+    rng = np.random.default_rng(seed)
+    h = rng.standard_normal(n)
+    H = np.outer(h, h)
+    c = np.arange(1.0, n + 1)
+    A = sp.vstack([sp.identity(n), -sp.identity(n)]).tocsr()
+    b = np.ones(2 * n)
+    return H, H @ c, A, b, [("R", 2 * n)], None, None, None
+
+
+def infeasible_eq(n=10, seed=0):
+    """test/runtests.jl:462-485 (y>=0 with y1 = -1)."""
+    rng = np.random.default_rng(seed)
+    h = rng.standard_normal(n)
+    H = np.outer(h, h)
+    c = np.arange(1.0, n + 1)
+    A = sp.identity(n, format="csr")
+    b = np.zeros(n)
+    G = np.zeros((1, n))
+    G[0, 0] = 1
+    d = np.array([-1.0])
+    return H, H @ c, A, b, [("R", n)], G, d, None
+
+
+def lp_doc():
+    """docs/src/tutorials/lp.jl:21-41 -- y2 = 4."""
+    n = 5
+    Q = sp.csr_matrix((n, n))
+    c = np.array([2.0, 3.0, 1.0, 1.0, 1.0])
+    A = sp.identity(n, format="csr")
+    b = np.zeros(n)
+    G = np.ones((1, n))
+    d = np.array([4.0])
+    return Q, c, A, b, [("R", n)], G, d, np.array([0, 4.0, 0, 0, 0])
+
+
+def random_mixed(n=40, nq=3, kq=6, p=4, seed=1, dense_A=True):
+    """Synthetic strictly feasible R+Q+equality problem in the pattern of
+    benchmark/profile.jl:95-114 (feasible at y = ones)."""
+    rng = np.random.default_rng(seed)
+    M = rng.standard_normal((n, n))
+    Q = M.T @ M / n + 0.1 * np.eye(n)
+    c = rng.standard_normal(n)
+    A_r = np.eye(n)
+    blocks = [A_r]
+    bs = [np.zeros(n)]
+    cone_dims = [("R", n)]
+    for _ in range(nq):
+        Aq = rng.standard_normal((kq, n)) * 0.2
+        Aq[0, :] = 0
+        blocks.append(Aq)
+        bq = np.zeros(kq)
+        bq[0] = -(np.linalg.norm(Aq[1:] @ np.ones(n)) + 1.0)
+        bs.append(bq)
+        cone_dims.append(("Q", kq))
+    A = np.vstack(blocks)
+    b = np.concatenate(bs)
+    G = rng.standard_normal((p, n))
+    d = G @ np.ones(n)
+    if not dense_A:
+        A = sp.csr_matrix(A)
+    return Q, c, A, b, cone_dims, G, d, None
