@@ -1,0 +1,102 @@
+"""ctypes binding of libcipkkt.so (the C ABI declared in include/cipkkt.h).
+
+The HIP library is the product; there is no CPU fallback: if the shared object is
+missing or no GPU is usable, everything here raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcipkkt.so")
+
+CONE_R, CONE_Q, CONE_S = 0, 1, 2
+ROUTE_SCHUR, ROUTE_FULL3X3 = 0, 1
+OP_F, OP_FT, OP_FINV, OP_FINVT = 0, 1, 2, 3
+MAT_Q, MAT_A, MAT_G = 0, 1, 2
+FLAG_DEVICE_PTRS = 1
+E_SINGULAR = -5
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+
+
+class CipProblem(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("p", C.c_int), ("ncones", C.c_int),
+                ("cone_type", c_int_p), ("cone_dim", c_int_p),
+                ("Q", C.c_void_p), ("ldq", C.c_int),
+                ("A", C.c_void_p), ("lda", C.c_int),
+                ("A_rowptr", C.c_void_p), ("A_colind", C.c_void_p), ("A_val", C.c_void_p),
+                ("G", C.c_void_p), ("ldg", C.c_int),
+                ("route", C.c_int), ("flags", C.c_int)]
+
+
+# name -> (restype, argtypes); every symbol include/cipkkt.h declares
+SIGNATURES = {
+    "cip_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "cip_create_ex": (C.c_int, [C.POINTER(CipProblem), C.POINTER(C.c_void_p)]),
+    "cip_destroy": (C.c_int, [C.c_void_p]),
+    "cip_last_error": (C.c_char_p, []),
+    "cip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cip_scaling_packed_len": (C.c_size_t, [C.c_void_p]),
+    "cip_set_scaling_packed": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cip_set_scaling_identity": (C.c_int, [C.c_void_p]),
+    "cip_set_scaling_from_iterate_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cip_get_scaling_packed": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cip_factor": (C.c_int, [C.c_void_p]),
+    "cip_check_factor": (C.c_int, [C.c_void_p]),
+    "cip_solve3x3": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6),
+    "cip_solve3x3_dev": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6),
+    "cip_solve4x4_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cip_apply_F_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "cip_cone_prod_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cip_cone_div_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cip_maxstep_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, c_double_p]),
+    "cip_cone_identity_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cip_gemv_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_double, C.c_void_p]),
+    "cip_dots_dev": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_int_p,
+                               c_double_p]),
+    "cip_axpby_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_double, C.c_void_p]),
+    "cip_ldlt_workspace_bytes": (C.c_int, [C.c_int, C.POINTER(C.c_size_t)]),
+    "cip_ldlt_factor_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_int_p]),
+    "cip_ldlt_solve_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "cip_gemm_nt_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "cip_kkt_order": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
+    "cip_get_kkt_matrix": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cip_assemble_only": (C.c_int, [C.c_void_p]),
+    "cip_stats": (C.c_int, [C.c_void_p, c_double_p]),
+    "cip_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "cip_set_ldlt_outer_block": (C.c_int, [C.c_int]),
+}
+
+_lib = None
+
+
+class CipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libcipkkt error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """Load libcipkkt.so and type every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libcipkkt.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "-- there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().cip_last_error()
+        raise CipError(rc, msg.decode() if msg else "?")

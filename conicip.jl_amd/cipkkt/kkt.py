@@ -1,0 +1,283 @@
+"""Host-side mirror of the reference's KKT-solver plugin interface, bound to the HIP
+library through the C ABI (include/cipkkt.h).
+
+Reference interface (src/ConicIP.jl:432-466, :667, :682, :688;
+docs/src/guides/kkt_solvers.md:84-115):
+
+    solve3x3gen = kktsolver(Q, A, G, cone_dims)     # level 1, once
+    solve3x3    = solve3x3gen(F, F_invT)            # level 2, per iteration
+    (a, b, c)   = solve3x3(x, y, z)                 # level 3, per right-hand side
+
+``kktsolver_hip`` is that closure trio; ``KKTSystem`` is the object behind it and
+also exposes the device-pointer entry points used by the device-resident driver
+(``cipkkt.driver.conicIP``).  PyTorch is used for device memory only.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_CONE_CODE = {"R": L.CONE_R, "Q": L.CONE_Q, "S": L.CONE_S}
+
+
+def _ptr(t):
+    """Device/host pointer of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.ctypes.data)
+
+
+def _is_sparse(M):
+    return hasattr(M, "tocsr") and not isinstance(M, np.ndarray)
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("cipkkt: no HIP device visible -- the KKT path is GPU-only (no CPU fallback)")
+
+
+class KKTSystem:
+    """Level-1 object: problem matrices resident in HBM, cone layout, workspaces.
+    ≙ what `kktsolver(Q,A,G,cone_dims)` captures (src/kktsolvers.jl:18-28, :180-190, :281-285)."""
+
+    def __init__(self, Q, A, G, cone_dims, route="schur", device=None):
+        _require_gpu()
+        self.lib = L.load()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        torch.cuda.set_device(self.device)
+        self.cone_dims = [(str(t), int(k)) for t, k in cone_dims]
+        n = Q.shape[0]
+        if Q.shape[0] != Q.shape[1]:
+            raise ValueError("Q is not square")                       # src/ConicIP.jl:538
+        m = A.shape[0] if A is not None else 0
+        if G is None:
+            G = np.zeros((0, n))
+        p = G.shape[0]
+        if (m > 0 and A.shape[1] != n) or (p > 0 and G.shape[1] != n):
+            raise ValueError("Inconsistency in inequalities/objective")  # :540-542
+        if sum(k for _, k in self.cone_dims) != m:
+            raise ValueError("cone_dims do not cover the rows of A")
+        self.n, self.m, self.p = n, m, p
+        self.route = L.ROUTE_SCHUR if route in ("schur", L.ROUTE_SCHUR) else L.ROUTE_FULL3X3
+
+        keep = []                      # keep staging buffers alive across the create call
+        flags = 0
+        pr = L.CipProblem()
+        pr.n, pr.m, pr.p, pr.ncones = n, m, p, len(self.cone_dims)
+        ct = (C.c_int * max(1, len(self.cone_dims)))(*[_CONE_CODE[t] for t, _ in self.cone_dims])
+        cdm = (C.c_int * max(1, len(self.cone_dims)))(*[k for _, k in self.cone_dims])
+        pr.cone_type, pr.cone_dim = ct, cdm
+        on_dev = isinstance(Q, torch.Tensor) and Q.is_cuda
+        if on_dev:
+            flags |= L.FLAG_DEVICE_PTRS
+
+        def dense(M, rows, cols):
+            """column-major fp64 buffer (host numpy, or device torch when Q is on the device)"""
+            if on_dev:
+                if not isinstance(M, torch.Tensor):
+                    M = torch.as_tensor(np.asarray(M.toarray() if _is_sparse(M) else M, dtype=np.float64),
+                                        device=self.device)
+                Mt = M.to(dtype=torch.float64, device=self.device).reshape(rows, cols).t().contiguous()
+                keep.append(Mt)        # row-major of M' == column-major of M
+                return C.c_void_p(Mt.data_ptr())
+            if isinstance(M, torch.Tensor):
+                M = M.cpu().numpy()
+            if _is_sparse(M):
+                M = M.toarray()
+            Mf = np.asfortranarray(np.asarray(M, dtype=np.float64).reshape(rows, cols))
+            keep.append(Mf)
+            return C.c_void_p(Mf.ctypes.data)
+
+        pr.Q, pr.ldq = dense(Q, n, n), n
+        if m > 0 and _is_sparse(A) and not any(t == "S" for t, _ in self.cone_dims):
+            csr = A.tocsr()
+            csr.sort_indices()
+            rp = np.ascontiguousarray(csr.indptr, dtype=np.int32)
+            ci = np.ascontiguousarray(csr.indices, dtype=np.int32)
+            av = np.ascontiguousarray(csr.data, dtype=np.float64)
+            if on_dev:
+                rp_t, ci_t, av_t = (torch.as_tensor(x, device=self.device) for x in (rp, ci, av))
+                keep += [rp_t, ci_t, av_t]
+                pr.A_rowptr, pr.A_colind, pr.A_val = _ptr(rp_t), _ptr(ci_t), _ptr(av_t)
+            else:
+                keep += [rp, ci, av]
+                pr.A_rowptr, pr.A_colind, pr.A_val = _ptr(rp), _ptr(ci), _ptr(av)
+            pr.A = None
+            self.A_sparse = True
+        else:
+            pr.A, pr.lda = (dense(A, m, n) if m > 0 else None), max(m, 1)
+            self.A_sparse = False
+        pr.G, pr.ldg = (dense(G, p, n) if p > 0 else None), max(p, 1)
+        pr.route, pr.flags = self.route, flags
+        h = C.c_void_p()
+        L.check(self.lib.cip_create_ex(C.byref(pr), C.byref(h)))
+        self.h = h
+        N, Np = C.c_int(), C.c_int()
+        L.check(self.lib.cip_kkt_order(self.h, C.byref(N), C.byref(Np)))
+        self.N, self.Npad = N.value, Np.value
+        self.scaling_len = int(self.lib.cip_scaling_packed_len(self.h))
+        del keep
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.cip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- level 2
+    def pack_scaling(self, F, FinvT=None):
+        """Read the packed scaling off Block elements shaped like the reference's
+        (src/ConicIP.jl:189-192 SymWoodbury(.A.diag,.B,.D); :208 VecCongurance(.R); :598 Diagonal(.diag))."""
+        blocks = F.Blocks if hasattr(F, "Blocks") else list(F)
+        iblocks = (FinvT.Blocks if hasattr(FinvT, "Blocks") else list(FinvT)) if FinvT is not None else [None] * len(blocks)
+        out = []
+        for (t, k), blk, iblk in zip(self.cone_dims, blocks, iblocks):
+            if t == "R":
+                out.append(np.asarray(blk.diag, dtype=np.float64).reshape(k))
+            elif t == "Q":
+                Ad = blk.A.diag if hasattr(blk.A, "diag") else blk.A
+                Ad = np.asarray(Ad, dtype=np.float64)
+                B = np.asarray(blk.B, dtype=np.float64).reshape(k, -1)
+                D = np.asarray(blk.D, dtype=np.float64).reshape(B.shape[1], B.shape[1])
+                if B.shape[1] != 1:
+                    raise ValueError("Q-cone scaling must be rank one (diag + w w')")
+                out.append(np.concatenate([[-Ad[0]], B[:, 0] * np.sqrt(D[0, 0])]))
+            else:
+                R = np.asarray(blk.R, dtype=np.float64)
+                Rinv = np.asarray(iblk.R, dtype=np.float64).T if iblk is not None else np.linalg.inv(R)
+                out.append(np.concatenate([R.reshape(-1, order="F"), Rinv.reshape(-1, order="F")]))
+        return np.ascontiguousarray(np.concatenate(out)) if out else np.zeros(0)
+
+    def set_scaling_packed(self, packed):
+        packed = np.ascontiguousarray(packed, dtype=np.float64)
+        if packed.size != self.scaling_len:
+            raise ValueError("packed scaling has %d entries, expected %d" % (packed.size, self.scaling_len))
+        L.check(self.lib.cip_set_scaling_packed(self.h, _ptr(packed)))
+
+    def get_scaling_packed(self):
+        out = np.zeros(self.scaling_len)
+        L.check(self.lib.cip_get_scaling_packed(self.h, _ptr(out)))
+        return out
+
+    def set_scaling_identity(self):
+        L.check(self.lib.cip_set_scaling_identity(self.h))
+
+    def set_scaling_from_iterate(self, v, s, lam_out=None):
+        L.check(self.lib.cip_set_scaling_from_iterate_dev(self.h, _ptr(v), _ptr(s), _ptr(lam_out)))
+
+    def assemble_only(self):
+        L.check(self.lib.cip_assemble_only(self.h))
+
+    def factor(self, check=False):
+        L.check(self.lib.cip_factor(self.h))
+        if check:
+            self.check_factor()
+
+    def check_factor(self):
+        L.check(self.lib.cip_check_factor(self.h))
+
+    # ---------------------------------------------------------------- level 3
+    def solve3x3(self, x, y, z):
+        """Host-pointer ABI (what the Julia ccall shim uses); returns fresh arrays,
+        as the reference requires of level 3 (src/ConicIP.jl:690)."""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.n)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(self.p)
+        z = np.ascontiguousarray(z, dtype=np.float64).reshape(self.m)
+        a, b, c = np.empty(self.n), np.empty(self.p), np.empty(self.m)
+        L.check(self.lib.cip_solve3x3(self.h, _ptr(x), _ptr(y), _ptr(z), _ptr(a), _ptr(b), _ptr(c)))
+        return a, b, c
+
+    def solve3x3_dev(self, x, y, z, a, b, c):
+        L.check(self.lib.cip_solve3x3_dev(self.h, _ptr(x), _ptr(y), _ptr(z), _ptr(a), _ptr(b), _ptr(c)))
+
+    def solve4x4_dev(self, lam, r, dz):
+        L.check(self.lib.cip_solve4x4_dev(self.h, _ptr(lam), _ptr(r), _ptr(dz)))
+
+    # ---------------------------------------------------------------- cone / vector helpers (device tensors)
+    def apply_F(self, mode, x, out):
+        L.check(self.lib.cip_apply_F_dev(self.h, mode, _ptr(x), _ptr(out)))
+
+    def cone_prod(self, x, y, out):
+        L.check(self.lib.cip_cone_prod_dev(self.h, _ptr(x), _ptr(y), _ptr(out)))
+
+    def cone_div(self, x, y, out):
+        L.check(self.lib.cip_cone_div_dev(self.h, _ptr(x), _ptr(y), _ptr(out)))
+
+    def maxstep(self, x, d=None, scale=1.0):
+        out = C.c_double()
+        L.check(self.lib.cip_maxstep_dev(self.h, _ptr(x), _ptr(d), float(scale), C.byref(out)))
+        return out.value
+
+    def cone_identity(self, e):
+        L.check(self.lib.cip_cone_identity_dev(self.h, _ptr(e)))
+
+    def gemv(self, which, trans, alpha, x, beta, y):
+        L.check(self.lib.cip_gemv_dev(self.h, which, int(trans), float(alpha), _ptr(x), float(beta), _ptr(y)))
+
+    def dots(self, pairs):
+        k = len(pairs)
+        xs = (C.c_void_p * k)(*[p[0].data_ptr() for p in pairs])
+        ys = (C.c_void_p * k)(*[p[1].data_ptr() for p in pairs])
+        ln = (C.c_int * k)(*[min(p[0].numel(), p[1].numel()) for p in pairs])
+        out = (C.c_double * k)()
+        L.check(self.lib.cip_dots_dev(self.h, k, xs, ys, ln, out))
+        return list(out)
+
+    def axpby(self, alpha, x, beta, y):
+        L.check(self.lib.cip_axpby_dev(self.h, y.numel(), float(alpha), _ptr(x), float(beta), _ptr(y)))
+
+    # ---------------------------------------------------------------- introspection
+    def kkt_matrix(self):
+        K = np.empty((self.Npad, self.Npad), order="F")
+        L.check(self.lib.cip_get_kkt_matrix(self.h, _ptr(K)))
+        return K
+
+    def stats(self):
+        out = (C.c_double * 8)()
+        L.check(self.lib.cip_stats(self.h, out))
+        return dict(n_factor=out[0], n_solve=out[1], ms_assemble=out[2], ms_ldlt=out[3], flops_ldlt=out[4],
+                    nbo=out[5], N=out[6], Npad=out[7])
+
+    def set_timing(self, on):
+        L.check(self.lib.cip_set_timing(self.h, int(bool(on))))
+
+    def set_stream(self, stream):
+        L.check(self.lib.cip_set_stream(self.h, C.c_void_p(stream)))
+
+
+def kktsolver_hip(Q, A, G, cone_dims, route="schur", device=None):
+    """The reference's 3-level plugin closure, backed by the HIP library.
+
+        solve3x3gen = kktsolver_hip(Q, A, G, cone_dims)
+        solve3x3    = solve3x3gen(F, F_invT)
+        a, b, c     = solve3x3(x, y, z)
+
+    solves [Q G' -A'; G 0 0; A 0 F'F][a;b;c] = [x;y;z] (src/ConicIP.jl:443-447).
+    F / F_invT are Block-like objects with the reference's element fields."""
+    sysm = KKTSystem(Q, A, G, cone_dims, route=route, device=device)
+
+    def solve3x3gen(F, FinvT=None):
+        sysm.set_scaling_packed(sysm.pack_scaling(F, FinvT))
+        sysm.factor()
+
+        def solve3x3(x, y, z):
+            return sysm.solve3x3(x, y, z)
+
+        return solve3x3
+
+    solve3x3gen.system = sysm
+    return solve3x3gen
+
+
+def kktsolver_hip_full3x3(Q, A, G, cone_dims, device=None):
+    """Same interface, literal 3x3 assembly route (src/kktsolvers.jl:254-256)."""
+    return kktsolver_hip(Q, A, G, cone_dims, route="full3x3", device=device)

@@ -1,0 +1,536 @@
+// C ABI of libcipkkt (see include/cipkkt.h for the contract and the reference lines
+// each entry point replaces).
+#include "cip_handle.h"
+#include "../../include/cipkkt.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <new>
+
+static thread_local char g_err[512] = "";
+void cip_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *cip_last_error(void) { return g_err; }
+
+static int rup(int x, int q) { return ((x + q - 1) / q) * q; }
+
+#define DMALLOC(ptr, bytes)                                                        \
+    do {                                                                           \
+        size_t b__ = (size_t)(bytes);                                              \
+        if (b__ == 0) b__ = 256;                                                   \
+        CIP_HIP_CHECK(hipMalloc((void **)&(ptr), b__));                            \
+    } while (0)
+
+static void free_all(cip_handle *h) {
+    void *ptrs[] = {h->Q, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->row_cone, h->G, h->Gt,
+                    h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->cs.d_partial, h->cs.d_scalar, h->K, h->Wt, h->Gm,
+                    h->ws_base, h->rhs, h->mt1, h->mt2, h->mt3, h->nt1, h->pt1, h->dot_scratch, h->dot_ptrs, h->stage};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev2) (void)hipEventDestroy(h->ev2);
+}
+
+// copy a (rows x cols, ld) column-major matrix from src (host or device) into a tight device buffer
+static int upload_matrix(double *dst, long ld_dst, const double *src, long ld_src, int rows, int cols, bool src_dev,
+                         hipStream_t s) {
+    if (rows == 0 || cols == 0) return 0;
+    CIP_HIP_CHECK(hipMemcpy2DAsync(dst, ld_dst * sizeof(double), src, ld_src * sizeof(double), rows * sizeof(double), cols,
+                                   src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+// dst (cols x rows, ld ld_dst) = src' ; tiled through LDS
+__global__ __launch_bounds__(256) void k_transpose(const double *src, long ld_src, int rows, int cols, double *dst, long ld_dst) {
+    __shared__ double t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // 32 x 8
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int q = 0; q < 32; q += 8) {
+        const int r = r0 + tx, c = c0 + ty + q;
+        if (r < rows && c < cols) t[ty + q][tx] = src[r + (long)c * ld_src];
+    }
+    __syncthreads();
+    for (int q = 0; q < 32; q += 8) {
+        const int c = c0 + tx, r = r0 + ty + q;
+        if (r < rows && c < cols) dst[c + (long)r * ld_dst] = t[tx][ty + q];
+    }
+}
+static int transpose_dev(hipStream_t s, const double *src, long ld_src, int rows, int cols, double *dst, long ld_dst) {
+    if (rows == 0 || cols == 0) return 0;
+    hipLaunchKernelGGL(k_transpose, dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0, s, src, ld_src, rows, cols, dst, ld_dst);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int create_impl(const cip_problem *pr, cip_handle *h) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        cip_set_error("no HIP device available (libcipkkt has no CPU fallback)");
+        return CIP_E_NODEVICE;
+    }
+    CIP_HIP_CHECK(hipGetDevice(&h->device));
+    const int n = pr->n, m = pr->m, p = pr->p;
+    if (n <= 0 || m < 0 || p < 0 || pr->ncones < 0) { cip_set_error("bad dimensions n=%d m=%d p=%d", n, m, p); return CIP_E_INVALID; }
+    if (!pr->Q) { cip_set_error("Q is NULL"); return CIP_E_INVALID; }
+    if (m > 0 && !pr->A && !(pr->A_rowptr && pr->A_colind && pr->A_val)) { cip_set_error("A is NULL"); return CIP_E_INVALID; }
+    if (p > 0 && !pr->G) { cip_set_error("G is NULL"); return CIP_E_INVALID; }
+    if (pr->route != CIP_ROUTE_SCHUR && pr->route != CIP_ROUTE_FULL3X3) { cip_set_error("bad route"); return CIP_E_INVALID; }
+    h->n = n; h->m = m; h->p = p; h->ncones = pr->ncones; h->route = pr->route;
+    const bool dev = (pr->flags & CIP_FLAG_DEVICE_PTRS) != 0;
+    hipStream_t s = h->stream;   // default (null) stream until cip_set_stream
+
+    // ---- cones
+    int off = 0, nq = 0;
+    size_t soff = 0;
+    bool has_S = false;
+    for (int c = 0; c < pr->ncones; ++c) {
+        ConeDesc cd = {};
+        cd.type = pr->cone_type[c]; cd.dim = pr->cone_dim[c]; cd.off = off; cd.soff = (int)soff; cd.r = 0; cd.qidx = -1;
+        if (cd.dim <= 0) { cip_set_error("cone %d has dimension %d", c, cd.dim); return CIP_E_INVALID; }
+        if (cd.type == CIP_CONE_R) { soff += cd.dim; }
+        else if (cd.type == CIP_CONE_Q) { soff += 1 + cd.dim; cd.qidx = nq++; }
+        else if (cd.type == CIP_CONE_S) {
+            const int r = (int)llround((sqrt(1.0 + 8.0 * cd.dim) - 1.0) / 2.0);     // ord() src/ConicIP.jl:85
+            if (r * (r + 1) / 2 != cd.dim) { cip_set_error("S cone %d: %d is not a triangular number", c, cd.dim); return CIP_E_INVALID; }
+            cd.r = r; soff += 2 * (size_t)r * r; has_S = true;
+        } else { cip_set_error("cone %d: unknown type %d", c, cd.type); return CIP_E_INVALID; }
+        if (soff > 0x7fffffffULL) { cip_set_error("scaling storage too large"); return CIP_E_INVALID; }
+        h->h_cones.push_back(cd);
+        if (cd.type == CIP_CONE_R) {
+            for (int st = 0; st < cd.dim; st += 2048) h->h_items.push_back(WorkItem{c, st, (cd.dim - st < 2048) ? cd.dim - st : 2048});
+        } else if (cd.type == CIP_CONE_Q) {
+            h->h_items.push_back(WorkItem{c, 0, cd.dim});
+        }
+        off += cd.dim;
+    }
+    if (off != m) { cip_set_error("cone_dims cover %d rows but A has %d", off, m); return CIP_E_INVALID; }
+    if (has_S) { cip_set_error("S cones are not implemented on the device yet"); return CIP_E_UNSUPPORTED; }
+    h->nq = nq; h->nqpad = rup(nq > 0 ? nq : 1, CIP_KT);
+    h->cs.ncones = pr->ncones; h->cs.nitems = (int)h->h_items.size(); h->cs.m = m; h->cs.scal_len = soff; h->cs.has_S = has_S;
+    DMALLOC(h->cs.d_cones, sizeof(ConeDesc) * h->h_cones.size());
+    DMALLOC(h->cs.d_items, sizeof(WorkItem) * h->h_items.size());
+    DMALLOC(h->cs.d_scal, sizeof(double) * soff);
+    DMALLOC(h->cs.d_partial, sizeof(double) * (h->h_items.size() + 1));
+    DMALLOC(h->cs.d_scalar, sizeof(double) * 8);
+    if (!h->h_cones.empty())
+        CIP_HIP_CHECK(hipMemcpy(h->cs.d_cones, h->h_cones.data(), sizeof(ConeDesc) * h->h_cones.size(), hipMemcpyHostToDevice));
+    if (!h->h_items.empty())
+        CIP_HIP_CHECK(hipMemcpy(h->cs.d_items, h->h_items.data(), sizeof(WorkItem) * h->h_items.size(), hipMemcpyHostToDevice));
+
+    // ---- sizes
+    h->npad = rup(n, CIP_NB);
+    h->mpad = rup(m > 0 ? m : 1, CIP_KT);
+    h->N = (h->route == CIP_ROUTE_SCHUR) ? n + p : n + p + m;
+    h->Npad = rup(h->N, CIP_NB);
+    h->ldk = h->Npad;
+
+    // ---- Q, G
+    DMALLOC(h->Q, sizeof(double) * (size_t)n * n);
+    int rc;
+    if ((rc = upload_matrix(h->Q, n, pr->Q, pr->ldq > 0 ? pr->ldq : n, n, n, dev, s))) return rc;
+    DMALLOC(h->G, sizeof(double) * (size_t)p * n);
+    DMALLOC(h->Gt, sizeof(double) * (size_t)p * n);
+    if (p > 0) {
+        if ((rc = upload_matrix(h->G, p, pr->G, pr->ldg > 0 ? pr->ldg : p, p, n, dev, s))) return rc;
+        if ((rc = transpose_dev(s, h->G, p, p, n, h->Gt, n))) return rc;
+    }
+
+    // ---- A
+    h->A_sparse = (pr->A == NULL && m > 0);
+    if (!h->A_sparse) {
+        DMALLOC(h->A, sizeof(double) * (size_t)m * n);
+        DMALLOC(h->At, sizeof(double) * (size_t)h->npad * h->mpad);
+        CIP_HIP_CHECK(hipMemsetAsync(h->At, 0, sizeof(double) * (size_t)h->npad * h->mpad, s));
+        if (m > 0) {
+            if ((rc = upload_matrix(h->A, m, pr->A, pr->lda > 0 ? pr->lda : m, m, n, dev, s))) return rc;
+            if ((rc = transpose_dev(s, h->A, m, m, n, h->At, h->npad))) return rc;
+        }
+        if (h->route == CIP_ROUTE_SCHUR) {
+            DMALLOC(h->Wt, sizeof(double) * (size_t)h->npad * h->mpad);
+            CIP_HIP_CHECK(hipMemsetAsync(h->Wt, 0, sizeof(double) * (size_t)h->npad * h->mpad, s));
+        }
+    } else {
+        // CSR of A (given) and of A' (built here on the host)
+        std::vector<int> rp(m + 1);
+        if (dev) CIP_HIP_CHECK(hipMemcpy(rp.data(), pr->A_rowptr, sizeof(int) * (m + 1), hipMemcpyDeviceToHost));
+        else memcpy(rp.data(), pr->A_rowptr, sizeof(int) * (m + 1));
+        const int nnz = rp[m];
+        if (rp[0] != 0 || nnz < 0) { cip_set_error("bad CSR row pointer"); return CIP_E_INVALID; }
+        std::vector<int> ci(nnz > 0 ? nnz : 1);
+        std::vector<double> av(nnz > 0 ? nnz : 1);
+        if (nnz > 0) {
+            if (dev) {
+                CIP_HIP_CHECK(hipMemcpy(ci.data(), pr->A_colind, sizeof(int) * nnz, hipMemcpyDeviceToHost));
+                CIP_HIP_CHECK(hipMemcpy(av.data(), pr->A_val, sizeof(double) * nnz, hipMemcpyDeviceToHost));
+            } else {
+                memcpy(ci.data(), pr->A_colind, sizeof(int) * nnz);
+                memcpy(av.data(), pr->A_val, sizeof(double) * nnz);
+            }
+        }
+        for (int q = 0; q < nnz; ++q)
+            if (ci[q] < 0 || ci[q] >= n) { cip_set_error("CSR column index out of range"); return CIP_E_INVALID; }
+        std::vector<int> trp(n + 1, 0), tci(nnz > 0 ? nnz : 1);
+        std::vector<double> tv(nnz > 0 ? nnz : 1);
+        for (int q = 0; q < nnz; ++q) trp[ci[q] + 1]++;
+        for (int i = 0; i < n; ++i) trp[i + 1] += trp[i];
+        {
+            std::vector<int> fill(trp.begin(), trp.end() - 1);
+            for (int r = 0; r < m; ++r)
+                for (int q = rp[r]; q < rp[r + 1]; ++q) { const int d = fill[ci[q]]++; tci[d] = r; tv[d] = av[q]; }
+        }
+        h->A_nnz = nnz;
+        DMALLOC(h->A_rp, sizeof(int) * (m + 1)); DMALLOC(h->A_ci, sizeof(int) * nnz); DMALLOC(h->A_v, sizeof(double) * nnz);
+        DMALLOC(h->T_rp, sizeof(int) * (n + 1)); DMALLOC(h->T_ci, sizeof(int) * nnz); DMALLOC(h->T_v, sizeof(double) * nnz);
+        CIP_HIP_CHECK(hipMemcpy(h->A_rp, rp.data(), sizeof(int) * (m + 1), hipMemcpyHostToDevice));
+        CIP_HIP_CHECK(hipMemcpy(h->T_rp, trp.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice));
+        if (nnz > 0) {
+            CIP_HIP_CHECK(hipMemcpy(h->A_ci, ci.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
+            CIP_HIP_CHECK(hipMemcpy(h->A_v, av.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
+            CIP_HIP_CHECK(hipMemcpy(h->T_ci, tci.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
+            CIP_HIP_CHECK(hipMemcpy(h->T_v, tv.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
+        }
+        std::vector<int> rc_(m > 0 ? m : 1);
+        for (size_t c = 0; c < h->h_cones.size(); ++c)
+            for (int e = 0; e < h->h_cones[c].dim; ++e) rc_[h->h_cones[c].off + e] = (int)c;
+        DMALLOC(h->row_cone, sizeof(int) * m);
+        if (m > 0) CIP_HIP_CHECK(hipMemcpy(h->row_cone, rc_.data(), sizeof(int) * m, hipMemcpyHostToDevice));
+        if (h->route == CIP_ROUTE_SCHUR) DMALLOC(h->Gm, sizeof(double) * (size_t)h->npad * h->nqpad);
+    }
+
+    // ---- KKT matrix, workspace, scratch
+    DMALLOC(h->K, sizeof(double) * (size_t)h->ldk * h->Npad);
+    DMALLOC(h->ws_base, cip_ldlt_ws_bytes(h->Npad));
+    cip_ldlt_ws_carve(h->ws_base, h->Npad, &h->ws);
+    DMALLOC(h->rhs, sizeof(double) * h->Npad);
+    DMALLOC(h->mt1, sizeof(double) * m); DMALLOC(h->mt2, sizeof(double) * m); DMALLOC(h->mt3, sizeof(double) * m);
+    DMALLOC(h->nt1, sizeof(double) * n); DMALLOC(h->pt1, sizeof(double) * p);
+    DMALLOC(h->dot_scratch, sizeof(double) * (32 * 32 + 64));
+    DMALLOC(h->dot_ptrs, 32 * 32);
+    DMALLOC(h->stage, sizeof(double) * 2 * (size_t)(n + p + m));
+    CIP_HIP_CHECK(hipEventCreate(&h->ev0)); CIP_HIP_CHECK(hipEventCreate(&h->ev1)); CIP_HIP_CHECK(hipEventCreate(&h->ev2));
+    if ((rc = cip_cones_identity_scaling(s, h->cs))) return rc;
+    CIP_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int cip_create_ex(const cip_problem *prob, cip_handle **out) {
+    if (!prob || !out) { cip_set_error("NULL argument"); return CIP_E_INVALID; }
+    *out = NULL;
+    cip_handle *h = new (std::nothrow) cip_handle();
+    if (!h) { cip_set_error("out of host memory"); return CIP_E_INVALID; }
+    const int rc = create_impl(prob, h);
+    if (rc) { free_all(h); delete h; return rc; }
+    *out = h;
+    return 0;
+}
+
+extern "C" int cip_create(int n, int m, int p, int ncones, const int *cone_type, const int *cone_dim, const double *Q,
+                          const double *A, const double *G, int route, cip_handle **out) {
+    cip_problem pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.n = n; pr.m = m; pr.p = p; pr.ncones = ncones; pr.cone_type = cone_type; pr.cone_dim = cone_dim;
+    pr.Q = Q; pr.ldq = n; pr.A = A; pr.lda = m; pr.G = G; pr.ldg = p; pr.route = route; pr.flags = 0;
+    if (m > 0 && !A) { cip_set_error("A is NULL"); return CIP_E_INVALID; }
+    return cip_create_ex(&pr, out);
+}
+
+extern "C" int cip_destroy(cip_handle *h) {
+    if (!h) return 0;
+    (void)hipStreamSynchronize(h->stream);
+    free_all(h);
+    delete h;
+    return 0;
+}
+
+extern "C" int cip_set_stream(cip_handle *h, void *stream) {
+    if (!h) return CIP_E_INVALID;
+    CIP_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->stream = (hipStream_t)stream;
+    return 0;
+}
+
+// ------------------------------------------------------------------ level 2
+extern "C" size_t cip_scaling_packed_len(const cip_handle *h) { return h ? h->cs.scal_len : 0; }
+
+extern "C" int cip_set_scaling_packed(cip_handle *h, const double *packedF) {
+    if (!h || !packedF) { cip_set_error("NULL argument"); return CIP_E_INVALID; }
+    CIP_HIP_CHECK(hipMemcpyAsync(h->cs.d_scal, packedF, sizeof(double) * h->cs.scal_len, hipMemcpyHostToDevice, h->stream));
+    CIP_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->assembled = h->factored = false;
+    return 0;
+}
+extern "C" int cip_get_scaling_packed(cip_handle *h, double *packedF) {
+    if (!h || !packedF) { cip_set_error("NULL argument"); return CIP_E_INVALID; }
+    CIP_HIP_CHECK(hipMemcpyAsync(packedF, h->cs.d_scal, sizeof(double) * h->cs.scal_len, hipMemcpyDeviceToHost, h->stream));
+    CIP_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+extern "C" int cip_set_scaling_identity(cip_handle *h) {
+    if (!h) return CIP_E_INVALID;
+    h->assembled = h->factored = false;
+    return cip_cones_identity_scaling(h->stream, h->cs);
+}
+extern "C" int cip_set_scaling_from_iterate_dev(cip_handle *h, const double *v, const double *s, double *lambda_out) {
+    if (!h || (h->m > 0 && (!v || !s))) { cip_set_error("NULL argument"); return CIP_E_INVALID; }
+    h->assembled = h->factored = false;
+    return cip_cones_nt_scaling(h->stream, h->cs, v, s, lambda_out);
+}
+
+extern "C" int cip_assemble_only(cip_handle *h) {
+    if (!h) return CIP_E_INVALID;
+    return cip_assemble(h);
+}
+
+extern "C" int cip_factor(cip_handle *h) {
+    if (!h) return CIP_E_INVALID;
+    int rc;
+    if (h->timing) CIP_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    if ((rc = cip_assemble(h))) return rc;
+    if (h->timing) CIP_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+    if ((rc = cip_ldlt_factor(h->stream, h->K, h->Npad, h->ldk, h->ws))) return rc;
+    h->n_factor += 1;
+    h->flops_ldlt = (double)h->N * h->N * h->N / 3.0;
+    if (h->timing) {
+        CIP_HIP_CHECK(hipEventRecord(h->ev2, h->stream));
+        CIP_HIP_CHECK(hipEventSynchronize(h->ev2));
+        float a = 0, b = 0;
+        CIP_HIP_CHECK(hipEventElapsedTime(&a, h->ev0, h->ev1));
+        CIP_HIP_CHECK(hipEventElapsedTime(&b, h->ev1, h->ev2));
+        h->ms_assemble = a; h->ms_ldlt = b;
+        int info = 0;
+        CIP_HIP_CHECK(hipMemcpy(&info, h->ws.info, sizeof(int), hipMemcpyDeviceToHost));
+        if (info) { cip_set_error("LDL': zero or non-finite pivot at column %d", info); return CIP_E_SINGULAR; }
+    }
+    h->factored = true;
+    return 0;
+}
+
+extern "C" int cip_check_factor(cip_handle *h) {
+    if (!h) return CIP_E_INVALID;
+    if (!h->factored) { cip_set_error("no factorisation"); return CIP_E_NOTFACTORED; }
+    int info = 0;
+    CIP_HIP_CHECK(hipMemcpyAsync(&info, h->ws.info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    CIP_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (info) { cip_set_error("LDL': zero or non-finite pivot at column %d", info); return CIP_E_SINGULAR; }
+    return 0;
+}
+
+// ------------------------------------------------------------------ products with A, A'
+static int mul_A(cip_handle *h, double alpha, const double *x, double beta, double *y) {      // y = alpha A x + beta y  (m)
+    if (h->m == 0) return 0;
+    if (h->A_sparse) return cip_spmv_csr(h->stream, h->m, h->A_rp, h->A_ci, h->A_v, alpha, x, beta, y);
+    return cip_gemv_t(h->stream, h->n, h->m, alpha, h->At, h->npad, x, beta, y);
+}
+static int mul_At(cip_handle *h, double alpha, const double *x, double beta, double *y) {     // y = alpha A' x + beta y (n)
+    if (h->m == 0) { if (beta == 0.0) CIP_HIP_CHECK(hipMemsetAsync(y, 0, sizeof(double) * h->n, h->stream)); return 0; }
+    if (h->A_sparse) return cip_spmv_csr(h->stream, h->n, h->T_rp, h->T_ci, h->T_v, alpha, x, beta, y);
+    return cip_gemv_t(h->stream, h->m, h->n, alpha, h->A, h->m, x, beta, y);
+}
+
+// (F'F)^-1 z = F^-1 F^-T z
+static int apply_FtF_inv(cip_handle *h, const double *z, double *tmp, double *out) {
+    int rc;
+    if ((rc = cip_cones_apply(h->stream, h->cs, CIP_OP_FINVT, z, tmp))) return rc;
+    return cip_cones_apply(h->stream, h->cs, CIP_OP_FINV, tmp, out);
+}
+
+// ------------------------------------------------------------------ level 3
+extern "C" int cip_solve3x3_dev(cip_handle *h, const double *x, const double *y, const double *z, double *a, double *b,
+                                double *c) {
+    if (!h) return CIP_E_INVALID;
+    if (!h->factored) { cip_set_error("cip_solve3x3: no factorisation (call cip_factor first)"); return CIP_E_NOTFACTORED; }
+    hipStream_t s = h->stream;
+    const int n = h->n, m = h->m, p = h->p;
+    int rc;
+    if (h->route == CIP_ROUTE_SCHUR) {
+        // algebra of pivotgen, src/kktsolvers.jl:324-330, with the exact (F'F)^-1 = F^-1 F^-T:
+        //   t = (F'F)^-1 z ; [S G'; G 0][a; b] = [x + A't; y] ; c = t - (F'F)^-1 A a
+        double *t = h->mt1, *tmp = h->mt2, *u = h->mt3;
+        if (m > 0 && (rc = apply_FtF_inv(h, z, tmp, t))) return rc;
+        CIP_HIP_CHECK(hipMemcpyAsync(h->rhs, x, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+        if (m > 0 && (rc = mul_At(h, 1.0, t, 1.0, h->rhs))) return rc;
+        if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(h->rhs + n, y, sizeof(double) * p, hipMemcpyDeviceToDevice, s));
+        if (h->Npad > h->N) CIP_HIP_CHECK(hipMemsetAsync(h->rhs + h->N, 0, sizeof(double) * (h->Npad - h->N), s));
+        if ((rc = cip_ldlt_solve(s, h->K, h->Npad, h->ldk, h->ws, h->rhs))) return rc;
+        CIP_HIP_CHECK(hipMemcpyAsync(a, h->rhs, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+        if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(b, h->rhs + n, sizeof(double) * p, hipMemcpyDeviceToDevice, s));
+        if (m > 0) {
+            if ((rc = mul_A(h, 1.0, h->rhs, 0.0, u))) return rc;
+            if ((rc = apply_FtF_inv(h, u, tmp, u))) return rc;
+            if ((rc = cip_axpby(s, m, 1.0, t, 0.0, c))) return rc;
+            if ((rc = cip_axpby(s, m, -1.0, u, 1.0, c))) return rc;
+        }
+    } else {
+        // [-F'F -A 0; -A' Q G'; 0 G 0] [c; a; b] = [-z; x; y]
+        if (m > 0 && (rc = cip_axpby(s, m, -1.0, z, 0.0, h->rhs))) return rc;
+        CIP_HIP_CHECK(hipMemcpyAsync(h->rhs + m, x, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+        if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(h->rhs + m + n, y, sizeof(double) * p, hipMemcpyDeviceToDevice, s));
+        if (h->Npad > h->N) CIP_HIP_CHECK(hipMemsetAsync(h->rhs + h->N, 0, sizeof(double) * (h->Npad - h->N), s));
+        if ((rc = cip_ldlt_solve(s, h->K, h->Npad, h->ldk, h->ws, h->rhs))) return rc;
+        if (m > 0) CIP_HIP_CHECK(hipMemcpyAsync(c, h->rhs, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+        CIP_HIP_CHECK(hipMemcpyAsync(a, h->rhs + m, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+        if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(b, h->rhs + m + n, sizeof(double) * p, hipMemcpyDeviceToDevice, s));
+    }
+    h->n_solve += 1;
+    return 0;
+}
+
+extern "C" int cip_solve3x3(cip_handle *h, const double *x, const double *y, const double *z, double *a, double *b,
+                            double *c) {
+    if (!h) return CIP_E_INVALID;
+    hipStream_t s = h->stream;
+    const int n = h->n, m = h->m, p = h->p;
+    double *in = h->stage, *out = h->stage + (n + p + m);
+    CIP_HIP_CHECK(hipMemcpyAsync(in, x, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(in + n, y, sizeof(double) * p, hipMemcpyHostToDevice, s));
+    if (m > 0) CIP_HIP_CHECK(hipMemcpyAsync(in + n + p, z, sizeof(double) * m, hipMemcpyHostToDevice, s));
+    const int rc = cip_solve3x3_dev(h, in, in + n, in + n + p, out, out + n, out + n + p);
+    if (rc) return rc;
+    CIP_HIP_CHECK(hipMemcpyAsync(a, out, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(b, out + n, sizeof(double) * p, hipMemcpyDeviceToHost, s));
+    if (m > 0) CIP_HIP_CHECK(hipMemcpyAsync(c, out + n + p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+    CIP_HIP_CHECK(hipStreamSynchronize(s));
+    int info = 0;
+    CIP_HIP_CHECK(hipMemcpy(&info, h->ws.info, sizeof(int), hipMemcpyDeviceToHost));
+    if (info) { cip_set_error("LDL': zero or non-finite pivot at column %d", info); return CIP_E_SINGULAR; }
+    return 0;
+}
+
+// solve4x4 (src/ConicIP.jl:684-692):  q = r.s (./) lambda ; t1 = F'q ; (dy,dw,dv) = solve3x3(r.y, r.w, r.v + t1) ;
+// ds = t1 - F'(F dv).   r, dz are contiguous (y[n], w[p], v[m], s[m]).
+extern "C" int cip_solve4x4_dev(cip_handle *h, const double *lambda, const double *r, double *dz) {
+    if (!h) return CIP_E_INVALID;
+    hipStream_t s = h->stream;
+    const int n = h->n, m = h->m, p = h->p;
+    const double *ry = r, *rw = r + n, *rv = r + n + p, *rs = r + n + p + m;
+    double *dy = dz, *dw = dz + n, *dv = dz + n + p, *ds = dz + n + p + m;
+    int rc;
+    // ds is used as t1; dv temporarily holds r.v + t1 (input z of the 3x3 solve; solve3x3 copies it before writing c)
+    if (m > 0) {
+        if ((rc = cip_cones_div(s, h->cs, rs, lambda, ds))) return rc;          // q
+        if ((rc = cip_cones_apply(s, h->cs, CIP_OP_FT, ds, ds))) return rc;     // t1 = F'q (in place)
+        if ((rc = cip_axpby(s, m, 1.0, rv, 0.0, dv))) return rc;
+        if ((rc = cip_axpby(s, m, 1.0, ds, 1.0, dv))) return rc;                // dv <- r.v + t1
+    }
+    if ((rc = cip_solve3x3_dev(h, ry, rw, dv, dy, dw, dv))) return rc;
+    if (m > 0) {
+        double *u = h->mt3;
+        if ((rc = cip_cones_apply(s, h->cs, CIP_OP_F, dv, u))) return rc;
+        if ((rc = cip_cones_apply(s, h->cs, CIP_OP_FT, u, u))) return rc;
+        if ((rc = cip_axpby(s, m, -1.0, u, 1.0, ds))) return rc;                // ds = t1 - F'(F dv)
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ cone algebra / vector helpers
+extern "C" int cip_apply_F_dev(cip_handle *h, int mode, const double *x, double *out) {
+    if (!h || mode < 0 || mode > 3) { cip_set_error("bad argument"); return CIP_E_INVALID; }
+    return cip_cones_apply(h->stream, h->cs, mode, x, out);
+}
+extern "C" int cip_cone_prod_dev(cip_handle *h, const double *x, const double *y, double *out) {
+    if (!h) return CIP_E_INVALID;
+    return cip_cones_prod(h->stream, h->cs, x, y, out);
+}
+extern "C" int cip_cone_div_dev(cip_handle *h, const double *x, const double *y, double *out) {
+    if (!h) return CIP_E_INVALID;
+    return cip_cones_div(h->stream, h->cs, x, y, out);
+}
+extern "C" int cip_maxstep_dev(cip_handle *h, const double *x, const double *d, double scale, double *alpha_host) {
+    if (!h || !alpha_host) return CIP_E_INVALID;
+    return cip_cones_maxstep(h->stream, h->cs, x, d, scale, alpha_host);
+}
+extern "C" int cip_cone_identity_dev(cip_handle *h, double *e) {
+    if (!h) return CIP_E_INVALID;
+    return cip_cones_identity(h->stream, h->cs, e);
+}
+
+extern "C" int cip_gemv_dev(cip_handle *h, int which, int trans, double alpha, const double *x, double beta, double *y) {
+    if (!h) return CIP_E_INVALID;
+    hipStream_t s = h->stream;
+    switch (which) {
+        case CIP_MAT_Q: return cip_gemv_t(s, h->n, h->n, alpha, h->Q, h->n, x, beta, y);   // Q symmetric
+        case CIP_MAT_A: return trans ? mul_At(h, alpha, x, beta, y) : mul_A(h, alpha, x, beta, y);
+        case CIP_MAT_G:
+            if (h->p == 0) {
+                if (trans && beta == 0.0) CIP_HIP_CHECK(hipMemsetAsync(y, 0, sizeof(double) * h->n, s));
+                else if (trans && beta != 1.0) return cip_axpby(s, h->n, 0.0, y, beta, y);
+                return 0;
+            }
+            return trans ? cip_gemv_t(s, h->p, h->n, alpha, h->G, h->p, x, beta, y)
+                         : cip_gemv_t(s, h->n, h->p, alpha, h->Gt, h->n, x, beta, y);
+        default: cip_set_error("bad matrix id"); return CIP_E_INVALID;
+    }
+}
+extern "C" int cip_dots_dev(cip_handle *h, int count, const double *const *x, const double *const *y, const int *len,
+                            double *out_host) {
+    if (!h) return CIP_E_INVALID;
+    return cip_dots(h->stream, count, x, y, len, h->dot_scratch, h->dot_ptrs, out_host);
+}
+extern "C" int cip_axpby_dev(cip_handle *h, int len, double alpha, const double *x, double beta, double *y) {
+    if (!h) return CIP_E_INVALID;
+    return cip_axpby(h->stream, len, alpha, x, beta, y);
+}
+
+// ------------------------------------------------------------------ stand-alone LDL' / GEMM
+extern "C" int cip_ldlt_workspace_bytes(int N, size_t *bytes) {
+    if (N <= 0 || N % CIP_NB || !bytes) { cip_set_error("N must be a positive multiple of 128"); return CIP_E_INVALID; }
+    *bytes = cip_ldlt_ws_bytes(N);
+    return 0;
+}
+extern "C" int cip_ldlt_factor_dev(void *stream, double *K, int N, int ld, void *workspace, int *info_host) {
+    if (!K || !workspace || N <= 0 || N % CIP_NB || ld < N || ld % 2) { cip_set_error("bad argument"); return CIP_E_INVALID; }
+    LdltWorkspace ws;
+    cip_ldlt_ws_carve(workspace, N, &ws);
+    int rc = cip_ldlt_factor((hipStream_t)stream, K, N, ld, ws);
+    if (rc) return rc;
+    if (info_host) {
+        CIP_HIP_CHECK(hipMemcpyAsync(info_host, ws.info, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        CIP_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    }
+    return 0;
+}
+extern "C" int cip_ldlt_solve_dev(void *stream, const double *K, int N, int ld, const void *workspace, double *rhs) {
+    if (!K || !workspace || !rhs || N <= 0 || N % CIP_NB) { cip_set_error("bad argument"); return CIP_E_INVALID; }
+    LdltWorkspace ws;
+    cip_ldlt_ws_carve((void *)workspace, N, &ws);
+    return cip_ldlt_solve((hipStream_t)stream, K, N, ld, ws, rhs);
+}
+extern "C" int cip_gemm_nt_dev(void *stream, int M, int N, int K, double alpha, const double *A, int lda, const double *B,
+                               int ldb, double *C, int ldc, int lower_only) {
+    GemmArgs g = {};
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha;
+    g.lower = lower_only ? 1 : 0;
+    return cip_launch_gemm((hipStream_t)stream, EPI_ACCUM, g);
+}
+
+// ------------------------------------------------------------------ introspection
+extern "C" int cip_kkt_order(const cip_handle *h, int *N, int *N_padded) {
+    if (!h) return CIP_E_INVALID;
+    if (N) *N = h->N;
+    if (N_padded) *N_padded = h->Npad;
+    return 0;
+}
+extern "C" int cip_get_kkt_matrix(cip_handle *h, double *K_host) {
+    if (!h || !K_host) return CIP_E_INVALID;
+    CIP_HIP_CHECK(hipStreamSynchronize(h->stream));
+    CIP_HIP_CHECK(hipMemcpy(K_host, h->K, sizeof(double) * (size_t)h->ldk * h->Npad, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int cip_stats(cip_handle *h, double *out8) {
+    if (!h || !out8) return CIP_E_INVALID;
+    out8[0] = h->n_factor; out8[1] = h->n_solve; out8[2] = h->ms_assemble; out8[3] = h->ms_ldlt; out8[4] = h->flops_ldlt;
+    out8[5] = cip_ldlt_outer_block(); out8[6] = h->N; out8[7] = h->Npad;
+    return 0;
+}
+extern "C" int cip_set_timing(cip_handle *h, int enabled) {
+    if (!h) return CIP_E_INVALID;
+    h->timing = enabled != 0;
+    return 0;
+}
+extern "C" int cip_set_ldlt_outer_block(int nbo) { cip_ldlt_set_outer_block(nbo); return cip_ldlt_outer_block(); }

@@ -1,0 +1,194 @@
+// KKT assembly on the device (level 2 of the plugin, before the factorisation).
+//
+//  CIP_ROUTE_SCHUR    K = [ Q + A'(F'F)^-1 A   G' ]   -- the elimination order of `pivot`
+//                         [ G                  0  ]      (src/kktsolvers.jl:289-293, :316-338)
+//  CIP_ROUTE_FULL3X3  K = [ -F'F  -A   0  ]            -- the literal 3x3 block assembly
+//                         [ -A'    Q   G' ]               [Q G' -A'; G 0 0; A 0 F'F]
+//                         [  0     G   0  ]               (src/kktsolvers.jl:254-256), symmetrised and
+//                                                         permuted to the static pivot order (3,1,2)
+// Only the lower triangle is written / referenced; K is padded to a multiple of 128 with an
+// identity block.
+#include "cip_handle.h"
+#include "../../include/cipkkt.h"
+
+// rows >= n of the Schur-route matrix: G block, zero block, identity padding (lower part)
+__global__ __launch_bounds__(256) void k_fill_rest(double *K, long ldk, int n, int p, int Npad, const double *G, long ldg) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Npad) return;
+    for (int i = n + blockIdx.y; i < Npad; i += gridDim.y) {
+        if (j > i) continue;
+        double v;
+        if (i < n + p) v = (j < n) ? G[(i - n) + (long)j * ldg] : 0.0;
+        else v = (i == j) ? 1.0 : 0.0;
+        K[i + (long)j * ldk] = v;
+    }
+}
+
+// K[r0 + i, c0 + j] = sign * M[i + j*ldm]   (i < rows, j < cols); coalesced along i
+__global__ __launch_bounds__(256) void k_copy_block(double *K, long ldk, int r0, int c0, const double *M, long ldm,
+                                                     int rows, int cols, double sign) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    for (int j = blockIdx.y; j < cols; j += gridDim.y)
+        K[(r0 + i) + (long)(c0 + j) * ldk] = sign * M[i + (long)j * ldm];
+}
+
+// ---------------------------------------------------------------- sparse-A Schur terms (R and Q cones)
+// per row r of A:  K[i,j] += w_r a_ri a_rj  (i >= j), w_r = 1/d_r^2 (R),  -J_rr/beta^2 (Q)
+__global__ __launch_bounds__(256) void k_schur_rows(int m, const int *rp, const int *ci, const double *av,
+                                                     const int *row_cone, const ConeDesc *cones, const double *scal,
+                                                     double *K, long ldk, int base) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    const ConeDesc cd = cones[row_cone[r]];
+    double w;
+    if (cd.type == CIP_CONE_R) {
+        const double d = scal[cd.soff + (r - cd.off)];
+        w = 1.0 / (d * d);
+    } else {
+        const double beta = scal[cd.soff];
+        w = ((r == cd.off) ? -1.0 : 1.0) / (beta * beta);
+    }
+    const int q0 = rp[r], q1 = rp[r + 1];
+    for (int a = q0; a < q1; ++a) {
+        const double wa = w * av[a];
+        const int ca = ci[a];
+        for (int b = q0; b <= a; ++b) {
+            const int cb = ci[b];
+            const int i = ca > cb ? ca : cb, j = ca > cb ? cb : ca;
+            unsafeAtomicAdd(&K[(base + i) + (long)(base + j) * ldk], wa * av[b]);
+        }
+    }
+}
+// Gm[:, qidx] += (sqrt2/beta) (J wbar)_r * A[r, :]'   for rows r of Q cones
+__global__ __launch_bounds__(256) void k_schur_qcols(int m, const int *rp, const int *ci, const double *av,
+                                                      const int *row_cone, const ConeDesc *cones, const double *scal,
+                                                      double *Gm, long ldgm) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    const ConeDesc cd = cones[row_cone[r]];
+    if (cd.type != CIP_CONE_Q) return;
+    const double beta = scal[cd.soff];
+    const double *w = scal + cd.soff + 1;
+    const int e = r - cd.off;
+    // wbar_1 = w1^2/beta - 1 ; wbar_t = w1 w_t / beta ; (J wbar)_t = -wbar_t
+    const double jw = (e == 0) ? (w[0] * w[0] / beta - 1.0) : -(w[0] * w[e] / beta);
+    const double coef = jw * 1.4142135623730951 / beta;
+    for (int q = rp[r]; q < rp[r + 1]; ++q)
+        unsafeAtomicAdd(&Gm[ci[q] + (long)cd.qidx * ldgm], coef * av[q]);
+}
+
+// ---------------------------------------------------------------- full 3x3 route: -F'F block
+__global__ __launch_bounds__(256) void k_fill_ftf(const ConeDesc *cones, const WorkItem *items, const double *scal,
+                                                   double *K, long ldk) {
+    const WorkItem it = items[blockIdx.x];
+    const ConeDesc cd = cones[it.cone];
+    const int tid = threadIdx.x;
+    if (cd.type == CIP_CONE_R) {
+        for (int e = it.start + tid; e < it.start + it.len; e += 256) {
+            const double d = scal[cd.soff + e];
+            const long g = cd.off + e;
+            K[g + g * ldk] = -d * d;
+        }
+    } else if (cd.type == CIP_CONE_Q) {
+        // F'F = F^2 = beta^2 (2 wbar wbar' - J)
+        const int k = cd.dim;
+        const double beta = scal[cd.soff];
+        const double *w = scal + cd.soff + 1;
+        const double b2 = beta * beta, w0 = w[0];
+        for (long e = tid; e < (long)k * k; e += 256) {
+            const int i = (int)(e % k), j = (int)(e / k);
+            if (i < j) continue;
+            const double wi = (i == 0) ? (w0 * w0 / beta - 1.0) : (w0 * w[i] / beta);
+            const double wj = (j == 0) ? (w0 * w0 / beta - 1.0) : (w0 * w[j] / beta);
+            double v = 2.0 * wi * wj;
+            if (i == j) v -= (i == 0) ? 1.0 : -1.0;
+            K[(cd.off + i) + (long)(cd.off + j) * ldk] = -b2 * v;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_scatter_negA(int nrowsT, const int *trp, const int *tci, const double *tv,
+                                                       double *K, long ldk, int r0) {
+    // CSR of A' (row i = variable, column = constraint r):  K[r0 + i, r] = -A[r, i]
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nrowsT) return;
+    for (int q = trp[i]; q < trp[i + 1]; ++q) K[(r0 + i) + (long)tci[q] * ldk] = -tv[q];
+}
+__global__ __launch_bounds__(256) void k_pad_identity(double *K, long ldk, int N, int Npad) {
+    const int i = N + blockIdx.x * 256 + threadIdx.x;
+    if (i < Npad) K[i + (long)i * ldk] = 1.0;
+}
+
+static int assemble_schur(cip_handle *h) {
+    hipStream_t s = h->stream;
+    int rc;
+    const int n = h->n, p = h->p;
+    if (!h->A_sparse) {
+        if ((rc = cip_cones_scale_At(s, h->cs, n, h->At, h->npad, h->Wt, h->npad))) return rc;
+        GemmArgs g = {};
+        g.A = h->Wt; g.lda = h->npad; g.B = h->Wt; g.ldb = h->npad;
+        g.C = h->K; g.ldc = h->ldk; g.M = h->npad; g.N = h->npad; g.K = h->mpad;
+        g.alpha = 1.0; g.lower = 1; g.Qin = h->Q; g.ldq = n; g.nvalid = n;
+        if ((rc = cip_launch_gemm(s, EPI_SYRKQ, g))) return rc;
+    } else {
+        if (n > 0) {
+            hipLaunchKernelGGL(k_copy_block, dim3((n + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, 0, 0, h->Q,
+                               (long)n, n, n, 1.0);
+        }
+        if (h->m > 0) {
+            hipLaunchKernelGGL(k_schur_rows, dim3((h->m + 255) / 256), dim3(256), 0, s, h->m, h->A_rp, h->A_ci, h->A_v,
+                               h->row_cone, h->cs.d_cones, h->cs.d_scal, h->K, h->ldk, 0);
+            if (h->nq > 0) {
+                CIP_HIP_CHECK(hipMemsetAsync(h->Gm, 0, sizeof(double) * (size_t)h->npad * h->nqpad, s));
+                hipLaunchKernelGGL(k_schur_qcols, dim3((h->m + 255) / 256), dim3(256), 0, s, h->m, h->A_rp, h->A_ci,
+                                   h->A_v, h->row_cone, h->cs.d_cones, h->cs.d_scal, h->Gm, (long)h->npad);
+            }
+        }
+    }
+    if (h->Npad > n) {
+        hipLaunchKernelGGL(k_fill_rest, dim3((h->Npad + 255) / 256, (h->Npad - n) < 32768 ? (h->Npad - n) : 32768), dim3(256), 0, s, h->K, h->ldk, n, p,
+                           h->Npad, h->G, (long)p);
+    }
+    if (h->A_sparse && h->nq > 0 && h->m > 0) {
+        // after k_fill_rest: the rank-nq update touches whole 128-tiles (adds exact zeros outside [0,n)^2)
+        GemmArgs g = {};
+        g.A = h->Gm; g.lda = h->npad; g.B = h->Gm; g.ldb = h->npad;
+        g.C = h->K; g.ldc = h->ldk; g.M = h->npad; g.N = h->npad; g.K = h->nqpad; g.alpha = 1.0; g.lower = 1;
+        if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
+    }
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int assemble_full(cip_handle *h) {
+    hipStream_t s = h->stream;
+    const int n = h->n, m = h->m, p = h->p;
+    CIP_HIP_CHECK(hipMemsetAsync(h->K, 0, sizeof(double) * (size_t)h->ldk * h->Npad, s));
+    if (h->cs.nitems > 0)
+        hipLaunchKernelGGL(k_fill_ftf, dim3(h->cs.nitems), dim3(256), 0, s, h->cs.d_cones, h->cs.d_items, h->cs.d_scal,
+                           h->K, h->ldk);
+    if (m > 0 && n > 0) {
+        if (!h->A_sparse)
+            hipLaunchKernelGGL(k_copy_block, dim3((n + 255) / 256, m < 32768 ? m : 32768), dim3(256), 0, s, h->K, h->ldk, m, 0, h->At,
+                               (long)h->npad, n, m, -1.0);
+        else
+            hipLaunchKernelGGL(k_scatter_negA, dim3((n + 255) / 256), dim3(256), 0, s, n, h->T_rp, h->T_ci, h->T_v,
+                               h->K, h->ldk, m);
+    }
+    if (n > 0)
+        hipLaunchKernelGGL(k_copy_block, dim3((n + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, m, m, h->Q, (long)n, n,
+                           n, 1.0);
+    if (p > 0)
+        hipLaunchKernelGGL(k_copy_block, dim3((p + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, m + n, m, h->G,
+                           (long)p, p, n, 1.0);
+    if (h->Npad > h->N)
+        hipLaunchKernelGGL(k_pad_identity, dim3((h->Npad - h->N + 255) / 256), dim3(256), 0, s, h->K, h->ldk, h->N, h->Npad);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int cip_assemble(cip_handle *h) {
+    int rc = (h->route == CIP_ROUTE_SCHUR) ? assemble_schur(h) : assemble_full(h);
+    if (rc == 0) { h->assembled = true; h->factored = false; }
+    return rc;
+}

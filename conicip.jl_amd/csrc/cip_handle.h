@@ -1,0 +1,52 @@
+// The opaque handle behind the C ABI (one KKT system, resident on one GPU).
+#pragma once
+#include "cip_internal.h"
+#include <vector>
+
+struct cip_handle {
+    int n = 0, m = 0, p = 0, ncones = 0, route = 0;
+    int N = 0, Npad = 0;            // KKT order for the route, and padded to a multiple of 128
+    int npad = 0, mpad = 0;         // n rounded up to 128, m rounded up to 16 (>= 16)
+    int nq = 0, nqpad = 0;          // number of Q cones, rounded up to 16 (>= 16)
+    hipStream_t stream = nullptr;
+    int device = 0;
+
+    // ---- problem data, device resident for the lifetime of the handle (level 1)
+    double *Q = nullptr;            // n x n, ld n
+    bool A_sparse = false;
+    double *A = nullptr;            // m x n, ld m            (dense A only)
+    double *At = nullptr;           // npad x mpad, ld npad   (dense A only; zero padded)  At[i + r*npad] = A[r,i]
+    int A_nnz = 0;
+    int *A_rp = nullptr, *A_ci = nullptr; double *A_v = nullptr;   // CSR of A  (m rows)
+    int *T_rp = nullptr, *T_ci = nullptr; double *T_v = nullptr;   // CSR of A' (n rows)
+    int *row_cone = nullptr;        // m ints: cone index of every row of A
+    double *G = nullptr;            // p x n, ld p
+    double *Gt = nullptr;           // n x p, ld n
+
+    // ---- cones / scaling (level 2 input)
+    std::vector<ConeDesc> h_cones;
+    std::vector<WorkItem> h_items;
+    ConeSet cs = {};
+
+    // ---- KKT matrix + factor (level 2 output)
+    double *K = nullptr; long ldk = 0;
+    double *Wt = nullptr;           // npad x mpad   At * F^-1           (dense-A Schur route)
+    double *Gm = nullptr;           // npad x nqpad  rank-1 columns of the Q cones (sparse-A Schur route)
+    void *ws_base = nullptr; LdltWorkspace ws = {};
+    bool assembled = false, factored = false;
+
+    // ---- scratch
+    double *rhs = nullptr;          // Npad
+    double *mt1 = nullptr, *mt2 = nullptr, *mt3 = nullptr;   // m-vectors
+    double *nt1 = nullptr;          // n-vector
+    double *pt1 = nullptr;          // p-vector
+    double *dot_scratch = nullptr; void *dot_ptrs = nullptr;
+    double *stage = nullptr;        // device staging for the host-pointer entry points: 2*(n+p+m) doubles
+
+    // ---- stats
+    double n_factor = 0, n_solve = 0, ms_assemble = 0, ms_ldlt = 0, flops_ldlt = 0;
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+};
+
+int cip_assemble(cip_handle *h);     // assemble.hip

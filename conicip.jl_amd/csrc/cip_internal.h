@@ -1,0 +1,102 @@
+// Internal declarations shared by the libcipkkt translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+#define CIP_NB 128            // inner panel width == GEMM tile edge
+#define CIP_KT 16             // GEMM k-tile
+
+// ---------------------------------------------------------------- error plumbing
+void cip_set_error(const char *fmt, ...);
+#define CIP_HIP_CHECK(expr)                                                       \
+    do {                                                                          \
+        hipError_t e__ = (expr);                                                  \
+        if (e__ != hipSuccess) {                                                  \
+            cip_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                          __FILE__, __LINE__);                                    \
+            return -3;                                                            \
+        }                                                                         \
+    } while (0)
+
+// ---------------------------------------------------------------- GEMM (gemm_f64.hip)
+enum { EPI_ACCUM = 0, EPI_TRSM = 1, EPI_SYRKQ = 2 };
+
+struct GemmArgs {
+    const double *A; long lda;   // M x K, element (i,k) at A[i + k*lda]
+    const double *B; long ldb;   // N x K, element (j,k) at B[j + k*ldb]
+    double *C; long ldc;         // M x N
+    int M, N, K;                 // M, N multiples of 128; K multiple of 16
+    double alpha;
+    int lower;                   // 1: only tiles with bi >= bj (M == N)
+    // EPI_TRSM: W = acc (ldw), C = acc * dinv[col]
+    double *W; long ldw;
+    const double *dinv;
+    // EPI_SYRKQ: C = Qin + acc for i,j < nvalid (lower tiles)
+    const double *Qin; long ldq; int nvalid;
+};
+int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g);
+
+// ---------------------------------------------------------------- LDL' (ldlt.hip)
+struct LdltWorkspace {        // carved out of one device allocation
+    double *Wbuf;             // Npad x NBO      (W = L*D panels of the current outer block)
+    double *Linv;             // (Npad/128) x 128 x 128   inverse of each unit-lower diagonal block
+    double *LinvT;            // same, transposed
+    double *dinv;             // Npad   1/d
+    double *dvec;             // Npad   d
+    double *tmp;              // Npad   scratch vector for the solves
+    int *info;                // device int: 0 ok, >0 = 1-based column of a bad pivot
+};
+size_t cip_ldlt_ws_bytes(int Npad);
+void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws);
+int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws);
+int cip_ldlt_solve(hipStream_t s, const double *K, int Npad, long ld, const LdltWorkspace &ws, double *rhs);
+int cip_ldlt_outer_block(void);          // NBO currently in use
+void cip_ldlt_set_outer_block(int nbo);
+
+// ---------------------------------------------------------------- cones (cones.hip)
+struct ConeDesc {             // one per cone
+    int type;                 // CIP_CONE_*
+    int off;                  // offset into the m-vector
+    int dim;                  // block length k
+    int soff;                 // offset into the packed scaling storage
+    int r;                    // S cone: matrix order
+    int qidx;                 // Q cone: running index among Q cones (else -1)
+};
+struct WorkItem {             // unit of work for the per-cone kernels
+    int cone;                 // index into ConeDesc[]
+    int start;                // first element (relative to the cone) -- R cones are chunked
+    int len;
+};
+struct ConeSet {
+    int ncones, nitems, m;
+    ConeDesc *d_cones;        // device
+    WorkItem *d_items;        // device
+    double *d_scal;           // device packed scaling
+    size_t scal_len;
+    double *d_partial;        // nitems doubles (reductions)
+    double *d_scalar;         // 8 doubles
+    int has_S;
+};
+int cip_cones_nt_scaling(hipStream_t s, const ConeSet &cs, const double *v, const double *sv, double *lambda);
+int cip_cones_identity_scaling(hipStream_t s, const ConeSet &cs);
+int cip_cones_apply(hipStream_t s, const ConeSet &cs, int mode, const double *x, double *out);
+int cip_cones_prod(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out);
+int cip_cones_div(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out);
+int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const double *d, double scale, double *alpha_host);
+int cip_cones_identity(hipStream_t s, const ConeSet &cs, double *e);
+// Wt[i, r] = (F^-T a_i)_r for every row i of At (n rows, ld ldat): Wt = At * F^-1
+int cip_cones_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, long ldat, double *Wt, long ldwt);
+
+// ---------------------------------------------------------------- vector ops (vecops.hip)
+int cip_gemv_t(hipStream_t s, int rows, int cols, double alpha, const double *A, long lda,
+               const double *x, double beta, double *y);     // y[j] = alpha * sum_i A[i + j*lda] x[i] + beta y[j]
+int cip_spmv_csr(hipStream_t s, int rows, const int *rowptr, const int *colind, const double *val,
+                 double alpha, const double *x, double beta, double *y);
+int cip_dots(hipStream_t s, int count, const double *const *x_host, const double *const *y_host,
+             const int *len_host, double *scratch_dev, void *ptrs_dev, double *out_host);
+int cip_axpby(hipStream_t s, int len, double alpha, const double *x, double beta, double *y);
+int cip_copy_neg(hipStream_t s, int len, const double *x, double *y, double scale);   // y = scale * x

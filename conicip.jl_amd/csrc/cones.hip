@@ -1,0 +1,384 @@
+// Per-cone kernels over the block-diagonal Nesterov-Todd scaling (R and Q cones here;
+// S-cone kernels live in sdp.hip).  Device counterparts of
+//   nt_scaling / nestod_soc         src/ConicIP.jl:589-605, :165-194
+//   Block * x, Block' * x, inv      src/blockmatrices.jl:173-200  (+ WoodburyMatrices SymWoodbury algebra)
+//   cone_prod! / cone_div!          src/ConicIP.jl:607-665, :305-345
+//   maxstep                         src/ConicIP.jl:212-270, :571-587
+//   cone identity e                 src/ConicIP.jl:559-565
+//
+// One workgroup (256 threads = 4 wave64) per work item; a work item is a whole Q cone
+// or a <=2048-element chunk of an R cone.  All reductions are wave shuffles + one LDS hop.
+//
+// Packed scaling storage per cone (== what the Julia shim reads off the Block elements):
+//   R: diag(F) (k)      Q: beta, w (1+k) with F = diag(-beta,beta,..) + w w'      S: R, inv(R)
+#include "cip_internal.h"
+#include "../../include/cipkkt.h"
+#include <math.h>
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+// block-wide sum of up to 3 values at once (256 threads); result broadcast to all threads
+__device__ __forceinline__ void block_sum3(double &a, double &b, double &c, double *sh /*>=12*/) {
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh[w] = a; sh[4 + w] = b; sh[8 + w] = c; }
+    __syncthreads();
+    a = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    b = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+    c = (sh[8] + sh[9]) + (sh[10] + sh[11]);
+}
+__device__ __forceinline__ double block_min(double a, double *sh) {
+    a = wave_min(a);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = a;
+    __syncthreads();
+    return fmin(fmin(sh[0], sh[1]), fmin(sh[2], sh[3]));
+}
+
+// ------------------------------------------------------------------ NT scaling
+__global__ __launch_bounds__(256) void k_nt_scaling(const ConeDesc *cones, const WorkItem *items, const double *v,
+                                                     const double *s, double *scal, double *lambda) {
+    __shared__ double sh[12];
+    const WorkItem it = items[blockIdx.x];
+    const ConeDesc cd = cones[it.cone];
+    const int tid = threadIdx.x;
+    if (cd.type == CIP_CONE_R) {
+        for (int e = it.start + tid; e < it.start + it.len; e += 256) {
+            const double vi = v[cd.off + e], si = s[cd.off + e];
+            const double d = sqrt(si / vi);                        // src/ConicIP.jl:598
+            scal[cd.soff + e] = d;
+            if (lambda) lambda[cd.off + e] = d * vi;
+        }
+    } else if (cd.type == CIP_CONE_Q) {
+        // nestod_soc(z = v block, s = s block)  src/ConicIP.jl:165-194
+        const double *z = v + cd.off, *sv = s + cd.off;
+        const int k = cd.dim;
+        double zz = 0, ss = 0, zs = 0;
+        for (int e = 1 + tid; e < k; e += 256) { zz += z[e] * z[e]; ss += sv[e] * sv[e]; zs += z[e] * sv[e]; }
+        block_sum3(zz, ss, zs, sh);
+        const double z0 = z[0], s0 = sv[0];
+        const double qfz = z0 * z0 - zz, qfs = s0 * s0 - ss;       // QF(.)
+        const double beta = sqrt(sqrt(qfs / qfz));                 // (QF(s)/QF(z))^(1/4)
+        const double rz = 1.0 / sqrt(qfz), rs = 1.0 / sqrt(qfs);
+        const double zdots = (z0 * s0 + zs) * rz * rs;             // zbar . sbar
+        const double gamma = sqrt((1.0 + zdots) * 0.5);
+        const double h = 1.0 / (2.0 * gamma);
+        const double wb0 = h * (s0 * rs + z0 * rz);                // wbar_1
+        const double c = sqrt(beta / (wb0 + 1.0));                 // sqrt(2 beta)/sqrt(2 w[1])
+        // w = c * (wbar + e1), wbar_t = h (sbar_t - zbar_t)
+        // w . v (v == z):  c * (wbar.z + z0),  wbar.z = h * (s.z * rs + QF(z) * rz)
+        const double wdotz = c * (h * ((z0 * s0 + zs) * rs + qfz * rz) + z0);
+        if (tid == 0) {
+            scal[cd.soff] = beta;
+            const double w0 = c * (wb0 + 1.0);
+            scal[cd.soff + 1] = w0;
+            if (lambda) lambda[cd.off] = -beta * z0 + w0 * wdotz;
+        }
+        for (int e = 1 + tid; e < k; e += 256) {
+            const double we = c * h * (sv[e] * rs - z[e] * rz);
+            scal[cd.soff + 1 + e] = we;
+            if (lambda) lambda[cd.off + e] = beta * z[e] + we * wdotz;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_identity_scaling(const ConeDesc *cones, const WorkItem *items, double *scal) {
+    const WorkItem it = items[blockIdx.x];
+    const ConeDesc cd = cones[it.cone];
+    const int tid = threadIdx.x;
+    if (cd.type == CIP_CONE_R) {
+        for (int e = it.start + tid; e < it.start + it.len; e += 256) scal[cd.soff + e] = 1.0;
+    } else if (cd.type == CIP_CONE_Q) {
+        // I = diag(-beta, beta, ...) + w w' with beta = 1, w = sqrt(2) e1
+        if (tid == 0) { scal[cd.soff] = 1.0; scal[cd.soff + 1] = sqrt(2.0); }
+        for (int e = 1 + tid; e < cd.dim; e += 256) scal[cd.soff + 1 + e] = 0.0;
+    } else {
+        const int r = cd.r;
+        for (int e = tid; e < r * r; e += 256) {
+            const double v = ((e % r) == (e / r)) ? 1.0 : 0.0;
+            scal[cd.soff + e] = v;
+            scal[cd.soff + r * r + e] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ F, F', F^-1, F^-T on a vector
+__global__ __launch_bounds__(256) void k_apply(const ConeDesc *cones, const WorkItem *items, const double *scal,
+                                                int mode, const double *x, double *out) {
+    __shared__ double sh[12];
+    const WorkItem it = items[blockIdx.x];
+    const ConeDesc cd = cones[it.cone];
+    const int tid = threadIdx.x;
+    const bool inv = (mode == CIP_OP_FINV || mode == CIP_OP_FINVT);
+    if (cd.type == CIP_CONE_R) {
+        for (int e = it.start + tid; e < it.start + it.len; e += 256) {
+            const double d = scal[cd.soff + e];
+            out[cd.off + e] = inv ? x[cd.off + e] / d : x[cd.off + e] * d;
+        }
+    } else if (cd.type == CIP_CONE_Q) {
+        const int k = cd.dim;
+        const double beta = scal[cd.soff];
+        const double *w = scal + cd.soff + 1;
+        const double *xb = x + cd.off;
+        double *ob = out + cd.off;
+        double wx = 0, d1 = 0, d2 = 0;
+        for (int e = 1 + tid; e < k; e += 256) wx += w[e] * xb[e];
+        const double w0 = w[0], x0 = xb[0];      // read before the barriers: out may alias x
+        block_sum3(wx, d1, d2, sh);
+        if (!inv) {
+            // F x = -beta J x + w (w.x)
+            const double t = w0 * x0 + wx;
+            if (tid == 0) ob[0] = -beta * x0 + w0 * t;
+            for (int e = 1 + tid; e < k; e += 256) ob[e] = beta * xb[e] + w[e] * t;
+        } else {
+            // F^-1 x = ( (Jw) (Jw.x)/beta - J x ) / beta
+            const double t = (w0 * x0 - wx) / beta;
+            const double ib = 1.0 / beta;
+            if (tid == 0) ob[0] = (w0 * t - x0) * ib;
+            for (int e = 1 + tid; e < k; e += 256) ob[e] = (xb[e] - w[e] * t) * ib;
+        }
+    }
+}
+
+// Wt[i, off + e] = (F^-T a_i)_e,  a_i = At[i, off:off+k]   (thread per row i of At, coalesced along i)
+__global__ __launch_bounds__(256) void k_scale_At(const ConeDesc *cones, const WorkItem *items, const double *scal,
+                                                   int n, const double *At, long ldat, double *Wt, long ldwt) {
+    const WorkItem it = items[blockIdx.y];
+    const ConeDesc cd = cones[it.cone];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (cd.type == CIP_CONE_R) {
+        for (int e = it.start; e < it.start + it.len; ++e) {
+            const long c = cd.off + e;
+            Wt[i + c * ldwt] = At[i + c * ldat] / scal[cd.soff + e];
+        }
+    } else if (cd.type == CIP_CONE_Q) {
+        const int k = cd.dim;
+        const double beta = scal[cd.soff];
+        const double *w = scal + cd.soff + 1;
+        const double *ap = At + i + (long)cd.off * ldat;
+        double *wp = Wt + i + (long)cd.off * ldwt;
+        double t = w[0] * ap[0];
+        for (int e = 1; e < k; ++e) t -= w[e] * ap[(long)e * ldat];
+        t /= beta;
+        const double ib = 1.0 / beta;
+        wp[0] = (w[0] * t - ap[0]) * ib;
+        for (int e = 1; e < k; ++e) wp[(long)e * ldwt] = (ap[(long)e * ldat] - w[e] * t) * ib;
+    }
+}
+
+// ------------------------------------------------------------------ Jordan product / division
+__global__ __launch_bounds__(256) void k_cone_prod(const ConeDesc *cones, const WorkItem *items, const double *x,
+                                                    const double *y, double *out) {
+    __shared__ double sh[12];
+    const WorkItem it = items[blockIdx.x];
+    const ConeDesc cd = cones[it.cone];
+    const int tid = threadIdx.x;
+    if (cd.type == CIP_CONE_R) {                                   // xrp! src/ConicIP.jl:311-315
+        for (int e = it.start + tid; e < it.start + it.len; e += 256)
+            out[cd.off + e] = x[cd.off + e] * y[cd.off + e];
+    } else if (cd.type == CIP_CONE_Q) {                            // xsoc! :340-345
+        const int k = cd.dim;
+        const double *xb = x + cd.off, *yb = y + cd.off;
+        double *ob = out + cd.off;
+        double xy = 0, d1 = 0, d2 = 0;
+        for (int e = 1 + tid; e < k; e += 256) xy += xb[e] * yb[e];
+        block_sum3(xy, d1, d2, sh);
+        const double x0 = xb[0], y0 = yb[0];
+        __syncthreads();
+        if (tid == 0) ob[0] = x0 * y0 + xy;
+        for (int e = 1 + tid; e < k; e += 256) ob[e] = x0 * yb[e] + y0 * xb[e];
+    }
+}
+
+// out = x (./) y : solves y o out = x   (cone_div!(o, x, y) src/ConicIP.jl:622-635)
+__global__ __launch_bounds__(256) void k_cone_div(const ConeDesc *cones, const WorkItem *items, const double *x,
+                                                   const double *y, double *out) {
+    __shared__ double sh[12];
+    const WorkItem it = items[blockIdx.x];
+    const ConeDesc cd = cones[it.cone];
+    const int tid = threadIdx.x;
+    if (cd.type == CIP_CONE_R) {                                   // drp! :305-309
+        for (int e = it.start + tid; e < it.start + it.len; e += 256)
+            out[cd.off + e] = x[cd.off + e] / y[cd.off + e];
+    } else if (cd.type == CIP_CONE_Q) {                            // dsoc! :317-338 (arrow inverse)
+        const int k = cd.dim;
+        const double *xb = x + cd.off, *yb = y + cd.off;
+        double *ob = out + cd.off;
+        double yy = 0, yx = 0, d2 = 0;
+        for (int e = 1 + tid; e < k; e += 256) { yy += yb[e] * yb[e]; yx += yb[e] * xb[e]; }
+        block_sum3(yy, yx, d2, sh);
+        const double y1 = yb[0], x1 = xb[0];
+        const double alpha = y1 * y1 - yy;
+        const double b1 = (-x1 / alpha) + yx / (y1 * alpha);
+        const double b2 = 1.0 / y1;
+        __syncthreads();
+        if (tid == 0) ob[0] = (y1 * x1 - yx) / alpha;
+        for (int e = 1 + tid; e < k; e += 256) ob[e] = yb[e] * b1 + xb[e] * b2;
+    }
+}
+
+// ------------------------------------------------------------------ max step
+// partial[item] = largest alpha with x - alpha*(scale*d) in the cone (d != NULL), or the
+// `nothing` variant (distance into the cone, <= 0) when d == NULL.
+__global__ __launch_bounds__(256) void k_maxstep(const ConeDesc *cones, const WorkItem *items, const double *x,
+                                                  const double *d, double scale, double *partial) {
+    __shared__ double sh[12];
+    const WorkItem it = items[blockIdx.x];
+    const ConeDesc cd = cones[it.cone];
+    const int tid = threadIdx.x;
+    const double INF = __builtin_inf();
+    if (cd.type == CIP_CONE_R) {
+        double mn = INF;
+        if (d) {                                                   // maxstep_rp :212-225
+            for (int e = it.start + tid; e < it.start + it.len; e += 256) {
+                const double de = d[cd.off + e] * scale;
+                if (de > 0) mn = fmin(mn, x[cd.off + e] / de);
+            }
+            mn = block_min(mn, sh);
+        } else {                                                   // :227-240
+            for (int e = it.start + tid; e < it.start + it.len; e += 256) mn = fmin(mn, x[cd.off + e]);
+            mn = block_min(mn, sh);
+            mn = (mn > 0) ? 0.0 : -1.0 + mn;
+        }
+        if (tid == 0) partial[blockIdx.x] = mn;
+    } else if (cd.type == CIP_CONE_Q) {
+        const int k = cd.dim;
+        const double *xb = x + cd.off;
+        if (!d) {                                                  // maxstep_soc(x, nothing) :264-270
+            double xx = 0, a1 = 0, a2 = 0;
+            for (int e = 1 + tid; e < k; e += 256) xx += xb[e] * xb[e];
+            block_sum3(xx, a1, a2, sh);
+            const double a = sqrt(xx) - xb[0];
+            if (tid == 0) partial[blockIdx.x] = (a < 0) ? 0.0 : -1.0 - a;
+        } else {                                                   // maxstep_soc(x, d) :242-262
+            const double *db = d + cd.off;
+            double xx = 0, xd = 0, a2 = 0;
+            for (int e = 1 + tid; e < k; e += 256) { xx += xb[e] * xb[e]; xd += xb[e] * (-scale * db[e]); }
+            block_sum3(xx, xd, a2, sh);
+            const double x0 = xb[0], d0 = -scale * db[0];
+            const double gam = x0 * x0 - xx;                       // Q(x,x)
+            const double rg = 1.0 / sqrt(gam);
+            const double bet = (x0 * d0 - xd) * rg;                // Q(xbar, d)
+            const double rho1 = bet * rg;
+            const double mu = (bet + d0) / (x0 * rg + 1.0);
+            double r2 = 0, b1 = 0, b2 = 0;
+            for (int e = 1 + tid; e < k; e += 256) {
+                const double t = (-scale * db[e]) - mu * xb[e] * rg;
+                r2 += t * t;
+            }
+            block_sum3(r2, b1, b2, sh);
+            const double alpha = sqrt(r2) * rg - rho1;
+            if (tid == 0) partial[blockIdx.x] = (alpha < 0) ? INF : 1.0 / alpha;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_min_reduce(const double *partial, int n, double *out) {
+    __shared__ double sh[12];
+    double mn = __builtin_inf();
+    int nan_seen = 0;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const double p = partial[e];
+        if (p != p) nan_seen = 1; else mn = fmin(mn, p);
+    }
+    // NaN-propagating block min (Julia's min propagates NaN, src/ConicIP.jl:582)
+    const double m2 = block_min(mn, sh);
+    const int bad = __syncthreads_or(nan_seen);
+    if (threadIdx.x == 0) out[0] = bad ? __builtin_nan("") : m2;
+}
+
+__global__ __launch_bounds__(256) void k_cone_identity(const ConeDesc *cones, const WorkItem *items, double *e) {
+    const WorkItem it = items[blockIdx.x];
+    const ConeDesc cd = cones[it.cone];
+    const int tid = threadIdx.x;
+    if (cd.type == CIP_CONE_R) {
+        for (int q = it.start + tid; q < it.start + it.len; q += 256) e[cd.off + q] = 1.0;
+    } else if (cd.type == CIP_CONE_Q) {
+        for (int q = tid; q < cd.dim; q += 256) e[cd.off + q] = (q == 0) ? 1.0 : 0.0;
+    } else {
+        // vecm(I): row-major upper triangle, diagonal entries at positions i*r - i(i-1)/2
+        const int r = cd.r;
+        for (int q = tid; q < cd.dim; q += 256) e[cd.off + q] = 0.0;
+        __syncthreads();
+        for (int i = tid; i < r; i += 256) e[cd.off + i * r - i * (i - 1) / 2] = 1.0;
+    }
+}
+
+// ------------------------------------------------------------------ host launchers
+int cip_sdp_nt_scaling(hipStream_t s, const ConeSet &cs, const double *v, const double *sv, double *lambda);
+int cip_sdp_apply(hipStream_t s, const ConeSet &cs, int mode, const double *x, double *out);
+int cip_sdp_prod(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out);
+int cip_sdp_div(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out);
+int cip_sdp_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const double *d, double scale, double *partial);
+int cip_sdp_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, long ldat, double *Wt, long ldwt);
+
+int cip_cones_nt_scaling(hipStream_t s, const ConeSet &cs, const double *v, const double *sv, double *lambda) {
+    if (cs.nitems == 0) return 0;
+    hipLaunchKernelGGL(k_nt_scaling, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, v, sv, cs.d_scal, lambda);
+    CIP_HIP_CHECK(hipGetLastError());
+    if (cs.has_S) return cip_sdp_nt_scaling(s, cs, v, sv, lambda);
+    return 0;
+}
+int cip_cones_identity_scaling(hipStream_t s, const ConeSet &cs) {
+    if (cs.nitems == 0) return 0;
+    hipLaunchKernelGGL(k_identity_scaling, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, cs.d_scal);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int cip_cones_apply(hipStream_t s, const ConeSet &cs, int mode, const double *x, double *out) {
+    if (cs.nitems == 0) return 0;
+    hipLaunchKernelGGL(k_apply, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, cs.d_scal, mode, x, out);
+    CIP_HIP_CHECK(hipGetLastError());
+    if (cs.has_S) return cip_sdp_apply(s, cs, mode, x, out);
+    return 0;
+}
+int cip_cones_prod(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out) {
+    if (cs.nitems == 0) return 0;
+    hipLaunchKernelGGL(k_cone_prod, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x, y, out);
+    CIP_HIP_CHECK(hipGetLastError());
+    if (cs.has_S) return cip_sdp_prod(s, cs, x, y, out);
+    return 0;
+}
+int cip_cones_div(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out) {
+    if (cs.nitems == 0) return 0;
+    hipLaunchKernelGGL(k_cone_div, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x, y, out);
+    CIP_HIP_CHECK(hipGetLastError());
+    if (cs.has_S) return cip_sdp_div(s, cs, x, y, out);
+    return 0;
+}
+int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const double *d, double scale, double *alpha_host) {
+    if (cs.nitems == 0) { *alpha_host = __builtin_inf(); return 0; }
+    hipLaunchKernelGGL(k_maxstep, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x, d, scale, cs.d_partial);
+    CIP_HIP_CHECK(hipGetLastError());
+    if (cs.has_S) { int rc = cip_sdp_maxstep(s, cs, x, d, scale, cs.d_partial); if (rc) return rc; }
+    hipLaunchKernelGGL(k_min_reduce, dim3(1), dim3(256), 0, s, cs.d_partial, cs.nitems, cs.d_scalar);
+    CIP_HIP_CHECK(hipGetLastError());
+    CIP_HIP_CHECK(hipMemcpyAsync(alpha_host, cs.d_scalar, sizeof(double), hipMemcpyDeviceToHost, s));
+    CIP_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+int cip_cones_identity(hipStream_t s, const ConeSet &cs, double *e) {
+    if (cs.nitems == 0) return 0;
+    hipLaunchKernelGGL(k_cone_identity, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, e);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int cip_cones_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, long ldat, double *Wt, long ldwt) {
+    if (cs.nitems == 0 || n == 0) return 0;
+    hipLaunchKernelGGL(k_scale_At, dim3((n + 255) / 256, cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items,
+                       cs.d_scal, n, At, ldat, Wt, ldwt);
+    CIP_HIP_CHECK(hipGetLastError());
+    if (cs.has_S) return cip_sdp_scale_At(s, cs, n, At, ldat, Wt, ldwt);
+    return 0;
+}

@@ -1,0 +1,176 @@
+// fp64 MFMA "NT" GEMM for gfx950:  C (+)= alpha * A * B'   (all column-major).
+//
+// This one kernel carries every O(N^3) term of the KKT path:
+//   * LDL' trailing update   C -= (L21 D) L21'      (lower tiles only, K = outer block)
+//   * panel TRSM-as-GEMM     W21 = A21 inv(L11)'    (EPI_TRSM also writes L21 = W21 D^-1)
+//   * Schur formation        S  = Q + (A'F^-1)(A'F^-1)'   (EPI_SYRKQ)
+// i.e. the work the reference does in src/kktsolvers.jl:32-35 (dense GEMMs + QR)
+// and :289-295 (Schur + LU), re-designed for CDNA4.
+//
+// Design (MI355X):
+//   * 128x128 C tile per 256-thread workgroup = 4 wave64s in a 2x2 grid, each wave
+//     a 64x64 sub-tile = 4x4 v_mfma_f64_16x16x4_f64 accumulators (128 acc VGPRs).
+//   * Both operands are "row-contiguous, k-strided" in memory (a panel column is
+//     a contiguous run of rows), so a k-tile of 16 columns is staged as
+//     lds[k][row]: global_load_dwordx4 (one wave reads 1 KB contiguous per k) ->
+//     ds_write_b128, double-buffered, one barrier per k-tile.
+//   * Fragments are read with ds_read_b128: lane c takes rows (2c, 2c+1) of a
+//     32-row group, feeding two MFMA tiles per read; the row pitch is 1024 B
+//     (== 0 mod 256 B), which is conflict-free for the b128 lane groups.
+//   * The MFMA is issued "transposed" (A-operand = B rows, B-operand = A rows)
+//     so that an accumulator's lane index runs along C's rows: the epilogue then
+//     moves 16-byte double2 per lane, 256 B contiguous per 16 lanes.
+//   * blockIdx is remapped so that each XCD (own L2) walks a contiguous run of
+//     tiles (bijective variant of the xcd swizzle).
+#include "cip_internal.h"
+
+#define LDS_TILE (CIP_KT * CIP_NB)        // doubles per operand per buffer (2048)
+
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_128(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * LDS_TILE];   // 64 KB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    // ---- tile coordinates
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    int bi, bj;
+    if (g.lower) {
+        bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((long)bi * (bi + 1) / 2 > t) --bi;
+        while ((long)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
+        bj = t - (int)((long)bi * (bi + 1) / 2);
+    } else {
+        const int tm = g.M / CIP_NB;
+        bi = t % tm;
+        bj = t / tm;
+    }
+    const long i0 = (long)bi * CIP_NB, j0 = (long)bj * CIP_NB;
+
+    const double *Ap = g.A + i0 + 2 * lane;
+    const double *Bp = g.B + j0 + 2 * lane;
+
+    v2d ra[4], rb[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long k = (long)kt * CIP_KT + q * 4 + wave;
+            ra[q] = *(const v2d *)(Ap + k * g.lda);
+            rb[q] = *(const v2d *)(Bp + k * g.ldb);
+        }
+    };
+    auto lstore = [&](int buf) {
+        double *la = lds + buf * (2 * LDS_TILE);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *(v2d *)(la + (q * 4 + wave) * CIP_NB + 2 * lane) = ra[q];
+            *(v2d *)(la + LDS_TILE + (q * 4 + wave) * CIP_NB + 2 * lane) = rb[q];
+        }
+    };
+
+    v4d acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    const int KT = g.K / CIP_KT;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) gload(kt + 1);
+        const double *la = lds + buf * (2 * LDS_TILE) + wm * 64 + 2 * l15;
+        const double *lb = lds + buf * (2 * LDS_TILE) + LDS_TILE + wn * 64 + 2 * l15;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kk = ks * 4 + l4;
+            const v2d fi0 = *(const v2d *)(la + kk * CIP_NB);
+            const v2d fi1 = *(const v2d *)(la + kk * CIP_NB + 32);
+            const v2d fj0 = *(const v2d *)(lb + kk * CIP_NB);
+            const v2d fj1 = *(const v2d *)(lb + kk * CIP_NB + 32);
+            const double fi[4] = {fi0.x, fi0.y, fi1.x, fi1.y};
+            const double fj[4] = {fj0.x, fj0.y, fj1.x, fj1.y};
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[tj], fi[ti], acc[ti][tj], 0, 0, 0);
+        }
+        if (kt + 1 < KT) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  lane holds, for tile (ti,tj), reg q:  C[row, col] with
+    //   row = i0 + wm*64 + (ti>>1)*32 + 2*l15 + (ti&1)
+    //   col = j0 + wn*64 + (tj>>1)*32 + 2*(l4 + 4q) + (tj&1)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long col = j0 + wn * 64 + (tj >> 1) * 32 + 2 * (l4 + 4 * q) + (tj & 1);
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                const long row = i0 + wm * 64 + gi * 32 + 2 * l15;
+                v2d val = (v2d){acc[2 * gi][tj][q], acc[2 * gi + 1][tj][q]};
+                if (EPI == EPI_ACCUM) {
+                    double *cp = g.C + row + col * g.ldc;
+                    v2d c = *(v2d *)cp;
+                    c += g.alpha * val;
+                    *(v2d *)cp = c;
+                } else if (EPI == EPI_TRSM) {
+                    *(v2d *)(g.W + row + col * g.ldw) = val;
+                    const double di = g.dinv[col];
+                    *(v2d *)(g.C + row + col * g.ldc) = val * di;
+                } else {   // EPI_SYRKQ
+                    if (col < g.nvalid) {
+                        if (row + 1 < g.nvalid) {
+                            // Q keeps the caller's (possibly odd) leading dimension: scalar loads
+                            const double *qp = g.Qin + row + col * g.ldq;
+                            const v2d qv = (v2d){qp[0], qp[1]};
+                            *(v2d *)(g.C + row + col * g.ldc) = qv + g.alpha * val;
+                        } else if (row < g.nvalid) {
+                            g.C[row + col * g.ldc] = g.Qin[row + col * g.ldq] + g.alpha * val.x;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
+    if (g.M <= 0 || g.N <= 0) return 0;
+    if (g.M % CIP_NB || g.N % CIP_NB || g.K % CIP_KT || g.K <= 0) {
+        cip_set_error("gemm: bad dims M=%d N=%d K=%d", g.M, g.N, g.K);
+        return -1;
+    }
+    const int tm = g.M / CIP_NB, tn = g.N / CIP_NB;
+    long tiles;
+    if (g.lower) {
+        if (g.M != g.N) { cip_set_error("gemm: lower needs M == N"); return -1; }
+        tiles = (long)tm * (tm + 1) / 2;
+    } else {
+        tiles = (long)tm * tn;
+    }
+    dim3 grid((unsigned)tiles), block(256);
+    switch (epi) {
+        case EPI_ACCUM: hipLaunchKernelGGL(k_gemm_nt_128<EPI_ACCUM>, grid, block, 0, s, g); break;
+        case EPI_TRSM:  hipLaunchKernelGGL(k_gemm_nt_128<EPI_TRSM>, grid, block, 0, s, g); break;
+        case EPI_SYRKQ: hipLaunchKernelGGL(k_gemm_nt_128<EPI_SYRKQ>, grid, block, 0, s, g); break;
+        default: cip_set_error("gemm: bad epilogue"); return -1;
+    }
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,278 @@
+// Dense symmetric LDL' (no pivoting) factor + solve for gfx950.
+//
+// Fills the role the reference gives to "dense factor + solve of the Newton system
+// behind the kktsolver callback" (src/kktsolvers.jl:35 `qr(...)`, :257/:295 `lu(Z)`;
+// solves at :39-48, :259, :299).  The matrix is the quasi-definite KKT matrix
+//   [S G'; G 0]  (Schur route)   or   [-F'F -A 0; -A' Q G'; 0 G 0]  (full 3x3 route),
+// whose LDL' exists for the static pivot order (S > 0, G full row rank).
+//
+// Blocked right-looking algorithm, two levels:
+//   outer block NBO (default 256) = NBO/128 inner panels of 128 columns
+//   per inner panel:  [strip update]  ->  diag 128x128 LDL' + inverse (1 workgroup, LDS)
+//                     ->  TRSM as MFMA GEMM with the explicit inverse (W = A21 inv(L11)', L = W D^-1)
+//   per outer block:  trailing update  C -= W L'  (lower tiles, K = NBO, MFMA GEMM)
+// >99% of the N^3/3 flops are in the trailing-update GEMM (gemm_f64.hip).
+//
+// Solves (HBM-bound, L read once per sweep): blocked substitution using the stored
+// inverses of the diagonal blocks, one launch per 128-column block and sweep.
+#include "cip_internal.h"
+
+static int g_nbo = 256;
+int cip_ldlt_outer_block(void) { return g_nbo; }
+void cip_ldlt_set_outer_block(int nbo) {
+    if (nbo >= CIP_NB && nbo % CIP_NB == 0 && nbo <= 1024) g_nbo = nbo;
+}
+#define CIP_NBO_MAX 1024
+
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t cip_ldlt_ws_bytes(int Npad) {
+    const size_t nblk = Npad / CIP_NB;
+    size_t b = 0;
+    b += al256((size_t)Npad * CIP_NBO_MAX * 8);          // Wbuf
+    b += al256(nblk * CIP_NB * CIP_NB * 8) * 2;          // Linv, LinvT
+    b += al256((size_t)Npad * 8) * 3;                    // dinv, dvec, tmp
+    b += 256;                                            // info
+    return b;
+}
+
+void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
+    const size_t nblk = Npad / CIP_NB;
+    char *p = (char *)base;
+    ws->Wbuf = (double *)p;  p += al256((size_t)Npad * CIP_NBO_MAX * 8);
+    ws->Linv = (double *)p;  p += al256(nblk * CIP_NB * CIP_NB * 8);
+    ws->LinvT = (double *)p; p += al256(nblk * CIP_NB * CIP_NB * 8);
+    ws->dinv = (double *)p;  p += al256((size_t)Npad * 8);
+    ws->dvec = (double *)p;  p += al256((size_t)Npad * 8);
+    ws->tmp = (double *)p;   p += al256((size_t)Npad * 8);
+    ws->info = (int *)p;
+}
+
+// ---------------------------------------------------------------------------
+// Diagonal block: in-LDS LDL' of a 128x128 block + explicit inverse of its unit
+// lower factor.  One workgroup of 256 threads.
+//   in : K block (lower triangle), ld
+//   out: K block strictly-lower <- L, diagonal <- d ; dvec/dinv ; Linv, LinvT (128x128)
+#define DLDA 129
+__global__ __launch_bounds__(256) void k_ldlt_diag128(double *Kb, long ld, double *Linv, double *LinvT,
+                                                       double *dvec, double *dinv, int *info, int col0) {
+    extern __shared__ double a[];   // a[i + j*DLDA]
+    const int tid = threadIdx.x;
+    for (int e = tid; e < CIP_NB * CIP_NB; e += 256) {
+        const int i = e & 127, j = e >> 7;
+        a[i + j * DLDA] = (i >= j) ? Kb[i + (long)j * ld] : 0.0;
+    }
+    __syncthreads();
+
+    const int i = tid & 127, ty = tid >> 7;
+    for (int k = 0; k < CIP_NB; ++k) {
+        const double d = a[k + k * DLDA];
+        if (tid == 0 && !(fabs(d) > 0.0 && fabs(d) < 1.7e308)) atomicCAS(info, 0, col0 + k + 1);
+        const double di = 1.0 / d;
+        if (i > k) {
+            const double wi = a[i + k * DLDA];
+            for (int j = k + 1 + ty; j <= i; j += 2) a[i + j * DLDA] -= wi * (a[j + k * DLDA] * di);
+        }
+        __syncthreads();
+        // column k is final now and never read unscaled again: scale it (no extra barrier needed,
+        // later steps only touch columns > k).
+        if (ty == 0 && i > k) a[i + k * DLDA] *= di;
+    }
+    __syncthreads();
+
+    // write back L (strictly lower), d on the diagonal
+    for (int e = tid; e < CIP_NB * CIP_NB; e += 256) {
+        const int r = e & 127, c = e >> 7;
+        if (r >= c) Kb[r + (long)c * ld] = a[r + c * DLDA];
+    }
+    if (tid < CIP_NB) {
+        const double d = a[tid + tid * DLDA];
+        dvec[tid] = d;
+        dinv[tid] = 1.0 / d;
+    }
+    __syncthreads();
+
+    // X = inv(L) (unit lower).  X[r][c] (r > c) is kept at a[c + r*DLDA] (the unused upper
+    // triangle).  Column c is owned by lanes (2c, 2c+1) of one wave, which split the inner
+    // sum over k by parity and combine with one shuffle: no barrier in the whole phase.
+    {
+        const int c = tid >> 1, h = tid & 1;
+        for (int r = 1; r < CIP_NB; ++r) {
+            double s = 0.0;
+            if (r > c) {
+                for (int k = c + 1 + h; k < r; k += 2) s += a[r + k * DLDA] * a[c + k * DLDA];
+            }
+            s += __shfl_xor(s, 1);
+            if (r > c && h == 0) a[c + r * DLDA] = -(s + a[r + c * DLDA]);
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < CIP_NB * CIP_NB; e += 256) {
+        const int r = e & 127, c = e >> 7;
+        const double x = (r > c) ? a[c + r * DLDA] : (r == c ? 1.0 : 0.0);
+        Linv[r + c * CIP_NB] = x;
+        const double xt = (c > r) ? a[r + c * DLDA] : (r == c ? 1.0 : 0.0);   // LinvT[r][c] = X[c][r]
+        LinvT[r + c * CIP_NB] = xt;
+    }
+}
+
+static bool g_diag_attr_set = false;
+static int launch_diag(hipStream_t s, double *Kb, long ld, double *Linv, double *LinvT, double *dvec,
+                       double *dinv, int *info, int col0) {
+    const size_t shm = (size_t)CIP_NB * DLDA * sizeof(double);
+    if (!g_diag_attr_set) {
+        CIP_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_diag128,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        g_diag_attr_set = true;
+    }
+    hipLaunchKernelGGL(k_ldlt_diag128, dim3(1), dim3(256), shm, s, Kb, ld, Linv, LinvT, dvec, dinv, info, col0);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws) {
+    if (Npad % CIP_NB) { cip_set_error("ldlt: N must be a multiple of 128"); return -1; }
+    const int NBO = g_nbo;
+    CIP_HIP_CHECK(hipMemsetAsync(ws.info, 0, sizeof(int), s));
+    int rc;
+    for (int C0 = 0; C0 < Npad; C0 += NBO) {
+        const int wblk = (Npad - C0 < NBO) ? (Npad - C0) : NBO;     // width of this outer block
+        const int T = wblk / CIP_NB;
+        for (int t = 0; t < T; ++t) {
+            const int c0 = C0 + t * CIP_NB;
+            const int jb = c0 / CIP_NB;
+            if (t > 0) {
+                // left-looking strip update inside the outer block:
+                //   K[c0:, c0:c0+128] -= W[c0:, 0:128t] * L[c0:c0+128, C0:C0+128t]'
+                GemmArgs g = {};
+                g.A = ws.Wbuf + c0; g.lda = Npad;
+                g.B = K + c0 + (long)C0 * ld; g.ldb = ld;
+                g.C = K + c0 + (long)c0 * ld; g.ldc = ld;
+                g.M = Npad - c0; g.N = CIP_NB; g.K = t * CIP_NB; g.alpha = -1.0; g.lower = 0;
+                if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
+            }
+            if ((rc = launch_diag(s, K + c0 + (long)c0 * ld, ld, ws.Linv + (size_t)jb * CIP_NB * CIP_NB,
+                                  ws.LinvT + (size_t)jb * CIP_NB * CIP_NB, ws.dvec + c0, ws.dinv + c0,
+                                  ws.info, c0)))
+                return rc;
+            const int r = Npad - c0 - CIP_NB;
+            if (r > 0) {
+                // W21 = A21 * inv(L11)'  ;  L21 = W21 * D^-1 (in place)
+                GemmArgs g = {};
+                g.A = K + (c0 + CIP_NB) + (long)c0 * ld; g.lda = ld;
+                g.B = ws.Linv + (size_t)jb * CIP_NB * CIP_NB; g.ldb = CIP_NB;
+                g.C = K + (c0 + CIP_NB) + (long)c0 * ld; g.ldc = ld;
+                g.W = ws.Wbuf + (c0 + CIP_NB) + (long)(t * CIP_NB) * Npad; g.ldw = Npad;
+                g.dinv = ws.dinv + c0;
+                g.M = r; g.N = CIP_NB; g.K = CIP_NB; g.alpha = 1.0; g.lower = 0;
+                if ((rc = cip_launch_gemm(s, EPI_TRSM, g))) return rc;
+            }
+        }
+        const int r0 = C0 + wblk;
+        if (r0 < Npad) {
+            // trailing update  K[r0:, r0:] -= W[r0:, 0:wblk] * L[r0:, C0:C0+wblk]'   (lower tiles)
+            GemmArgs g = {};
+            g.A = ws.Wbuf + r0; g.lda = Npad;
+            g.B = K + r0 + (long)C0 * ld; g.ldb = ld;
+            g.C = K + r0 + (long)r0 * ld; g.ldc = ld;
+            g.M = Npad - r0; g.N = Npad - r0; g.K = wblk; g.alpha = -1.0; g.lower = 1;
+            if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Solves.  y = M v for a 128x128 column-major M (ld ldm), v in LDS; 256 threads
+// (two per row, k split in halves); result returned to the threads with tid < 128.
+__device__ __forceinline__ double gemv128(const double *M, long ldm, const double *v_lds, double *red_lds, int tid) {
+    const int i = tid & 127, h = tid >> 7;
+    const double *Mp = M + i + (long)(h * 64) * ldm;
+    const double *vp = v_lds + h * 64;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < 64; k += 4) {
+        s0 += Mp[(long)(k + 0) * ldm] * vp[k + 0];
+        s1 += Mp[(long)(k + 1) * ldm] * vp[k + 1];
+        s2 += Mp[(long)(k + 2) * ldm] * vp[k + 2];
+        s3 += Mp[(long)(k + 3) * ldm] * vp[k + 3];
+    }
+    double s = (s0 + s1) + (s2 + s3);
+    if (h == 1) red_lds[i] = s;
+    __syncthreads();
+    if (h == 0) s += red_lds[i];
+    return s;
+}
+
+// forward step for block column j:  y_j = inv(L_jj) b_j ;  b[R] -= L[R, j] y_j  (R = block row j+g, g >= 1)
+// workgroup 0 writes the D^-1-scaled y_j to yout; every workgroup recomputes y_j (128x128 gemv, L2-resident).
+__global__ __launch_bounds__(256) void k_solve_fwd(const double *K, long ld, const double *Linv, const double *dinv,
+                                                    double *b, double *yout, int j) {
+    __shared__ double v[CIP_NB], y[CIP_NB], red[CIP_NB];
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x;
+    if (tid < CIP_NB) v[tid] = b[j * CIP_NB + tid];
+    __syncthreads();
+    const double yj = gemv128(Linv + (size_t)j * CIP_NB * CIP_NB, CIP_NB, v, red, tid);
+    if (tid < CIP_NB) {
+        y[tid] = yj;
+        if (g == 0) yout[j * CIP_NB + tid] = yj * dinv[j * CIP_NB + tid];
+    }
+    __syncthreads();
+    if (g == 0) return;
+    const long R = (long)(j + g) * CIP_NB;
+    const double u = gemv128(K + R + (long)j * CIP_NB * ld, ld, y, red, tid);
+    if (tid < CIP_NB) b[R + tid] -= u;
+}
+
+// backward step for block j:  x_j = inv(L_jj)' z_j ;  z[c] -= L[j-rows, c-cols]' x_j  for block c < j
+// (z = D^-1 y, updated in place; x written to xout).
+__global__ __launch_bounds__(256) void k_solve_bwd(const double *K, long ld, const double *LinvT, double *z,
+                                                    double *xout, int j) {
+    __shared__ double v[CIP_NB], x[CIP_NB], red[CIP_NB];
+    __shared__ double T[32 * DLDA];
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x;
+    if (tid < CIP_NB) v[tid] = z[j * CIP_NB + tid];
+    __syncthreads();
+    const double xj = gemv128(LinvT + (size_t)j * CIP_NB * CIP_NB, CIP_NB, v, red, tid);
+    if (tid < CIP_NB) {
+        x[tid] = xj;
+        if (g == 0) xout[j * CIP_NB + tid] = xj;
+    }
+    __syncthreads();
+    if (g == 0) return;
+    const int c = g - 1;                       // column block c < j
+    const double *Lp = K + (long)j * CIP_NB + (long)c * CIP_NB * ld;
+    for (int q = 0; q < 4; ++q) {
+        for (int it = 0; it < 16; ++it) {
+            const int e = it * 256 + tid;
+            const int i = e & 127, cc = e >> 7;
+            T[cc * DLDA + i] = Lp[i + (long)(q * 32 + cc) * ld];
+        }
+        __syncthreads();
+        const int cc = tid >> 3, part = tid & 7;
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += T[cc * DLDA + part * 16 + i] * x[part * 16 + i];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (part == 0) z[c * CIP_NB + q * 32 + cc] -= s;
+        __syncthreads();
+    }
+}
+
+int cip_ldlt_solve(hipStream_t s, const double *K, int Npad, long ld, const LdltWorkspace &ws, double *rhs) {
+    const int nblk = Npad / CIP_NB;
+    // forward: L y = b ; z = D^-1 y -> ws.tmp
+    for (int j = 0; j < nblk; ++j) {
+        hipLaunchKernelGGL(k_solve_fwd, dim3(nblk - j), dim3(256), 0, s, K, ld, ws.Linv, ws.dinv, rhs, ws.tmp, j);
+    }
+    // backward: L' x = z -> rhs
+    for (int j = nblk - 1; j >= 0; --j) {
+        hipLaunchKernelGGL(k_solve_bwd, dim3(j + 1), dim3(256), 0, s, K, ld, ws.LinvT, ws.tmp, rhs, j);
+    }
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,162 @@
+/*
+ * libcipkkt -- MI355X (gfx950) native KKT-solve path for ConicIP-style
+ * interior-point solvers.  C ABI: plain pointers and sizes only.
+ *
+ * This is the drop-in boundary for the reference's `kktsolver` plugin hook
+ * (reference = MPF-Optimization-Laboratory/ConicIP.jl, paths relative to its
+ * root):
+ *
+ *   level 1  kktsolver(Q, A, G, cone_dims)        src/ConicIP.jl:667
+ *   level 2  solve3x3gen(F, F^-T)                 src/ConicIP.jl:682
+ *   level 3  solve3x3(x, y, z) -> (a, b, c)       src/ConicIP.jl:688
+ *
+ * which the reference documents at src/ConicIP.jl:432-466 and
+ * docs/src/guides/kkt_solvers.md:84-115, and implements three times in
+ * src/kktsolvers.jl (kktsolver_qr :18-58, kktsolver_sparse :180-270,
+ * pivot(kktsolver_2x2) :281-349).  The Julia-side `ccall` shim that binds these
+ * entry points is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - all matrices column-major (Julia / LAPACK), fp64, 0-based C indices
+ *   - the m-vector (v, s, lambda, z) is the concatenation of cone blocks in
+ *     cone_dims order (src/ConicIP.jl:519-522); a Q block stores the bound t
+ *     first; an S block stores `vecm` order (src/ConicIP.jl:128-151)
+ *   - every entry point returns 0 on success, a negative CIP_E_* otherwise;
+ *     cip_last_error() gives a message.  Nothing falls back to the CPU: when no
+ *     HIP device is usable cip_create fails with CIP_E_NODEVICE.
+ *   - `*_dev` entry points take DEVICE pointers and enqueue on the handle's
+ *     stream without synchronising (except where a host scalar is returned);
+ *     the un-suffixed ones take HOST pointers and are synchronous.
+ */
+#ifndef CIPKKT_H
+#define CIPKKT_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cip_handle cip_handle;
+
+/* cone types: "R", "Q", "S" of cone_dims (src/ConicIP.jl:421-430) */
+#define CIP_CONE_R 0
+#define CIP_CONE_Q 1
+#define CIP_CONE_S 2
+
+/* elimination route */
+#define CIP_ROUTE_SCHUR   0  /* pivot on the F'F block first (algebra of src/kktsolvers.jl:316-338), dense LDL' of [S G';G 0] */
+#define CIP_ROUTE_FULL3X3 1  /* literal 3x3 assembly (src/kktsolvers.jl:254-256), symmetrised, dense LDL' of order n+p+m */
+
+/* block-operator modes for cip_apply_F_dev (src/blockmatrices.jl:173-200) */
+#define CIP_OP_F      0
+#define CIP_OP_FT     1
+#define CIP_OP_FINV   2
+#define CIP_OP_FINVT  3
+
+/* which problem matrix (cip_gemv_dev) */
+#define CIP_MAT_Q 0
+#define CIP_MAT_A 1
+#define CIP_MAT_G 2
+
+/* flags for cip_create_ex */
+#define CIP_FLAG_DEVICE_PTRS 1   /* Q/A/G arrays are device pointers */
+
+#define CIP_OK            0
+#define CIP_E_INVALID    -1
+#define CIP_E_NODEVICE   -2
+#define CIP_E_HIP        -3
+#define CIP_E_NOTFACTORED -4
+#define CIP_E_SINGULAR   -5   /* zero / non-finite pivot met in the LDL' */
+#define CIP_E_UNSUPPORTED -6
+
+/* Problem description for cip_create_ex.  A may be given dense (A != NULL) or
+ * in CSR (A == NULL, A_rowptr/A_colind/A_val != NULL, 0-based). */
+typedef struct cip_problem {
+    int n, m, p;
+    int ncones;
+    const int *cone_type;      /* ncones entries, CIP_CONE_* */
+    const int *cone_dim;       /* ncones entries; for S: vectorised length k = r(r+1)/2 */
+    const double *Q;  int ldq; /* n x n */
+    const double *A;  int lda; /* m x n dense, or NULL */
+    const int *A_rowptr; const int *A_colind; const double *A_val; /* CSR, m+1 / nnz / nnz */
+    const double *G;  int ldg; /* p x n (may be NULL when p == 0) */
+    int route;                 /* CIP_ROUTE_* */
+    int flags;                 /* CIP_FLAG_* */
+} cip_problem;
+
+/* ---- level 1: kktsolver(Q, A, G, cone_dims)  (src/ConicIP.jl:667; src/kktsolvers.jl:18-28, :180-190, :281-285) */
+int cip_create(int n, int m, int p, int ncones, const int *cone_type, const int *cone_dim,
+               const double *Q, const double *A, const double *G, int route, cip_handle **out);
+int cip_create_ex(const cip_problem *prob, cip_handle **out);
+int cip_destroy(cip_handle *h);
+const char *cip_last_error(void);
+int cip_set_stream(cip_handle *h, void *hip_stream);
+
+/* ---- level 2: solve3x3gen(F, F^-T)  (src/ConicIP.jl:682; src/kktsolvers.jl:30-35, :250-257, :287-295)
+ * The scaling F is handed over in packed form, read off the reference's Block
+ * elements (src/ConicIP.jl:189-192, :208, :598):
+ *   R cone (k)   : k doubles        diag(F)
+ *   Q cone (k)   : 1 + k doubles    beta, w      (F = diag(-beta, beta, ...) + w w')
+ *   S cone (k)   : 2 r^2 doubles    R (r x r col-major), then inv(R) (r x r col-major)
+ * cip_scaling_packed_len() returns the total length. */
+size_t cip_scaling_packed_len(const cip_handle *h);
+int cip_set_scaling_packed(cip_handle *h, const double *packedF);       /* host pointer */
+int cip_set_scaling_identity(cip_handle *h);                            /* F = I (src/ConicIP.jl:704) */
+/* nt_scaling on the device (src/ConicIP.jl:589-605, :165-210): F from (v, s); also
+ * writes lambda = F v (src/ConicIP.jl:735) when lambda_out != NULL. */
+int cip_set_scaling_from_iterate_dev(cip_handle *h, const double *v, const double *s, double *lambda_out);
+int cip_get_scaling_packed(cip_handle *h, double *packedF);             /* host pointer (tests) */
+/* assemble + factor the KKT system for the current scaling (asynchronous on the handle's stream) */
+int cip_factor(cip_handle *h);
+/* synchronise and report the factorisation status: CIP_OK or CIP_E_SINGULAR */
+int cip_check_factor(cip_handle *h);
+
+/* ---- level 3: solve3x3(x, y, z) -> (a, b, c)  (src/ConicIP.jl:688; src/kktsolvers.jl:37-50, :324-330)
+ *   Q a + G' b - A' c = x ;  G a = y ;  A a + F'F c = z */
+int cip_solve3x3(cip_handle *h, const double *x, const double *y, const double *z,
+                 double *a, double *b, double *c);                       /* host pointers */
+int cip_solve3x3_dev(cip_handle *h, const double *x, const double *y, const double *z,
+                     double *a, double *b, double *c);                   /* device pointers */
+
+/* ---- the 4x4 -> 3x3 reduction of solve4x4 (src/ConicIP.jl:684-692), device pointers.
+ * r and dz are 4-block vectors (y[n], w[p], v[m], s[m]) stored contiguously. */
+int cip_solve4x4_dev(cip_handle *h, const double *lambda, const double *r, double *dz);
+
+/* ---- block operator / cone algebra on the device (device pointers, length m) */
+int cip_apply_F_dev(cip_handle *h, int mode, const double *x, double *out);              /* src/blockmatrices.jl:173-200 */
+int cip_cone_prod_dev(cip_handle *h, const double *x, const double *y, double *out);     /* src/ConicIP.jl:637-665 */
+int cip_cone_div_dev(cip_handle *h, const double *x, const double *y, double *out);      /* src/ConicIP.jl:607-635: solve y o out = x */
+int cip_maxstep_dev(cip_handle *h, const double *x, const double *d, double scale, double *alpha_host); /* src/ConicIP.jl:571-587; d == NULL -> the `nothing` variant; steps along d*scale */
+int cip_cone_identity_dev(cip_handle *h, double *e);                                     /* src/ConicIP.jl:559-565 */
+
+/* ---- vector helpers for a device-resident driver loop (device pointers) */
+int cip_gemv_dev(cip_handle *h, int which, int trans, double alpha, const double *x, double beta, double *y);
+/* out_host[i] = dot(x_i[0:len_i], y_i[0:len_i]); pointer arrays live on the host */
+int cip_dots_dev(cip_handle *h, int count, const double *const *x, const double *const *y,
+                 const int *len, double *out_host);
+int cip_axpby_dev(cip_handle *h, int len, double alpha, const double *x, double beta, double *y); /* y = alpha x + beta y */
+
+/* ---- dense symmetric LDL' building blocks (device pointers), usable on their own.
+ * K is N x N column-major with leading dimension ld; only the lower triangle is
+ * referenced.  N and ld must be multiples of 128 (pad with an identity block). */
+int cip_ldlt_workspace_bytes(int N, size_t *bytes);
+int cip_ldlt_factor_dev(void *hip_stream, double *K, int N, int ld, void *workspace, int *info_host);
+int cip_ldlt_solve_dev(void *hip_stream, const double *K, int N, int ld, const void *workspace, double *rhs);
+/* C(lower or full) += alpha * A * B'   (A: M x K, B: N x K, all column-major; M,N % 128 == 0, K % 16 == 0) */
+int cip_gemm_nt_dev(void *hip_stream, int M, int N, int K, double alpha,
+                    const double *A, int lda, const double *B, int ldb, double *C, int ldc, int lower_only);
+
+/* ---- introspection (tests, bench) */
+int cip_kkt_order(const cip_handle *h, int *N, int *N_padded);
+int cip_get_kkt_matrix(cip_handle *h, double *K_host /* N_padded^2 */); /* assembled (before cip_factor) or factored */
+int cip_assemble_only(cip_handle *h);                                   /* level-2 assembly without the factorisation */
+/* stats: [0] factor calls, [1] solve calls, [2] last factor ms (assemble), [3] last factor ms (ldlt), [4] flops of last ldlt */
+int cip_stats(cip_handle *h, double *out8);
+int cip_set_timing(cip_handle *h, int enabled);
+int cip_set_ldlt_outer_block(int nbo);   /* tuning knob: outer block of the blocked LDL' (multiple of 128); returns the value in use */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIPKKT_H */

@@ -1,0 +1,112 @@
+"""GPU parity of the whole Newton-step path inside the interior-point loop: the
+product driver (HIP KKT path) against the oracle's restatement of conicIP on the
+reference's own known-answer problems (test/runtests.jl) -- same status, same
+iteration count, iterates equal to 1e-6 relative (the tolerance the north-star asks
+to be stated), and the analytic answers the reference asserts."""
+import numpy as np
+import pytest
+
+import problems as P
+from oracle.conicip import conicIP as oracle_conicIP
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+OPT = 1e-7
+ROUTES = ["schur", "full3x3"]
+
+
+def run_both(prob, route, **kw):
+    import cipkkt
+    Q, c, A, b, K, G, d, expect = prob
+    ref = oracle_conicIP(Q, c, A, b, K, G, d, **kw)
+    got = cipkkt.conicIP(Q, c, A, b, K, G, d, kktsolver=route, **kw)
+    return got, ref, expect
+
+
+def assert_same_trajectory(got, ref, rtol=1e-6):
+    assert got.status == ref.status
+    assert got.Iter == ref.Iter, "iterations differ: hip %d vs oracle %d" % (got.Iter, ref.Iter)
+    assert got.n_factor == ref.n_factor
+    for tg, tr in zip(got.trace, ref.trace):
+        assert tg["mu"] == pytest.approx(tr["mu"], rel=1e-5, abs=1e-14)
+    if ref.status == "Optimal":
+        scale = 1 + np.linalg.norm(ref.y)
+        assert np.linalg.norm(got.y - ref.y) / scale < rtol
+        assert np.linalg.norm(got.v - ref.v) / (1 + np.linalg.norm(ref.v)) < rtol
+        if len(ref.w):
+            assert np.linalg.norm(got.w - ref.w) / (1 + np.linalg.norm(ref.w)) < rtol
+        assert got.pobj == pytest.approx(ref.pobj, rel=1e-7, abs=1e-9)
+
+
+@pytest.mark.parametrize("route", ROUTES)
+@pytest.mark.parametrize("name", ["sphere", "combined", "simplex", "soc_direct", "lp_doc"])
+def test_reference_kats(name, route):
+    got, ref, expect = run_both(getattr(P, name)(), route, optTol=OPT, DTB=0.01, maxRefinementSteps=3)
+    assert got.status == "Optimal"
+    assert np.linalg.norm(got.y - expect) < TOL           # the reference's own assertion
+    assert_same_trajectory(got, ref)
+
+
+@pytest.mark.parametrize("route", ROUTES)
+def test_statuses(route):
+    import cipkkt
+    Q, c, A, b, K, G, d, _ = P.simplex()
+    assert cipkkt.conicIP(Q, c, A, b, K, G, d, optTol=OPT, maxIters=2, kktsolver=route).status == "Abandoned"
+    for prob in (P.infeasible_box(), P.infeasible_eq()):
+        Q, c, A, b, K, G, d, _ = prob
+        assert cipkkt.conicIP(Q, c, A, b, K, G, d, optTol=OPT, kktsolver=route).status == "Infeasible"
+
+
+def test_unbounded_status():
+    """test/runtests.jl:487-505 (Q = 0: Schur matrix is A'F^-2A = F^-2 > 0)."""
+    import cipkkt
+    Q, c, A, b, K, G, d, _ = P.unbounded()
+    sol = cipkkt.conicIP(Q, c, A, b, K, G, d, optTol=OPT)
+    assert sol.status == "Unbounded"
+
+
+@pytest.mark.parametrize("route", ROUTES)
+@pytest.mark.parametrize("dense_A", [True, False])
+def test_random_mixed(route, dense_A):
+    got, ref, _ = run_both(P.random_mixed(n=60, nq=4, kq=7, p=5, dense_A=dense_A), route, optTol=1e-8)
+    assert got.status == "Optimal"
+    assert_same_trajectory(got, ref)
+
+
+def test_box_qp_n1000():
+    """README / runtests.jl:90-131 box QP at n=1000 (m=2000, sparse A): optimality condition."""
+    import cipkkt
+    Q, c, A, b, K, G, d, _ = P.box_qp(1000)
+    sol = cipkkt.conicIP(Q, c, A, b, K, optTol=OPT, DTB=0.01, maxRefinementSteps=3)
+    assert sol.status == "Optimal"
+    cvec = np.arange(1.0, 1001)
+    grad = 0.5 * (sol.y - cvec)
+    assert np.linalg.norm(sol.y - np.clip(sol.y - grad, -1, 1)) / 1000 < TOL
+    ref = oracle_conicIP(Q, c, A, b, K, optTol=OPT, DTB=0.01, maxRefinementSteps=3,
+                         kktsolver=__import__("oracle.kktsolvers", fromlist=["x"]).pivot(
+                             __import__("oracle.kktsolvers", fromlist=["x"]).kktsolver_2x2))
+    assert_same_trajectory(sol, ref)
+
+
+def test_dense_qp_2048_properties():
+    """BASELINE config family (dense QP, A = I, R cone) at n = 2048: size-independent
+    properties -- KKT optimality conditions of the returned point and agreement of the two
+    elimination routes."""
+    import cipkkt
+    rng = np.random.default_rng(7)
+    n = 2048
+    M = rng.standard_normal((n, n))
+    Q = M.T @ M / n
+    c = rng.standard_normal(n)
+    import scipy.sparse as sp
+    A = sp.identity(n, format="csr")
+    b = np.zeros(n)
+    s1 = cipkkt.conicIP(Q, c, A, b, [("R", n)], optTol=1e-6)
+    assert s1.status == "Optimal"
+    y, v = s1.y, s1.v
+    assert np.linalg.norm(Q @ y - c - v) / (1 + np.linalg.norm(c)) < 1e-6      # stationarity
+    assert y.min() > -1e-6 and v.min() > -1e-9                                # primal / dual feasibility
+    assert abs(y @ v) / n < 1e-5                                              # complementarity
+    s2 = cipkkt.conicIP(Q, c, A, b, [("R", n)], optTol=1e-6, kktsolver="full3x3")
+    assert s2.status == "Optimal" and s2.Iter == s1.Iter
+    assert np.linalg.norm(s1.y - s2.y) / (1 + np.linalg.norm(s1.y)) < 1e-6

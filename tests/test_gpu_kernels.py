@@ -1,0 +1,379 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP kernel family of the
+KKT path against the oracle / numpy on the same seeded inputs, through the C ABI.
+Tolerances are stated per test (fp64; the path is not bit-reproducible against
+LAPACK because the elimination order differs, so parity is to rounding-level
+backward error, as the reference's own tests compare solvers, runtests.jl:133-135)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import problems as P
+from oracle import cones as ocones
+from oracle.block import Block, Diagonal, SymWoodbury
+from oracle.conicip import make_cone_ops
+from oracle.kktsolvers import assemble3x3, kktsolver_2x2, kktsolver_qr, kktsolver_sparse, pivot, schur2x2
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float64, device="cuda")
+
+
+def colmajor_dev(M):
+    """device buffer holding M column-major"""
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(M).T), dtype=torch.float64, device="cuda")
+
+
+def from_colmajor(t, rows, cols):
+    return t.cpu().numpy().reshape(cols, rows).T
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import cipkkt
+    return cipkkt._lib.load()
+
+
+# ----------------------------------------------------------------- MFMA GEMM
+@pytest.mark.parametrize("M,N,K,lower", [(128, 128, 16, 0), (256, 128, 32, 0), (384, 384, 256, 1),
+                                         (512, 256, 128, 0), (1024, 1024, 256, 1)])
+def test_gemm_nt(lib, M, N, K, lower):
+    from cipkkt import _lib as L
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((N, K))
+    Cm = rng.standard_normal((M, N))
+    dA, dB, dC = colmajor_dev(A), colmajor_dev(B), colmajor_dev(Cm)
+    L.check(lib.cip_gemm_nt_dev(None, M, N, K, -1.0, dA.data_ptr(), M, dB.data_ptr(), N, dC.data_ptr(), M, lower))
+    torch.cuda.synchronize()
+    got = from_colmajor(dC, M, N)
+    ref = Cm - A @ B.T
+    if lower:
+        # tiles with bi >= bj are updated (diagonal tiles fully), others untouched
+        for bi in range(M // 128):
+            for bj in range(N // 128):
+                blk = (slice(bi * 128, bi * 128 + 128), slice(bj * 128, bj * 128 + 128))
+                want = ref[blk] if bi >= bj else Cm[blk]
+                np.testing.assert_allclose(got[blk], want, rtol=0, atol=1e-11 * K)
+    else:
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11 * K)
+
+
+def test_gemm_mfma_layout_asymmetric(lib):
+    """A = I-like pattern against an asymmetric B catches a transposed C write."""
+    from cipkkt import _lib as L
+    M = N = 128
+    K = 128
+    A = np.eye(M, K)
+    B = np.arange(N * K, dtype=np.float64).reshape(N, K) / 7.0
+    dA, dB = colmajor_dev(A), colmajor_dev(B)
+    dC = torch.zeros(M * N, dtype=torch.float64, device="cuda")
+    L.check(lib.cip_gemm_nt_dev(None, M, N, K, 1.0, dA.data_ptr(), M, dB.data_ptr(), N, dC.data_ptr(), M, 0))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(from_colmajor(dC, M, N), A @ B.T)
+
+
+# ----------------------------------------------------------------- LDL'
+def _ldlt_roundtrip(lib, Kmat, nbo):
+    from cipkkt import _lib as L
+    N = Kmat.shape[0]
+    lib.cip_set_ldlt_outer_block(nbo)
+    nbytes = C.c_size_t()
+    L.check(lib.cip_ldlt_workspace_bytes(N, C.byref(nbytes)))
+    ws = torch.zeros(nbytes.value // 8 + 8, dtype=torch.float64, device="cuda")
+    dK = colmajor_dev(Kmat)
+    info = C.c_int(-1)
+    L.check(lib.cip_ldlt_factor_dev(None, dK.data_ptr(), N, N, ws.data_ptr(), C.byref(info)))
+    assert info.value == 0
+    F = from_colmajor(dK, N, N)
+    Lf = np.tril(F, -1) + np.eye(N)
+    D = np.diag(F).copy()
+    rec = (Lf * D[None, :]) @ Lf.T
+    err = np.abs(np.tril(rec - Kmat)).max() / np.abs(Kmat).max()
+    rng = np.random.default_rng(5)
+    x_true = rng.standard_normal(N)
+    rhs = Kmat @ x_true
+    drhs = dev(rhs)
+    L.check(lib.cip_ldlt_solve_dev(None, dK.data_ptr(), N, N, ws.data_ptr(), drhs.data_ptr()))
+    torch.cuda.synchronize()
+    x = drhs.cpu().numpy()
+    res = np.linalg.norm(Kmat @ x - rhs) / (np.linalg.norm(Kmat, 2) * np.linalg.norm(x))
+    lib.cip_set_ldlt_outer_block(256)
+    return err, res, D
+
+
+@pytest.mark.parametrize("N,nbo", [(128, 128), (256, 256), (384, 256), (512, 128), (640, 256), (1024, 512)])
+def test_ldlt_spd(lib, N, nbo):
+    rng = np.random.default_rng(N)
+    M = rng.standard_normal((N, N))
+    Kmat = M @ M.T / N + np.eye(N)
+    err, res, D = _ldlt_roundtrip(lib, Kmat, nbo)
+    assert err < 1e-13, "||L D L' - K|| / ||K|| = %g" % err
+    assert res < 1e-14, "normwise backward error of the solve = %g" % res
+    assert np.all(D > 0)
+
+
+def test_ldlt_quasidefinite(lib):
+    """[S G'; G 0] with S > 0: n positive then p negative pivots, no pivoting needed."""
+    rng = np.random.default_rng(11)
+    n, p = 300, 84
+    M = rng.standard_normal((n, n))
+    S = M @ M.T / n + np.eye(n)
+    G = rng.standard_normal((p, n))
+    Kmat = np.zeros((384, 384))
+    Kmat[:n, :n] = S
+    Kmat[n:, :n] = G
+    Kmat[:n, n:] = G.T
+    err, res, D = _ldlt_roundtrip(lib, Kmat, 256)
+    assert err < 1e-12 and res < 1e-13
+    assert np.all(D[:n] > 0) and np.all(D[n:] < 0)
+
+
+def test_ldlt_reports_zero_pivot(lib):
+    from cipkkt import _lib as L
+    N = 128
+    Kmat = np.eye(N)
+    Kmat[5, 5] = 0.0
+    nbytes = C.c_size_t()
+    L.check(lib.cip_ldlt_workspace_bytes(N, C.byref(nbytes)))
+    ws = torch.zeros(nbytes.value // 8 + 8, dtype=torch.float64, device="cuda")
+    dK = colmajor_dev(Kmat)
+    info = C.c_int(0)
+    L.check(lib.cip_ldlt_factor_dev(None, dK.data_ptr(), N, N, ws.data_ptr(), C.byref(info)))
+    assert info.value == 6
+
+
+# ----------------------------------------------------------------- cone kernels vs oracle
+CONESETS = [
+    [("R", 5)],
+    [("Q", 3)],
+    [("Q", 8)] * 5,
+    [("R", 7), ("Q", 4), ("R", 3), ("Q", 9)],
+    [("R", 5000), ("Q", 700)],
+]
+
+
+def interior_point(cone_dims, rng):
+    xs = []
+    for t, k in cone_dims:
+        if t == "R":
+            xs.append(rng.random(k) + 0.1)
+        else:
+            x = rng.standard_normal(k)
+            x[0] = np.linalg.norm(x[1:]) + rng.random() + 0.1
+            xs.append(x)
+    return np.concatenate(xs)
+
+
+def make_system(cone_dims, n=6, p=0, seed=0, sparse=False, route="schur"):
+    import cipkkt
+    rng = np.random.default_rng(seed)
+    m = sum(k for _, k in cone_dims)
+    M = rng.standard_normal((n, n))
+    Q = M @ M.T / n + 0.5 * np.eye(n)
+    A = rng.standard_normal((m, n))
+    if sparse:
+        A = A * (rng.random((m, n)) < 0.3)
+        A[np.arange(m), rng.integers(0, n, m)] = 1.0
+        A = sp.csr_matrix(A)
+    G = rng.standard_normal((p, n)) if p else None
+    return cipkkt.KKTSystem(Q, A, G, cone_dims, route=route), Q, A, G
+
+
+@pytest.mark.parametrize("cone_dims", CONESETS, ids=[str(i) for i in range(len(CONESETS))])
+def test_cone_ops(cone_dims):
+    from cipkkt import OP_F, OP_FT, OP_FINV, OP_FINVT
+    rng = np.random.default_rng(len(cone_dims))
+    ks, *_ = make_system(cone_dims)
+    m = ks.m
+    maxstep, nt_scaling, cone_div, cone_prod = make_cone_ops(cone_dims)
+    v = interior_point(cone_dims, rng)
+    s = interior_point(cone_dims, rng)
+    dv, dsv = dev(v), dev(s)
+    lam = torch.zeros(m, dtype=torch.float64, device="cuda")
+    ks.set_scaling_from_iterate(dv, dsv, lam)
+    F = nt_scaling(v, s)
+    packed_ref = ks.pack_scaling(F)
+    np.testing.assert_allclose(ks.get_scaling_packed(), packed_ref, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(lam.cpu().numpy(), F.mul(v), rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(lam.cpu().numpy(), F.inv_adjoint().mul(s), rtol=1e-9, atol=1e-10)
+    x = rng.standard_normal(m)
+    dx = dev(x)
+    out = torch.zeros_like(dx)
+    for mode, ref in ((OP_F, F.mul(x)), (OP_FT, F.tmul(x)), (OP_FINV, F.inv().mul(x)),
+                      (OP_FINVT, F.inv_adjoint().mul(x))):
+        ks.apply_F(mode, dx, out)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-10, atol=1e-11)
+    # in-place apply
+    y = dx.clone()
+    ks.apply_F(OP_F, y, y)
+    np.testing.assert_allclose(y.cpu().numpy(), F.mul(x), rtol=1e-10, atol=1e-11)
+    # Jordan product / division
+    yv = interior_point(cone_dims, rng)
+    dy = dev(yv)
+    ks.cone_prod(dx, dy, out)
+    np.testing.assert_allclose(out.cpu().numpy(), cone_prod(x, yv), rtol=1e-12, atol=1e-12)
+    ks.cone_div(dx, dy, out)
+    np.testing.assert_allclose(out.cpu().numpy(), cone_div(x, yv), rtol=1e-10, atol=1e-11)
+    # max step, both variants
+    d = rng.standard_normal(m)
+    for scale in (1.0, 1.0 / 0.99):
+        got = ks.maxstep(dv, dev(d), scale)
+        ref = maxstep(v, d * scale)
+        assert got == pytest.approx(ref, rel=1e-10) or (np.isinf(ref) and np.isinf(got))
+    assert ks.maxstep(dv, None) == 0.0
+    xo = x.copy()
+    assert ks.maxstep(dev(xo), None) == pytest.approx(maxstep(xo, None), rel=1e-12)
+    # identity
+    e = torch.zeros(m, dtype=torch.float64, device="cuda")
+    ks.cone_identity(e)
+    from oracle.conicip import cone_identity
+    np.testing.assert_array_equal(e.cpu().numpy(), cone_identity(cone_dims)[0])
+    # identity scaling: F = I
+    ks.set_scaling_identity()
+    ks.apply_F(OP_FINV, dx, out)
+    np.testing.assert_allclose(out.cpu().numpy(), x, rtol=1e-15, atol=0)
+    ks.close()
+
+
+# ----------------------------------------------------------------- assembly + factor + solve3x3
+ASM_CASES = [
+    dict(cone_dims=[("R", 9)], n=9, p=0),
+    dict(cone_dims=[("R", 30), ("Q", 6), ("Q", 4)], n=17, p=3),
+    dict(cone_dims=[("Q", 8)] * 20, n=150, p=10),
+    dict(cone_dims=[("R", 100), ("Q", 40)], n=130, p=7),
+]
+
+
+def oracle_F(cone_dims, rng):
+    _, nt_scaling, _, _ = make_cone_ops(cone_dims)
+    v = interior_point(cone_dims, rng)
+    s = interior_point(cone_dims, rng)
+    return nt_scaling(v, s)
+
+
+@pytest.mark.parametrize("case", ASM_CASES, ids=[str(i) for i in range(len(ASM_CASES))])
+@pytest.mark.parametrize("sparse", [False, True], ids=["denseA", "csrA"])
+@pytest.mark.parametrize("route", ["schur", "full3x3"])
+def test_assembly_factor_solve(case, sparse, route):
+    rng = np.random.default_rng(42)
+    cone_dims, n, p = case["cone_dims"], case["n"], case["p"]
+    ks, Q, A, G = make_system(cone_dims, n=n, p=p, seed=3, sparse=sparse, route=route)
+    m = ks.m
+    F = oracle_F(cone_dims, rng)
+    ks.set_scaling_packed(ks.pack_scaling(F, F.inv_adjoint()))
+    ks.assemble_only()
+    Kd = ks.kkt_matrix()
+    Gd = np.zeros((0, n)) if G is None else G
+    if route == "schur":
+        ref = schur2x2(Q, A, Gd, F)
+        N = n + p
+        got = np.tril(Kd[:N, :N])
+        np.testing.assert_allclose(got, np.tril(ref), rtol=1e-10, atol=1e-10 * np.abs(ref).max())
+    else:
+        Z = assemble3x3(Q, A, Gd, F)             # [Q G' -A'; G 0 0; A 0 F'F]  order (y, w, v)
+        N = n + p + m
+        # device order is (v, y, w), symmetrised: [-F'F -A 0; -A' Q G'; 0 G 0]
+        perm = np.concatenate([np.arange(n + p, n + p + m), np.arange(n + p)])
+        Zs = Z.copy()
+        Zs[n + p:, :] *= -1.0                    # negate the third block row -> symmetric
+        ref = Zs[np.ix_(perm, perm)]
+        np.testing.assert_allclose(ref, ref.T, atol=1e-12)
+        np.testing.assert_allclose(np.tril(Kd[:N, :N]), np.tril(ref), rtol=1e-10, atol=1e-10 * np.abs(ref).max())
+    # padding is an identity block
+    np.testing.assert_array_equal(np.tril(Kd[N:, :]), np.tril(np.eye(Kd.shape[0])[N:, :]))
+    # factor + level-3 solve against all three reference solvers (oracle)
+    ks.factor(check=True)
+    x, y, z = rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(m)
+    a, b, c = ks.solve3x3(x, y, z)
+    Z = assemble3x3(Q, A, Gd, F)
+    sol = np.concatenate([a, b, c])
+    rhs = np.concatenate([x, y, z])
+    berr = np.linalg.norm(Z @ sol - rhs) / (np.linalg.norm(Z, 2) * np.linalg.norm(sol) + np.linalg.norm(rhs))
+    assert berr < 1e-12, "backward error %g" % berr
+    for kk in (kktsolver_qr, kktsolver_sparse, pivot(kktsolver_2x2)):
+        ra, rb, rc = kk(Q, A, Gd, cone_dims)(F, F.inv_adjoint())(x, y, z)
+        ref = np.concatenate([ra, rb, rc])
+        assert np.linalg.norm(sol - ref) / np.linalg.norm(ref) < 1e-8
+    ks.close()
+
+
+def test_plugin_closure_matches_reference_interface():
+    """kktsolver_hip(Q,A,G,cone_dims)(F,F_invT)(x,y,z) -- same call shape as the reference's solvers."""
+    import cipkkt
+    rng = np.random.default_rng(9)
+    Q, c, A, b, cone_dims, G, d, _ = P.random_mixed(n=40, nq=3, kq=6, p=4)
+    F = oracle_F(cone_dims, rng)
+    n, m, p = Q.shape[0], A.shape[0], G.shape[0]
+    x, y, z = rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(m)
+    ref = np.concatenate(kktsolver_qr(Q, A, G, cone_dims)(F, F.inv_adjoint())(x, y, z))
+    for solver in (cipkkt.kktsolver_hip, cipkkt.kktsolver_hip_full3x3):
+        gen = solver(Q, A, G, cone_dims)
+        got = np.concatenate(gen(F, F.inv_adjoint())(x, y, z))
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-9
+        # a second level-2 call with another scaling reuses level 1
+        F2 = oracle_F(cone_dims, rng)
+        got2 = np.concatenate(gen(F2, F2.inv_adjoint())(x, y, z))
+        ref2 = np.concatenate(kktsolver_qr(Q, A, G, cone_dims)(F2, F2.inv_adjoint())(x, y, z))
+        assert np.linalg.norm(got2 - ref2) / np.linalg.norm(ref2) < 1e-9
+        gen.system.close()
+
+
+def test_solve4x4_matches_oracle():
+    from oracle.conicip import V4
+    rng = np.random.default_rng(21)
+    Q, c, A, b, cone_dims, G, d, _ = P.random_mixed(n=30, nq=2, kq=5, p=3)
+    import cipkkt
+    ks = cipkkt.KKTSystem(Q, A, G, cone_dims)
+    n, m, p = ks.n, ks.m, ks.p
+    maxstep, nt_scaling, cone_div, cone_prod = make_cone_ops(cone_dims)
+    v, s = interior_point(cone_dims, rng), interior_point(cone_dims, rng)
+    F = nt_scaling(v, s)
+    lam = F.mul(v)
+    r = rng.standard_normal(n + p + 2 * m)
+    # oracle solve4x4 (src/ConicIP.jl:684-692)
+    s3 = kktsolver_qr(Q, A, G, cone_dims)(F, F.inv_adjoint())
+    q = cone_div(r[n + p + m:], lam)
+    t1 = F.tmul(q)
+    dy, dw, dv = s3(r[:n], r[n:n + p], r[n + p:n + p + m] + t1)
+    ds = t1 - F.tmul(F.mul(dv))
+    ref = np.concatenate([dy, dw, dv, ds])
+    dlam = torch.zeros(m, dtype=torch.float64, device="cuda")
+    ks.set_scaling_from_iterate(dev(v), dev(s), dlam)
+    ks.factor(check=True)
+    dz = torch.zeros(n + p + 2 * m, dtype=torch.float64, device="cuda")
+    ks.solve4x4_dev(dlam, dev(r), dz)
+    got = dz.cpu().numpy()
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-9
+    ks.close()
+
+
+def test_gemv_and_dots():
+    from cipkkt import MAT_A, MAT_G, MAT_Q
+    rng = np.random.default_rng(2)
+    for sparse in (False, True):
+        ks, Q, A, G = make_system([("R", 33), ("Q", 10)], n=21, p=5, seed=8, sparse=sparse)
+        Ad = A.toarray() if sparse else A
+        x, w, v = rng.standard_normal(21), rng.standard_normal(5), rng.standard_normal(43)
+        out_n = dev(rng.standard_normal(21))
+        o0 = out_n.cpu().numpy().copy()
+        ks.gemv(MAT_Q, 0, 2.0, dev(x), 0.5, out_n)
+        np.testing.assert_allclose(out_n.cpu().numpy(), 2 * Q @ x + 0.5 * o0, rtol=1e-12, atol=1e-12)
+        out_m = torch.zeros(43, dtype=torch.float64, device="cuda")
+        ks.gemv(MAT_A, 0, 1.0, dev(x), 0.0, out_m)
+        np.testing.assert_allclose(out_m.cpu().numpy(), Ad @ x, rtol=1e-12, atol=1e-12)
+        ks.gemv(MAT_A, 1, -1.0, dev(v), 0.0, out_n)
+        np.testing.assert_allclose(out_n.cpu().numpy(), -Ad.T @ v, rtol=1e-12, atol=1e-12)
+        out_p = torch.zeros(5, dtype=torch.float64, device="cuda")
+        ks.gemv(MAT_G, 0, 1.0, dev(x), 0.0, out_p)
+        np.testing.assert_allclose(out_p.cpu().numpy(), G @ x, rtol=1e-12, atol=1e-12)
+        ks.gemv(MAT_G, 1, 1.0, dev(w), 1.0, out_n)
+        np.testing.assert_allclose(out_n.cpu().numpy(), -Ad.T @ v + G.T @ w, rtol=1e-12, atol=1e-12)
+        big = rng.standard_normal(100003)
+        d = ks.dots([(dev(x), dev(x)), (dev(big), dev(big)), (dev(v), dev(v)[:0])])
+        np.testing.assert_allclose(d, [x @ x, big @ big, 0.0], rtol=1e-13)
+        ks.close()
