@@ -68,6 +68,8 @@ SIGNATURES = {
     "cip_stats": (C.c_int, [C.c_void_p, c_double_p]),
     "cip_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "cip_set_ldlt_outer_block": (C.c_int, [C.c_int]),
+    "cip_profile_trailing": (C.c_int, [C.c_void_p, C.c_int]),
+    "cip_profile_get": (C.c_int, [C.c_void_p, c_double_p]),
 }
 
 _lib = None

@@ -247,6 +247,14 @@ class KKTSystem:
         return dict(n_factor=out[0], n_solve=out[1], ms_assemble=out[2], ms_ldlt=out[3], flops_ldlt=out[4],
                     nbo=out[5], N=out[6], Npad=out[7])
 
+    def profile_trailing(self, on):
+        L.check(self.lib.cip_profile_trailing(self.h, int(bool(on))))
+
+    def profile_get(self):
+        out = (C.c_double * 3)()
+        L.check(self.lib.cip_profile_get(self.h, out))
+        return dict(launches=out[0], ms=out[1], flops=out[2])
+
     def set_timing(self, on):
         L.check(self.lib.cip_set_timing(self.h, int(bool(on))))
 

@@ -35,6 +35,7 @@ static void free_all(cip_handle *h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
+    if (h->ws.prof) { cip_ldlt_profile_destroy(h->ws.prof); h->ws.prof = nullptr; }
 }
 
 // copy a (rows x cols, ld) column-major matrix from src (host or device) into a tight device buffer
@@ -532,5 +533,17 @@ extern "C" int cip_set_timing(cip_handle *h, int enabled) {
     if (!h) return CIP_E_INVALID;
     h->timing = enabled != 0;
     return 0;
+}
+// per-launch timing of the LDL' trailing-update kernel (HIP events on the handle's stream)
+extern "C" int cip_profile_trailing(cip_handle *h, int enabled) {
+    if (!h) return CIP_E_INVALID;
+    if (enabled && !h->ws.prof) h->ws.prof = cip_ldlt_profile_create();
+    if (!enabled && h->ws.prof) { cip_ldlt_profile_destroy(h->ws.prof); h->ws.prof = nullptr; }
+    return 0;
+}
+// out3 = [launches, total ms, total algorithmic flops] accumulated since profiling was enabled
+extern "C" int cip_profile_get(cip_handle *h, double *out3) {
+    if (!h || !out3 || !h->ws.prof) { cip_set_error("profiling not enabled"); return CIP_E_INVALID; }
+    return cip_ldlt_profile_collect(h->ws.prof, &out3[0], &out3[1], &out3[2]);
 }
 extern "C" int cip_set_ldlt_outer_block(int nbo) { cip_ldlt_set_outer_block(nbo); return cip_ldlt_outer_block(); }

@@ -41,6 +41,12 @@ struct GemmArgs {
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g);
 
 // ---------------------------------------------------------------- LDL' (ldlt.hip)
+struct LdltProfile;           // optional per-launch event timing of the trailing-update kernel (ldlt.hip)
+LdltProfile *cip_ldlt_profile_create(void);
+void cip_ldlt_profile_destroy(LdltProfile *p);
+// synchronises; adds the elapsed time of every recorded trailing-update launch to the totals
+int cip_ldlt_profile_collect(LdltProfile *p, double *launches, double *ms, double *flops);
+
 struct LdltWorkspace {        // carved out of one device allocation
     double *Wbuf;             // Npad x NBO      (W = L*D panels of the current outer block)
     double *Linv;             // (Npad/128) x 128 x 128   inverse of each unit-lower diagonal block
@@ -49,6 +55,7 @@ struct LdltWorkspace {        // carved out of one device allocation
     double *dvec;             // Npad   d
     double *tmp;              // Npad   scratch vector for the solves
     int *info;                // device int: 0 ok, >0 = 1-based column of a bad pivot
+    LdltProfile *prof;        // host object or NULL
 };
 size_t cip_ldlt_ws_bytes(int Npad);
 void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws);

@@ -24,6 +24,47 @@ void cip_ldlt_set_outer_block(int nbo) {
 }
 #define CIP_NBO_MAX 1024
 
+// ---- optional instrumentation: HIP events around every trailing-update launch (bench.py roofline)
+#include <vector>
+struct LdltProfile {
+    std::vector<hipEvent_t> pool;     // event pairs
+    size_t used = 0;
+    std::vector<double> flops;        // algorithmic flops of each recorded launch
+    double tot_launches = 0, tot_ms = 0, tot_flops = 0;
+};
+LdltProfile *cip_ldlt_profile_create(void) { return new LdltProfile(); }
+void cip_ldlt_profile_destroy(LdltProfile *p) {
+    if (!p) return;
+    for (hipEvent_t e : p->pool) (void)hipEventDestroy(e);
+    delete p;
+}
+static int prof_event(LdltProfile *p, hipStream_t s) {
+    if (p->used == p->pool.size()) {
+        hipEvent_t e;
+        CIP_HIP_CHECK(hipEventCreate(&e));
+        p->pool.push_back(e);
+    }
+    CIP_HIP_CHECK(hipEventRecord(p->pool[p->used++], s));
+    return 0;
+}
+int cip_ldlt_profile_collect(LdltProfile *p, double *launches, double *ms, double *flops) {
+    if (!p) return -1;
+    if (p->used) CIP_HIP_CHECK(hipEventSynchronize(p->pool[p->used - 1]));
+    for (size_t i = 0; i + 1 < p->used; i += 2) {
+        float t = 0;
+        CIP_HIP_CHECK(hipEventElapsedTime(&t, p->pool[i], p->pool[i + 1]));
+        p->tot_ms += t;
+        p->tot_flops += p->flops[i / 2];
+        p->tot_launches += 1;
+    }
+    p->used = 0;
+    p->flops.clear();
+    if (launches) *launches = p->tot_launches;
+    if (ms) *ms = p->tot_ms;
+    if (flops) *flops = p->tot_flops;
+    return 0;
+}
+
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 size_t cip_ldlt_ws_bytes(int Npad) {
@@ -46,6 +87,7 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     ws->dvec = (double *)p;  p += al256((size_t)Npad * 8);
     ws->tmp = (double *)p;   p += al256((size_t)Npad * 8);
     ws->info = (int *)p;
+    ws->prof = nullptr;
 }
 
 // ---------------------------------------------------------------------------
@@ -176,7 +218,13 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
             g.B = K + r0 + (long)C0 * ld; g.ldb = ld;
             g.C = K + r0 + (long)r0 * ld; g.ldc = ld;
             g.M = Npad - r0; g.N = Npad - r0; g.K = wblk; g.alpha = -1.0; g.lower = 1;
+            if (ws.prof) {
+                if ((rc = prof_event(ws.prof, s))) return rc;
+                const double r = (double)(Npad - r0);
+                ws.prof->flops.push_back(r * (r + 1.0) * (double)wblk);   // 2 flop/MAC on the lower triangle
+            }
             if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
+            if (ws.prof && (rc = prof_event(ws.prof, s))) return rc;
         }
     }
     return 0;

@@ -154,7 +154,11 @@ int cip_assemble_only(cip_handle *h);                                   /* level
 /* stats: [0] factor calls, [1] solve calls, [2] last factor ms (assemble), [3] last factor ms (ldlt), [4] flops of last ldlt */
 int cip_stats(cip_handle *h, double *out8);
 int cip_set_timing(cip_handle *h, int enabled);
-int cip_set_ldlt_outer_block(int nbo);   /* tuning knob: outer block of the blocked LDL' (multiple of 128); returns the value in use */
+int cip_set_ldlt_outer_block(int nbo);
+/* HIP-event timing of every LDL' trailing-update launch (bench.py roofline): enable, then read
+ * out3 = [launches, total ms, total algorithmic flops (r(r+1)K per launch)] */
+int cip_profile_trailing(cip_handle *h, int enabled);
+int cip_profile_get(cip_handle *h, double *out3);   /* tuning knob: outer block of the blocked LDL' (multiple of 128); returns the value in use */
 
 #ifdef __cplusplus
 }
