@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- KKT solves/sec (+ wall-clock to converge) of the MI355X-native KKT path.
+
+Workload (BASELINE.json configs[1]): dense random QP, n = m = 8192, p = 0,
+K = [("R", 8192)], Q = M'M/n (M iid N(0,1)), c ~ N(0,1), A = I (sparse), b = 0, fp64,
+optTol = 1e-6 -- the README box-QP form at the headline size.
+
+A "step" = one KKT solve = one Newton system of the interior-point loop:
+    NT scaling from the iterate (device)  +  KKT assembly  +  dense LDL' factorisation
+    +  SOLVES_PER_FACTOR back-solves (cip_solve4x4: cone division, 3x3 solve, ds recovery)
+with SOLVES_PER_FACTOR = the rounded mean the real solve used (predictor, corrector,
+refinement).  The scaling comes from a mid-trajectory iterate of the same problem; all
+inputs are resident in HBM before the timed region.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): every rank owns
+an independent problem of the same size (seed + rank): weak scaling, no data-path
+collective; one all-reduce (MAX) of the timing, as the contract asks.
+
+Output: ONE JSON line on rank 0 with `roofline` (LDL' trailing-update kernel, fp64 MFMA,
+HIP-event timed per launch on the launch stream) and `cpu_baseline` (the oracle's
+reference-faithful kktsolver_qr restatement timed on the host cores).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "conicip.jl_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+
+FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X vendor fp64 matrix peak (dense); see DESIGN.md §5
+HBM_PEAK_GBS = 8000.0
+
+
+def build_problem(n, seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    M = torch.randn(n, n, generator=g, dtype=torch.float64, device=device)
+    Q = (M.t() @ M) / n                       # setup only (rocBLAS via torch); not part of the timed path
+    Q = 0.5 * (Q + Q.t())
+    c = torch.randn(n, generator=g, dtype=torch.float64, device=device)
+    del M
+    return Q, c
+
+
+def cpu_baseline(Q_host, n, solves_per_factor, budget_s=40.0):
+    """Reference-faithful CPU path: the oracle's restatement of kktsolver_qr
+    (src/kktsolvers.jl:18-58: dense F^-T, Atil = F^-T A, Q + Atil'Atil, QR, null-space solve),
+    all host cores via OpenBLAS.  Bounded sample: the full n when a small probe predicts it
+    fits the budget, otherwise the largest power-of-two n that does (scaled by the n^3 law)."""
+    from oracle.block import Block, Diagonal
+    from oracle.kktsolvers import kktsolver_qr
+    import scipy.linalg as sla
+    cores = os.cpu_count() or 1
+
+    def one(nn):
+        rng = np.random.default_rng(1)
+        Qs = np.ascontiguousarray(Q_host[:nn, :nn])
+        A = np.eye(nn)
+        G = np.zeros((0, nn))
+        F = Block([Diagonal(np.exp(rng.standard_normal(nn)))])
+        t0 = time.perf_counter()
+        gen = kktsolver_qr(Qs, A, G, [("R", nn)])
+        t1 = time.perf_counter()
+        s3 = gen(F, None)
+        t2 = time.perf_counter()
+        for _ in range(solves_per_factor):
+            s3(rng.standard_normal(nn), np.zeros(0), rng.standard_normal(nn))
+        t3 = time.perf_counter()
+        # strong CPU variant: same Schur + Cholesky route as the GPU (LAPACK potrf/potrs)
+        t4 = time.perf_counter()
+        S = Qs + np.diag(1.0 / F.Blocks[0].diag ** 2)
+        cf = sla.cho_factor(S, lower=True, overwrite_a=True, check_finite=False)
+        for _ in range(solves_per_factor):
+            sla.cho_solve(cf, rng.standard_normal(nn), check_finite=False)
+        t5 = time.perf_counter()
+        return dict(level1=t1 - t0, factor=t2 - t1, solves=t3 - t2, strong=t5 - t4)
+
+    probe_n = 1024
+    tp = one(probe_n)
+    per_step_probe = tp["factor"] + tp["solves"]
+    pred_full = per_step_probe * (n / probe_n) ** 3
+    nn = n
+    while nn > probe_n and per_step_probe * (nn / probe_n) ** 3 > budget_s:
+        nn //= 2
+    t = one(nn)
+    step_s = (t["factor"] + t["solves"]) * (n / nn) ** 3
+    strong_s = t["strong"] * (n / nn) ** 3
+    sample = ("1 factorisation + %d solves of the kktsolver_qr restatement at n=%d%s (level-1 setup %.2fs excluded)"
+              % (solves_per_factor, nn, "" if nn == n else " scaled to n=%d by (n/n_s)^3" % n, t["level1"]))
+    return dict(value=1.0 / step_s, unit="KKT solves/s", cores=cores, kind="port", sample=sample,
+                strong_cpu_value=1.0 / strong_s,
+                strong_cpu_note="Schur + LAPACK Cholesky (same elimination route as the GPU), same sample"), pred_full
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--route", default="schur", choices=["schur", "full3x3"])
+    ap.add_argument("--nbo", type=int, default=0, help="LDL' outer block (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-converge", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the KKT path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=device)   # nccl == RCCL on ROCm
+
+    import cipkkt
+    import scipy.sparse as sp
+    n = args.n
+    if args.nbo:
+        cipkkt._lib.load().cip_set_ldlt_outer_block(args.nbo)
+
+    Q, c = build_problem(n, 1234 + rank, device)
+    A = sp.identity(n, format="csr")
+    b = np.zeros(n)
+    cone_dims = [("R", n)]
+    ks = cipkkt.KKTSystem(Q, A, None, cone_dims, route=args.route, device=device)
+    c_host = c.cpu().numpy()
+
+    # ---- wall-clock to converge (the second half of the metric) + the statistics that define a step
+    iters = n_factor = n_solve = None
+    converge_s = None
+    status = None
+    iterates = []
+    if not args.no_converge:
+        torch.cuda.synchronize()
+        sol = cipkkt.conicIP(Q, c_host, A, b, cone_dims, optTol=1e-6, system=ks, kktsolver=args.route,
+                             keep_iterates=iterates)
+        converge_s, iters, n_factor, n_solve, status = sol.wall_s, sol.Iter, sol.n_factor, sol.n_solve, sol.status
+        spf = max(1, int(round(n_solve / n_factor)))
+        zmid = iterates[max(0, len(iterates) // 2 - 1)]
+        v_mid = zmid[n:2 * n].clone()
+        s_mid = zmid[2 * n:3 * n].clone()
+    else:
+        spf = 2
+        g = torch.Generator(device=device)
+        g.manual_seed(7)
+        v_mid = torch.rand(n, generator=g, dtype=torch.float64, device=device) + 0.01
+        s_mid = torch.rand(n, generator=g, dtype=torch.float64, device=device) + 0.01
+    del iterates
+
+    lam = torch.zeros(n, dtype=torch.float64, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(99)
+    rhs = torch.randn(3 * n, generator=g, dtype=torch.float64, device=device)
+    dz = torch.zeros(3 * n, dtype=torch.float64, device=device)
+
+    def step():
+        ks.set_scaling_from_iterate(v_mid, s_mid, lam)
+        ks.factor()
+        for _ in range(spf):
+            ks.solve4x4_dev(lam, rhs, dz)
+
+    for _ in range(args.warmup):
+        step()
+    ks.check_factor()
+    ks.profile_trailing(True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = ks.profile_get()
+    ks.profile_trailing(False)
+    ks.check_factor()
+
+    # separate factor / solve split (untimed region, for the report)
+    ks.set_timing(True)
+    ks.factor()
+    st = ks.stats()
+    ks.set_timing(False)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        ks.solve4x4_dev(lam, rhs, dz)
+    torch.cuda.synchronize()
+    solve_ms = (time.perf_counter() - t1) / 5 * 1e3
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
+        N = ks.N
+        out = {
+            "metric": "KKT solves/sec + wall-clock to converge, dense QP n=%d, 1 GPU" % n,
+            "value": value, "unit": "KKT solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "dense QP n=m=%d p=0 K=[(R,%d)] Q=M'M/n A=I(sparse) b=0 optTol=1e-6; "
+                                   "step = NT scaling + assembly + LDL' + %d solve4x4" % (n, n, spf),
+                       "route": args.route, "kkt_order": N, "solves_per_factor": spf,
+                       "ldlt_outer_block": int(st["nbo"]), "parallelism": "problem-per-GPU x%d" % world},
+            "converge": {"wall_s": converge_s, "iters": iters, "status": status, "n_factor": n_factor,
+                         "n_solve": n_solve},
+            "breakdown_ms": {"assemble": st["ms_assemble"], "ldlt_factor": st["ms_ldlt"], "solve4x4": solve_ms,
+                             "ldlt_tflops_whole_factor": (N ** 3 / 3.0) / (st["ms_ldlt"] * 1e-3) / 1e12
+                             if st["ms_ldlt"] > 0 else None},
+            "roofline": {"bound": "mfma", "kernel": "k_gemm_nt_128<EPI_ACCUM> (LDL' trailing update)",
+                         "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(1.0, prof["launches"]),
+                         "algorithmic_flops_per_launch_avg": prof["flops"] / max(1.0, prof["launches"])},
+        }
+        if not args.no_cpu_baseline:
+            Qh = Q.cpu().numpy()
+            cb, _ = cpu_baseline(Qh, n, spf)
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = (value / world) / cb["value"]
+        print(json.dumps(out), flush=True)
+    ks.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

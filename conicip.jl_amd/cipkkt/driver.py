@@ -57,7 +57,7 @@ def conicIP(Q, c, A, b, cone_dims, G=None, d=None, *,
             optTol=1e-6, DTB=0.01, verbose=False,
             maxRefinementSteps=3, maxIters=100, cache_nestodd=False,
             infeasTol=None, refinementThreshold=None,
-            device=None, system=None):
+            device=None, system=None, keep_iterates=None):
     """minimize 1/2 y'Qy - c'y  s.t.  Ay - b in K,  Gy = d   (src/ConicIP.jl:411-430).
 
     `kktsolver` selects the elimination route of the HIP KKT path: "schur"
@@ -171,6 +171,8 @@ def conicIP(Q, c, A, b, cone_dims, G=None, d=None, *,
     rly, rlw, rlv, rls = parts(rleft)
     ry, rw, rv, rs = parts(r)
     for Iter in range(1, maxIters + 1):                                    # :730
+        if keep_iterates is not None:
+            keep_iterates.append(z.clone())
         if m > 0:
             ks.set_scaling_from_iterate(zv, zs, lam)                       # :732-735 (F, lambda = F v)
         ks.factor()                                                        # :737 -> :682
