@@ -158,9 +158,15 @@ __global__ __launch_bounds__(256) void k_ldlt_diag128(double *Kb, long ld, doubl
     }
 }
 
+int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *Linv, double *LinvT, double *dvec, double *dinv,
+                       int *info, int col0);     // diag.hip
+#include <stdlib.h>
 static bool g_diag_attr_set = false;
+static int g_diag_version = 0;                   // 0 = not decided yet
 static int launch_diag(hipStream_t s, double *Kb, long ld, double *Linv, double *LinvT, double *dvec,
                        double *dinv, int *info, int col0) {
+    if (g_diag_version == 0) g_diag_version = getenv("CIP_DIAG_V1") ? 1 : 2;   // v1 = plain LDS reference kernel
+    if (g_diag_version == 2) return cip_launch_diag_v2(s, Kb, ld, Linv, LinvT, dvec, dinv, info, col0);
     const size_t shm = (size_t)CIP_NB * DLDA * sizeof(double);
     if (!g_diag_attr_set) {
         CIP_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_diag128,
