@@ -51,6 +51,7 @@ struct LdltWorkspace {        // carved out of one device allocation
     double *Wbuf;             // Npad x NBO      (W = L*D panels of the current outer block)
     double *Linv;             // (Npad/128) x 128 x 128   inverse of each unit-lower diagonal block
     double *LinvT;            // same, transposed
+    double *Xm;               // (Npad/128) x 8 x 256   inverses of the 16x16 unit-lower micro-blocks
     double *dinv;             // Npad   1/d
     double *dvec;             // Npad   d
     double *tmp;              // Npad   scratch vector for the solves

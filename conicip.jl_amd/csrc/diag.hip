@@ -20,6 +20,9 @@
 #include "cip_internal.h"
 
 #define DP 144
+#ifndef DIAG_SKIP
+#define DIAG_SKIP 0        // development switch (tools/diag_bench.hip): bit mask of phases to skip
+#endif
 #define XM_OFF (CIP_NB * DP)             // 8 x 256 doubles: xm[kb][k*16 + jj] = Xm_kb[jj][k]
 #define DIAG2_LDS_BYTES ((CIP_NB * DP + 8 * 256) * 8)
 
@@ -108,18 +111,36 @@ __device__ __forceinline__ void diag_inverse_row(double *a, const double *xm, in
         }
 }
 
-__global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, double *Linv, double *LinvT,
-                                                          double *dvec, double *dinv, int *info, int col0) {
+// 128x128 block <-> LDS image, 16-byte accesses, all loads of a thread in flight before the first store
+__device__ __forceinline__ void diag_load_block(double *a, const double *Kb, long ld, int tid) {
+    v2d tmp[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const int e = q * 256 + tid;             // pair index: rows 2*(e&63), +1 ; column e>>6
+        tmp[q] = *(const v2d *)(Kb + 2 * (e & 63) + (long)(e >> 6) * ld);
+    }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const int e = q * 256 + tid;
+        const int i = 2 * (e & 63), j = e >> 6;
+        v2d v = tmp[q];
+        if (i < j) v.x = 0.0;                    // strictly upper part -> 0
+        if (i + 1 < j) v.y = 0.0;
+        *(v2d *)(a + i + j * DP) = v;
+    }
+}
+
+// Factor-only diagonal kernel: L (strictly lower) and d back into K, d / 1/d vectors, and the 8 micro
+// inverses Xm (xm_out[kb][k*16 + jj] = inv(L11_kb)[jj][k]) for the TRSM and the block-inverse kernels.
+__global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
+                                                          int *info, int col0) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *a = sm;
     double *xm = sm + XM_OFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
 
-    for (int e = tid; e < CIP_NB * CIP_NB; e += 256) {
-        const int i = e & 127, j = e >> 7;
-        a[i + j * DP] = (i >= j) ? Kb[i + (long)j * ld] : 0.0;
-    }
+    diag_load_block(a, Kb, ld, tid);
     __syncthreads();
 
     const int tA = wave, tB = 7 - wave;          // owned row tiles
@@ -127,44 +148,46 @@ __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, do
         const int c = kb * 16;
         // ------------------------------------------------------------ A: 16x16 micro-block on wave 0
         if (wave == 0) {
-            double u[16];
+            // rows of the 16x16 micro-block one per lane (lanes >= 16 mirror lanes 0..15).  The pivot
+            // column is broadcast with v_readlane; the same broadcasts drive the right-looking update
+            // of X = inv(L11) (lane cc owns column cc of X), so the inverse costs one extra FMA per entry.
+            double u[16], x[16];
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) u[jj] = a[(c + l15) + (c + jj) * DP];
+            for (int jj = 0; jj < 16; ++jj) {
+                u[jj] = a[(c + l15) + (c + jj) * DP];
+                x[jj] = (l15 == jj) ? 1.0 : 0.0;
+            }
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const double d = rlane(u[j], j);
-                if (lane == 0 && !(fabs(d) > 0.0 && fabs(d) < 1.7e308)) atomicCAS(info, 0, col0 + c + j + 1);
                 const double di = fast_rcp(d);
-                if (lane == j) {
-                    a[128 + (c + j) * DP] = d;
-                    a[129 + (c + j) * DP] = di;
-                }
                 const double wi = u[j];
+                const double ti = wi * di;                       // l_ij for lanes i > j
 #pragma unroll
-                for (int jj = j + 1; jj < 16; ++jj) u[jj] -= wi * (rlane(u[j], jj) * di);
-                u[j] = (l15 == j) ? d : wi * di;          // column j final: l_ij (i > j), d on the diagonal
-            }
-            // micro inverse: lane cc owns column cc of X = inv(L11):  x[r] = [r == cc] - sum_{k<r} L[r][k] x[k]
-            double x[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                double s = (l15 == r) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < r; ++k) s -= rlane(u[k], r) * x[k];
-                x[r] = s;
+                for (int jj = j + 1; jj < 16; ++jj) {
+                    const double cj = rlane(u[j], jj);           // a[jj][j] (unscaled)
+                    u[jj] -= ti * cj;                            // a[i][jj] -= l_ij * a[jj][j]
+                    x[jj] -= (cj * di) * x[j];                   // X[jj][cc] -= l_{jj,j} X[j][cc]
+                }
+                u[j] = (l15 == j) ? d : ti;
             }
             if (lane < 16) {
+                double dsel = 0.0;
 #pragma unroll
                 for (int jj = 0; jj < 16; ++jj) {
+                    if (jj == l15) dsel = u[jj];
                     if (jj <= l15) a[(c + l15) + (c + jj) * DP] = u[jj];
                     xm[kb * 256 + l15 * 16 + jj] = x[jj];            // xm[k = cc][jj = r] = X[r][cc]
                 }
+                if (!(fabs(dsel) > 0.0 && fabs(dsel) < 1.7e308)) atomicCAS(info, 0, col0 + c + l15 + 1);
+                a[128 + (c + l15) * DP] = dsel;
+                a[129 + (c + l15) * DP] = fast_rcp(dsel);
             }
         }
         __syncthreads();
         // ------------------------------------------------------------ B: panel rows below
         double wA[4] = {0, 0, 0, 0}, wB[4] = {0, 0, 0, 0};
-        const bool hasA = tA > kb, hasB = tB > kb;
+        const bool hasA = tA > kb && !(DIAG_SKIP & 4), hasB = tB > kb && !(DIAG_SKIP & 4);
         if (hasA || hasB) {
             double xa[4], di4[4];
 #pragma unroll
@@ -184,21 +207,41 @@ __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, do
         __syncthreads();
     }
 
-    // ---- L, d out
-    for (int e = tid; e < CIP_NB * CIP_NB; e += 256) {
-        const int r = e & 127, cc = e >> 7;
-        if (r >= cc) Kb[r + (long)cc * ld] = a[r + cc * DP];
+    // ---- L (strictly lower) and d out, 16-byte stores; the strictly upper part of K is left untouched
+#pragma unroll 8
+    for (int q = 0; q < 32; ++q) {
+        const int e = q * 256 + tid;
+        const int i = 2 * (e & 63), j = e >> 6;
+        if (i >= j) *(v2d *)(Kb + i + (long)j * ld) = *(const v2d *)(a + i + j * DP);
+        else if (i + 1 == j) Kb[i + 1 + (long)j * ld] = a[i + 1 + j * DP];
     }
     if (tid < CIP_NB) {
         dvec[tid] = a[128 + tid * DP];
         dinv[tid] = a[129 + tid * DP];
     }
-    __syncthreads();          // everyone has read the diagonal before the upper triangle is reused
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xm_out[q * 256 + tid] = xm[q * 256 + tid];
+}
 
-    // ---- X = inv(L), block rows (w, 7-w); results parked in the upper triangle of the LDS image
-    diag_inverse_row(a, xm, tA, l15, g);
-    diag_inverse_row(a, xm, tB, l15, g);
+// X = inv(L) for every 128x128 diagonal block of a factored matrix, one workgroup per block (they are
+// independent, so this is ONE launch after the factorisation instead of a serial link in it).  Only the
+// solves use X (gemv with the block inverses).
+__global__ __launch_bounds__(256) void k_diag_inverse_batched(const double *K, long ld, const double *xm_all, double *Linv,
+                                                               double *LinvT) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *a = sm;
+    double *xm = sm + XM_OFF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int jb = blockIdx.x;
+    diag_load_block(a, K + (long)jb * CIP_NB * (ld + 1), ld, tid);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xm[q * 256 + tid] = xm_all[(size_t)jb * 2048 + q * 256 + tid];
     __syncthreads();
+    diag_inverse_row(a, xm, wave, l15, g);
+    diag_inverse_row(a, xm, 7 - wave, l15, g);
+    __syncthreads();
+    double *Li = Linv + (size_t)jb * CIP_NB * CIP_NB, *Lt = LinvT + (size_t)jb * CIP_NB * CIP_NB;
     for (int e = tid; e < CIP_NB * CIP_NB; e += 256) {
         const int r = e & 127, cc = e >> 7;
         const int tr = r >> 4, tc = cc >> 4;
@@ -210,20 +253,77 @@ __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, do
             x = (tr > tc) ? a[cc + r * DP] : 0.0;                    // X[r][cc]
             xt = (tc > tr) ? a[r + cc * DP] : 0.0;                   // X[cc][r]
         }
-        Linv[r + cc * CIP_NB] = x;
-        LinvT[r + cc * CIP_NB] = xt;
+        Li[r + cc * CIP_NB] = x;
+        Lt[r + cc * CIP_NB] = xt;
     }
 }
 
-int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *Linv, double *LinvT, double *dvec, double *dinv,
-                       int *info, int col0) {
-    static bool attr_set = false;
-    if (!attr_set) {
+// Panel TRSM by blocked substitution (replaces "multiply by the explicit inverse"):
+//   W21 = A21 inv(L11)' ,  L21 = W21 D^-1      for the rows below a factored 128x128 diagonal block.
+// One wave per 16-row tile keeps its 8 finished W tiles in registers (accumulator layout == operand
+// layout for f64 16x16x4), and for each 16-column block kb does
+//   T = A21[:,kb] - sum_{q<kb} W[:,q] L11[kb][q]'      (4 kb MFMAs, operands straight from L2)
+//   W[:,kb] = T inv(L11[kb][kb])'                       (4 MFMAs with the micro inverse)
+// Half the flops of the inverse-GEMM form, 4x more workgroups, no 128x128 inverse on the critical path.
+__global__ __launch_bounds__(256) void k_trsm_subst(double *Ap, long ld, const double *L11, const double *xm,
+                                                     const double *dinv, double *W, long ldw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const long row = (long)blockIdx.x * 64 + wave * 16 + l15;
+    double *ap = Ap + row + (long)g * ld;
+    double *wp = W + row + (long)g * ldw;
+    const double *lp = L11 + l15 + (long)g * ld;       // + kb*16 rows, + (q*16 + 4s) columns
+    double wneg[8][4];
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        v4d acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = ap[(long)(kb * 16 + 4 * q) * ld];
+#pragma unroll
+        for (int qq = 0; qq < kb; ++qq) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc = MFMA(lp[kb * 16 + (long)(qq * 16 + 4 * s) * ld], wneg[qq][s], acc);
+        }
+        v4d w = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) w = MFMA(xm[kb * 256 + (g + 4 * s) * 16 + l15], acc[s], w);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long col = kb * 16 + 4 * q;
+            wneg[kb][q] = -w[q];
+            wp[col * ldw] = w[q];
+            ap[col * ld] = w[q] * dinv[col + g];
+        }
+    }
+}
+
+static bool g_attr_diag = false, g_attr_inv = false;
+int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0) {
+    if (!g_attr_diag) {
         CIP_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_diag128_v2, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           DIAG2_LDS_BYTES));
-        attr_set = true;
+        g_attr_diag = true;
     }
-    hipLaunchKernelGGL(k_ldlt_diag128_v2, dim3(1), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, Linv, LinvT, dvec, dinv, info, col0);
+    hipLaunchKernelGGL(k_ldlt_diag128_v2, dim3(1), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int cip_launch_diag_inverse(hipStream_t s, const double *K, long ld, int nblk, const double *xm_all, double *Linv,
+                            double *LinvT) {
+    if (!g_attr_inv) {
+        CIP_HIP_CHECK(hipFuncSetAttribute((const void *)k_diag_inverse_batched, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          DIAG2_LDS_BYTES));
+        g_attr_inv = true;
+    }
+    hipLaunchKernelGGL(k_diag_inverse_batched, dim3(nblk), dim3(256), DIAG2_LDS_BYTES, s, K, ld, xm_all, Linv, LinvT);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int cip_launch_trsm_subst(hipStream_t s, double *Ap, long ld, int rows, const double *L11, const double *xm,
+                          const double *dinv, double *W, long ldw) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_trsm_subst, dim3(rows / 64), dim3(256), 0, s, Ap, ld, L11, xm, dinv, W, ldw);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -72,6 +72,7 @@ size_t cip_ldlt_ws_bytes(int Npad) {
     size_t b = 0;
     b += al256((size_t)Npad * CIP_NBO_MAX * 8);          // Wbuf
     b += al256(nblk * CIP_NB * CIP_NB * 8) * 2;          // Linv, LinvT
+    b += al256(nblk * 2048 * 8);                         // Xm
     b += al256((size_t)Npad * 8) * 3;                    // dinv, dvec, tmp
     b += 256;                                            // info
     return b;
@@ -83,6 +84,7 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     ws->Wbuf = (double *)p;  p += al256((size_t)Npad * CIP_NBO_MAX * 8);
     ws->Linv = (double *)p;  p += al256(nblk * CIP_NB * CIP_NB * 8);
     ws->LinvT = (double *)p; p += al256(nblk * CIP_NB * CIP_NB * 8);
+    ws->Xm = (double *)p;    p += al256(nblk * 2048 * 8);
     ws->dinv = (double *)p;  p += al256((size_t)Npad * 8);
     ws->dvec = (double *)p;  p += al256((size_t)Npad * 8);
     ws->tmp = (double *)p;   p += al256((size_t)Npad * 8);
@@ -158,15 +160,21 @@ __global__ __launch_bounds__(256) void k_ldlt_diag128(double *Kb, long ld, doubl
     }
 }
 
-int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *Linv, double *LinvT, double *dvec, double *dinv,
-                       int *info, int col0);     // diag.hip
+// diag.hip
+int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0);
+int cip_launch_diag_inverse(hipStream_t s, const double *K, long ld, int nblk, const double *xm_all, double *Linv,
+                            double *LinvT);
+int cip_launch_trsm_subst(hipStream_t s, double *Ap, long ld, int rows, const double *L11, const double *xm,
+                          const double *dinv, double *W, long ldw);
 #include <stdlib.h>
 static bool g_diag_attr_set = false;
-static int g_diag_version = 0;                   // 0 = not decided yet
+static int g_diag_version = 0;                   // 0 = not decided yet; 1 = plain-LDS reference kernels (CIP_DIAG_V1)
+static int diag_version(void) {
+    if (g_diag_version == 0) g_diag_version = getenv("CIP_DIAG_V1") ? 1 : 2;
+    return g_diag_version;
+}
 static int launch_diag(hipStream_t s, double *Kb, long ld, double *Linv, double *LinvT, double *dvec,
                        double *dinv, int *info, int col0) {
-    if (g_diag_version == 0) g_diag_version = getenv("CIP_DIAG_V1") ? 1 : 2;   // v1 = plain LDS reference kernel
-    if (g_diag_version == 2) return cip_launch_diag_v2(s, Kb, ld, Linv, LinvT, dvec, dinv, info, col0);
     const size_t shm = (size_t)CIP_NB * DLDA * sizeof(double);
     if (!g_diag_attr_set) {
         CIP_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_diag128,
@@ -199,11 +207,23 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
                 g.M = Npad - c0; g.N = CIP_NB; g.K = t * CIP_NB; g.alpha = -1.0; g.lower = 0;
                 if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
             }
+            const int r = Npad - c0 - CIP_NB;
+            if (diag_version() == 2) {
+                // MFMA micro-blocked diagonal kernel + substitution TRSM (the block inverses the solves
+                // need are produced by one batched launch after the loop)
+                if ((rc = cip_launch_diag_v2(s, K + c0 + (long)c0 * ld, ld, ws.Xm + (size_t)jb * 2048, ws.dvec + c0,
+                                             ws.dinv + c0, ws.info, c0)))
+                    return rc;
+                if ((rc = cip_launch_trsm_subst(s, K + (c0 + CIP_NB) + (long)c0 * ld, ld, r, K + c0 + (long)c0 * ld,
+                                                ws.Xm + (size_t)jb * 2048, ws.dinv + c0,
+                                                ws.Wbuf + (c0 + CIP_NB) + (long)(t * CIP_NB) * Npad, Npad)))
+                    return rc;
+                continue;
+            }
             if ((rc = launch_diag(s, K + c0 + (long)c0 * ld, ld, ws.Linv + (size_t)jb * CIP_NB * CIP_NB,
                                   ws.LinvT + (size_t)jb * CIP_NB * CIP_NB, ws.dvec + c0, ws.dinv + c0,
                                   ws.info, c0)))
                 return rc;
-            const int r = Npad - c0 - CIP_NB;
             if (r > 0) {
                 // W21 = A21 * inv(L11)'  ;  L21 = W21 * D^-1 (in place)
                 GemmArgs g = {};
@@ -233,6 +253,8 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
             if (ws.prof && (rc = prof_event(ws.prof, s))) return rc;
         }
     }
+    if (diag_version() == 2)
+        return cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.Linv, ws.LinvT);
     return 0;
 }
 

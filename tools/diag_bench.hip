@@ -1,0 +1,35 @@
+// Micro-benchmark of the diagonal-block kernel (development tool, not part of the library).
+// Build variants with -DDIAG_SKIP=<mask>: 1 = skip micro inverse in step A, 2 = skip X phase,
+// 4 = skip steps B/C, 8 = skip step A factor loop, 16 = skip global load/store loops
+#include "../conicip.jl_amd/csrc/diag.hip"
+#include <vector>
+#include <cstdio>
+#include <cmath>
+void cip_set_error(const char *fmt, ...) {}
+int main() {
+    const int N = 128;
+    std::vector<double> K(N * N);
+    for (int j = 0; j < N; ++j)
+        for (int i = 0; i < N; ++i) K[i + j * N] = (i == j ? 4.0 + 0.01 * i : 0.0) + 1.0 / (1.0 + abs(i - j));
+    double *dK, *dLi, *dLt, *dd, *ddi, *dK0; int *dinfo;
+    hipMalloc(&dK, N * N * 8); hipMalloc(&dK0, N * N * 8); hipMalloc(&dLi, N * N * 8); hipMalloc(&dLt, N * N * 8);
+    hipMalloc(&dd, N * 8); hipMalloc(&ddi, N * 8); hipMalloc(&dinfo, 4);
+    hipMemcpy(dK0, K.data(), N * N * 8, hipMemcpyHostToDevice);
+    hipMemset(dinfo, 0, 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int reps = 200;
+    for (int w = 0; w < 3; ++w) { hipMemcpy(dK, dK0, N * N * 8, hipMemcpyDeviceToDevice); cip_launch_diag_v2(0, dK, N, dLi, dd, ddi, dinfo, 0); }
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) cip_launch_diag_v2(0, dK, N, dLi, dd, ddi, dinfo, 0);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("DIAG_SKIP=%d avg %.2f us per launch\n",
+#ifdef DIAG_SKIP
+           DIAG_SKIP,
+#else
+           0,
+#endif
+           ms * 1e3 / reps);
+    return 0;
+}
