@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, do
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
 
-    diag_load_block(a, Kb, ld, tid);
+    if (!(DIAG_SKIP & 16)) diag_load_block(a, Kb, ld, tid);
     __syncthreads();
 
     const int tA = wave, tB = 7 - wave;          // owned row tiles
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, do
                 x[jj] = (l15 == jj) ? 1.0 : 0.0;
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < ((DIAG_SKIP & 8) ? 0 : 16); ++j) {
                 const double d = rlane(u[j], j);
                 const double di = fast_rcp(d);
                 const double wi = u[j];
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, do
 
     // ---- L (strictly lower) and d out, 16-byte stores; the strictly upper part of K is left untouched
 #pragma unroll 8
-    for (int q = 0; q < 32; ++q) {
+    for (int q = 0; q < ((DIAG_SKIP & 16) ? 0 : 32); ++q) {
         const int e = q * 256 + tid;
         const int i = 2 * (e & 63), j = e >> 6;
         if (i >= j) *(v2d *)(Kb + i + (long)j * ld) = *(const v2d *)(a + i + j * DP);
