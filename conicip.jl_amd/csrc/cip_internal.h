@@ -37,6 +37,10 @@ struct GemmArgs {
     const double *dinv;
     // EPI_SYRKQ: C = Qin + acc for i,j < nvalid (lower tiles)
     const double *Qin; long ldq; int nvalid;
+    // batching (EPI_ACCUM only): grid.y x grid.z independent problems, pointer strides in doubles
+    int by, bz;
+    long sAy, sAz, sBy, sBz, sCy, sCz;
+    int overwrite;               // EPI_ACCUM: C = alpha*acc instead of C += alpha*acc
 };
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g);
 
@@ -52,12 +56,17 @@ struct LdltWorkspace {        // carved out of one device allocation
     double *Linv;             // (Npad/128) x 128 x 128   inverse of each unit-lower diagonal block
     double *LinvT;            // same, transposed
     double *Xm;               // (Npad/128) x 8 x 256   inverses of the 16x16 unit-lower micro-blocks
+    int Bs;                   // solve block: largest of {1024,512,256,128} dividing Npad
+    double *X, *XT;           // (Npad/Bs) x Bs x Bs   inverse (and its transpose) of each Bs x Bs unit-lower diagonal block
+    double *Tt;               // (Npad/Bs) x (Bs/2)^2  scratch of the block-inverse doubling
+    double *zbuf;             // Npad scratch
     double *dinv;             // Npad   1/d
     double *dvec;             // Npad   d
     double *tmp;              // Npad   scratch vector for the solves
     int *info;                // device int: 0 ok, >0 = 1-based column of a bad pivot
     LdltProfile *prof;        // host object or NULL
 };
+int cip_solve_block(int Npad);
 size_t cip_ldlt_ws_bytes(int Npad);
 void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws);
 int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws);

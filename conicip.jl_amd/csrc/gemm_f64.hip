@@ -55,6 +55,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_128(GemmArgs g) {
         bj = t / tm;
     }
     const long i0 = (long)bi * CIP_NB, j0 = (long)bj * CIP_NB;
+    if (EPI == EPI_ACCUM) {       // batched problems: grid.y x grid.z
+        g.A += blockIdx.y * g.sAy + blockIdx.z * g.sAz;
+        g.B += blockIdx.y * g.sBy + blockIdx.z * g.sBz;
+        g.C += blockIdx.y * g.sCy + blockIdx.z * g.sCz;
+    }
 
     const double *Ap = g.A + i0 + 2 * lane;
     const double *Bp = g.B + j0 + 2 * lane;
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_128(GemmArgs g) {
                 v2d val = (v2d){acc[2 * gi][tj][q], acc[2 * gi + 1][tj][q]};
                 if (EPI == EPI_ACCUM) {
                     double *cp = g.C + row + col * g.ldc;
-                    v2d c = *(v2d *)cp;
+                    v2d c = g.overwrite ? (v2d){0.0, 0.0} : *(v2d *)cp;
                     c += g.alpha * val;
                     *(v2d *)cp = c;
                 } else if (EPI == EPI_TRSM) {
@@ -150,6 +155,86 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_128(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small-tile variant (64x64 C tile, wave = 32x32 = 2x2 MFMA tiles) for the latency-critical skinny
+// updates on the factorisation's critical path (look-ahead column strip, in-block strip update):
+// 4x the workgroups and a quarter of the per-tile latency of the 128x128 kernel, at twice the LDS
+// traffic per flop -- these launches carry < 10 % of the flops.  Accumulate epilogue only.
+#define SB 64
+__global__ __launch_bounds__(256, 4) void k_gemm_nt_64(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int tm = g.M / SB;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int bi = t % tm, bj = t / tm;
+    const long i0 = (long)bi * SB, j0 = (long)bj * SB;
+
+    // staging: 64 rows x 16 k per operand = 512 double2 -> 2 per thread: e = q*256 + tid, k = e >> 5, rp = e & 31
+    const int k_ld = tid >> 5, rp = tid & 31;
+    const double *Ap = g.A + i0 + 2 * rp;
+    const double *Bp = g.B + j0 + 2 * rp;
+    v2d ra[2], rb[2];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const long k = (long)kt * CIP_KT + q * 8 + k_ld;
+            ra[q] = *(const v2d *)(Ap + k * g.lda);
+            rb[q] = *(const v2d *)(Bp + k * g.ldb);
+        }
+    };
+    auto lstore = [&](int buf) {
+        double *la = lds + buf * (2 * CIP_KT * SB);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            *(v2d *)(la + (q * 8 + k_ld) * SB + 2 * rp) = ra[q];
+            *(v2d *)(la + CIP_KT * SB + (q * 8 + k_ld) * SB + 2 * rp) = rb[q];
+        }
+    };
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int KT = g.K / CIP_KT;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) gload(kt + 1);
+        const double *la = lds + buf * (2 * CIP_KT * SB) + wm * 32 + 2 * l15;
+        const double *lb = lds + buf * (2 * CIP_KT * SB) + CIP_KT * SB + wn * 32 + 2 * l15;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kk = ks * 4 + l4;
+            const v2d fi = *(const v2d *)(la + kk * SB);
+            const v2d fj = *(const v2d *)(lb + kk * SB);
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.x, fi.x, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.x, fi.y, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.y, fi.x, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.y, fi.y, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < KT) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // lane holds, for tile (ti,tj), reg q: row = i0 + wm*32 + 2*l15 + ti, col = j0 + wn*32 + 2*(l4 + 4q) + tj
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long col = j0 + wn * 32 + 2 * (l4 + 4 * q) + tj;
+            const long row = i0 + wm * 32 + 2 * l15;
+            double *cp = g.C + row + col * g.ldc;
+            v2d c = *(v2d *)cp;
+            c += g.alpha * (v2d){acc[0][tj][q], acc[1][tj][q]};
+            *(v2d *)cp = c;
+        }
+}
+
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.M % CIP_NB || g.N % CIP_NB || g.K % CIP_KT || g.K <= 0) {
@@ -163,6 +248,20 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
         tiles = (long)tm * (tm + 1) / 2;
     } else {
         tiles = (long)tm * tn;
+    }
+    const int by = g.by > 0 ? g.by : 1, bz = g.bz > 0 ? g.bz : 1;
+    if (by * bz > 1) {
+        if (epi != EPI_ACCUM || g.lower) { cip_set_error("gemm: batching needs the plain accumulate form"); return -1; }
+        hipLaunchKernelGGL(k_gemm_nt_128<EPI_ACCUM>, dim3((unsigned)tiles, by, bz), dim3(256), 0, s, g);
+        CIP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    if (epi == EPI_ACCUM && !g.lower && !g.overwrite && tiles < 256 && g.M % SB == 0 && g.N % SB == 0) {
+        // skinny, latency-critical: quarter-size tiles
+        const long t64 = (long)(g.M / SB) * (g.N / SB);
+        hipLaunchKernelGGL(k_gemm_nt_64, dim3((unsigned)t64), dim3(256), 0, s, g);
+        CIP_HIP_CHECK(hipGetLastError());
+        return 0;
     }
     dim3 grid((unsigned)tiles), block(256);
     switch (epi) {

@@ -67,12 +67,26 @@ int cip_ldlt_profile_collect(LdltProfile *p, double *launches, double *ms, doubl
 
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// solve block: largest of {1024, 512, 256, 128} that divides the (128-padded) order
+int cip_solve_block(int Npad) {
+    for (int b = 1024; b > CIP_NB; b >>= 1)
+        if (Npad % b == 0) return b;
+    return CIP_NB;
+}
+
 size_t cip_ldlt_ws_bytes(int Npad) {
     const size_t nblk = Npad / CIP_NB;
     size_t b = 0;
-    b += al256((size_t)Npad * CIP_NBO_MAX * 8);          // Wbuf
+    b += al256((size_t)Npad * CIP_NBO_MAX * 8) * 2;      // Wbuf (double buffered for the look-ahead)
     b += al256(nblk * CIP_NB * CIP_NB * 8) * 2;          // Linv, LinvT
     b += al256(nblk * 2048 * 8);                         // Xm
+    {
+        const int Bs = cip_solve_block(Npad);
+        const size_t nbk = Npad / Bs;
+        b += al256(nbk * (size_t)Bs * Bs * 8) * 2;       // X, XT
+        b += al256(nbk * (size_t)(Bs / 2) * (Bs / 2) * 8 + 256);   // Tt
+        b += al256((size_t)Npad * 8);                    // zbuf
+    }
     b += al256((size_t)Npad * 8) * 3;                    // dinv, dvec, tmp
     b += 256;                                            // info
     return b;
@@ -81,10 +95,18 @@ size_t cip_ldlt_ws_bytes(int Npad) {
 void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     const size_t nblk = Npad / CIP_NB;
     char *p = (char *)base;
-    ws->Wbuf = (double *)p;  p += al256((size_t)Npad * CIP_NBO_MAX * 8);
+    ws->Wbuf = (double *)p;  p += al256((size_t)Npad * CIP_NBO_MAX * 8) * 2;
     ws->Linv = (double *)p;  p += al256(nblk * CIP_NB * CIP_NB * 8);
     ws->LinvT = (double *)p; p += al256(nblk * CIP_NB * CIP_NB * 8);
     ws->Xm = (double *)p;    p += al256(nblk * 2048 * 8);
+    ws->Bs = cip_solve_block(Npad);
+    {
+        const size_t nbk = Npad / ws->Bs;
+        ws->X = (double *)p;     p += al256(nbk * (size_t)ws->Bs * ws->Bs * 8);
+        ws->XT = (double *)p;    p += al256(nbk * (size_t)ws->Bs * ws->Bs * 8);
+        ws->Tt = (double *)p;    p += al256(nbk * (size_t)(ws->Bs / 2) * (ws->Bs / 2) * 8 + 256);
+        ws->zbuf = (double *)p;  p += al256((size_t)Npad * 8);
+    }
     ws->dinv = (double *)p;  p += al256((size_t)Npad * 8);
     ws->dvec = (double *)p;  p += al256((size_t)Npad * 8);
     ws->tmp = (double *)p;   p += al256((size_t)Npad * 8);
@@ -186,76 +208,243 @@ static int launch_diag(hipStream_t s, double *Kb, long ld, double *Linv, double 
     return 0;
 }
 
+// one inner-panel sweep of an outer block: [strip update] -> diagonal kernel -> TRSM, for each 128 columns
+static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws, double *Wb, int C0,
+                               int wblk) {
+    int rc;
+    const int T = wblk / CIP_NB;
+    for (int t = 0; t < T; ++t) {
+        const int c0 = C0 + t * CIP_NB;
+        const int jb = c0 / CIP_NB;
+        if (t > 0) {
+            // left-looking strip update inside the outer block:
+            //   K[c0:, c0:c0+128] -= W[c0:, 0:128t] * L[c0:c0+128, C0:C0+128t]'
+            GemmArgs g = {};
+            g.A = Wb + c0; g.lda = Npad;
+            g.B = K + c0 + (long)C0 * ld; g.ldb = ld;
+            g.C = K + c0 + (long)c0 * ld; g.ldc = ld;
+            g.M = Npad - c0; g.N = CIP_NB; g.K = t * CIP_NB; g.alpha = -1.0; g.lower = 0;
+            if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
+        }
+        const int r = Npad - c0 - CIP_NB;
+        if (diag_version() == 2) {
+            // MFMA micro-blocked diagonal kernel + substitution TRSM (the block inverses the solves
+            // need are produced by one batched launch after the factorisation)
+            if ((rc = cip_launch_diag_v2(s, K + c0 + (long)c0 * ld, ld, ws.Xm + (size_t)jb * 2048, ws.dvec + c0,
+                                         ws.dinv + c0, ws.info, c0)))
+                return rc;
+            if ((rc = cip_launch_trsm_subst(s, K + (c0 + CIP_NB) + (long)c0 * ld, ld, r, K + c0 + (long)c0 * ld,
+                                            ws.Xm + (size_t)jb * 2048, ws.dinv + c0,
+                                            Wb + (c0 + CIP_NB) + (long)(t * CIP_NB) * Npad, Npad)))
+                return rc;
+            continue;
+        }
+        if ((rc = launch_diag(s, K + c0 + (long)c0 * ld, ld, ws.Linv + (size_t)jb * CIP_NB * CIP_NB,
+                              ws.LinvT + (size_t)jb * CIP_NB * CIP_NB, ws.dvec + c0, ws.dinv + c0, ws.info, c0)))
+            return rc;
+        if (r > 0) {
+            // W21 = A21 * inv(L11)'  ;  L21 = W21 * D^-1 (in place)
+            GemmArgs g = {};
+            g.A = K + (c0 + CIP_NB) + (long)c0 * ld; g.lda = ld;
+            g.B = ws.Linv + (size_t)jb * CIP_NB * CIP_NB; g.ldb = CIP_NB;
+            g.C = K + (c0 + CIP_NB) + (long)c0 * ld; g.ldc = ld;
+            g.W = Wb + (c0 + CIP_NB) + (long)(t * CIP_NB) * Npad; g.ldw = Npad;
+            g.dinv = ws.dinv + c0;
+            g.M = r; g.N = CIP_NB; g.K = CIP_NB; g.alpha = 1.0; g.lower = 0;
+            if ((rc = cip_launch_gemm(s, EPI_TRSM, g))) return rc;
+        }
+    }
+    return 0;
+}
+
+// Look-ahead plumbing: the panel chain (diag -> TRSM -> strip, serial, tiny grids) runs on a high-priority
+// side stream while the big trailing update of the previous outer block runs on the caller's stream.
+// One process-wide side stream and event ring (factorisations of one process are issued from one thread).
+static hipStream_t g_side = nullptr;      // panel chain: high priority, all CUs
+static hipStream_t g_upd = nullptr;       // trailing updates: CU-masked so that a few CUs stay free for the panel chain
+static hipEvent_t g_evP[2] = {nullptr, nullptr}, g_evU[2] = {nullptr, nullptr}, g_evStart = nullptr, g_evEnd = nullptr;
+static int g_lookahead = -1;
+static int lookahead_init(void) {
+    if (g_lookahead >= 0) return 0;
+    g_lookahead = getenv("CIP_NO_LOOKAHEAD") ? 0 : 1;
+    int lo = 0, hi = 0;
+    CIP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    CIP_HIP_CHECK(hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, hi));
+    for (int i = 0; i < 2; ++i) {
+        CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evP[i], hipEventDisableTiming));
+        CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evU[i], hipEventDisableTiming));
+    }
+    CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evStart, hipEventDisableTiming));
+    CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evEnd, hipEventDisableTiming));
+    // The diagonal kernel needs a whole CU's LDS (160 KB); the trailing-update GEMM keeps two 64 KB
+    // workgroups on every CU and refills each half as it frees, so without a reservation the panel
+    // chain only gets a CU in the GEMM's tail.  Keep CIP_RESERVED_CUS CUs out of the update stream.
+    if (getenv("CIP_RESERVED_CUS")) {      // off by default: measured to slow the masked GEMM far more than it helps
+        hipDeviceProp_t prop;
+        int dev = 0;
+        CIP_HIP_CHECK(hipGetDevice(&dev));
+        CIP_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        const int ncu = prop.multiProcessorCount;
+        int reserve = 16;
+        if (const char *e = getenv("CIP_RESERVED_CUS")) reserve = atoi(e);
+        if (reserve > 0 && reserve < ncu / 2) {
+            const int words = (ncu + 31) / 32;
+            uint32_t mask[32] = {0};
+            for (int c = 0; c < ncu; ++c) mask[c >> 5] |= (1u << (c & 31));
+            // leave out CUs spread over the mask (the bit -> physical CU map is not documented; any set works)
+            for (int k = 0; k < reserve; ++k) { const int c = (int)((long)k * ncu / reserve); mask[c >> 5] &= ~(1u << (c & 31)); }
+            if (hipExtStreamCreateWithCUMask(&g_upd, words, mask) != hipSuccess) { g_upd = nullptr; (void)hipGetLastError(); }
+        }
+    }
+    return 0;
+}
+
+// upper triangle <- (strictly lower triangle)': gives the forward sweep the same coalesced
+// "column-dot" access as the backward sweep (U[k, i] = L[i, k])
+__global__ __launch_bounds__(256) void k_mirror_lower(double *K, long ld) {
+    __shared__ double t[32][33];
+    const int bi = blockIdx.x, bj = blockIdx.y;      // 32x32 tile (row tile bi, column tile bj), bi >= bj
+    if (bi < bj) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int q = 0; q < 32; q += 8) t[ty + q][tx] = K[(long)(bi * 32 + tx) + (long)(bj * 32 + ty + q) * ld];
+    __syncthreads();
+    for (int q = 0; q < 32; q += 8) {
+        const int r = bj * 32 + tx, c = bi * 32 + ty + q;          // destination (r, c) = source (c, r)
+        if (c > r) K[(long)r + (long)c * ld] = t[tx][ty + q];
+    }
+}
+// X/XT diagonal 128-blocks <- Linv/LinvT
+__global__ __launch_bounds__(256) void k_seed_block_inverse(const double *Linv, const double *LinvT, double *X, double *XT,
+                                                             int Bs) {
+    const int jb = blockIdx.x;                       // 128-block index
+    const int per = Bs / CIP_NB;
+    const int q = jb / per, o = (jb % per) * CIP_NB;
+    const double *li = Linv + (size_t)jb * CIP_NB * CIP_NB, *lt = LinvT + (size_t)jb * CIP_NB * CIP_NB;
+    double *x = X + (size_t)q * Bs * Bs + o + (size_t)o * Bs, *xt = XT + (size_t)q * Bs * Bs + o + (size_t)o * Bs;
+    for (int e = threadIdx.x; e < CIP_NB * CIP_NB / 2; e += 256) {
+        const int i = 2 * (e & 63), j = e >> 6;
+        *(v2d *)(x + i + (size_t)j * Bs) = *(const v2d *)(li + i + j * CIP_NB);
+        *(v2d *)(xt + i + (size_t)j * Bs) = *(const v2d *)(lt + i + j * CIP_NB);
+    }
+}
+
+// After the factorisation: inverses of the Bs x Bs unit-lower diagonal blocks by doubling,
+//   inv([L11 0; L21 L22]) = [X11 0; -X22 L21 X11  X22],
+// three batched MFMA GEMMs per level (Tt = X11' L21', X21 = -X22 Tt', X21' = -Tt X22'), so that a
+// triangular solve is Npad/Bs block steps (8 at n = 8192) instead of Npad/128 (64).
+static int build_solve_blocks(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws) {
+    const int Bs = ws.Bs;
+    const int nbk = Npad / Bs;
+    int rc;
+    hipLaunchKernelGGL(k_mirror_lower, dim3(Npad / 32, Npad / 32), dim3(256), 0, s, K, ld);
+    if (Bs == CIP_NB) { CIP_HIP_CHECK(hipGetLastError()); return 0; }   // X == Linv, XT == LinvT
+    CIP_HIP_CHECK(hipMemsetAsync(ws.X, 0, sizeof(double) * (size_t)nbk * Bs * Bs, s));
+    CIP_HIP_CHECK(hipMemsetAsync(ws.XT, 0, sizeof(double) * (size_t)nbk * Bs * Bs, s));
+    hipLaunchKernelGGL(k_seed_block_inverse, dim3(Npad / CIP_NB), dim3(256), 0, s, ws.Linv, ws.LinvT, ws.X, ws.XT, Bs);
+    CIP_HIP_CHECK(hipGetLastError());
+    const long bs2 = (long)Bs * Bs, tt2 = (long)(Bs / 2) * (Bs / 2);
+    for (int h = CIP_NB; h < Bs; h *= 2) {
+        const int P = Bs / (2 * h);                          // pairs per block
+        const long pX = 2L * h * (Bs + 1);                   // pair stride inside a block of X / XT
+        const long pK = 2L * h * (ld + 1);                   // pair stride along the diagonal of K
+        GemmArgs g = {};
+        g.M = g.N = g.K = h; g.lower = 0; g.overwrite = 1; g.by = nbk; g.bz = P;
+        // Tt = XT11 * L21'
+        g.alpha = 1.0;
+        g.A = ws.XT; g.lda = Bs; g.sAy = bs2; g.sAz = pX;
+        g.B = K + h; g.ldb = ld; g.sBy = (long)Bs * (ld + 1); g.sBz = pK;
+        g.C = ws.Tt; g.ldc = h; g.sCy = tt2; g.sCz = (long)h * h;
+        if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
+        // X21 = -X22 * Tt'
+        g.alpha = -1.0;
+        g.A = ws.X + h + (long)h * Bs; g.lda = Bs; g.sAy = bs2; g.sAz = pX;
+        g.B = ws.Tt; g.ldb = h; g.sBy = tt2; g.sBz = (long)h * h;
+        g.C = ws.X + h; g.ldc = Bs; g.sCy = bs2; g.sCz = pX;
+        if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
+        // XT12 = X21' = -Tt * X22'
+        g.A = ws.Tt; g.lda = h; g.sAy = tt2; g.sAz = (long)h * h;
+        g.B = ws.X + h + (long)h * Bs; g.ldb = Bs; g.sBy = bs2; g.sBz = pX;
+        g.C = ws.XT + (long)h * Bs; g.ldc = Bs; g.sCy = bs2; g.sCz = pX;
+        if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
+    }
+    return 0;
+}
+
 int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws) {
     if (Npad % CIP_NB) { cip_set_error("ldlt: N must be a multiple of 128"); return -1; }
     const int NBO = g_nbo;
-    CIP_HIP_CHECK(hipMemsetAsync(ws.info, 0, sizeof(int), s));
     int rc;
-    for (int C0 = 0; C0 < Npad; C0 += NBO) {
-        const int wblk = (Npad - C0 < NBO) ? (Npad - C0) : NBO;     // width of this outer block
-        const int T = wblk / CIP_NB;
-        for (int t = 0; t < T; ++t) {
-            const int c0 = C0 + t * CIP_NB;
-            const int jb = c0 / CIP_NB;
-            if (t > 0) {
-                // left-looking strip update inside the outer block:
-                //   K[c0:, c0:c0+128] -= W[c0:, 0:128t] * L[c0:c0+128, C0:C0+128t]'
-                GemmArgs g = {};
-                g.A = ws.Wbuf + c0; g.lda = Npad;
-                g.B = K + c0 + (long)C0 * ld; g.ldb = ld;
-                g.C = K + c0 + (long)c0 * ld; g.ldc = ld;
-                g.M = Npad - c0; g.N = CIP_NB; g.K = t * CIP_NB; g.alpha = -1.0; g.lower = 0;
-                if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
-            }
-            const int r = Npad - c0 - CIP_NB;
-            if (diag_version() == 2) {
-                // MFMA micro-blocked diagonal kernel + substitution TRSM (the block inverses the solves
-                // need are produced by one batched launch after the loop)
-                if ((rc = cip_launch_diag_v2(s, K + c0 + (long)c0 * ld, ld, ws.Xm + (size_t)jb * 2048, ws.dvec + c0,
-                                             ws.dinv + c0, ws.info, c0)))
-                    return rc;
-                if ((rc = cip_launch_trsm_subst(s, K + (c0 + CIP_NB) + (long)c0 * ld, ld, r, K + c0 + (long)c0 * ld,
-                                                ws.Xm + (size_t)jb * 2048, ws.dinv + c0,
-                                                ws.Wbuf + (c0 + CIP_NB) + (long)(t * CIP_NB) * Npad, Npad)))
-                    return rc;
-                continue;
-            }
-            if ((rc = launch_diag(s, K + c0 + (long)c0 * ld, ld, ws.Linv + (size_t)jb * CIP_NB * CIP_NB,
-                                  ws.LinvT + (size_t)jb * CIP_NB * CIP_NB, ws.dvec + c0, ws.dinv + c0,
-                                  ws.info, c0)))
-                return rc;
-            if (r > 0) {
-                // W21 = A21 * inv(L11)'  ;  L21 = W21 * D^-1 (in place)
-                GemmArgs g = {};
-                g.A = K + (c0 + CIP_NB) + (long)c0 * ld; g.lda = ld;
-                g.B = ws.Linv + (size_t)jb * CIP_NB * CIP_NB; g.ldb = CIP_NB;
-                g.C = K + (c0 + CIP_NB) + (long)c0 * ld; g.ldc = ld;
-                g.W = ws.Wbuf + (c0 + CIP_NB) + (long)(t * CIP_NB) * Npad; g.ldw = Npad;
-                g.dinv = ws.dinv + c0;
-                g.M = r; g.N = CIP_NB; g.K = CIP_NB; g.alpha = 1.0; g.lower = 0;
-                if ((rc = cip_launch_gemm(s, EPI_TRSM, g))) return rc;
-            }
+    if ((rc = lookahead_init())) return rc;
+    CIP_HIP_CHECK(hipMemsetAsync(ws.info, 0, sizeof(int), s));
+    const size_t wstride = (size_t)Npad * CIP_NBO_MAX;
+    const bool la = g_lookahead && Npad > NBO;
+    hipStream_t sp = la ? g_side : s;                 // panel stream
+    hipStream_t s_user = s;
+    if (la) {
+        CIP_HIP_CHECK(hipEventRecord(g_evStart, s));
+        CIP_HIP_CHECK(hipStreamWaitEvent(sp, g_evStart, 0));
+        if (g_upd) {
+            CIP_HIP_CHECK(hipStreamWaitEvent(g_upd, g_evStart, 0));
+            s = g_upd;                                // trailing updates on the CU-masked stream
         }
+    }
+    // panel of outer block 0
+    {
+        const int wblk = (Npad < NBO) ? Npad : NBO;
+        if ((rc = factor_outer_panels(sp, K, Npad, ld, ws, ws.Wbuf, 0, wblk))) return rc;
+        if (la) CIP_HIP_CHECK(hipEventRecord(g_evP[0], sp));
+    }
+    int J = 0;
+    for (int C0 = 0; C0 < Npad; C0 += NBO, ++J) {
+        const int wblk = (Npad - C0 < NBO) ? (Npad - C0) : NBO;     // width of this outer block
         const int r0 = C0 + wblk;
-        if (r0 < Npad) {
-            // trailing update  K[r0:, r0:] -= W[r0:, 0:wblk] * L[r0:, C0:C0+wblk]'   (lower tiles)
+        if (r0 >= Npad) break;
+        const int w1 = (Npad - r0 < NBO) ? (Npad - r0) : NBO;       // width of the next outer block
+        double *Wcur = ws.Wbuf + (size_t)(J & 1) * wstride;
+        double *Wnext = ws.Wbuf + (size_t)((J + 1) & 1) * wstride;
+        if (la) CIP_HIP_CHECK(hipStreamWaitEvent(s, g_evP[J & 1], 0));
+        {
+            // U1: the column strip of the NEXT outer block first (all its rows), so that its panel
+            // factorisation can start while the rest of the trailing matrix is still being updated
             GemmArgs g = {};
-            g.A = ws.Wbuf + r0; g.lda = Npad;
+            g.A = Wcur + r0; g.lda = Npad;
             g.B = K + r0 + (long)C0 * ld; g.ldb = ld;
             g.C = K + r0 + (long)r0 * ld; g.ldc = ld;
-            g.M = Npad - r0; g.N = Npad - r0; g.K = wblk; g.alpha = -1.0; g.lower = 1;
+            g.M = Npad - r0; g.N = w1; g.K = wblk; g.alpha = -1.0; g.lower = 0;
+            if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
+        }
+        if (la) {
+            CIP_HIP_CHECK(hipEventRecord(g_evU[J & 1], s));
+            CIP_HIP_CHECK(hipStreamWaitEvent(sp, g_evU[J & 1], 0));
+        }
+        if ((rc = factor_outer_panels(sp, K, Npad, ld, ws, Wnext, r0, w1))) return rc;
+        if (la) CIP_HIP_CHECK(hipEventRecord(g_evP[(J + 1) & 1], sp));
+        const int r2 = r0 + w1;
+        if (r2 < Npad) {
+            // U2: the rest of the trailing matrix, K[r2:, r2:] -= W[r2:, :] L[r2:, C0:C0+wblk]'  (lower tiles)
+            GemmArgs g = {};
+            g.A = Wcur + r2; g.lda = Npad;
+            g.B = K + r2 + (long)C0 * ld; g.ldb = ld;
+            g.C = K + r2 + (long)r2 * ld; g.ldc = ld;
+            g.M = Npad - r2; g.N = Npad - r2; g.K = wblk; g.alpha = -1.0; g.lower = 1;
             if (ws.prof) {
                 if ((rc = prof_event(ws.prof, s))) return rc;
-                const double r = (double)(Npad - r0);
+                const double r = (double)(Npad - r2);
                 ws.prof->flops.push_back(r * (r + 1.0) * (double)wblk);   // 2 flop/MAC on the lower triangle
             }
             if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
             if (ws.prof && (rc = prof_event(ws.prof, s))) return rc;
         }
     }
-    if (diag_version() == 2)
-        return cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.Linv, ws.LinvT);
-    return 0;
+    if (la) CIP_HIP_CHECK(hipStreamWaitEvent(s, g_evP[J & 1], 0));
+    if (s != s_user) {
+        CIP_HIP_CHECK(hipEventRecord(g_evEnd, s));
+        CIP_HIP_CHECK(hipStreamWaitEvent(s_user, g_evEnd, 0));
+        s = s_user;
+    }
+    if (diag_version() == 2 && (rc = cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.Linv, ws.LinvT)))
+        return rc;
+    return build_solve_blocks(s, K, Npad, ld, ws);
 }
 
 // ---------------------------------------------------------------------------
@@ -339,15 +528,45 @@ __global__ __launch_bounds__(256) void k_solve_bwd(const double *K, long ld, con
     }
 }
 
+__global__ __launch_bounds__(256) void k_scale_vec(int n, const double *x, const double *d, double *y) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = x[i] * d[i];
+}
+
+// L D L' x = b with the Bs-block inverses: every step is two coalesced, deterministic column-dot gemvs
+//   forward   y_J = X_J b_J            (gemv_t on XT_J)      b[below] -= U[J rows, below]' y_J   (U = L' mirrored)
+//   backward  x_J = X_J' z_J           (gemv_t on X_J)       z[above] -= L[J rows, above]' x_J
+// HBM-bound: L is read once per sweep (8 N^2/2 B) plus the block inverses (8 N Bs B).
 int cip_ldlt_solve(hipStream_t s, const double *K, int Npad, long ld, const LdltWorkspace &ws, double *rhs) {
-    const int nblk = Npad / CIP_NB;
-    // forward: L y = b ; z = D^-1 y -> ws.tmp
-    for (int j = 0; j < nblk; ++j) {
-        hipLaunchKernelGGL(k_solve_fwd, dim3(nblk - j), dim3(256), 0, s, K, ld, ws.Linv, ws.dinv, rhs, ws.tmp, j);
+    if (getenv("CIP_SOLVE_V1")) {
+        const int nblk = Npad / CIP_NB;
+        for (int j = 0; j < nblk; ++j)
+            hipLaunchKernelGGL(k_solve_fwd, dim3(nblk - j), dim3(256), 0, s, K, ld, ws.Linv, ws.dinv, rhs, ws.tmp, j);
+        for (int j = nblk - 1; j >= 0; --j)
+            hipLaunchKernelGGL(k_solve_bwd, dim3(j + 1), dim3(256), 0, s, K, ld, ws.LinvT, ws.tmp, rhs, j);
+        CIP_HIP_CHECK(hipGetLastError());
+        return 0;
     }
-    // backward: L' x = z -> rhs
-    for (int j = nblk - 1; j >= 0; --j) {
-        hipLaunchKernelGGL(k_solve_bwd, dim3(j + 1), dim3(256), 0, s, K, ld, ws.LinvT, ws.tmp, rhs, j);
+    const int Bs = ws.Bs;
+    const int nbk = Npad / Bs;
+    const double *X = (Bs == CIP_NB) ? ws.Linv : ws.X;
+    const double *XT = (Bs == CIP_NB) ? ws.LinvT : ws.XT;
+    const size_t bs2 = (size_t)Bs * Bs;
+    int rc;
+    double *y = ws.tmp, *z = ws.zbuf;
+    for (int J = 0; J < nbk; ++J) {
+        const long C0 = (long)J * Bs;
+        if ((rc = cip_gemv_t(s, Bs, Bs, 1.0, XT + J * bs2, Bs, rhs + C0, 0.0, y + C0))) return rc;
+        const int below = Npad - (int)C0 - Bs;
+        if (below > 0 &&
+            (rc = cip_gemv_t(s, Bs, below, -1.0, K + C0 + (C0 + Bs) * ld, ld, y + C0, 1.0, rhs + C0 + Bs)))
+            return rc;
+    }
+    hipLaunchKernelGGL(k_scale_vec, dim3((Npad + 255) / 256), dim3(256), 0, s, Npad, y, ws.dinv, z);
+    for (int J = nbk - 1; J >= 0; --J) {
+        const long C0 = (long)J * Bs;
+        if ((rc = cip_gemv_t(s, Bs, Bs, 1.0, X + J * bs2, Bs, z + C0, 0.0, rhs + C0))) return rc;
+        if (C0 > 0 && (rc = cip_gemv_t(s, Bs, (int)C0, -1.0, K + C0, ld, rhs + C0, 1.0, z))) return rc;
     }
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
