@@ -41,6 +41,8 @@ struct GemmArgs {
     int by, bz;
     long sAy, sAz, sBy, sBz, sCy, sCz;
     int overwrite;               // EPI_ACCUM: C = alpha*acc instead of C += alpha*acc
+    unsigned *queue_counter;     // non-NULL: persistent work-queue form (look-ahead trailing update)
+    int reserve;                 // 1: keep one CU per XCD free, 2: two
 };
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g);
 
@@ -64,6 +66,7 @@ struct LdltWorkspace {        // carved out of one device allocation
     double *dvec;             // Npad   d
     double *tmp;              // Npad   scratch vector for the solves
     int *info;                // device int: 0 ok, >0 = 1-based column of a bad pivot
+    unsigned *qcounter;       // device tile counter of the work-queue trailing update
     LdltProfile *prof;        // host object or NULL
 };
 int cip_solve_block(int Npad);

@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, do
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
 
+    __builtin_amdgcn_s_setprio(3);
     if (!(DIAG_SKIP & 16)) diag_load_block(a, Kb, ld, tid);
     __syncthreads();
 
@@ -265,8 +266,12 @@ __global__ __launch_bounds__(256) void k_diag_inverse_batched(const double *K, l
 //   T = A21[:,kb] - sum_{q<kb} W[:,q] L11[kb][q]'      (4 kb MFMAs, operands straight from L2)
 //   W[:,kb] = T inv(L11[kb][kb])'                       (4 MFMAs with the micro inverse)
 // Half the flops of the inverse-GEMM form, 4x more workgroups, no 128x128 inverse on the critical path.
-__global__ __launch_bounds__(256) void k_trsm_subst(double *Ap, long ld, const double *L11, const double *xm,
-                                                     const double *dinv, double *W, long ldw) {
+// Register budget: <= 96 VGPRs (launch bound 5 waves/SIMD) so that these workgroups co-reside with the two
+// 208-register GEMM workgroups of the look-ahead trailing update on any CU.
+__global__ __launch_bounds__(256, 5) void k_trsm_subst(double *__restrict__ Ap, long ld, const double *__restrict__ L11,
+                                                        const double *__restrict__ xm, const double *__restrict__ dinv,
+                                                        double *__restrict__ W, long ldw) {
+    __builtin_amdgcn_s_setprio(3);       // panel chain is latency-critical: win issue arbitration against co-resident GEMM waves
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const long row = (long)blockIdx.x * 64 + wave * 16 + l15;

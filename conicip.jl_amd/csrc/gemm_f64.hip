@@ -31,9 +31,21 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 
+// linear tile index -> (block row, block column): row-major over the lower triangle, or column-major rectangle
+__device__ __forceinline__ void tile_coords(int t, int lower, int tm, int &bi, int &bj) {
+    if (lower) {
+        bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((long)bi * (bi + 1) / 2 > t) --bi;
+        while ((long)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
+        bj = t - (int)((long)bi * (bi + 1) / 2);
+    } else {
+        bi = t % tm;
+        bj = t / tm;
+    }
+}
+
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void k_gemm_nt_128(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * LDS_TILE];   // 64 KB
+__device__ __forceinline__ void gemm_tile_128(GemmArgs &g, double *lds, int bi, int bj) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -41,19 +53,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_128(GemmArgs g) {
     const int wm = wave & 1, wn = wave >> 1;
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    // ---- tile coordinates
-    int t = xcd_remap(blockIdx.x, gridDim.x);
-    int bi, bj;
-    if (g.lower) {
-        bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while ((long)bi * (bi + 1) / 2 > t) --bi;
-        while ((long)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
-        bj = t - (int)((long)bi * (bi + 1) / 2);
-    } else {
-        const int tm = g.M / CIP_NB;
-        bi = t % tm;
-        bj = t / tm;
-    }
     const long i0 = (long)bi * CIP_NB, j0 = (long)bj * CIP_NB;
     if (EPI == EPI_ACCUM) {       // batched problems: grid.y x grid.z
         g.A += blockIdx.y * g.sAy + blockIdx.z * g.sAz;
@@ -155,6 +154,42 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_128(GemmArgs g) {
     }
 }
 
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_128(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * LDS_TILE];   // 64 KB
+    int bi, bj;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), g.lower, g.M / CIP_NB, bi, bj);
+    gemm_tile_128<EPI>(g, lds, bi, bj);
+}
+
+// Persistent form of the trailing update for the look-ahead: 2 workgroups per CU pull tiles from an
+// atomic counter, and workgroups that find themselves on a RESERVED CU (one per XCD: SE 0, CU 0 of every
+// XCC, read from HW_ID / XCC_ID) exit at once.  The reserved CUs stay empty for the whole launch, so the
+// serial panel chain of the next outer block (whose diagonal kernel needs a CU's entire LDS) starts
+// immediately on the high-priority side stream instead of waiting for the GEMM's tail.  Placement is used
+// for speed only: any workgroup can take any tile.
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_128_queue(GemmArgs g, int ntiles, unsigned *counter, int reserve) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * LDS_TILE];   // 64 KB
+    __shared__ int s_tile;
+    if (reserve) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID: cu [11:8], se [15:13]
+        const unsigned cu = (hw >> 8) & 0xf, se = (hw >> 13) & 0x7;
+        if (cu == 0 && (se == 0 || (reserve > 1 && se == 2))) return;
+    }
+    const int tm = g.M / CIP_NB;
+    while (true) {
+        if (threadIdx.x == 0) s_tile = (int)atomicAdd(counter, 1u);
+        __syncthreads();
+        const int t = s_tile;
+        if (t >= ntiles) return;
+        int bi, bj;
+        tile_coords(t, g.lower, tm, bi, bj);
+        GemmArgs gt = g;
+        gemm_tile_128<EPI_ACCUM>(gt, lds, bi, bj);
+        __syncthreads();      // LDS buffers and s_tile are reused by the next tile
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Small-tile variant (64x64 C tile, wave = 32x32 = 2x2 MFMA tiles) for the latency-critical skinny
 // updates on the factorisation's critical path (look-ahead column strip, in-block strip update):
@@ -163,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_128(GemmArgs g) {
 #define SB 64
 __global__ __launch_bounds__(256, 4) void k_gemm_nt_64(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
+    __builtin_amdgcn_s_setprio(3);       // skinny critical-path updates: priority over co-resident trailing-update waves
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -253,6 +289,12 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     if (by * bz > 1) {
         if (epi != EPI_ACCUM || g.lower) { cip_set_error("gemm: batching needs the plain accumulate form"); return -1; }
         hipLaunchKernelGGL(k_gemm_nt_128<EPI_ACCUM>, dim3((unsigned)tiles, by, bz), dim3(256), 0, s, g);
+        CIP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    if (epi == EPI_ACCUM && g.lower && g.queue_counter && tiles >= 512) {
+        CIP_HIP_CHECK(hipMemsetAsync(g.queue_counter, 0, sizeof(unsigned), s));
+        hipLaunchKernelGGL(k_gemm_nt_128_queue, dim3(512), dim3(256), 0, s, g, (int)tiles, g.queue_counter, g.reserve);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }

@@ -111,6 +111,7 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     ws->dvec = (double *)p;  p += al256((size_t)Npad * 8);
     ws->tmp = (double *)p;   p += al256((size_t)Npad * 8);
     ws->info = (int *)p;
+    ws->qcounter = (unsigned *)(p + 64);
     ws->prof = nullptr;
 }
 
@@ -264,9 +265,11 @@ static hipStream_t g_side = nullptr;      // panel chain: high priority, all CUs
 static hipStream_t g_upd = nullptr;       // trailing updates: CU-masked so that a few CUs stay free for the panel chain
 static hipEvent_t g_evP[2] = {nullptr, nullptr}, g_evU[2] = {nullptr, nullptr}, g_evStart = nullptr, g_evEnd = nullptr;
 static int g_lookahead = -1;
+static int g_reserve = 0;                 // CUs per XCD kept free by the work-queue trailing update (0 = plain launch)
 static int lookahead_init(void) {
     if (g_lookahead >= 0) return 0;
     g_lookahead = getenv("CIP_NO_LOOKAHEAD") ? 0 : 1;
+    if (const char *e = getenv("CIP_RESERVE")) g_reserve = atoi(e);
     int lo = 0, hi = 0;
     CIP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     CIP_HIP_CHECK(hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, hi));
@@ -427,6 +430,7 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
             g.B = K + r2 + (long)C0 * ld; g.ldb = ld;
             g.C = K + r2 + (long)r2 * ld; g.ldc = ld;
             g.M = Npad - r2; g.N = Npad - r2; g.K = wblk; g.alpha = -1.0; g.lower = 1;
+            if (la && g_reserve) { g.queue_counter = ws.qcounter; g.reserve = g_reserve; }
             if (ws.prof) {
                 if ((rc = prof_event(ws.prof, s))) return rc;
                 const double r = (double)(Npad - r2);
