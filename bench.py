@@ -59,6 +59,26 @@ def cpu_baseline(Q_host, n, solves_per_factor, budget_s=40.0):
     from oracle.kktsolvers import kktsolver_qr
     import scipy.linalg as sla
     cores = os.cpu_count() or 1
+    # OpenBLAS does not scale to every hardware thread of a 2-socket box: probe a dgemm at a few
+    # thread counts and run the baseline at the fastest one (reported as `cores`).
+    limiter = None
+    try:
+        from threadpoolctl import threadpool_limits
+        rngp = np.random.default_rng(0)
+        Mp = rngp.standard_normal((2048, 2048))
+        best = (1e30, cores)
+        for nt in sorted({c for c in (8, 16, 32, 64, 128, cores) if c <= cores}):
+            with threadpool_limits(limits=nt):
+                Mp @ Mp
+                t0 = time.perf_counter()
+                Mp @ Mp
+                dt = time.perf_counter() - t0
+            if dt < best[0]:
+                best = (dt, nt)
+        cores = best[1]
+        limiter = threadpool_limits(limits=cores)
+    except Exception:
+        pass
 
     def one(nn):
         rng = np.random.default_rng(1)
@@ -95,6 +115,8 @@ def cpu_baseline(Q_host, n, solves_per_factor, budget_s=40.0):
     strong_s = t["strong"] * (n / nn) ** 3
     sample = ("1 factorisation + %d solves of the kktsolver_qr restatement at n=%d%s (level-1 setup %.2fs excluded)"
               % (solves_per_factor, nn, "" if nn == n else " scaled to n=%d by (n/n_s)^3" % n, t["level1"]))
+    if limiter is not None:
+        limiter.restore_original_limits()
     return dict(value=1.0 / step_s, unit="KKT solves/s", cores=cores, kind="port", sample=sample,
                 strong_cpu_value=1.0 / strong_s,
                 strong_cpu_note="Schur + LAPACK Cholesky (same elimination route as the GPU), same sample"), pred_full

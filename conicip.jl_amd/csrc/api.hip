@@ -27,7 +27,7 @@ static int rup(int x, int q) { return ((x + q - 1) / q) * q; }
     } while (0)
 
 static void free_all(cip_handle *h) {
-    void *ptrs[] = {h->Q, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->row_cone, h->G, h->Gt,
+    void *ptrs[] = {h->cs.d_sidx, h->cs.d_sdpws, h->cs.d_sdpvec, h->cs.d_sdpflag, h->Q, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->row_cone, h->G, h->Gt,
                     h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->cs.d_partial, h->cs.d_scalar, h->K, h->Wt, h->Gm,
                     h->ws_base, h->rhs, h->mt1, h->mt2, h->mt3, h->nt1, h->pt1, h->dot_scratch, h->dot_ptrs, h->stage};
     for (void *p : ptrs)
@@ -90,6 +90,8 @@ static int create_impl(const cip_problem *pr, cip_handle *h) {
     int off = 0, nq = 0;
     size_t soff = 0;
     bool has_S = false;
+    std::vector<int> sidx;
+    int rmax = 0, kmax = 0;
     for (int c = 0; c < pr->ncones; ++c) {
         ConeDesc cd = {};
         cd.type = pr->cone_type[c]; cd.dim = pr->cone_dim[c]; cd.off = off; cd.soff = (int)soff; cd.r = 0; cd.qidx = -1;
@@ -100,18 +102,22 @@ static int create_impl(const cip_problem *pr, cip_handle *h) {
             const int r = (int)llround((sqrt(1.0 + 8.0 * cd.dim) - 1.0) / 2.0);     // ord() src/ConicIP.jl:85
             if (r * (r + 1) / 2 != cd.dim) { cip_set_error("S cone %d: %d is not a triangular number", c, cd.dim); return CIP_E_INVALID; }
             cd.r = r; soff += 2 * (size_t)r * r; has_S = true;
+            sidx.push_back(c);
+            if (r > rmax) rmax = r;
+            if (cd.dim > kmax) kmax = cd.dim;
         } else { cip_set_error("cone %d: unknown type %d", c, cd.type); return CIP_E_INVALID; }
         if (soff > 0x7fffffffULL) { cip_set_error("scaling storage too large"); return CIP_E_INVALID; }
+        cd.item = (int)h->h_items.size();
         h->h_cones.push_back(cd);
         if (cd.type == CIP_CONE_R) {
             for (int st = 0; st < cd.dim; st += 2048) h->h_items.push_back(WorkItem{c, st, (cd.dim - st < 2048) ? cd.dim - st : 2048});
-        } else if (cd.type == CIP_CONE_Q) {
-            h->h_items.push_back(WorkItem{c, 0, cd.dim});
+        } else {
+            h->h_items.push_back(WorkItem{c, 0, cd.dim});       // Q and S cones: one item per cone
         }
         off += cd.dim;
     }
     if (off != m) { cip_set_error("cone_dims cover %d rows but A has %d", off, m); return CIP_E_INVALID; }
-    if (has_S) { cip_set_error("S cones are not implemented on the device yet"); return CIP_E_UNSUPPORTED; }
+    if (has_S && pr->A == NULL && m > 0) { cip_set_error("S cones need a dense A"); return CIP_E_UNSUPPORTED; }
     h->nq = nq; h->nqpad = rup(nq > 0 ? nq : 1, CIP_KT);
     h->cs.ncones = pr->ncones; h->cs.nitems = (int)h->h_items.size(); h->cs.m = m; h->cs.scal_len = soff; h->cs.has_S = has_S;
     DMALLOC(h->cs.d_cones, sizeof(ConeDesc) * h->h_cones.size());
@@ -119,6 +125,17 @@ static int create_impl(const cip_problem *pr, cip_handle *h) {
     DMALLOC(h->cs.d_scal, sizeof(double) * soff);
     DMALLOC(h->cs.d_partial, sizeof(double) * (h->h_items.size() + 1));
     DMALLOC(h->cs.d_scalar, sizeof(double) * 8);
+    h->cs.ns = (int)sidx.size(); h->cs.rmax = rmax; h->cs.kmax = kmax;
+    if (has_S) {
+        const int per = n < 64 ? n : 64;
+        h->cs.sdp_slots = h->cs.ns * (per > 0 ? per : 1);
+        DMALLOC(h->cs.d_sidx, sizeof(int) * sidx.size());
+        CIP_HIP_CHECK(hipMemcpy(h->cs.d_sidx, sidx.data(), sizeof(int) * sidx.size(), hipMemcpyHostToDevice));
+        DMALLOC(h->cs.d_sdpws, sizeof(double) * (size_t)h->cs.sdp_slots * 6 * rmax * rmax);
+        DMALLOC(h->cs.d_sdpvec, sizeof(double) * (size_t)h->cs.sdp_slots * 2 * kmax);
+        DMALLOC(h->cs.d_sdpflag, sizeof(int) * 4);
+        CIP_HIP_CHECK(hipMemset(h->cs.d_sdpflag, 0, sizeof(int) * 4));
+    }
     if (!h->h_cones.empty())
         CIP_HIP_CHECK(hipMemcpy(h->cs.d_cones, h->h_cones.data(), sizeof(ConeDesc) * h->h_cones.size(), hipMemcpyHostToDevice));
     if (!h->h_items.empty())

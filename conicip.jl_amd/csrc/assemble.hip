@@ -160,6 +160,8 @@ static int assemble_schur(cip_handle *h) {
     return 0;
 }
 
+int cip_sdp_fill_ftf(hipStream_t s, const ConeSet &cs, double *K, long ldk);     // sdp.hip
+
 static int assemble_full(cip_handle *h) {
     hipStream_t s = h->stream;
     const int n = h->n, m = h->m, p = h->p;
@@ -167,6 +169,7 @@ static int assemble_full(cip_handle *h) {
     if (h->cs.nitems > 0)
         hipLaunchKernelGGL(k_fill_ftf, dim3(h->cs.nitems), dim3(256), 0, s, h->cs.d_cones, h->cs.d_items, h->cs.d_scal,
                            h->K, h->ldk);
+    if (h->cs.has_S) { int rc = cip_sdp_fill_ftf(s, h->cs, h->K, h->ldk); if (rc) return rc; }
     if (m > 0 && n > 0) {
         if (!h->A_sparse)
             hipLaunchKernelGGL(k_copy_block, dim3((n + 255) / 256, m < 32768 ? m : 32768), dim3(256), 0, s, h->K, h->ldk, m, 0, h->At,

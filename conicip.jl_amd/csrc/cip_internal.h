@@ -85,6 +85,7 @@ struct ConeDesc {             // one per cone
     int soff;                 // offset into the packed scaling storage
     int r;                    // S cone: matrix order
     int qidx;                 // Q cone: running index among Q cones (else -1)
+    int item;                 // index of this cone's (first) work item
 };
 struct WorkItem {             // unit of work for the per-cone kernels
     int cone;                 // index into ConeDesc[]
@@ -100,6 +101,13 @@ struct ConeSet {
     double *d_partial;        // nitems doubles (reductions)
     double *d_scalar;         // 8 doubles
     int has_S;
+    // S cones (sdp.hip)
+    int ns, rmax, kmax;       // number of S cones, largest matrix order / vectorised length
+    int *d_sidx;              // device: cone index of every S cone
+    int sdp_slots;            // workgroup workspace slots
+    double *d_sdpws;          // sdp_slots x 6 x rmax^2
+    double *d_sdpvec;         // sdp_slots x 2 x kmax
+    int *d_sdpflag;           // device int: Cholesky failure (iterate left the cone)
 };
 int cip_cones_nt_scaling(hipStream_t s, const ConeSet &cs, const double *v, const double *sv, double *lambda);
 int cip_cones_identity_scaling(hipStream_t s, const ConeSet &cs);

@@ -281,6 +281,8 @@ __global__ __launch_bounds__(256) void k_maxstep(const ConeDesc *cones, const Wo
             const double alpha = sqrt(r2) * rg - rho1;
             if (tid == 0) partial[blockIdx.x] = (alpha < 0) ? INF : 1.0 / alpha;
         }
+    } else {
+        if (tid == 0) partial[blockIdx.x] = INF;      // S cone: written by k_sdp_maxstep afterwards
     }
 }
 

@@ -91,7 +91,7 @@ def test_hip_cone_kernels_match_golden():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["sphere", "combined", "simplex", "soc_direct", "lp_doc"])
+@pytest.mark.parametrize("name", ["sphere", "combined", "simplex", "soc_direct", "lp_doc", "psd_projection"])
 def test_hip_driver_matches_golden_trajectory(name):
     import cipkkt
     t = TRAJ[name]

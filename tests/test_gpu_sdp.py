@@ -1,0 +1,170 @@
+"""GPU parity for the semidefinite cone: scaling / operator / Jordan algebra / max-step kernels
+against the oracle (restatement of src/ConicIP.jl:35-40, :69, :196-210, :272-303, :347-360) and the
+reference's SDP known-answer test (test/runtests.jl:527-552) through the product driver."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import problems as P
+from oracle import cones as oc
+from oracle.block import VecCongurance
+from oracle.conicip import conicIP as oracle_conicIP, make_cone_ops
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float64, device="cuda")
+
+
+def psd_vec(r, rng, shift=0.5):
+    M = rng.standard_normal((r, r))
+    return oc.vecm(M @ M.T / r + shift * np.eye(r))
+
+
+def interior(cone_dims, rng):
+    out = []
+    for t, k in cone_dims:
+        if t == "R":
+            out.append(rng.random(k) + 0.1)
+        elif t == "Q":
+            x = rng.standard_normal(k)
+            x[0] = np.linalg.norm(x[1:]) + 0.3
+            out.append(x)
+        else:
+            out.append(psd_vec(oc.ord_(np.zeros(k)), rng))
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("cone_dims", [[("S", 6)], [("S", 21)], [("S", 15), ("S", 3)],
+                                       [("R", 5), ("Q", 4), ("S", 10)], [("S", 465)]],
+                         ids=["r3", "r6", "r5+r2", "mixed", "r30"])
+def test_sdp_cone_ops(cone_dims):
+    import cipkkt
+    from cipkkt import OP_F, OP_FT, OP_FINV, OP_FINVT
+    rng = np.random.default_rng(17)
+    m = sum(k for _, k in cone_dims)
+    n = 4
+    ks = cipkkt.KKTSystem(np.eye(n), rng.standard_normal((m, n)), None, cone_dims)
+    maxstep, nt_scaling, cone_div, cone_prod = make_cone_ops(cone_dims)
+    v, s = interior(cone_dims, rng), interior(cone_dims, rng)
+    lam = torch.zeros(m, dtype=torch.float64, device="cuda")
+    ks.set_scaling_from_iterate(dev(v), dev(s), lam)
+    F = nt_scaling(v, s)
+    lam_h = lam.cpu().numpy()
+    # lambda is unique up to the ordering of the eigenvalues inside each S block: compare F'F-invariant quantities
+    off = 0
+    for (t, k), blk in zip(cone_dims, F.Blocks):
+        ref = F.mul(v)[off:off + k]
+        if t == "S":
+            np.testing.assert_allclose(np.sort(np.linalg.eigvalsh(oc.mat(lam_h[off:off + k]))),
+                                       np.sort(np.linalg.eigvalsh(oc.mat(ref))), rtol=1e-9, atol=1e-11)
+        else:
+            np.testing.assert_allclose(lam_h[off:off + k], ref, rtol=1e-10, atol=1e-12)
+        off += k
+    x = rng.standard_normal(m)
+    dx = dev(x)
+    t1 = torch.zeros_like(dx)
+    t2 = torch.zeros_like(dx)
+    # F'F x is invariant under the column ambiguity of R
+    ks.apply_F(OP_F, dx, t1)
+    ks.apply_F(OP_FT, t1, t2)
+    np.testing.assert_allclose(t2.cpu().numpy(), F.tmul(F.mul(x)), rtol=1e-8, atol=1e-9)
+    # F^-1 F = I, F^-T F' = I, and F v = F^-T s (the defining property, src/ConicIP.jl:591-592)
+    ks.apply_F(OP_FINV, t1, t2)
+    np.testing.assert_allclose(t2.cpu().numpy(), x, rtol=1e-8, atol=1e-9)
+    ks.apply_F(OP_FT, dx, t1)
+    ks.apply_F(OP_FINVT, t1, t2)
+    np.testing.assert_allclose(t2.cpu().numpy(), x, rtol=1e-8, atol=1e-9)
+    ks.apply_F(OP_FINVT, dev(s), t1)
+    np.testing.assert_allclose(t1.cpu().numpy(), lam_h, rtol=1e-7, atol=1e-8)
+    # Jordan product / division
+    y = interior(cone_dims, rng)
+    ks.cone_prod(dx, dev(y), t1)
+    np.testing.assert_allclose(t1.cpu().numpy(), cone_prod(x, y), rtol=1e-11, atol=1e-11)
+    ks.cone_div(dx, dev(y), t1)
+    np.testing.assert_allclose(t1.cpu().numpy(), cone_div(x, y), rtol=1e-8, atol=1e-9)
+    # max step
+    d = rng.standard_normal(m)
+    for scale in (1.0, 1.0 / 0.99):
+        got, ref = ks.maxstep(dev(v), dev(d), scale), maxstep(v, d * scale)
+        assert got == pytest.approx(ref, rel=1e-8)
+    assert ks.maxstep(dev(v), None) == 0.0
+    assert ks.maxstep(dx, None) == pytest.approx(maxstep(x, None), rel=1e-9)
+    # identity element and identity scaling
+    e = torch.zeros(m, dtype=torch.float64, device="cuda")
+    ks.cone_identity(e)
+    from oracle.conicip import cone_identity
+    np.testing.assert_array_equal(e.cpu().numpy(), cone_identity(cone_dims)[0])
+    ks.set_scaling_identity()
+    ks.apply_F(OP_F, dx, t1)
+    np.testing.assert_allclose(t1.cpu().numpy(), x, rtol=1e-14, atol=1e-15)
+    ks.close()
+
+
+def test_maxstep_sdc_infinite():
+    """test/runtests.jl:79-82: X = -I is not PD -> Inf."""
+    import cipkkt
+    ks = cipkkt.KKTSystem(np.eye(2), np.zeros((6, 2)), None, [("S", 6)])
+    assert ks.maxstep(dev(oc.vecm(-np.eye(3))), dev(oc.vecm(np.eye(3)))) == np.inf
+    ks.close()
+
+
+@pytest.mark.parametrize("route", ["schur", "full3x3"])
+def test_kkt_solve_with_s_cone(route):
+    """level-2/3 with a VecCongurance block handed over in packed form (R, inv(R))."""
+    import cipkkt
+    from oracle.kktsolvers import kktsolver_qr
+    rng = np.random.default_rng(4)
+    cone_dims = [("R", 4), ("S", 10), ("Q", 3)]
+    m = 17
+    n, p = 9, 2
+    M = rng.standard_normal((n, n))
+    Q = M @ M.T / n + np.eye(n)
+    A = rng.standard_normal((m, n))
+    G = rng.standard_normal((p, n))
+    _, nt_scaling, _, _ = make_cone_ops(cone_dims)
+    F = nt_scaling(interior(cone_dims, rng), interior(cone_dims, rng))
+    x, y, z = rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(m)
+    ref = np.concatenate(kktsolver_qr(Q, A, G, cone_dims)(F, F.inv_adjoint())(x, y, z))
+    solver = cipkkt.kktsolver_hip if route == "schur" else cipkkt.kktsolver_hip_full3x3
+    gen = solver(Q, A, G, cone_dims)
+    got = np.concatenate(gen(F, F.inv_adjoint())(x, y, z))
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-9
+    gen.system.close()
+
+
+@pytest.mark.parametrize("route", ["schur", "full3x3"])
+def test_psd_projection_kat(route):
+    """test/runtests.jl:527-552: projection of diag(1,1,1,-1,-1,-1) onto the PSD cone."""
+    import cipkkt
+    Q, c, A, b, K, G, d, y = P.psd_projection()
+    sol = cipkkt.conicIP(Q, c, A, b, K, G, d, optTol=1e-7, kktsolver=route)
+    ref = oracle_conicIP(Q, c, A, b, K, G, d, optTol=1e-7)
+    assert sol.status == "Optimal"
+    assert np.abs(oc.mat(sol.y) - oc.mat(y)).max() < 1e-3            # the reference's assertion
+    assert sol.Iter == ref.Iter == 6                                  # the pinned Iter (:547)
+    np.testing.assert_allclose(sol.y, ref.y, rtol=1e-6, atol=1e-8)
+    for key, val in dict(prFeas=4.2341217602756234e-16, Mu=3.4583513329836624e-10,
+                         muFeas=1.48267911727847e-9, duFeas=4.2341217602756234e-16).items():
+        assert abs(getattr(sol, key) - val) < 1e-3
+
+
+def test_mixed_rqs_problem():
+    """benchmark/profile.jl:116-131 pattern (R + Q + S cones, A = I) against the oracle."""
+    import cipkkt
+    rng = np.random.default_rng(42)
+    n_r, n_q, k_s = 50, 21, 5
+    n_s = k_s * (k_s + 1) // 2
+    n = m = n_r + n_q + n_s
+    Q = sp.identity(n, format="csr")
+    c = rng.standard_normal(n)
+    A = sp.identity(m, format="csr")
+    b = np.concatenate([np.zeros(n_r), [-1.0], np.zeros(n_q - 1), np.zeros(n_s)])
+    K = [("R", n_r), ("Q", n_q), ("S", n_s)]
+    ref = oracle_conicIP(Q, c, A, b, K, optTol=1e-7)
+    sol = cipkkt.conicIP(Q, c, A, b, K, optTol=1e-7)
+    assert sol.status == ref.status == "Optimal"
+    assert sol.Iter == ref.Iter
+    np.testing.assert_allclose(sol.y, ref.y, rtol=1e-6, atol=1e-8)
