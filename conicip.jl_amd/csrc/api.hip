@@ -225,6 +225,7 @@ static int create_impl(const cip_problem *pr, cip_handle *h) {
     DMALLOC(h->K, sizeof(double) * (size_t)h->ldk * h->Npad);
     DMALLOC(h->ws_base, cip_ldlt_ws_bytes(h->Npad));
     cip_ldlt_ws_carve(h->ws_base, h->Npad, &h->ws);
+    h->ws.x_zeroed = &h->x_zeroed;
     DMALLOC(h->rhs, sizeof(double) * h->Npad);
     DMALLOC(h->mt1, sizeof(double) * m); DMALLOC(h->mt2, sizeof(double) * m); DMALLOC(h->mt3, sizeof(double) * m);
     DMALLOC(h->nt1, sizeof(double) * n); DMALLOC(h->pt1, sizeof(double) * p);

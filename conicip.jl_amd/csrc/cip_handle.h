@@ -34,6 +34,7 @@ struct cip_handle {
     double *Gm = nullptr;           // npad x nqpad  rank-1 columns of the Q cones (sparse-A Schur route)
     void *ws_base = nullptr; LdltWorkspace ws = {};
     bool assembled = false, factored = false;
+    int x_zeroed = 0;               // block-inverse storage zero-initialised
 
     // ---- scratch
     double *rhs = nullptr;          // Npad

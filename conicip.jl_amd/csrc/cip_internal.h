@@ -62,6 +62,7 @@ struct LdltWorkspace {        // carved out of one device allocation
     double *X, *XT;           // (Npad/Bs) x Bs x Bs   inverse (and its transpose) of each Bs x Bs unit-lower diagonal block
     double *Tt;               // (Npad/Bs) x (Bs/2)^2  scratch of the block-inverse doubling
     double *zbuf;             // Npad scratch
+    int *x_zeroed;            // host flag owned by the handle (NULL: zero X/XT on every factorisation)
     double *dinv;             // Npad   1/d
     double *dvec;             // Npad   d
     double *tmp;              // Npad   scratch vector for the solves

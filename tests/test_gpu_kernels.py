@@ -102,7 +102,7 @@ def _ldlt_roundtrip(lib, Kmat, nbo):
     torch.cuda.synchronize()
     x = drhs.cpu().numpy()
     res = np.linalg.norm(Kmat @ x - rhs) / (np.linalg.norm(Kmat, 2) * np.linalg.norm(x))
-    lib.cip_set_ldlt_outer_block(256)
+    lib.cip_set_ldlt_outer_block(512)
     return err, res, D
 
 
