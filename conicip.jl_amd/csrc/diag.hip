@@ -42,26 +42,75 @@ __device__ __forceinline__ double fast_rcp(double d) {
 }
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-// step B for one owned row tile: returns -W in wneg (operand layout), writes L into the LDS image
+__device__ __forceinline__ double shfl_d(double x, int src) { return __shfl(x, src, 64); }
+
+// Step A: LDL' of the 16x16 diagonal micro-block kb and the inverse X of its unit-lower factor, by one wave.
+// The tile is held in the f64-MFMA accumulator layout -- lane (row i = l15, group g) owns columns g, g+4, g+8,
+// g+12 -- so each of the 16 pivot steps costs a quarter of the column updates per lane; the pivot is broadcast
+// with v_readlane, the pivot column / pivot row entries move between lane groups with ds_bpermute.  X is updated
+// right-looking by the same multipliers (lane (cc = l15, g) owns rows g+4q of column cc).
+__device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int lane, int *info, int col0) {
+    const int l15 = lane & 15, g = lane >> 4;
+    const int c = kb * 16;
+    double u[4], x[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        u[q] = a[(c + l15) + (c + g + 4 * q) * DP];
+        x[q] = (g + 4 * q == l15) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < ((DIAG_SKIP & 8) ? 0 : 16); ++j) {
+        const int gj = j & 3, qj = j >> 2;
+        const double d = rlane(u[qj], 16 * gj + j);
+        const double di = fast_rcp(d);
+        const double wi = shfl_d(u[qj], 16 * gj + l15);        // a[i][j], own row
+        const double xj = shfl_d(x[qj], 16 * gj + l15);        // X[j][cc], own column
+        const double ti = wi * di;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (4 * q + 3 > j) {                               // some lane group still has column g+4q > j
+                const double cj = shfl_d(u[qj], 16 * gj + ((g + 4 * q) & 15));   // a[g+4q][j]
+                if (g + 4 * q > j) {
+                    u[q] -= ti * cj;
+                    x[q] -= (cj * di) * xj;
+                }
+            }
+        }
+        if (g == gj) u[qj] = (l15 == j) ? d : ti;              // column j final: l_ij below, d on the diagonal
+    }
+    double dsel = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int col = g + 4 * q;
+        if (col <= l15) a[(c + l15) + (c + col) * DP] = u[q];
+        if (col == l15) dsel = u[q];
+        xm[kb * 256 + l15 * 16 + col] = x[q];                  // xm[k = cc][jj = r] = X[r][cc]
+    }
+    if (g == (l15 & 3)) {
+        if (!(fabs(dsel) > 0.0 && fabs(dsel) < 1.7e308)) atomicCAS(info, 0, col0 + c + l15 + 1);
+        a[128 + (c + l15) * DP] = dsel;
+        a[129 + (c + l15) * DP] = fast_rcp(dsel);
+    }
+}
+
+// step B for one row tile: W = U inv(L11)' (4 MFMAs), L = W D^-1 written back into the LDS image
 __device__ __forceinline__ void diag_step_b(double *a, int it, int c, int l15, int g, const double (&xa)[4],
-                                            const double (&di4)[4], double (&wneg)[4]) {
+                                            const double (&di4)[4]) {
     double *p = a + (it * 16 + l15) + (c + g) * DP;
     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = MFMA(xa[s], p[4 * s * DP], acc);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        p[4 * q * DP] = acc[q] * di4[q];
-        wneg[q] = -acc[q];
-    }
+    for (int q = 0; q < 4; ++q) p[4 * q * DP] = acc[q] * di4[q];
 }
-// step C for one tile (it, jt)
-__device__ __forceinline__ void diag_step_c(double *a, int it, int jt, int c, int l15, int g, const double (&wneg)[4]) {
+// step C for one tile (it, jt): C -= (L[it] D) L[jt]', both operands from the LDS image (any wave can take any tile)
+__device__ __forceinline__ void diag_step_c(double *a, int it, int jt, int c, int l15, int g, const double (&d4)[4]) {
     double *cp = a + (it * 16 + l15) + (jt * 16 + g) * DP;
-    const double *lp = a + (jt * 16 + l15) + (c + g) * DP;
+    const double *lj = a + (jt * 16 + l15) + (c + g) * DP;
+    const double *li = a + (it * 16 + l15) + (c + g) * DP;
     v4d acc = (v4d){cp[0], cp[4 * DP], cp[8 * DP], cp[12 * DP]};
 #pragma unroll
-    for (int s = 0; s < 4; ++s) acc = MFMA(lp[4 * s * DP], wneg[s], acc);
+    for (int s = 0; s < 4; ++s) acc = MFMA(lj[4 * s * DP], -(li[4 * s * DP] * d4[s]), acc);
 #pragma unroll
     for (int q = 0; q < 4; ++q) cp[4 * q * DP] = acc[q];
 }
@@ -144,67 +193,38 @@ __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, do
     if (!(DIAG_SKIP & 16)) diag_load_block(a, Kb, ld, tid);
     __syncthreads();
 
-    const int tA = wave, tB = 7 - wave;          // owned row tiles
-    for (int kb = 0; kb < 8; ++kb) {
+    // Schedule per 16-column micro-panel kb (A(0) first):
+    //   B(kb)   all waves   : L tiles of the panel rows below (round-robin over the waves)
+    //   barrier
+    //   wave 0              : trailing update of the NEXT diagonal micro-block, then A(kb+1)      } overlapped
+    //   waves 1-3           : all other trailing tiles of step kb (any tile, operands from LDS)   }
+    //   barrier
+    if (wave == 0) diag_step_a(a, xm, 0, lane, info, col0);
+    __syncthreads();
+    for (int kb = 0; kb < 7; ++kb) {
         const int c = kb * 16;
-        // ------------------------------------------------------------ A: 16x16 micro-block on wave 0
+        double xa[4], di4[4], d4[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            xa[s] = xm[kb * 256 + (g + 4 * s) * 16 + l15];       // Aop[jj = l15][k = g + 4s]
+            di4[s] = a[129 + (c + g + 4 * s) * DP];
+            d4[s] = a[128 + (c + g + 4 * s) * DP];
+        }
+        if (!(DIAG_SKIP & 4))
+            for (int it = kb + 1 + wave; it < 8; it += 4) diag_step_b(a, it, c, l15, g, xa, di4);
+        __syncthreads();
         if (wave == 0) {
-            // rows of the 16x16 micro-block one per lane (lanes >= 16 mirror lanes 0..15).  The pivot
-            // column is broadcast with v_readlane; the same broadcasts drive the right-looking update
-            // of X = inv(L11) (lane cc owns column cc of X), so the inverse costs one extra FMA per entry.
-            double u[16], x[16];
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                u[jj] = a[(c + l15) + (c + jj) * DP];
-                x[jj] = (l15 == jj) ? 1.0 : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < ((DIAG_SKIP & 8) ? 0 : 16); ++j) {
-                const double d = rlane(u[j], j);
-                const double di = fast_rcp(d);
-                const double wi = u[j];
-                const double ti = wi * di;                       // l_ij for lanes i > j
-#pragma unroll
-                for (int jj = j + 1; jj < 16; ++jj) {
-                    const double cj = rlane(u[j], jj);           // a[jj][j] (unscaled)
-                    u[jj] -= ti * cj;                            // a[i][jj] -= l_ij * a[jj][j]
-                    x[jj] -= (cj * di) * x[j];                   // X[jj][cc] -= l_{jj,j} X[j][cc]
+            if (!(DIAG_SKIP & 4)) diag_step_c(a, kb + 1, kb + 1, c, l15, g, d4);
+            diag_step_a(a, xm, kb + 1, lane, info, col0);
+        } else if (!(DIAG_SKIP & 4)) {
+            int idx = 0;
+            for (int it = kb + 1; it < 8; ++it)
+                for (int jt = kb + 1; jt <= it; ++jt) {
+                    if (it == kb + 1) continue;                   // (kb+1, kb+1) belongs to wave 0
+                    if (idx % 3 == wave - 1) diag_step_c(a, it, jt, c, l15, g, d4);
+                    ++idx;
                 }
-                u[j] = (l15 == j) ? d : ti;
-            }
-            if (lane < 16) {
-                double dsel = 0.0;
-#pragma unroll
-                for (int jj = 0; jj < 16; ++jj) {
-                    if (jj == l15) dsel = u[jj];
-                    if (jj <= l15) a[(c + l15) + (c + jj) * DP] = u[jj];
-                    xm[kb * 256 + l15 * 16 + jj] = x[jj];            // xm[k = cc][jj = r] = X[r][cc]
-                }
-                if (!(fabs(dsel) > 0.0 && fabs(dsel) < 1.7e308)) atomicCAS(info, 0, col0 + c + l15 + 1);
-                a[128 + (c + l15) * DP] = dsel;
-                a[129 + (c + l15) * DP] = fast_rcp(dsel);
-            }
         }
-        __syncthreads();
-        // ------------------------------------------------------------ B: panel rows below
-        double wA[4] = {0, 0, 0, 0}, wB[4] = {0, 0, 0, 0};
-        const bool hasA = tA > kb && !(DIAG_SKIP & 4), hasB = tB > kb && !(DIAG_SKIP & 4);
-        if (hasA || hasB) {
-            double xa[4], di4[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                xa[s] = xm[kb * 256 + (g + 4 * s) * 16 + l15];       // Aop[jj = l15][k = g + 4s]
-                di4[s] = a[129 + (c + g + 4 * s) * DP];
-            }
-            if (hasA) diag_step_b(a, tA, c, l15, g, xa, di4, wA);
-            if (hasB) diag_step_b(a, tB, c, l15, g, xa, di4, wB);
-        }
-        __syncthreads();
-        // ------------------------------------------------------------ C: trailing tiles
-        if (hasA)
-            for (int jt = kb + 1; jt <= tA; ++jt) diag_step_c(a, tA, jt, c, l15, g, wA);
-        if (hasB)
-            for (int jt = kb + 1; jt <= tB; ++jt) diag_step_c(a, tB, jt, c, l15, g, wB);
         __syncthreads();
     }
 
