@@ -43,6 +43,7 @@ struct GemmArgs {
     int overwrite;               // EPI_ACCUM: C = alpha*acc instead of C += alpha*acc
     unsigned *queue_counter;     // non-NULL: persistent work-queue form (look-ahead trailing update)
     int reserve;                 // 1: keep one CU per XCD free, 2: two
+    int stagger;                 // work-queue form: max random start delay in cycles (0 = none)
 };
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g);
 

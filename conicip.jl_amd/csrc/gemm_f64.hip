@@ -177,6 +177,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_128_queue(GemmArgs g, int nt
         if (cu == 0 && (se == 0 || (reserve > 1 && se == 2))) return;
     }
     const int tm = g.M / CIP_NB;
+    if (g.stagger > 0) {
+        // de-phase the two persistent workgroups of a CU (and the CUs among themselves): random start delay
+        // of up to g.stagger cycles.  Performance device only.
+        const unsigned h = (blockIdx.x * 2654435761u) >> 12;
+        const long wait = (long)(h & 1023) * g.stagger / 1024;
+        const long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
     while (true) {
         if (threadIdx.x == 0) s_tile = (int)atomicAdd(counter, 1u);
         __syncthreads();

@@ -266,6 +266,7 @@ static hipStream_t g_side = nullptr;      // panel chain: high priority, all CUs
 static hipStream_t g_upd = nullptr;       // trailing updates: CU-masked so that a few CUs stay free for the panel chain
 static hipEvent_t g_evP[2] = {nullptr, nullptr}, g_evU[2] = {nullptr, nullptr}, g_evStart = nullptr, g_evEnd = nullptr;
 static int g_lookahead = -1;
+static int g_queue = 0;                   // CIP_GEMM_QUEUE=1: persistent work-queue trailing update
 static int g_reserve = 0;                 // CUs per XCD kept free by the work-queue trailing update (0 = plain launch)
 static int lookahead_init(void) {
     if (g_lookahead >= 0) return 0;
@@ -274,6 +275,7 @@ static int lookahead_init(void) {
     // selects the serial schedule (one unsplit trailing update per outer block).
     g_lookahead = getenv("CIP_NO_LOOKAHEAD") ? 0 : 1;
     if (const char *e = getenv("CIP_RESERVE")) g_reserve = atoi(e);
+    g_queue = (getenv("CIP_GEMM_QUEUE") || g_reserve) ? 1 : 0;
     int lo = 0, hi = 0;
     CIP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     CIP_HIP_CHECK(hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, hi));
@@ -401,6 +403,7 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
                 g.B = K + r0 + (long)C0 * ld; g.ldb = ld;
                 g.C = K + r0 + (long)r0 * ld; g.ldc = ld;
                 g.M = Npad - r0; g.N = Npad - r0; g.K = wblk; g.alpha = -1.0; g.lower = 1;
+                if (g_queue) { g.queue_counter = ws.qcounter; g.stagger = wblk * 70; }
                 if (ws.prof) {
                     if ((rc = prof_event(ws.prof, s))) return rc;
                     const double r = (double)(Npad - r0);
@@ -463,7 +466,8 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
             g.B = K + r2 + (long)C0 * ld; g.ldb = ld;
             g.C = K + r2 + (long)r2 * ld; g.ldc = ld;
             g.M = Npad - r2; g.N = Npad - r2; g.K = wblk; g.alpha = -1.0; g.lower = 1;
-            if (la && g_reserve) { g.queue_counter = ws.qcounter; g.reserve = g_reserve; }
+            // optional persistent work-queue form (CIP_GEMM_QUEUE=1: +5 % standalone, no gain measured in situ)
+            if (g_queue) { g.queue_counter = ws.qcounter; g.reserve = g_reserve; g.stagger = wblk * 70; }
             if (ws.prof) {
                 if ((rc = prof_event(ws.prof, s))) return rc;
                 const double r = (double)(Npad - r2);
