@@ -44,6 +44,7 @@ struct GemmArgs {
     unsigned *queue_counter;     // non-NULL: persistent work-queue form (look-ahead trailing update)
     int reserve;                 // 1: keep one CU per XCD free, 2: two
     int stagger;                 // work-queue form: max random start delay in cycles (0 = none)
+    int t_first;                 // quarter-tile remainder launch: first 128-tile index it covers
 };
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g);
 

@@ -23,6 +23,7 @@
 //   * blockIdx is remapped so that each XCD (own L2) walks a contiguous run of
 //     tiles (bijective variant of the xcd swizzle).
 #include "cip_internal.h"
+#include <stdlib.h>
 
 #define LDS_TILE (CIP_KT * CIP_NB)        // doubles per operand per buffer (2048)
 
@@ -158,7 +159,7 @@ template <int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_128(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 2 * LDS_TILE];   // 64 KB
     int bi, bj;
-    tile_coords(xcd_remap(blockIdx.x, gridDim.x), g.lower, g.M / CIP_NB, bi, bj);
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), g.lower, g.M / CIP_NB, bi, bj);   // grid may cover only the first tiles
     gemm_tile_128<EPI>(g, lds, bi, bj);
 }
 
@@ -212,10 +213,21 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_64(GemmArgs g) {
     const int wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int tm = g.M / SB;
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
-    const int bi = t % tm, bj = t / tm;
-    const long i0 = (long)bi * SB, j0 = (long)bj * SB;
+    long i0, j0;
+    if (g.lower) {
+        // remainder of a lower-triangular update in quarter tiles: block b -> 128-tile g.t_first + b/4, quadrant b%4
+        int bi, bj;
+        tile_coords(g.t_first + (int)(blockIdx.x >> 2), 1, g.M / CIP_NB, bi, bj);
+        const int sub = blockIdx.x & 3;
+        if (bi == bj && sub == 2) return;            // strictly-upper quadrant of a diagonal tile: never referenced
+        i0 = (long)bi * CIP_NB + (sub & 1) * SB;
+        j0 = (long)bj * CIP_NB + (sub >> 1) * SB;
+    } else {
+        const int tm = g.M / SB;
+        const int t = xcd_remap(blockIdx.x, gridDim.x);
+        i0 = (long)(t % tm) * SB;
+        j0 = (long)(t / tm) * SB;
+    }
 
     // staging: 64 rows x 16 k per operand = 512 double2 -> 2 per thread: e = q*256 + tid, k = e >> 5, rp = e & 31
     const int k_ld = tid >> 5, rp = tid & 31;
@@ -279,6 +291,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_64(GemmArgs g) {
         }
 }
 
+static int g_rem_mode = -1;
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.M % CIP_NB || g.N % CIP_NB || g.K % CIP_KT || g.K <= 0) {
@@ -297,6 +310,27 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     if (by * bz > 1) {
         if (epi != EPI_ACCUM || g.lower) { cip_set_error("gemm: batching needs the plain accumulate form"); return -1; }
         hipLaunchKernelGGL(k_gemm_nt_128<EPI_ACCUM>, dim3((unsigned)tiles, by, bz), dim3(256), 0, s, g);
+        CIP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    if (g_rem_mode < 0) g_rem_mode = getenv("CIP_GEMM_REM") ? atoi(getenv("CIP_GEMM_REM")) : 2;
+    if (epi == EPI_ACCUM && g.lower && !g.queue_counter && g_rem_mode && by * bz == 1) {
+        // Tile-count quantisation: 512 tiles are in flight (2 per CU); a last partial generation leaves most of
+        // the chip idle for a whole tile time (measured 62 % MFMA-busy at 1596 tiles = 3.12 generations).  The
+        // remainder is issued as quarter tiles (64x64), which spread over all CUs and finish in ~1/4 of the time.
+        const long slots = 512;
+        long nfull = (tiles / slots) * slots;
+        long rem = tiles - nfull;
+        if (rem * 4 > slots * 3) { nfull = tiles; rem = 0; }        // nearly full last generation: keep big tiles
+        if (tiles < slots && g_rem_mode != 2) { nfull = tiles; rem = 0; }   // mode 2: quarter tiles for small launches too
+        if (nfull > 0) {
+            hipLaunchKernelGGL(k_gemm_nt_128<EPI_ACCUM>, dim3((unsigned)nfull), dim3(256), 0, s, g);
+        }
+        if (rem > 0) {
+            GemmArgs gr = g;
+            gr.t_first = (int)nfull;
+            hipLaunchKernelGGL(k_gemm_nt_64, dim3((unsigned)(4 * rem)), dim3(256), 0, s, gr);
+        }
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }

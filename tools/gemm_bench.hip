@@ -17,7 +17,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int dbg = argc > 1 ? atoi(argv[1]) : 0;
     printf("dbg=%d\n", dbg);
-    const int shapes[][2] = {{8192, 256}, {4096, 256}, {8192, 512}, {8192, 128}};
+    const int shapes[][2] = {{1024, 512}, {2048, 512}, {3072, 512}, {4096, 512}, {5120, 512}, {6144, 512}, {7168, 512}, {8192, 512}, {8192, 256}, {4096, 256}, {2048, 256}};
     for (auto &sh : shapes) {
         const int r = sh[0], K = sh[1];
         GemmArgs g = {};
