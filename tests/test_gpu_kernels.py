@@ -53,12 +53,17 @@ def test_gemm_nt(lib, M, N, K, lower):
     got = from_colmajor(dC, M, N)
     ref = Cm - A @ B.T
     if lower:
-        # tiles with bi >= bj are updated (diagonal tiles fully), others untouched
+        # contract: the lower triangle is updated; tiles strictly above the diagonal are untouched
+        # (the strictly-upper part of DIAGONAL tiles is scratch: never referenced by the LDL')
         for bi in range(M // 128):
             for bj in range(N // 128):
                 blk = (slice(bi * 128, bi * 128 + 128), slice(bj * 128, bj * 128 + 128))
-                want = ref[blk] if bi >= bj else Cm[blk]
-                np.testing.assert_allclose(got[blk], want, rtol=0, atol=1e-11 * K)
+                if bi > bj:
+                    np.testing.assert_allclose(got[blk], ref[blk], rtol=0, atol=1e-11 * K)
+                elif bi == bj:
+                    np.testing.assert_allclose(np.tril(got[blk]), np.tril(ref[blk]), rtol=0, atol=1e-11 * K)
+                else:
+                    np.testing.assert_array_equal(got[blk], Cm[blk])
     else:
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11 * K)
 
