@@ -8,7 +8,7 @@
 //
 // Blocked right-looking algorithm, two levels:
 //   outer block NBO (default 256) = NBO/128 inner panels of 128 columns
-//   per inner panel:  [strip update]  ->  diag 128x128 LDL' + inverse (1 workgroup, LDS)
+//   per inner panel:  diag 128x128 LDL' (1 workgroup, LDS) -> TRSM -> update of the block's remaining panel columns
 //                     ->  TRSM as MFMA GEMM with the explicit inverse (W = A21 inv(L11)', L = W D^-1)
 //   per outer block:  trailing update  C -= W L'  (lower tiles, K = NBO, MFMA GEMM)
 // >99% of the N^3/3 flops are in the trailing-update GEMM (gemm_f64.hip).
@@ -210,6 +210,21 @@ static int launch_diag(hipStream_t s, double *Kb, long ld, double *Linv, double 
     return 0;
 }
 
+// right-looking update inside the outer block: after inner panel t, the remaining panel columns of the block
+//   K[c0+128:, c0+128 : C0+wblk] -= W_t[c0+128:, :] * L_t[c0+128 : C0+wblk, :]'        (K = 128, wide and short:
+// many quarter tiles, one short k-loop -- the latency-critical shape; the left-looking form had K up to 384)
+static int update_rest_of_block(hipStream_t s, double *K, int Npad, long ld, double *Wb, int C0, int wblk, int t) {
+    const int c1 = C0 + (t + 1) * CIP_NB;            // first row / column still to be factored in this block
+    const int ncols = C0 + wblk - c1;
+    if (ncols <= 0 || c1 >= Npad) return 0;
+    GemmArgs g = {};
+    g.A = Wb + c1 + (long)(t * CIP_NB) * Npad; g.lda = Npad;
+    g.B = K + c1 + (long)(c1 - CIP_NB) * ld; g.ldb = ld;
+    g.C = K + c1 + (long)c1 * ld; g.ldc = ld;
+    g.M = Npad - c1; g.N = ncols; g.K = CIP_NB; g.alpha = -1.0; g.lower = 0;
+    return cip_launch_gemm(s, EPI_ACCUM, g);
+}
+
 // one inner-panel sweep of an outer block: [strip update] -> diagonal kernel -> TRSM, for each 128 columns
 static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws, double *Wb, int C0,
                                int wblk) {
@@ -218,16 +233,6 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
     for (int t = 0; t < T; ++t) {
         const int c0 = C0 + t * CIP_NB;
         const int jb = c0 / CIP_NB;
-        if (t > 0) {
-            // left-looking strip update inside the outer block:
-            //   K[c0:, c0:c0+128] -= W[c0:, 0:128t] * L[c0:c0+128, C0:C0+128t]'
-            GemmArgs g = {};
-            g.A = Wb + c0; g.lda = Npad;
-            g.B = K + c0 + (long)C0 * ld; g.ldb = ld;
-            g.C = K + c0 + (long)c0 * ld; g.ldc = ld;
-            g.M = Npad - c0; g.N = CIP_NB; g.K = t * CIP_NB; g.alpha = -1.0; g.lower = 0;
-            if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
-        }
         const int r = Npad - c0 - CIP_NB;
         if (diag_version() == 2) {
             // MFMA micro-blocked diagonal kernel + substitution TRSM (the block inverses the solves
@@ -239,6 +244,7 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
                                             ws.Xm + (size_t)jb * 2048, ws.dinv + c0,
                                             Wb + (c0 + CIP_NB) + (long)(t * CIP_NB) * Npad, Npad)))
                 return rc;
+            if ((rc = update_rest_of_block(s, K, Npad, ld, Wb, C0, wblk, t))) return rc;
             continue;
         }
         if ((rc = launch_diag(s, K + c0 + (long)c0 * ld, ld, ws.Linv + (size_t)jb * CIP_NB * CIP_NB,
@@ -255,6 +261,7 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
             g.M = r; g.N = CIP_NB; g.K = CIP_NB; g.alpha = 1.0; g.lower = 0;
             if ((rc = cip_launch_gemm(s, EPI_TRSM, g))) return rc;
         }
+        if ((rc = update_rest_of_block(s, K, Npad, ld, Wb, C0, wblk, t))) return rc;
     }
     return 0;
 }
@@ -270,10 +277,11 @@ static int g_queue = 0;                   // CIP_GEMM_QUEUE=1: persistent work-q
 static int g_reserve = 0;                 // CUs per XCD kept free by the work-queue trailing update (0 = plain launch)
 static int lookahead_init(void) {
     if (g_lookahead >= 0) return 0;
-    // On by default.  Same-session A/B at n = 8192: 107.7 vs 94.5 KKT solves/s (the overlap is partial: the
-    // chain kernels run 1.5-2x slower while they share CUs with the trailing GEMM).  CIP_NO_LOOKAHEAD=1
-    // selects the serial schedule (one unsplit trailing update per outer block).
-    g_lookahead = getenv("CIP_NO_LOOKAHEAD") ? 0 : 1;
+    // Off by default.  Same-session A/B at n = 8192 (3 alternations): look-ahead 117.4 vs serial 115.7 KKT
+    // solves/s (+1.5 %), but the trailing-update kernel runs at 43.3 vs 47.2 TFLOP/s because it shares the chip
+    // with the panel chain, and the chain kernels themselves run 1.5-2x slower under that load.  The serial
+    // single-stream schedule is the default; CIP_LOOKAHEAD=1 selects the two-stream look-ahead.
+    g_lookahead = getenv("CIP_LOOKAHEAD") ? 1 : 0;
     if (const char *e = getenv("CIP_RESERVE")) g_reserve = atoi(e);
     g_queue = (getenv("CIP_GEMM_QUEUE") || g_reserve) ? 1 : 0;
     int lo = 0, hi = 0;
