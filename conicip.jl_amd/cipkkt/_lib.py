@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcipkkt.so")
+LIB_PATH = os.environ.get("CIPKKT_LIB", os.path.join(_HERE, "libcipkkt.so"))   # override: A/B two builds in one session
 
 CONE_R, CONE_Q, CONE_S = 0, 1, 2
 ROUTE_SCHUR, ROUTE_FULL3X3 = 0, 1

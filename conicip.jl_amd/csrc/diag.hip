@@ -286,9 +286,9 @@ __global__ __launch_bounds__(256) void k_diag_inverse_batched(const double *K, l
 //   T = A21[:,kb] - sum_{q<kb} W[:,q] L11[kb][q]'      (4 kb MFMAs, operands straight from L2)
 //   W[:,kb] = T inv(L11[kb][kb])'                       (4 MFMAs with the micro inverse)
 // Half the flops of the inverse-GEMM form, 4x more workgroups, no 128x128 inverse on the critical path.
-// Register budget: <= 96 VGPRs (launch bound 5 waves/SIMD) so that these workgroups co-reside with the two
-// 208-register GEMM workgroups of the look-ahead trailing update on any CU.
-__global__ __launch_bounds__(256, 5) void k_trsm_subst(double *__restrict__ Ap, long ld, const double *__restrict__ L11,
+// (A 96-register cap -- launch bound 5 waves/SIMD -- lets these workgroups co-reside with the look-ahead's GEMM
+// workgroups, but serialises the operand loads: same-session A/B 117.0 vs 118.8 KKT solves/s without the cap.)
+__global__ __launch_bounds__(256) void k_trsm_subst(double *__restrict__ Ap, long ld, const double *__restrict__ L11,
                                                         const double *__restrict__ xm, const double *__restrict__ dinv,
                                                         double *__restrict__ W, long ldw) {
     __builtin_amdgcn_s_setprio(3);       // panel chain is latency-critical: win issue arbitration against co-resident GEMM waves
