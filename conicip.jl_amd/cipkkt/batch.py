@@ -16,20 +16,49 @@ def shard_indices(n_problems, rank, world):
     return list(range(rank, n_problems, world))
 
 
-def solve_batch(problems, solve_fn=None, rank=0, world=1, dist=None, device=None):
+def _solve_on_stream(pr, device):
+    """One problem on its own HIP stream: small systems (n ~ 2048) are latency-bound -- a factorisation is a
+    chain of tiny dependent launches -- so several of them in flight on different streams fill the chip."""
+    from .driver import conicIP
+    from .kkt import KKTSystem
+    st = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(st):
+        ks = KKTSystem(pr["Q"], pr["A"], pr.get("G"), pr["cone_dims"], device=device)
+        ks.set_stream(st.cuda_stream)
+        try:
+            sol = conicIP(pr["Q"], pr["c"], pr["A"], pr["b"], pr["cone_dims"], pr.get("G"), pr.get("d"), system=ks,
+                          **pr.get("kwargs", {}))
+        finally:
+            st.synchronize()
+            ks.close()
+    return sol
+
+
+def solve_batch(problems, solve_fn=None, rank=0, world=1, dist=None, device=None, concurrency=1):
     """problems: list of dicts(Q, c, A, b, cone_dims, G, d, kwargs).  Each rank solves its
     shard with `solve_fn` (default: the HIP-backed cipkkt.conicIP) and the statistics are
     reduced over ranks:  SUM(iters, n_factor, n_solve, n_optimal, n_problems), MAX(wall).
+    `concurrency` > 1 (default solver only) keeps that many problems in flight on separate
+    HIP streams, one host thread each (ctypes releases the GIL during library calls).
     Returns (local_solutions, stats_dict)."""
+    default_solver = solve_fn is None
     if solve_fn is None:
         from .driver import conicIP as solve_fn
     mine = shard_indices(len(problems), rank, world)
     sols = {}
     t0 = time.perf_counter()
-    for i in mine:
-        pr = problems[i]
-        sols[i] = solve_fn(pr["Q"], pr["c"], pr["A"], pr["b"], pr["cone_dims"], pr.get("G"), pr.get("d"),
-                           **pr.get("kwargs", {}))
+    if default_solver and concurrency > 1 and len(mine) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        with ThreadPoolExecutor(max_workers=concurrency) as ex:
+            futs = {i: ex.submit(_solve_on_stream, problems[i], dev) for i in mine}
+            for i, f in futs.items():
+                sols[i] = f.result()
+    else:
+        for i in mine:
+            pr = problems[i]
+            sols[i] = solve_fn(pr["Q"], pr["c"], pr["A"], pr["b"], pr["cone_dims"], pr.get("G"), pr.get("d"),
+                               **pr.get("kwargs", {}))
     wall = time.perf_counter() - t0
     sums = np.array([sum(s.Iter for s in sols.values()),
                      sum(getattr(s, "n_factor", 0) for s in sols.values()),

@@ -41,6 +41,8 @@ def main():
     run("C3 SOCP n=4096 512xQ(8) p=512 dense A", socp_problem(4096, 512, 8, 512, 11), optTol=1e-6)
     if only == "c3":
         return
+    if only == "c5":
+        pass
     # C4: single S cone.  ("S",256) is not a legal cone spec (256 is not triangular, src/ConicIP.jl:85);
     # measured here at matrix order r=64 (k=2080) and r=128 (k=8256), n=256, p=16
     for r in (64, 128):
@@ -68,6 +70,15 @@ def main():
     st["wall_s"] = dt
     print(json.dumps(dict(config="C5 batch 8 x dense QP n=2048 (sequential on 1 GPU)", **st,
                           kkt_solves_per_s=st["n_factor"] / dt)), flush=True)
+    for conc in (2, 4, 8):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sols, st = solve_batch(probs, concurrency=conc)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st["wall_s"] = dt
+        print(json.dumps(dict(config="C5 batch 8 x dense QP n=2048, %d streams in flight" % conc, **st,
+                              kkt_solves_per_s=st["n_factor"] / dt)), flush=True)
 
 
 if __name__ == "__main__":
