@@ -84,7 +84,7 @@ __device__ void sd_solve_LT(const double *L, double *X, int r) {
 }
 // Two-sided Jacobi, parallel (round-robin) ordering.  A (symmetric) is destroyed: eigenvalues end on its
 // diagonal; V (may be NULL) receives the eigenvectors as columns: A_in = V diag V'.
-__device__ void sd_jacobi(double *A, double *V, int r, double *sh /* >= 4*(r/2+1) + 8 doubles */) {
+__device__ void sd_jacobi_core(double *A, double *V, int r, double *sh /* >= 4*(r/2+1) + 8 doubles */) {
     const int tid = threadIdx.x;
     if (V) {
         for (int e = tid; e < r * r; e += SD_T) V[e] = (e % r == e / r) ? 1.0 : 0.0;
@@ -157,6 +157,24 @@ __device__ void sd_jacobi(double *A, double *V, int r, double *sh /* >= 4*(r/2+1
             }
             __syncthreads();
         }
+    }
+    __syncthreads();
+}
+
+// Jacobi with the matrices staged in LDS when they fit (r <= SD_LDS_RMAX: A and V, 2 r^2 doubles): the sweep is a
+// chain of ~3 (r-1) barrier-separated passes per sweep, each a handful of dependent accesses per thread, so LDS
+// latency instead of global-memory latency is a ~10x difference.  `sh` = rotation scratch followed by the staging area.
+#define SD_LDS_RMAX 88
+__device__ void sd_jacobi(double *A, double *V, int r, double *sh) {
+    if (r > SD_LDS_RMAX) { sd_jacobi_core(A, V, r, sh); return; }
+    double *la = sh + 4 * ((r + 2) / 2 + 1) + 16;
+    double *lv = V ? la + r * r : nullptr;
+    for (int e = threadIdx.x; e < r * r; e += SD_T) la[e] = A[e];
+    __syncthreads();
+    sd_jacobi_core(la, lv, r, sh);
+    for (int e = threadIdx.x; e < r * r; e += SD_T) {
+        A[e] = la[e];
+        if (V) V[e] = lv[e];
     }
     __syncthreads();
 }
@@ -347,9 +365,18 @@ __global__ __launch_bounds__(SD_T) void k_sdp_maxstep(const ConeDesc *cones, con
 }
 
 // ---------------------------------------------------------------------------------- host launchers
-static size_t sd_shmem(int rmax) { return (4 * ((size_t)(rmax + 2) / 2 + 1) + 16) * sizeof(double); }
+static size_t sd_shmem(int rmax) {
+    size_t d = 4 * ((size_t)(rmax + 2) / 2 + 1) + 16;
+    if (rmax <= SD_LDS_RMAX) d += 2 * (size_t)rmax * rmax;          // LDS-resident Jacobi
+    return d * sizeof(double);
+}
+static int sd_set_lds_attr(const void *fn, int rmax) {
+    CIP_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sd_shmem(rmax)));
+    return 0;
+}
 
 int cip_sdp_nt_scaling(hipStream_t s, const ConeSet &cs, const double *v, const double *sv, double *lambda) {
+    if (sd_set_lds_attr((const void *)k_sdp_nt_scaling, cs.rmax)) return -3;
     hipLaunchKernelGGL(k_sdp_nt_scaling, dim3(cs.ns), dim3(SD_T), sd_shmem(cs.rmax), s, cs.d_cones, cs.d_sidx, v, sv, cs.d_scal,
                        lambda, cs.d_sdpws, cs.d_sdpflag);
     CIP_HIP_CHECK(hipGetLastError());
@@ -366,11 +393,13 @@ int cip_sdp_prod(hipStream_t s, const ConeSet &cs, const double *x, const double
     return 0;
 }
 int cip_sdp_div(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out) {
+    if (sd_set_lds_attr((const void *)k_sdp_div, cs.rmax)) return -3;
     hipLaunchKernelGGL(k_sdp_div, dim3(cs.ns), dim3(SD_T), sd_shmem(cs.rmax), s, cs.d_cones, cs.d_sidx, x, y, out, cs.d_sdpws);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 int cip_sdp_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const double *d, double scale, double *partial) {
+    if (sd_set_lds_attr((const void *)k_sdp_maxstep, cs.rmax)) return -3;
     hipLaunchKernelGGL(k_sdp_maxstep, dim3(cs.ns), dim3(SD_T), sd_shmem(cs.rmax), s, cs.d_cones, cs.d_sidx, x, d, scale, partial,
                        cs.d_sdpws);
     CIP_HIP_CHECK(hipGetLastError());

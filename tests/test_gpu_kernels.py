@@ -382,3 +382,43 @@ def test_gemv_and_dots():
         d = ks.dots([(dev(x), dev(x)), (dev(big), dev(big)), (dev(v), dev(v)[:0])])
         np.testing.assert_allclose(d, [x @ x, big @ big, 0.0], rtol=1e-13)
         ks.close()
+
+
+def test_plain_c_abi_sequence_as_the_julia_shim_calls_it(lib):
+    """cip_create -> cip_set_scaling_packed -> cip_factor -> cip_solve3x3 -> cip_destroy with HOST pointers only,
+    exactly the sequence of the ccall shim in INTEGRATION.md (levels 1-3 of src/ConicIP.jl:667,682,688)."""
+    from cipkkt import _lib as L
+    rng = np.random.default_rng(77)
+    cone_dims = [("R", 6), ("Q", 5), ("R", 2)]
+    n, p = 11, 3
+    m = sum(k for _, k in cone_dims)
+    M = rng.standard_normal((n, n))
+    Q = np.asfortranarray(M @ M.T / n + np.eye(n))
+    A = np.asfortranarray(rng.standard_normal((m, n)))
+    G = np.asfortranarray(rng.standard_normal((p, n)))
+    F = oracle_F(cone_dims, rng)
+    ctype = (C.c_int * 3)(0, 1, 0)
+    cdim = (C.c_int * 3)(6, 5, 2)
+    h = C.c_void_p()
+    L.check(lib.cip_create(n, m, p, 3, ctype, cdim, Q.ctypes.data, A.ctypes.data, G.ctypes.data, 0, C.byref(h)))
+    assert lib.cip_scaling_packed_len(h) == 6 + (1 + 5) + 2
+    packed = np.concatenate([F.Blocks[0].diag, [-F.Blocks[1].A[0]], F.Blocks[1].B[:, 0], F.Blocks[2].diag])
+    L.check(lib.cip_set_scaling_packed(h, packed.ctypes.data))
+    L.check(lib.cip_factor(h))
+    L.check(lib.cip_check_factor(h))
+    x, y, z = rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(m)
+    a, b, c = np.empty(n), np.empty(p), np.empty(m)
+    L.check(lib.cip_solve3x3(h, x.ctypes.data, y.ctypes.data, z.ctypes.data, a.ctypes.data, b.ctypes.data, c.ctypes.data))
+    # the defining equations (src/ConicIP.jl:443-447)
+    FtF = F.square().matrix()
+    assert np.linalg.norm(Q @ a + G.T @ b - A.T @ c - x) < 1e-10
+    assert np.linalg.norm(G @ a - y) < 1e-10
+    assert np.linalg.norm(A @ a + FtF @ c - z) < 1e-9
+    # errors are reported, not swallowed
+    assert lib.cip_solve3x3(None, x.ctypes.data, y.ctypes.data, z.ctypes.data, a.ctypes.data, b.ctypes.data,
+                            c.ctypes.data) != 0
+    bad = C.c_void_p()
+    rc = lib.cip_create(n, m, p, 3, ctype, (C.c_int * 3)(6, 5, 3), Q.ctypes.data, A.ctypes.data, G.ctypes.data, 0,
+                        C.byref(bad))
+    assert rc != 0 and b"cone_dims" in lib.cip_last_error()
+    L.check(lib.cip_destroy(h))
