@@ -163,71 +163,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_128(GemmArgs g) {
     gemm_tile_128<EPI>(g, lds, bi, bj);
 }
 
-// Persistent form of the trailing update for the look-ahead: 2 workgroups per CU pull tiles from an
-// atomic counter, and workgroups that find themselves on a RESERVED CU (one per XCD: SE 0, CU 0 of every
-// XCC, read from HW_ID / XCC_ID) exit at once.  The reserved CUs stay empty for the whole launch, so the
-// serial panel chain of the next outer block (whose diagonal kernel needs a CU's entire LDS) starts
-// immediately on the high-priority side stream instead of waiting for the GEMM's tail.  Placement is used
-// for speed only: any workgroup can take any tile.
-__global__ __launch_bounds__(256, 2) void k_gemm_nt_128_queue(GemmArgs g, int ntiles, unsigned *counter, int reserve) {
-    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * LDS_TILE];   // 64 KB
-    __shared__ int s_tile;
-    if (reserve) {
-        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID: cu [11:8], se [15:13]
-        const unsigned cu = (hw >> 8) & 0xf, se = (hw >> 13) & 0x7;
-        if (cu == 0 && (se == 0 || (reserve > 1 && se == 2))) return;
-    }
-    const int tm = g.M / CIP_NB;
-    if (g.stagger > 0) {
-        // de-phase the two persistent workgroups of a CU (and the CUs among themselves): random start delay
-        // of up to g.stagger cycles.  Performance device only.
-        const unsigned h = (blockIdx.x * 2654435761u) >> 12;
-        const long wait = (long)(h & 1023) * g.stagger / 1024;
-        const long t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
-    while (true) {
-        if (threadIdx.x == 0) s_tile = (int)atomicAdd(counter, 1u);
-        __syncthreads();
-        const int t = s_tile;
-        if (t >= ntiles) return;
-        int bi, bj;
-        tile_coords(t, g.lower, tm, bi, bj);
-        GemmArgs gt = g;
-        gemm_tile_128<EPI_ACCUM>(gt, lds, bi, bj);
-        __syncthreads();      // LDS buffers and s_tile are reused by the next tile
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Small-tile variant (64x64 C tile, wave = 32x32 = 2x2 MFMA tiles) for the latency-critical skinny
 // updates on the factorisation's critical path (look-ahead column strip, in-block strip update):
 // 4x the workgroups and a quarter of the per-tile latency of the 128x128 kernel, at twice the LDS
 // traffic per flop -- these launches carry < 10 % of the flops.  Accumulate epilogue only.
 #define SB 64
-__global__ __launch_bounds__(256, 4) void k_gemm_nt_64(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
-    __builtin_amdgcn_s_setprio(3);       // skinny critical-path updates: priority over co-resident trailing-update waves
+__device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, long i0, long j0) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int l15 = lane & 15, l4 = lane >> 4;
-    long i0, j0;
-    if (g.lower) {
-        // remainder of a lower-triangular update in quarter tiles: block b -> 128-tile g.t_first + b/4, quadrant b%4
-        int bi, bj;
-        tile_coords(g.t_first + (int)(blockIdx.x >> 2), 1, g.M / CIP_NB, bi, bj);
-        const int sub = blockIdx.x & 3;
-        if (bi == bj && sub == 2) return;            // strictly-upper quadrant of a diagonal tile: never referenced
-        i0 = (long)bi * CIP_NB + (sub & 1) * SB;
-        j0 = (long)bj * CIP_NB + (sub >> 1) * SB;
-    } else {
-        const int tm = g.M / SB;
-        const int t = xcd_remap(blockIdx.x, gridDim.x);
-        i0 = (long)(t % tm) * SB;
-        j0 = (long)(t / tm) * SB;
-    }
 
     // staging: 64 rows x 16 k per operand = 512 double2 -> 2 per thread: e = q*256 + tid, k = e >> 5, rp = e & 31
     const int k_ld = tid >> 5, rp = tid & 31;
@@ -291,6 +238,99 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_64(GemmArgs g) {
         }
 }
 
+__global__ __launch_bounds__(256, 4) void k_gemm_nt_64(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
+    __builtin_amdgcn_s_setprio(3);       // skinny critical-path updates: priority over co-resident trailing-update waves
+    long i0, j0;
+    if (g.lower) {
+        // lower-triangular update in quarter tiles: block b -> 128-tile g.t_first + b/4, quadrant b%4
+        int bi, bj;
+        tile_coords(g.t_first + (int)(blockIdx.x >> 2), 1, g.M / CIP_NB, bi, bj);
+        const int sub = blockIdx.x & 3;
+        if (bi == bj && sub == 2) return;            // strictly-upper quadrant of a diagonal tile: never referenced
+        i0 = (long)bi * CIP_NB + (sub & 1) * SB;
+        j0 = (long)bj * CIP_NB + (sub >> 1) * SB;
+    } else {
+        const int tm = g.M / SB;
+        const int t = xcd_remap(blockIdx.x, gridDim.x);
+        i0 = (long)(t % tm) * SB;
+        j0 = (long)(t / tm) * SB;
+    }
+    gemm_tile_64(g, lds, i0, j0);
+}
+
+// Persistent form of the lower-triangular trailing update for the look-ahead schedule: 5 workgroups per CU pull
+// quarter tiles from an atomic counter, and workgroups that find themselves on a RESERVED CU exit at once, so the
+// reserved CUs stay empty for the whole launch.  The serial panel chain of the next outer block -- whose diagonal
+// kernel needs a CU's entire LDS and otherwise waits until the last workgroup of this grid has been placed --
+// then starts at once on the side stream.  Workgroups are dealt round-robin to the XCDs and, inside an XCD, to the
+// shader engines whatever their occupancy (measured: with the reservation in one SE only, the single-workgroup
+// diagonal kernel started at once in one launch out of four), so EVERY (XCD, SE) pair keeps `reserve` (1 or 2) CUs
+// free.  CU ids differ per SE (harvesting); the ids are found once by a probe launch.  Placement is used for speed
+// only: any workgroup can take any tile.
+struct ReserveMap { unsigned char cu[32][2]; };       // [xcc*4 + se][k] = k-th lowest CU id present (0xff: none)
+__global__ void k_probe_cus(unsigned *out) {
+    if (threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID: cu [11:8], se [15:13]
+        const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0x7;  // HW_REG_XCC_ID
+        out[blockIdx.x] = (xcc << 8) | (((hw >> 13) & 0x3) << 4) | ((hw >> 8) & 0xf);
+    }
+    const long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < 100000) __builtin_amdgcn_s_sleep(10);   // keep the CU busy: ~1 ms
+}
+static ReserveMap g_rmap;
+static int g_rmap_ready = 0;
+static int reserve_map_init(void) {
+    if (g_rmap_ready) return 0;
+    const int nb = 1024;
+    unsigned *d = nullptr;
+    CIP_HIP_CHECK(hipMalloc(&d, nb * sizeof(unsigned)));
+    hipLaunchKernelGGL(k_probe_cus, dim3(nb), dim3(256), 65536, 0, d);           // 64 KB of LDS each: 2 per CU
+    CIP_HIP_CHECK(hipGetLastError());
+    unsigned h[1024];
+    CIP_HIP_CHECK(hipMemcpy(h, d, nb * sizeof(unsigned), hipMemcpyDeviceToHost));
+    CIP_HIP_CHECK(hipFree(d));
+    unsigned present[32] = {0};
+    for (int b = 0; b < nb; ++b) present[((h[b] >> 8) & 7) * 4 + ((h[b] >> 4) & 3)] |= 1u << (h[b] & 0xf);
+    for (int gse = 0; gse < 32; ++gse) {
+        int k = 0;
+        g_rmap.cu[gse][0] = g_rmap.cu[gse][1] = 0xff;
+        for (int c = 0; c < 16 && k < 2; ++c)
+            if (present[gse] & (1u << c)) g_rmap.cu[gse][k++] = (unsigned char)c;
+    }
+    g_rmap_ready = 1;
+    return 0;
+}
+__global__ __launch_bounds__(256, 4) void k_gemm_nt_64_queue(GemmArgs g, int nq, unsigned *counter, int reserve,
+                                                              ReserveMap rm) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
+    __shared__ int s_t;
+    if (reserve) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0x7;
+        const unsigned cu = (hw >> 8) & 0xf, gse = xcc * 4 + ((hw >> 13) & 0x3);
+        if (cu == rm.cu[gse][0] || (reserve > 1 && cu == rm.cu[gse][1])) return;
+    }
+    const int tm = g.M / CIP_NB;
+    while (true) {
+        if (threadIdx.x == 0) s_t = (int)atomicAdd(counter, 1u);
+        __syncthreads();
+        const int t = s_t;
+        if (t >= nq) return;
+        if (g.lower) {
+            int bi, bj;
+            tile_coords(t >> 2, 1, tm, bi, bj);
+            const int sub = t & 3;
+            if (!(bi == bj && sub == 2))
+                gemm_tile_64(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB);
+        } else {
+            const int tm64 = g.M / SB;
+            gemm_tile_64(g, lds, (long)(t % tm64) * SB, (long)(t / tm64) * SB);
+        }
+        __syncthreads();      // LDS buffers and s_t are reused by the next tile
+    }
+}
+
 static int g_rem_mode = -1;
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     if (g.M <= 0 || g.N <= 0) return 0;
@@ -313,7 +353,26 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    if (g_rem_mode < 0) g_rem_mode = getenv("CIP_GEMM_REM") ? atoi(getenv("CIP_GEMM_REM")) : 2;
+    if (g_rem_mode < 0) g_rem_mode = getenv("CIP_GEMM_REM") ? atoi(getenv("CIP_GEMM_REM")) : 3;
+    if (epi == EPI_ACCUM && g.queue_counter && g_rem_mode == 3 && !g.overwrite) {
+        // persistent work-queue form; the caller hands over a zeroed counter
+        static int ncu = 0;
+        if (!ncu) {
+            hipDeviceProp_t prop;
+            int dev = 0;
+            CIP_HIP_CHECK(hipGetDevice(&dev));
+            CIP_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+            ncu = prop.multiProcessorCount;
+        }
+        const long nq = 4 * tiles;
+        long grid = (long)ncu * 5;                    // 32 KB of LDS each: 5 per CU, the whole grid is co-resident
+        if (grid > nq) grid = nq;
+        if (g.reserve && reserve_map_init()) return -1;
+        hipLaunchKernelGGL(k_gemm_nt_64_queue, dim3((unsigned)grid), dim3(256), 0, s, g, (int)nq, g.queue_counter, g.reserve,
+                           g_rmap);
+        CIP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (epi == EPI_ACCUM && g.lower && !g.queue_counter && g_rem_mode && by * bz == 1) {
         // Tile-count quantisation: 512 tiles are in flight (2 per CU); a last partial generation leaves most of
         // the chip idle for a whole tile time (measured 62 % MFMA-busy at 1596 tiles = 3.12 generations).  The
@@ -322,7 +381,8 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
         long nfull = (tiles / slots) * slots;
         long rem = tiles - nfull;
         if (rem * 4 > slots * 3) { nfull = tiles; rem = 0; }        // nearly full last generation: keep big tiles
-        if (tiles < slots && g_rem_mode != 2) { nfull = tiles; rem = 0; }   // mode 2: quarter tiles for small launches too
+        if (tiles < slots && g_rem_mode == 1) { nfull = tiles; rem = 0; }   // mode >= 2: quarter tiles for small launches too
+        if (g_rem_mode == 3) { nfull = 0; rem = tiles; }                    // mode 3: quarter tiles only (experiment)
         if (nfull > 0) {
             hipLaunchKernelGGL(k_gemm_nt_128<EPI_ACCUM>, dim3((unsigned)nfull), dim3(256), 0, s, g);
         }
@@ -331,12 +391,6 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
             gr.t_first = (int)nfull;
             hipLaunchKernelGGL(k_gemm_nt_64, dim3((unsigned)(4 * rem)), dim3(256), 0, s, gr);
         }
-        CIP_HIP_CHECK(hipGetLastError());
-        return 0;
-    }
-    if (epi == EPI_ACCUM && g.lower && g.queue_counter && tiles >= 512) {
-        CIP_HIP_CHECK(hipMemsetAsync(g.queue_counter, 0, sizeof(unsigned), s));
-        hipLaunchKernelGGL(k_gemm_nt_128_queue, dim3(512), dim3(256), 0, s, g, (int)tiles, g.queue_counter, g.reserve);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }

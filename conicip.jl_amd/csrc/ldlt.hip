@@ -88,7 +88,7 @@ size_t cip_ldlt_ws_bytes(int Npad) {
         b += al256((size_t)Npad * 8);                    // zbuf
     }
     b += al256((size_t)Npad * 8) * 3;                    // dinv, dvec, tmp
-    b += 256;                                            // info
+    b += al256(64 + 4 * (2 * nblk + 8));                 // info, work-queue counters
     return b;
 }
 
@@ -227,7 +227,7 @@ static int update_rest_of_block(hipStream_t s, double *K, int Npad, long ld, dou
 
 // one inner-panel sweep of an outer block: [strip update] -> diagonal kernel -> TRSM, for each 128 columns
 static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws, double *Wb, int C0,
-                               int wblk) {
+                               int wblk, hipEvent_t rest_ready = nullptr) {
     int rc;
     const int T = wblk / CIP_NB;
     for (int t = 0; t < T; ++t) {
@@ -244,6 +244,8 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
                                             ws.Xm + (size_t)jb * 2048, ws.dinv + c0,
                                             Wb + (c0 + CIP_NB) + (long)(t * CIP_NB) * Npad, Npad)))
                 return rc;
+            // look-ahead: columns 128.. of this block are still receiving the previous block's update
+            if (t == 0 && rest_ready) CIP_HIP_CHECK(hipStreamWaitEvent(s, rest_ready, 0));
             if ((rc = update_rest_of_block(s, K, Npad, ld, Wb, C0, wblk, t))) return rc;
             continue;
         }
@@ -271,9 +273,11 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
 // One process-wide side stream and event ring (factorisations of one process are issued from one thread).
 static hipStream_t g_side = nullptr;      // panel chain: high priority, all CUs
 static hipStream_t g_upd = nullptr;       // trailing updates: CU-masked so that a few CUs stay free for the panel chain
-static hipEvent_t g_evP[2] = {nullptr, nullptr}, g_evU[2] = {nullptr, nullptr}, g_evStart = nullptr, g_evEnd = nullptr;
+static hipEvent_t g_evP[2] = {nullptr, nullptr}, g_evU[2] = {nullptr, nullptr}, g_evR[2] = {nullptr, nullptr};
+static hipEvent_t g_evStart = nullptr, g_evEnd = nullptr;
 static int g_lookahead = -1;
 static int g_queue = 0;                   // CIP_GEMM_QUEUE=1: persistent work-queue trailing update
+static int g_split = 1;                   // look-ahead: update the next block's first 128 columns separately
 static int g_reserve = 0;                 // CUs per XCD kept free by the work-queue trailing update (0 = plain launch)
 static int lookahead_init(void) {
     if (g_lookahead >= 0) return 0;
@@ -282,14 +286,17 @@ static int lookahead_init(void) {
     // with the panel chain, and the chain kernels themselves run 1.5-2x slower under that load.  The serial
     // single-stream schedule is the default; CIP_LOOKAHEAD=1 selects the two-stream look-ahead.
     g_lookahead = getenv("CIP_LOOKAHEAD") ? 1 : 0;
+    g_reserve = g_lookahead ? 1 : 0;          // CUs per (XCD, SE) the persistent trailing update keeps free: 32 or 64 in all
     if (const char *e = getenv("CIP_RESERVE")) g_reserve = atoi(e);
-    g_queue = (getenv("CIP_GEMM_QUEUE") || g_reserve) ? 1 : 0;
+    if (const char *e = getenv("CIP_LA_SPLIT")) g_split = atoi(e);
+    g_queue = getenv("CIP_GEMM_QUEUE") ? atoi(getenv("CIP_GEMM_QUEUE")) : (g_reserve ? 1 : 0);
     int lo = 0, hi = 0;
     CIP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     CIP_HIP_CHECK(hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, hi));
     for (int i = 0; i < 2; ++i) {
         CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evP[i], hipEventDisableTiming));
         CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evU[i], hipEventDisableTiming));
+        CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evR[i], hipEventDisableTiming));
     }
     CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evStart, hipEventDisableTiming));
     CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evEnd, hipEventDisableTiming));
@@ -396,7 +403,7 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
     const int NBO = g_nbo;
     int rc;
     if ((rc = lookahead_init())) return rc;
-    CIP_HIP_CHECK(hipMemsetAsync(ws.info, 0, sizeof(int), s));
+    CIP_HIP_CHECK(hipMemsetAsync(ws.info, 0, g_lookahead ? 64 + 4 * (2 * (size_t)(Npad / CIP_NB) + 8) : sizeof(int), s));
     const size_t wstride = (size_t)Npad * CIP_NBO_MAX;
     const bool la = g_lookahead && Npad > NBO;
     if (!la) {
@@ -411,7 +418,6 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
                 g.B = K + r0 + (long)C0 * ld; g.ldb = ld;
                 g.C = K + r0 + (long)r0 * ld; g.ldc = ld;
                 g.M = Npad - r0; g.N = Npad - r0; g.K = wblk; g.alpha = -1.0; g.lower = 1;
-                if (g_queue) { g.queue_counter = ws.qcounter; g.stagger = wblk * 70; }
                 if (ws.prof) {
                     if ((rc = prof_event(ws.prof, s))) return rc;
                     const double r = (double)(Npad - r0);
@@ -450,21 +456,37 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
         double *Wcur = ws.Wbuf + (size_t)(J & 1) * wstride;
         double *Wnext = ws.Wbuf + (size_t)((J + 1) & 1) * wstride;
         if (la) CIP_HIP_CHECK(hipStreamWaitEvent(s, g_evP[J & 1], 0));
+        unsigned *qc = ws.qcounter + 2 * J;                         // zeroed at the start of the factorisation
         {
-            // U1: the column strip of the NEXT outer block first (all its rows), so that its panel
-            // factorisation can start while the rest of the trailing matrix is still being updated
+            // U1a: the first 128 columns of the NEXT outer block (all its rows), so that its first diagonal block
+            // and TRSM can start at once
             GemmArgs g = {};
             g.A = Wcur + r0; g.lda = Npad;
             g.B = K + r0 + (long)C0 * ld; g.ldb = ld;
             g.C = K + r0 + (long)r0 * ld; g.ldc = ld;
-            g.M = Npad - r0; g.N = w1; g.K = wblk; g.alpha = -1.0; g.lower = 0;
+            g.M = Npad - r0; g.N = (g_queue && g_split) ? CIP_NB : w1; g.K = wblk; g.alpha = -1.0; g.lower = 0;
             if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
         }
         if (la) {
             CIP_HIP_CHECK(hipEventRecord(g_evU[J & 1], s));
             CIP_HIP_CHECK(hipStreamWaitEvent(sp, g_evU[J & 1], 0));
         }
-        if ((rc = factor_outer_panels(sp, K, Npad, ld, ws, Wnext, r0, w1))) return rc;
+        hipEvent_t rest_ready = nullptr;
+        if (g_queue && g_split && w1 > CIP_NB && Npad - r0 - CIP_NB > 0) {
+            // U1b: the other columns of the next block, concurrently with its first diagonal block / TRSM
+            // (persistent form: leaves the reserved CUs to the panel chain)
+            GemmArgs g = {};
+            const int r1 = r0 + CIP_NB;
+            g.A = Wcur + r1; g.lda = Npad;
+            g.B = K + r1 + (long)C0 * ld; g.ldb = ld;
+            g.C = K + r1 + (long)r1 * ld; g.ldc = ld;
+            g.M = Npad - r1; g.N = w1 - CIP_NB; g.K = wblk; g.alpha = -1.0; g.lower = 0;
+            g.queue_counter = qc; g.reserve = g_reserve;
+            if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
+            CIP_HIP_CHECK(hipEventRecord(g_evR[J & 1], s));
+            rest_ready = g_evR[J & 1];
+        }
+        if ((rc = factor_outer_panels(sp, K, Npad, ld, ws, Wnext, r0, w1, rest_ready))) return rc;
         if (la) CIP_HIP_CHECK(hipEventRecord(g_evP[(J + 1) & 1], sp));
         const int r2 = r0 + w1;
         if (r2 < Npad) {
@@ -475,7 +497,7 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
             g.C = K + r2 + (long)r2 * ld; g.ldc = ld;
             g.M = Npad - r2; g.N = Npad - r2; g.K = wblk; g.alpha = -1.0; g.lower = 1;
             // optional persistent work-queue form (CIP_GEMM_QUEUE=1: +5 % standalone, no gain measured in situ)
-            if (g_queue) { g.queue_counter = ws.qcounter; g.reserve = g_reserve; g.stagger = wblk * 70; }
+            if (g_queue) { g.queue_counter = qc + 1; g.reserve = g_reserve; }
             if (ws.prof) {
                 if ((rc = prof_event(ws.prof, s))) return rc;
                 const double r = (double)(Npad - r2);
