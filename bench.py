@@ -131,8 +131,7 @@ def pmc_traffic_per_launch():
             out = {}
             with open(os.path.join(ROOT, "profiles", "r1", name)) as f:
                 for r in csv.DictReader(f):
-                    if r["Counter_Name"] == counter and r["Kernel"].startswith("void k_gemm_nt_128<0>") \
-                            and int(r["Grid_Size"]) // 256 >= 512:
+                    if r["Counter_Name"] == counter and r["Kernel"].startswith("k_ldlt_trailing_64"):
                         out[int(r["Dispatch_Id"])] = float(r["Counter_Value"])
             return out
         fe = load("final_pmc_fetch.csv", "FETCH_SIZE")
@@ -271,7 +270,7 @@ def main():
                              "ldlt_tflops_whole_factor": (N ** 3 / 3.0) / (st["ms_ldlt"] * 1e-3) / 1e12
                              if st["ms_ldlt"] > 0 else None},
             "roofline": {"bound": "mfma",
-                         "kernel": "LDL' trailing update: k_gemm_nt_128<EPI_ACCUM> + k_gemm_nt_64 quarter-tile remainder",
+                         "kernel": "LDL' trailing update: k_ldlt_trailing_64 (64x64 fp64-MFMA tiles, K = outer block)",
                          "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic_per_launch(),
                          "traffic_note": "HBM bytes per trailing-update launch = (2*FETCH_SIZE + WRITE_SIZE) KiB of the "

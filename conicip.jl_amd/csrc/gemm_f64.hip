@@ -240,23 +240,24 @@ __device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, lon
 
 __global__ __launch_bounds__(256, 4) void k_gemm_nt_64(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
-    __builtin_amdgcn_s_setprio(3);       // skinny critical-path updates: priority over co-resident trailing-update waves
-    long i0, j0;
-    if (g.lower) {
-        // lower-triangular update in quarter tiles: block b -> 128-tile g.t_first + b/4, quadrant b%4
-        int bi, bj;
-        tile_coords(g.t_first + (int)(blockIdx.x >> 2), 1, g.M / CIP_NB, bi, bj);
-        const int sub = blockIdx.x & 3;
-        if (bi == bj && sub == 2) return;            // strictly-upper quadrant of a diagonal tile: never referenced
-        i0 = (long)bi * CIP_NB + (sub & 1) * SB;
-        j0 = (long)bj * CIP_NB + (sub >> 1) * SB;
-    } else {
-        const int tm = g.M / SB;
-        const int t = xcd_remap(blockIdx.x, gridDim.x);
-        i0 = (long)(t % tm) * SB;
-        j0 = (long)(t / tm) * SB;
-    }
-    gemm_tile_64(g, lds, i0, j0);
+    __builtin_amdgcn_s_setprio(3);       // skinny critical-path updates: priority over co-resident waves
+    const int tm = g.M / SB;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    gemm_tile_64(g, lds, (long)(t % tm) * SB, (long)(t / tm) * SB);
+}
+
+// The LDL' trailing update C -= (L21 D) L21' on the lower triangle, in 64x64 quarter tiles (its own symbol so that
+// profiles separate it from the skinny in-block updates): block b -> 128-tile g.t_first + b/4, quadrant b%4.
+// 5 workgroups (20 waves) per CU; measured against the 128x128-tile kernel at 2 workgroups per CU:
+// 55.0 vs 52.4 TFLOP/s at r = 8192, K = 512 and 53.1 vs 44.0 at K = 256 (tools/gemm_bench.hip, same session).
+__global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
+    __builtin_amdgcn_s_setprio(3);       // measured: 58.0 vs 56.6 TFLOP/s without
+    int bi, bj;
+    tile_coords(g.t_first + (int)(blockIdx.x >> 2), 1, g.M / CIP_NB, bi, bj);
+    const int sub = blockIdx.x & 3;
+    if (bi == bj && sub == 2) return;            // strictly-upper quadrant of a diagonal tile: never referenced
+    gemm_tile_64(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB);
 }
 
 // Persistent form of the lower-triangular trailing update for the look-ahead schedule: 5 workgroups per CU pull
@@ -389,7 +390,7 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
         if (rem > 0) {
             GemmArgs gr = g;
             gr.t_first = (int)nfull;
-            hipLaunchKernelGGL(k_gemm_nt_64, dim3((unsigned)(4 * rem)), dim3(256), 0, s, gr);
+            hipLaunchKernelGGL(k_ldlt_trailing_64, dim3((unsigned)(4 * rem)), dim3(256), 0, s, gr);
         }
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
