@@ -1,0 +1,109 @@
+# Reference-side binding of libcipkkt (include/cipkkt.h) -- the file a ConicIP.jl maintainer adds as
+# src/kktsolver_hip.jl and includes after kktsolvers.jl.  It cannot be executed in this repository's build
+# image (no Julia); INTEGRATION.md explains each call and the C-ABI entry point it binds.
+# src/kktsolver_hip.jl  -- include("kktsolver_hip.jl") after kktsolvers.jl
+const libcipkkt = get(ENV, "CONICIP_LIBCIPKKT", "libcipkkt")
+const CIP_ROUTE_SCHUR, CIP_ROUTE_FULL3X3 = Cint(0), Cint(1)
+const _CONE_CODE = Dict("R" => Cint(0), "Q" => Cint(1), "S" => Cint(2))
+
+_cipcheck(rc) = rc == 0 ? nothing :
+    error("libcipkkt: " * unsafe_string(ccall((:cip_last_error, libcipkkt), Cstring, ())))
+
+mutable struct CipHandle
+    ptr::Ptr{Cvoid}
+    function CipHandle(p)
+        h = new(p)
+        finalizer(x -> ccall((:cip_destroy, libcipkkt), Cint, (Ptr{Cvoid},), x.ptr), h)
+        h
+    end
+end
+
+# packed scaling, in cone order (layout documented in include/cipkkt.h)
+function _pack_scaling(F::Block, F⁻ᵀ::Block, cone_dims)
+    out = Float64[]
+    for (i, (ctype, k)) in enumerate(cone_dims)
+        Fi = F[i]
+        if ctype == "R"
+            append!(out, Fi.diag)                       # Diagonal(sqrt.(s./v))       ConicIP.jl:598
+        elseif ctype == "Q"
+            push!(out, -Fi.A.diag[1])                   # β   (J = Diagonal([-β; β…])) ConicIP.jl:189-192
+            append!(out, vec(Fi.B) .* sqrt(Fi.D[1]))    # w
+        else
+            append!(out, vec(Fi.R))                     # VecCongurance(R)            ConicIP.jl:208
+            append!(out, vec(Matrix(F⁻ᵀ[i].R')))        # inv(R)  (F⁻ᵀ[i] = VecCongurance(inv(R)'))
+        end
+    end
+    out
+end
+
+"""
+    kktsolver_hip(Q, A, G, cone_dims; route = CIP_ROUTE_SCHUR)
+
+Drop-in `kktsolver` for `conicIP` running the Newton step on an AMD MI355X.
+"""
+function kktsolver_hip(Q, A, G, cone_dims; route = CIP_ROUTE_SCHUR)
+    n, m, p = size(Q, 1), size(A, 1), size(G, 1)
+    Qd, Ad, Gd = Matrix{Float64}(Q), Matrix{Float64}(A), Matrix{Float64}(G)   # column-major, as the C ABI expects
+    ctype = Cint[_CONE_CODE[c[1]] for c in cone_dims]
+    cdim  = Cint[c[2] for c in cone_dims]
+    href = Ref{Ptr{Cvoid}}(C_NULL)
+    _cipcheck(ccall((:cip_create, libcipkkt), Cint,
+        (Cint, Cint, Cint, Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Ref{Ptr{Cvoid}}),
+        n, m, p, length(cone_dims), ctype, cdim, Qd, Ad, Gd, route, href))
+    h = CipHandle(href[])
+
+    function solve3x3gen(F, F⁻ᵀ)                                              # level 2
+        packed = _pack_scaling(F, F⁻ᵀ, cone_dims)
+        _cipcheck(ccall((:cip_set_scaling_packed, libcipkkt), Cint, (Ptr{Cvoid}, Ptr{Float64}), h.ptr, packed))
+        _cipcheck(ccall((:cip_factor, libcipkkt), Cint, (Ptr{Cvoid},), h.ptr))
+        function solve3x3(x, y, z)                                            # level 3
+            a, b, c = zeros(n), zeros(p), zeros(m)    # fresh, Julia-owned (they become fields of z / Δz, ConicIP.jl:690)
+            _cipcheck(ccall((:cip_solve3x3, libcipkkt), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                h.ptr, Vector{Float64}(x), Vector{Float64}(y), Vector{Float64}(z), a, b, c))
+            return (a, b, c)
+        end
+        return solve3x3
+    end
+    return solve3x3gen
+end
+
+# --- sparse A (e.g. the README box-QP, A = I): hand the CSR of A to cip_create_ex -------------------
+# The SparseMatrixCSC of A' holds exactly the CSR arrays of A (colptr -> rowptr, rowval -> colind).
+struct CipProblem                      # mirrors `cip_problem` of include/cipkkt.h field by field
+    n::Cint; m::Cint; p::Cint
+    ncones::Cint
+    cone_type::Ptr{Cint}
+    cone_dim::Ptr{Cint}
+    Q::Ptr{Float64}; ldq::Cint
+    A::Ptr{Float64}; lda::Cint
+    A_rowptr::Ptr{Cint}; A_colind::Ptr{Cint}; A_val::Ptr{Float64}
+    G::Ptr{Float64}; ldg::Cint
+    route::Cint
+    flags::Cint
+end
+
+function _cip_create_sparse(Q, A::SparseMatrixCSC, G, cone_dims, route)
+    n, m, p = size(Q, 1), size(A, 1), size(G, 1)
+    At = sparse(A')                                        # CSC of A' == CSR of A
+    rowptr = Cint.(At.colptr .- 1); colind = Cint.(At.rowval .- 1); val = Vector{Float64}(At.nzval)
+    Qd, Gd = Matrix{Float64}(Q), Matrix{Float64}(G)
+    ctype = Cint[_CONE_CODE[c[1]] for c in cone_dims]
+    cdim  = Cint[c[2] for c in cone_dims]
+    href = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve Qd Gd rowptr colind val ctype cdim begin
+        prob = Ref(CipProblem(n, m, p, length(cone_dims), pointer(ctype), pointer(cdim),
+                              pointer(Qd), n, Ptr{Float64}(C_NULL), 0,
+                              pointer(rowptr), pointer(colind), pointer(val),
+                              p > 0 ? pointer(Gd) : Ptr{Float64}(C_NULL), max(p, 1), route, 0))
+        _cipcheck(ccall((:cip_create_ex, libcipkkt), Cint, (Ref{CipProblem}, Ref{Ptr{Cvoid}}), prob, href))
+    end
+    CipHandle(href[])
+end
+
+# --- the 2x2 form (src/ConicIP.jl:450-466; src/kktsolvers.jl:316-349): conicIP accepts either -------
+# `pivot(kktsolver_2x2)` wraps a 2x2 solver into the 3x3 interface; the HIP solver already IS a 3x3
+# solver (its Schur route performs the same block elimination on the device), so no wrapper is needed:
+#     conicIP(Q, c, A, b, cone_dims, G, d; kktsolver = kktsolver_hip)
+# and for the literal 3x3 assembly of kktsolver_sparse (src/kktsolvers.jl:254-256):
+#     conicIP(...; kktsolver = (Q, A, G, cd) -> kktsolver_hip(Q, A, G, cd; route = CIP_ROUTE_FULL3X3))
