@@ -18,18 +18,39 @@
 #include <math.h>
 
 #define SD_T 256
+#ifdef SD_PROFILE
+#include <stdio.h>
+// development timers: s_memtime stamps collected in LDS, printed once at the end of the kernel
+#define SD_TICK_INIT __shared__ long sd_ts[16]; int sd_nt = 0; \
+    if (threadIdx.x == 0) sd_ts[0] = __builtin_amdgcn_s_memtime()
+#define SD_TICK(name) do { __syncthreads(); ++sd_nt; if (threadIdx.x == 0) sd_ts[sd_nt] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SD_TICK_DUMP do { if (threadIdx.x == 0 && blockIdx.x == 0) { for (int i_ = 1; i_ <= sd_nt; ++i_) \
+    printf("[sd] phase %d: %ld ticks\n", i_, (long)(sd_ts[i_] - sd_ts[i_ - 1])); printf("[sd] total %ld\n", (long)(sd_ts[sd_nt] - sd_ts[0])); } } while (0)
+#else
+#define SD_TICK(name)
+#define SD_TICK_INIT
+#define SD_TICK_DUMP
+#endif
 #define SQRT2 1.4142135623730951
 #define SQRT1_2 0.7071067811865476
 
+// Workgroup barrier.  lds_only: the data exchanged lives in LDS, so only lgkmcnt has to drain -- __syncthreads() also
+// waits for every outstanding global access (vmcnt(0)), which would expose the latency of prefetched global loads at
+// every step of the serial chains below.  The argument is a compile-time constant after inlining.
+__device__ __forceinline__ void sd_sync(bool lds_only) {
+    if (lds_only) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+}
 __device__ __forceinline__ int vidx(int i, int j, int r) { return i * r - i * (i - 1) / 2 + (j - i); }   // i <= j
 
 // X (r x r, col-major) = mat(x)
-__device__ void sd_mat(const double *x, long xs, double *X, int r) {
+__device__ __forceinline__ void sd_mat(const double *x, long xs, double *X, int r, int ld = 0) {
+    if (!ld) ld = r;
     for (int e = threadIdx.x; e < r * r; e += SD_T) {
         const int i = e % r, j = e / r;
         const int a = i < j ? i : j, b = i < j ? j : i;
         const double v = x[(long)vidx(a, b, r) * xs];
-        X[e] = (a == b) ? v : v * SQRT1_2;
+        X[i + j * ld] = (a == b) ? v : v * SQRT1_2;
     }
     __syncthreads();
 }
@@ -41,34 +62,74 @@ __device__ void sd_vecm(const double *X, double *x, long xs, int r, double scale
     }
     __syncthreads();
 }
-// C = op(A) * op(B), all r x r col-major
+// C = op(A) * op(B), all r x r col-major (C must not alias A or B).  One workgroup, v_mfma_f64_16x16x4_f64 with
+// the operands read straight from global memory (the matrices are L2-resident): each wave owns 32x32 super-tiles
+// (2x2 MFMA tiles: two A and two B fragments per four MFMAs).  The MFMA is issued "transposed" (first operand =
+// B columns, second = A rows) so that the accumulator's lane index runs along C's rows: contiguous 128-B stores.
+// Any r: out-of-range rows / columns / k are fed as zeros.
 __device__ void sd_gemm(double *C, const double *A, bool ta, const double *B, bool tb, int r) {
-    for (int e = threadIdx.x; e < r * r; e += SD_T) {
-        const int i = e % r, j = e / r;
-        double s = 0.0;
-        for (int k = 0; k < r; ++k) s += (ta ? A[k + i * r] : A[i + k * r]) * (tb ? B[j + k * r] : B[k + j * r]);
-        C[e] = s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int nt = (r + 31) / 32;
+    const long sa_i = ta ? r : 1, sa_k = ta ? 1 : r;          // opA[i][k] = A[i*sa_i + k*sa_k]
+    const long sb_k = tb ? r : 1, sb_j = tb ? 1 : r;          // opB[k][j] = B[k*sb_k + j*sb_j]
+    const int kfull = r & ~3;
+    for (int t = wave; t < nt * nt; t += SD_T / 64) {
+        const int i0 = (t % nt) * 32, j0 = (t / nt) * 32;
+        const int ia = i0 + l15, ib = i0 + 16 + l15, ja = j0 + l15, jb = j0 + 16 + l15;
+        const bool via = ia < r, vib = ib < r, vja = ja < r, vjb = jb < r;
+        const double *pa0 = A + (via ? ia : 0) * sa_i + g * sa_k, *pa1 = A + (vib ? ib : 0) * sa_i + g * sa_k;
+        const double *pb0 = B + (vja ? ja : 0) * sb_j + g * sb_k, *pb1 = B + (vjb ? jb : 0) * sb_j + g * sb_k;
+        v4d acc00 = {0, 0, 0, 0}, acc01 = acc00, acc10 = acc00, acc11 = acc00;     // acc[x][y]: rows i0+16x, cols j0+16y
+#pragma unroll 4
+        for (int k0 = 0; k0 < kfull; k0 += 4) {
+            const double a0 = via ? pa0[k0 * sa_k] : 0.0, a1 = vib ? pa1[k0 * sa_k] : 0.0;
+            const double b0 = vja ? pb0[k0 * sb_k] : 0.0, b1 = vjb ? pb1[k0 * sb_k] : 0.0;
+            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc11, 0, 0, 0);
+        }
+        if (kfull < r) {
+            const bool vk = kfull + g < r;
+            const double a0 = (via && vk) ? pa0[kfull * sa_k] : 0.0, a1 = (vib && vk) ? pa1[kfull * sa_k] : 0.0;
+            const double b0 = (vja && vk) ? pb0[kfull * sb_k] : 0.0, b1 = (vjb && vk) ? pb1[kfull * sb_k] : 0.0;
+            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc11, 0, 0, 0);
+        }
+        // D[x][y] reg q of lane (l15, g): C[i0 + 16x + l15][j0 + 16y + g + 4q]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = j0 + g + 4 * q, c1 = c0 + 16;
+            if (via && c0 < r) C[ia + (long)c0 * r] = acc00[q];
+            if (via && c1 < r) C[ia + (long)c1 * r] = acc01[q];
+            if (vib && c0 < r) C[ib + (long)c0 * r] = acc10[q];
+            if (vib && c1 < r) C[ib + (long)c1 * r] = acc11[q];
+        }
     }
     __syncthreads();
 }
-// in-place lower Cholesky (strict upper zeroed); returns 0 or (column+1) of a non-positive pivot in *flag
-__device__ void sd_chol(double *A, int r, int *flag) {
+// in-place lower Cholesky (strict upper zeroed); *flag <- (column+1) of a non-positive pivot (left untouched otherwise)
+__device__ __forceinline__ void sd_chol(double *A, int r, int *flag, int ld = 0, bool lds = false) {
+    if (!ld) ld = r;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int j = 0; j < r; ++j) {
-        const double d = A[j + j * r];
+        const double d = A[j + j * ld];
         if (!(d > 0.0)) { if (threadIdx.x == 0) *flag = j + 1; }
         const double l = sqrt(d);
-        __syncthreads();
-        for (int i = j + threadIdx.x; i < r; i += SD_T) A[i + j * r] = (i == j) ? l : A[i + j * r] / l;
-        __syncthreads();
-        const int m = r - j - 1;
-        for (int e = threadIdx.x; e < m * m; e += SD_T) {
-            const int i = j + 1 + e % m, k = j + 1 + e / m;
-            if (i >= k) A[i + k * r] -= A[i + j * r] * A[k + j * r];
+        sd_sync(lds);
+        for (int i = j + threadIdx.x; i < r; i += SD_T) A[i + j * ld] = (i == j) ? l : A[i + j * ld] / l;
+        sd_sync(lds);
+        for (int k = j + 1 + wave; k < r; k += SD_T / 64) {                 // one wave per trailing column
+            const double akj = A[k + j * ld];
+            for (int i = k + lane; i < r; i += 64) A[i + k * ld] -= A[i + j * ld] * akj;
         }
-        __syncthreads();
+        sd_sync(lds);
     }
-    for (int e = threadIdx.x; e < r * r; e += SD_T) if (e % r < e / r) A[e] = 0.0;
-    __syncthreads();
+    for (int e = threadIdx.x; e < r * r; e += SD_T) if (e % r < e / r) A[e % r + (e / r) * ld] = 0.0;
+    sd_sync(lds);
 }
 // X <- L^-T X  (L lower), column per thread
 __device__ void sd_solve_LT(const double *L, double *X, int r) {
@@ -161,13 +222,15 @@ __device__ void sd_jacobi_core(double *A, double *V, int r, double *sh /* >= 4*(
     __syncthreads();
 }
 
-// Jacobi with the matrices staged in LDS when they fit (r <= SD_LDS_RMAX: A and V, 2 r^2 doubles): the sweep is a
-// chain of ~3 (r-1) barrier-separated passes per sweep, each a handful of dependent accesses per thread, so LDS
-// latency instead of global-memory latency is a ~10x difference.  `sh` = rotation scratch followed by the staging area.
-#define SD_LDS_RMAX 88
-__device__ void sd_jacobi(double *A, double *V, int r, double *sh) {
-    if (r > SD_LDS_RMAX) { sd_jacobi_core(A, V, r, sh); return; }
-    double *la = sh + 4 * ((r + 2) / 2 + 1) + 16;
+// Jacobi with the matrices staged in LDS when they fit (`cap` doubles behind the rotation scratch; A alone when no
+// vectors are wanted, A and V otherwise): the sweep is a chain of ~3 (r-1) barrier-separated passes per sweep,
+// each a handful of dependent accesses per thread, so LDS latency instead of global-memory latency is a ~10x
+// difference (r = 128, values only: 80 ms -> ~1 ms).
+#define SD_SCRATCH(r) (4 * (((r) + 2) / 2 + 1) + 16)
+#define SD_LDS_CAPMAX ((160 * 1024 - 1024) / 8)          // doubles of dynamic LDS a kernel may ask for
+__device__ void sd_jacobi(double *A, double *V, int r, double *sh, int cap) {
+    if ((V ? 2 : 1) * r * r > cap) { sd_jacobi_core(A, V, r, sh); return; }
+    double *la = sh + SD_SCRATCH(r);
     double *lv = V ? la + r * r : nullptr;
     for (int e = threadIdx.x; e < r * r; e += SD_T) la[e] = A[e];
     __syncthreads();
@@ -179,6 +242,330 @@ __device__ void sd_jacobi(double *A, double *V, int r, double *sh) {
     __syncthreads();
 }
 
+// B <- L^-1 B  (L lower r x r pitch ldl, B r x r pitch ldb): right-looking by rows.  Lanes own rows, waves own
+// columns: a lane fetches its entries of column j of L once per step (L may sit in global memory while B is in LDS)
+// and reuses them for every column of B; the next step's entries are fetched before the barrier.
+#define SD_RPL 8                                             // rows per lane kept in registers: r <= 512
+__device__ __forceinline__ void sd_trsm_l(const double *L, double *B, int r, int ldl = 0, int ldb = 0, bool lds = false) {
+    if (!ldl) ldl = r;
+    if (!ldb) ldb = r;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double lcol[SD_RPL];
+#pragma unroll
+    for (int q = 0; q < SD_RPL; ++q) { const int i = lane + 64 * q; lcol[q] = (i < r) ? L[i] : 0.0; }      // column 0
+    for (int j = 0; j < r; ++j) {
+        double ljj = 0.0;
+#pragma unroll
+        for (int q = 0; q < SD_RPL; ++q) if (lane + 64 * q == j) ljj = lcol[q];
+        ljj = __shfl(ljj, j & 63);                           // the diagonal entry sits in lane j % 64
+        const double inv = 1.0 / ljj;
+        double lcur[SD_RPL];
+#pragma unroll
+        for (int q = 0; q < SD_RPL; ++q) lcur[q] = lcol[q];
+        if (j + 1 < r) {
+#pragma unroll
+            for (int q = 0; q < SD_RPL; ++q) { const int i = lane + 64 * q; lcol[q] = (i < r) ? L[i + (long)(j + 1) * ldl] : 0.0; }
+        }
+        // four columns of B per pass: their LDS reads are issued together (the loop is latency-, not bandwidth-bound)
+        for (int c0 = wave * 4; c0 < r; c0 += (SD_T / 64) * 4) {
+            double bj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bj[u] = (c0 + u < r) ? B[j + (long)(c0 + u) * ldb] * inv : 0.0;
+#pragma unroll
+            for (int q = 0; q < SD_RPL; ++q) {
+                const int i = lane + 64 * q;
+                if (i > j && i < r) {
+                    double t[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) t[u] = (c0 + u < r) ? B[i + (long)(c0 + u) * ldb] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (c0 + u < r) B[i + (long)(c0 + u) * ldb] = t[u] - lcur[q] * bj[u];
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (c0 + u < r) B[j + (long)(c0 + u) * ldb] = bj[u];
+            }
+        }
+        sd_sync(lds);
+    }
+}
+// B <- L^-T B: the same from the last row upwards; row j of L' is column j of L, so a lane's multipliers L[j][i]
+// (i < j) are a strided row of L: fetched once per step as well
+__device__ __forceinline__ void sd_trsm_lt(const double *L, double *B, int r, int ldl = 0, int ldb = 0, bool lds = false) {
+    if (!ldl) ldl = r;
+    if (!ldb) ldb = r;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double lrow[SD_RPL];
+#pragma unroll
+    for (int q = 0; q < SD_RPL; ++q) { const int i = lane + 64 * q; lrow[q] = (i < r) ? L[(r - 1) + (long)i * ldl] : 0.0; }
+    for (int j = r - 1; j >= 0; --j) {
+        double ljj = 0.0;
+#pragma unroll
+        for (int q = 0; q < SD_RPL; ++q) if (lane + 64 * q == j) ljj = lrow[q];
+        ljj = __shfl(ljj, j & 63);
+        const double inv = 1.0 / ljj;
+        double lcur[SD_RPL];
+#pragma unroll
+        for (int q = 0; q < SD_RPL; ++q) lcur[q] = lrow[q];
+        if (j > 0) {
+#pragma unroll
+            for (int q = 0; q < SD_RPL; ++q) { const int i = lane + 64 * q; lrow[q] = (i < j) ? L[(j - 1) + (long)i * ldl] : 0.0; }
+        }
+        // four columns of B per pass: their LDS reads are issued together (the loop is latency-, not bandwidth-bound)
+        for (int c0 = wave * 4; c0 < r; c0 += (SD_T / 64) * 4) {
+            double bj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bj[u] = (c0 + u < r) ? B[j + (long)(c0 + u) * ldb] * inv : 0.0;
+#pragma unroll
+            for (int q = 0; q < SD_RPL; ++q) {
+                const int i = lane + 64 * q;
+                if (i < j) {
+                    double t[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) t[u] = (c0 + u < r) ? B[i + (long)(c0 + u) * ldb] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (c0 + u < r) B[i + (long)(c0 + u) * ldb] = t[u] - lcur[q] * bj[u];
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (c0 + u < r) B[j + (long)(c0 + u) * ldb] = bj[u];
+            }
+        }
+        sd_sync(lds);
+    }
+}
+__device__ __forceinline__ void sd_transpose(double *A, int r, int ld = 0, bool lds = false) {
+    if (!ld) ld = r;
+    for (int e = threadIdx.x; e < r * r; e += SD_T) {
+        const int i = e % r, j = e / r;
+        if (i < j) { const double a = A[i + j * ld], b = A[j + i * ld]; A[i + j * ld] = b; A[j + i * ld] = a; }
+    }
+    sd_sync(lds);
+}
+
+// ---- extreme eigenvalue of a symmetric matrix: Householder tridiagonalisation + multisection on the Sturm count.
+// maxstep_sdc needs only the largest eigenvalue of X^-1/2 D X^-1/2 (or the smallest of X) (:272-303): r^3 4/3 flops
+// and r barrier-separated steps instead of ~10 Jacobi sweeps of 3 (r - 1) steps each.
+#define SD_SCRATCH_TRI(r) (4 * (r) + SD_T + 32)
+__device__ __forceinline__ double sd_block_sum(double x, double *red) {
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    sd_sync(true);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    sd_sync(true);
+    return red[0] + red[1] + red[2] + red[3];
+}
+// A (full symmetric storage, pitch ld, destroyed).  sc: SD_SCRATCH_TRI(r) doubles of LDS.  Result returned to all threads.
+__device__ __forceinline__ double sd_extreme_eig(double *A, int r, int ld, double *sc, bool want_max, bool lds = false) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *dg = sc, *of = sc + r, *v = sc + 2 * r, *w = sc + 3 * r, *pb = sc + 4 * r, *red = sc + 4 * r + SD_T;
+    for (int k = 0; k + 1 < r; ++k) {
+        const int m = r - k - 1;
+        double *x = A + (k + 1) + (long)k * ld;                 // column k below the diagonal
+        double *A22 = A + (k + 1) + (long)(k + 1) * ld;
+        double part = 0.0;
+        for (int i = tid; i < m; i += SD_T) part += x[i] * x[i];
+        const double sigma = sd_block_sum(part, red);
+        const double x0 = x[0];
+        if (tid == 0) dg[k] = A[k + (long)k * ld];
+        if (m == 1 || !(sigma - x0 * x0 > 0.0)) {               // already tridiagonal in this column (uniform branch)
+            if (tid == 0) of[k] = x0;
+            sd_sync(lds);
+            continue;
+        }
+        const double alpha = -copysign(sqrt(sigma), x0);
+        const double beta = 1.0 / (sigma - x0 * alpha);        // 2 / ||v||^2 with v = x - alpha e1
+        for (int i = tid; i < m; i += SD_T) v[i] = x[i] - (i == 0 ? alpha : 0.0);
+        if (tid == 0) of[k] = alpha;
+        sd_sync(lds);
+        // p = beta A22 v, as a sum of columns (rows on consecutive lanes); the column range is split over the
+        // workgroup's spare threads and combined through pb
+        int mp = 64;
+        while (mp < m && mp < SD_T) mp *= 2;
+        const int nparts = SD_T / mp, jpart = tid / mp;
+        for (int i0 = 0; i0 < m; i0 += mp) {
+            const int i = i0 + tid % mp;
+            double acc = 0.0;
+            if (i < m) {
+                for (int j0 = jpart; j0 < m; j0 += 8 * nparts) {
+                    double av[8], vv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int j = j0 + u * nparts; av[u] = (j < m) ? A22[i + (long)j * ld] : 0.0; vv[u] = (j < m) ? v[j] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += av[u] * vv[u];
+                }
+            }
+            pb[tid] = acc;
+            sd_sync(lds);
+            if (tid < mp && i < m) {
+                double sum = 0.0;
+                for (int q = 0; q < nparts; ++q) sum += pb[q * mp + tid];
+                w[i] = beta * sum;
+            }
+            sd_sync(lds);
+        }
+        part = 0.0;
+        for (int i = tid; i < m; i += SD_T) part += v[i] * w[i];
+        const double kk = 0.5 * beta * sd_block_sum(part, red);
+        for (int i = tid; i < m; i += SD_T) w[i] -= kk * v[i];
+        sd_sync(lds);
+        {                                                       // A22 -= v w' + w v': lanes own rows, four columns per pass
+            double vi[SD_RPL], wi[SD_RPL];
+#pragma unroll
+            for (int q = 0; q < SD_RPL; ++q) { const int i = lane + 64 * q; vi[q] = (i < m) ? v[i] : 0.0; wi[q] = (i < m) ? w[i] : 0.0; }
+            for (int j0 = wave * 4; j0 < m; j0 += (SD_T / 64) * 4) {
+                double vj[4], wj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { vj[u] = (j0 + u < m) ? v[j0 + u] : 0.0; wj[u] = (j0 + u < m) ? w[j0 + u] : 0.0; }
+#pragma unroll
+                for (int q = 0; q < SD_RPL; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < m) {
+                        double t[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) t[u] = (j0 + u < m) ? A22[i + (long)(j0 + u) * ld] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (j0 + u < m) A22[i + (long)(j0 + u) * ld] = t[u] - (vi[q] * wj[u] + wi[q] * vj[u]);
+                    }
+                }
+            }
+        }
+        sd_sync(lds);
+    }
+    if (tid == 0) { dg[r - 1] = A[(r - 1) + (long)(r - 1) * ld]; of[r - 1] = 0.0; }
+    sd_sync(lds);
+    // Gershgorin interval
+    double lo = __builtin_inf(), hi = -__builtin_inf();
+    for (int i = tid; i < r; i += SD_T) {
+        const double rad = (i > 0 ? fabs(of[i - 1]) : 0.0) + (i + 1 < r ? fabs(of[i]) : 0.0);
+        lo = fmin(lo, dg[i] - rad);
+        hi = fmax(hi, dg[i] + rad);
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
+    sd_sync(lds);
+    if (lane == 0) { red[wave] = lo; red[4 + wave] = hi; }
+    sd_sync(lds);
+    lo = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    hi = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+    const double span = fmax(fabs(lo), fabs(hi));
+    hi += 1e-15 * span + 1e-300;                               // the count at hi must be r, at lo 0
+    lo -= 1e-15 * span + 1e-300;
+    int *first = (int *)(red + 8);
+    for (int round = 0; round < 12; ++round) {
+        if (!(hi - lo > 4.4e-16 * fmax(fabs(lo), fabs(hi)))) break;
+        const double step = (hi - lo) / (SD_T + 1);
+        const double xs = lo + step * (tid + 1);
+        // Sturm count: number of eigenvalues below xs
+        int cnt = 0;
+        double q = dg[0] - xs;
+        if (q < 0.0) ++cnt;
+        for (int i = 1; i < r; ++i) {
+            if (q == 0.0) q = 1e-300;
+            q = (dg[i] - xs) - of[i - 1] * of[i - 1] / q;
+            if (q < 0.0) ++cnt;
+        }
+        const bool hit = want_max ? (cnt >= r) : (cnt >= 1);   // monotone in tid
+        if (tid == 0) *first = SD_T;
+        sd_sync(lds);
+        if (hit) atomicMin(first, tid);
+        sd_sync(lds);
+        const int f = *first;
+        sd_sync(lds);
+        const double nlo = (f == 0) ? lo : lo + step * f;       // x_{f-1}
+        const double nhi = (f == SD_T) ? hi : lo + step * (f + 1);
+        lo = nlo; hi = nhi;
+    }
+    return 0.5 * (lo + hi);
+}
+
+// LDS pitch of the one-sided Jacobi's matrix: == 4 (mod 32) doubles, so that the 8 column pairs x 4 row-interleaved
+// lanes of a half-wave (columns p, p+1, ... of consecutive pairs) fall on 32 different 8-byte bank pairs
+__host__ __device__ __forceinline__ int sd_pitch(int r) { return r + ((4 - r % 32) + 32) % 32; }
+// One-sided (Hestenes) Jacobi: right rotations until the columns of G (r x r, ld) are mutually orthogonal:
+// G_in V = U diag(sigma), i.e. column i ends as sigma_i u_i -- the left singular vectors and singular values of
+// G_in, which is all nestod_sdc needs of svd(Lz' Ls) (src/ConicIP.jl:204-208).  Only ONE matrix is live, so r = 128
+// (padded pitch 129: the 64 column pairs of a round then fall on different LDS banks) stays LDS-resident.  A round
+// rotates r/2 disjoint column pairs at once, `tpp` lanes per pair, one barrier per round.
+__device__ __forceinline__ void sd_jacobi_onesided(double *G, int r, int ld, int *sflag, bool lds = false) {
+    const int tid = threadIdx.x;
+    const int m = (r + 1) & ~1, np = m / 2;
+    int tpp = 1;
+    while (tpp < 64 && 2 * tpp * np <= SD_T) tpp *= 2;
+    const int ngroups = SD_T / tpp;
+    const int part = tid % tpp;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        if (tid == 0) *sflag = 0;
+        sd_sync(lds);
+        for (int t = 0; t < m - 1; ++t) {
+            for (int k = tid / tpp; k < np; k += ngroups) {
+                int p, q;
+                if (k == 0) { p = m - 1; q = t; }
+                else { p = (t + k) % (m - 1); q = (t - k + (m - 1)) % (m - 1); }
+                const bool live = p < r && q < r;              // dummy player (index r) when r is odd
+                double *gp = G + (long)(live ? p : 0) * ld, *gq = G + (long)(live ? q : 0) * ld;
+                double a = 0.0, b = 0.0, c = 0.0;
+                if (r <= 32 * tpp) {
+                    // both columns stay in registers between the dot products and the rotation
+                    double xv[32], yv[32];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) {
+                        const int i = part + u * tpp;
+                        const bool in = live && i < r;
+                        xv[u] = in ? gp[i] : 0.0;
+                        yv[u] = in ? gq[i] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) { a += xv[u] * xv[u]; b += yv[u] * yv[u]; c += xv[u] * yv[u]; }
+                    for (int o = tpp >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+                    if (live && fabs(c) > 1e-15 * sqrt(a * b) && c != 0.0) {
+                        const double zeta = (b - a) / (2.0 * c);
+                        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+#pragma unroll
+                        for (int u = 0; u < 32; ++u) {
+                            const int i = part + u * tpp;
+                            if (i < r) { gp[i] = cs * xv[u] - sn * yv[u]; gq[i] = sn * xv[u] + cs * yv[u]; }
+                        }
+                        if (part == 0) *sflag = 1;
+                    }
+                    continue;
+                }
+                if (live) {
+                    for (int i0 = part; i0 < r; i0 += 8 * tpp) {       // 16 LDS reads in flight per pass
+                        double xv[8], yv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { const int i = i0 + u * tpp; xv[u] = (i < r) ? gp[i] : 0.0; yv[u] = (i < r) ? gq[i] : 0.0; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { a += xv[u] * xv[u]; b += yv[u] * yv[u]; c += xv[u] * yv[u]; }
+                    }
+                }
+                for (int o = tpp >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+                if (live && fabs(c) > 1e-15 * sqrt(a * b) && c != 0.0) {
+                    const double zeta = (b - a) / (2.0 * c);
+                    const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+                    for (int i0 = part; i0 < r; i0 += 8 * tpp) {
+                        double xv[8], yv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { const int i = i0 + u * tpp; xv[u] = (i < r) ? gp[i] : 0.0; yv[u] = (i < r) ? gq[i] : 0.0; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int i = i0 + u * tpp;
+                            if (i < r) { gp[i] = cs * xv[u] - sn * yv[u]; gq[i] = sn * xv[u] + cs * yv[u]; }
+                        }
+                    }
+                    if (part == 0) *sflag = 1;
+                }
+            }
+            sd_sync(lds);
+        }
+        const int again = *sflag;
+        sd_sync(lds);
+        if (!again) break;
+    }
+}
+
 // workspace of one workgroup: NW r x r matrices
 #define SD_NW 6
 __device__ __forceinline__ double *sd_ws(double *base, int slot, int r, int which) {
@@ -186,44 +573,76 @@ __device__ __forceinline__ double *sd_ws(double *base, int slot, int r, int whic
 }
 
 // ---------------------------------------------------------------------------------- NT scaling
-__global__ __launch_bounds__(SD_T) void k_sdp_nt_scaling(const ConeDesc *cones, const int *sidx, const double *v,
-                                                          const double *s, double *scal, double *lambda, double *wsb,
-                                                          int *flag) {
-    extern __shared__ double sh[];
-    const ConeDesc cd = cones[sidx[blockIdx.x]];
+// The body is inlined twice (live matrix W in LDS / in global memory) so that the LDS instance is compiled to ds_*
+// instructions: a pointer selected at run time between the two address spaces makes every access a FLAT one
+// (measured: 6.6 ms instead of sub-millisecond for the one-sided Jacobi at r = 128).
+__device__ __forceinline__ void sd_nt_body(const ConeDesc &cd, const double *v, const double *s, double *R, double *Ri,
+                                           double *lambda, double *Z, double *S, double *T, double *U, double *W, int ld,
+                                           int *flag, int *sflagp, bool lds) {
     const int r = cd.r;
-    double *Z = sd_ws(wsb, blockIdx.x, r, 0), *S = sd_ws(wsb, blockIdx.x, r, 1), *T = sd_ws(wsb, blockIdx.x, r, 2),
-           *M = sd_ws(wsb, blockIdx.x, r, 3), *U = sd_ws(wsb, blockIdx.x, r, 4);
-    double *R = scal + cd.soff, *Ri = R + (size_t)r * r;
-    sd_mat(v + cd.off, 1, Z, r);
-    sd_mat(s + cd.off, 1, S, r);
-    sd_chol(Z, r, flag);                       // Z <- Lz
-    sd_gemm(T, S, false, Z, false, r);         // S Lz
-    sd_gemm(M, Z, true, T, false, r);          // Lz' S Lz  = U Lambda^2 U'
-    // symmetrise against rounding
-    for (int e = threadIdx.x; e < r * r; e += SD_T) { const int i = e % r, j = e / r; if (i > j) { const double a = 0.5 * (M[e] + M[j + i * r]); M[e] = a; M[j + i * r] = a; } }
+    SD_TICK_INIT;
+    sd_mat(v + cd.off, 1, W, r, ld);
+    SD_TICK("nt mat");
+    sd_chol(W, r, flag, ld, lds);                                       // Lz     (src/ConicIP.jl:202-203)
+    SD_TICK("nt chol");
+    for (int e = threadIdx.x; e < r * r; e += SD_T) Z[e] = W[e % r + (e / r) * ld];
     __syncthreads();
-    sd_jacobi(M, U, r, sh);
-    // R = Lz^-T U Lambda^(1/2);  Rinv = Lambda^(-1/2) U' Lz'
-    for (int e = threadIdx.x; e < r * r; e += SD_T) T[e] = U[e];
+    sd_mat(s + cd.off, 1, W, r, ld);
+    sd_chol(W, r, flag, ld, lds);                                       // Ls
+    for (int e = threadIdx.x; e < r * r; e += SD_T) S[e] = W[e % r + (e / r) * ld];
     __syncthreads();
-    sd_solve_LT(Z, T, r);                      // T = Lz^-T U
-    for (int e = threadIdx.x; e < r * r; e += SD_T) {
-        const int j = e / r;
-        R[e] = T[e] * sqrt(sqrt(fmax(M[j + j * r], 0.0)));       // Lambda_j = sqrt(eig_j)
+    SD_TICK("nt chol2+copy");
+    sd_gemm(U, Z, true, S, false, r);                              // G = Lz' Ls = U Lambda V'   (:204)
+    SD_TICK("nt gemm");
+    for (int e = threadIdx.x; e < r * r; e += SD_T) W[e % r + (e / r) * ld] = U[e];
+    __syncthreads();
+    sd_jacobi_onesided(W, r, ld, sflagp, lds);                          // column i = Lambda_i u_i
+    SD_TICK("nt jacobi1");
+    double *lam = S;                                               // Ls is no longer needed: first r entries hold Lambda
+    for (int i = threadIdx.x; i < r; i += SD_T) {
+        double n2 = 0.0;
+        for (int k = 0; k < r; ++k) { const double g = W[k + i * ld]; n2 += g * g; }
+        lam[i] = sqrt(n2);
     }
     __syncthreads();
-    sd_gemm(T, U, true, Z, true, r);           // U' Lz'
     for (int e = threadIdx.x; e < r * r; e += SD_T) {
-        const int i = e % r;
-        Ri[e] = T[e] / sqrt(sqrt(fmax(M[i + i * r], 0.0)));
+        const int i = e % r, j = e / r;
+        const double u = W[i + j * ld] / lam[j];
+        U[e] = u;
+        W[i + j * ld] = u;
     }
+    __syncthreads();
+    // R = Lz^-T U Lambda^(1/2) (:206-208);  Rinv = Lambda^(-1/2) U' Lz'
+    SD_TICK("nt lam/U");
+    sd_trsm_lt(Z, W, r, r, ld, lds);                                    // Lz^-T U
+    SD_TICK("nt trsm_lt");
+    for (int e = threadIdx.x; e < r * r; e += SD_T) R[e] = W[e % r + (e / r) * ld] * sqrt(lam[e / r]);
+    __syncthreads();
+    sd_gemm(T, U, true, Z, true, r);                               // U' Lz'
+    for (int e = threadIdx.x; e < r * r; e += SD_T) Ri[e] = T[e] / sqrt(lam[e % r]);
+    SD_TICK("nt gemm2+Ri");
+    SD_TICK_DUMP;
     if (lambda) {
         // lambda = F v = vecm(R' Z R) = vecm(diag(Lambda))
         for (int e = threadIdx.x; e < cd.dim; e += SD_T) lambda[cd.off + e] = 0.0;
         __syncthreads();
-        for (int i = threadIdx.x; i < r; i += SD_T) lambda[cd.off + vidx(i, i, r)] = sqrt(fmax(M[i + i * r], 0.0));
+        for (int i = threadIdx.x; i < r; i += SD_T) lambda[cd.off + vidx(i, i, r)] = lam[i];
     }
+}
+__global__ __launch_bounds__(SD_T) void k_sdp_nt_scaling(const ConeDesc *cones, const int *sidx, const double *v,
+                                                          const double *s, double *scal, double *lambda, double *wsb,
+                                                          int *flag, int cap) {
+    extern __shared__ double sh[];
+    __shared__ int sflag;
+    const ConeDesc cd = cones[sidx[blockIdx.x]];
+    const int r = cd.r;
+    double *Z = sd_ws(wsb, blockIdx.x, r, 0), *S = sd_ws(wsb, blockIdx.x, r, 1), *T = sd_ws(wsb, blockIdx.x, r, 2),
+           *U = sd_ws(wsb, blockIdx.x, r, 4);
+    double *R = scal + cd.soff, *Ri = R + (size_t)r * r;
+    // Every O(r^3) stage with a serial chain works on ONE matrix at a time, LDS-resident (pitch r + 1) when
+    // r (r + 1) doubles fit; the finished factor is parked in global memory for the next stage.
+    if (r * sd_pitch(r) <= cap) sd_nt_body(cd, v, s, R, Ri, lambda, Z, S, T, U, sh, sd_pitch(r), flag, &sflag, true);
+    else sd_nt_body(cd, v, s, R, Ri, lambda, Z, S, T, U, T, r, flag, &sflag, false);
 }
 
 // out = vecm(P' X P) with P = R (F), R' (F'), Rinv (F^-1), Rinv' (F^-T); x / out strided (xs, os)
@@ -294,7 +713,7 @@ __global__ __launch_bounds__(SD_T) void k_sdp_prod(const ConeDesc *cones, const 
 
 // out: Y O + O Y = X  (dsdc! = vecm(lyap(Y, -X)) src/ConicIP.jl:347-353)
 __global__ __launch_bounds__(SD_T) void k_sdp_div(const ConeDesc *cones, const int *sidx, const double *x, const double *y,
-                                                   double *out, double *wsb) {
+                                                   double *out, double *wsb, int cap) {
     extern __shared__ double sh[];
     const ConeDesc cd = cones[sidx[blockIdx.x]];
     const int r = cd.r;
@@ -302,7 +721,7 @@ __global__ __launch_bounds__(SD_T) void k_sdp_div(const ConeDesc *cones, const i
            *T = sd_ws(wsb, blockIdx.x, r, 3), *W = sd_ws(wsb, blockIdx.x, r, 4);
     sd_mat(x + cd.off, 1, X, r);
     sd_mat(y + cd.off, 1, Y, r);
-    sd_jacobi(Y, V, r, sh);                                  // Y = V diag V'
+    sd_jacobi(Y, V, r, sh, cap);                             // Y = V diag V'
     sd_gemm(T, X, false, V, false, r);
     sd_gemm(W, V, true, T, false, r);                        // V' X V
     for (int e = threadIdx.x; e < r * r; e += SD_T) { const int i = e % r, j = e / r; W[e] /= (Y[i + i * r] + Y[j + j * r]); }
@@ -313,72 +732,77 @@ __global__ __launch_bounds__(SD_T) void k_sdp_div(const ConeDesc *cones, const i
 }
 
 // ---------------------------------------------------------------------------------- max step
-__global__ __launch_bounds__(SD_T) void k_sdp_maxstep(const ConeDesc *cones, const int *sidx, const double *x, const double *d,
-                                                       double scale, double *partial, double *wsb) {
-    extern __shared__ double sh[];
-    __shared__ double sres;
-    const ConeDesc cd = cones[sidx[blockIdx.x]];
+// eigvals(X^-1/2 D X^-1/2) (:272-293) are the eigenvalues of L^-1 D L^-T with X = L L' (the two matrices are
+// similar through the orthogonal X^-1/2 L), and only the largest is used: one Cholesky, two triangular solves, one
+// tridiagonalisation + bisection -- with the ONE live matrix LDS-resident (pitch r + 1) up to r = 139 -- instead of
+// an eigendecomposition with vectors, three GEMMs and a second Jacobi, all in global memory at r = 128 (80 ms per
+// call -> see DESIGN.md).  `cap` = doubles of dynamic LDS behind the scratch.
+__device__ __forceinline__ void sd_maxstep_body(const ConeDesc &cd, const double *x, const double *d, double scale,
+                                                double *partial, double *Lg, double *M, int ld, double *sc, int *sflagp, bool lds) {
     const int r = cd.r;
     const double INF = __builtin_inf();
-    double *X = sd_ws(wsb, blockIdx.x, r, 0), *V = sd_ws(wsb, blockIdx.x, r, 1), *D = sd_ws(wsb, blockIdx.x, r, 2),
-           *T = sd_ws(wsb, blockIdx.x, r, 3), *W = sd_ws(wsb, blockIdx.x, r, 4);
-    sd_mat(x + cd.off, 1, X, r);
+    SD_TICK_INIT;
+    sd_mat(x + cd.off, 1, M, r, ld);
     if (!d) {                                                // maxstep_sdc(x, nothing) :295-303
-        sd_jacobi(X, nullptr, r, sh);
-        if (threadIdx.x == 0) {
-            double mn = INF;
-            for (int i = 0; i < r; ++i) mn = fmin(mn, X[i + i * r]);
-            partial[cd.item] = (mn > 0.0) ? 0.0 : -1.0 + mn;
-        }
+        const double mn = sd_extreme_eig(M, r, ld, sc, false, lds);
+        if (threadIdx.x == 0) partial[cd.item] = (mn > 0.0) ? 0.0 : -1.0 + mn;
         return;
     }
-    sd_jacobi(X, V, r, sh);                                  // X = V diag V'
-    if (threadIdx.x == 0) {
-        double mn = INF;
-        for (int i = 0; i < r; ++i) mn = fmin(mn, X[i + i * r]);
-        sres = mn;
-    }
+    if (threadIdx.x == 0) *sflagp = 0;
     __syncthreads();
-    if (!(sres > 0.0)) {                                     // X not PD -> Inf (:277-280)
+    sd_chol(M, r, sflagp, ld, lds);                               // M <- L
+    if (*sflagp) {                                           // X not PD -> Inf (:277-280)
         if (threadIdx.x == 0) partial[cd.item] = INF;
         return;
     }
-    // Xih = V diag^-1/2 V'
-    for (int e = threadIdx.x; e < r * r; e += SD_T) { const int j = e / r; T[e] = V[e] / sqrt(X[j + j * r]); }
+    for (int e = threadIdx.x; e < r * r; e += SD_T) Lg[e] = M[e % r + (e / r) * ld];
     __syncthreads();
-    sd_gemm(W, T, false, V, true, r);                        // W = Xih
-    sd_mat(d + cd.off, 1, D, r);
-    sd_gemm(T, D, false, W, false, r);
-    sd_gemm(X, W, false, T, false, r);                       // Xih D Xih
-    for (int e = threadIdx.x; e < r * r; e += SD_T) { const int i = e % r, j = e / r; if (i > j) { const double a = 0.5 * (X[e] + X[j + i * r]); X[e] = a; X[j + i * r] = a; } }
-    __syncthreads();
-    sd_jacobi(X, nullptr, r, sh);
-    if (threadIdx.x == 0) {
-        double mx = -INF;
-        bool allneg = true;
-        for (int i = 0; i < r; ++i) {
-            const double l = X[i + i * r] * scale;
-            if (!(l < 0.0)) { allneg = false; mx = fmax(mx, l); }
-        }
-        partial[cd.item] = allneg ? INF : 1.0 / mx;
+    sd_mat(d + cd.off, 1, M, r, ld);
+    SD_TICK("ms chol+copy+mat");
+    sd_trsm_l(Lg, M, r, r, ld, lds);                              // L^-1 D
+    SD_TICK("ms trsm1");
+    sd_transpose(M, r, ld, lds);                                  // D L^-T
+    sd_trsm_l(Lg, M, r, r, ld, lds);                              // L^-1 D L^-T
+    SD_TICK("ms trsm2");
+    for (int e = threadIdx.x; e < r * r; e += SD_T) {
+        const int i = e % r, j = e / r;
+        if (i > j) { const double a = 0.5 * (M[i + j * ld] + M[j + i * ld]); M[i + j * ld] = a; M[j + i * ld] = a; }
     }
+    __syncthreads();
+    const double mx = sd_extreme_eig(M, r, ld, sc, true, lds) * scale;
+    SD_TICK("ms tridiag+bis");
+    SD_TICK_DUMP;
+    if (threadIdx.x == 0) partial[cd.item] = (mx < 0.0) ? INF : 1.0 / mx;
+}
+__global__ __launch_bounds__(SD_T) void k_sdp_maxstep(const ConeDesc *cones, const int *sidx, const double *x, const double *d,
+                                                       double scale, double *partial, double *wsb, int cap) {
+    extern __shared__ double sh[];
+    __shared__ int sflag;
+    const ConeDesc cd = cones[sidx[blockIdx.x]];
+    const int r = cd.r;
+    double *Lg = sd_ws(wsb, blockIdx.x, r, 0);               // L in global memory (pitch r)
+    if (r * (r + 1) <= cap) sd_maxstep_body(cd, x, d, scale, partial, Lg, sh + SD_SCRATCH_TRI(r), r + 1, sh, &sflag, true);
+    else sd_maxstep_body(cd, x, d, scale, partial, Lg, sd_ws(wsb, blockIdx.x, r, 2), r, sh, &sflag, false);
 }
 
 // ---------------------------------------------------------------------------------- host launchers
-static size_t sd_shmem(int rmax) {
-    size_t d = 4 * ((size_t)(rmax + 2) / 2 + 1) + 16;
-    if (rmax <= SD_LDS_RMAX) d += 2 * (size_t)rmax * rmax;          // LDS-resident Jacobi
-    return d * sizeof(double);
+// dynamic LDS: rotation scratch + up to `nmat` matrices of the largest cone (pitch r+1 allowed for), capped
+static int sd_cap(int rmax, int nmat) {
+    const int pitch = sd_pitch(rmax) > rmax + 1 ? sd_pitch(rmax) : rmax + 1;
+    const long want = (long)nmat * rmax * pitch;
+    const long room = SD_LDS_CAPMAX - SD_SCRATCH(rmax);
+    return (int)(want < room ? want : room);
 }
-static int sd_set_lds_attr(const void *fn, int rmax) {
-    CIP_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sd_shmem(rmax)));
+static size_t sd_shmem(int rmax, int nmat) { return ((size_t)SD_SCRATCH(rmax) + sd_cap(rmax, nmat)) * sizeof(double); }
+static int sd_set_lds_attr(const void *fn, int rmax, int nmat) {
+    CIP_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sd_shmem(rmax, nmat)));
     return 0;
 }
 
 int cip_sdp_nt_scaling(hipStream_t s, const ConeSet &cs, const double *v, const double *sv, double *lambda) {
-    if (sd_set_lds_attr((const void *)k_sdp_nt_scaling, cs.rmax)) return -3;
-    hipLaunchKernelGGL(k_sdp_nt_scaling, dim3(cs.ns), dim3(SD_T), sd_shmem(cs.rmax), s, cs.d_cones, cs.d_sidx, v, sv, cs.d_scal,
-                       lambda, cs.d_sdpws, cs.d_sdpflag);
+    if (sd_set_lds_attr((const void *)k_sdp_nt_scaling, cs.rmax, 1)) return -3;
+    hipLaunchKernelGGL(k_sdp_nt_scaling, dim3(cs.ns), dim3(SD_T), sd_shmem(cs.rmax, 1), s, cs.d_cones, cs.d_sidx, v, sv,
+                       cs.d_scal, lambda, cs.d_sdpws, cs.d_sdpflag, sd_cap(cs.rmax, 1) + SD_SCRATCH(cs.rmax));
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -393,15 +817,20 @@ int cip_sdp_prod(hipStream_t s, const ConeSet &cs, const double *x, const double
     return 0;
 }
 int cip_sdp_div(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out) {
-    if (sd_set_lds_attr((const void *)k_sdp_div, cs.rmax)) return -3;
-    hipLaunchKernelGGL(k_sdp_div, dim3(cs.ns), dim3(SD_T), sd_shmem(cs.rmax), s, cs.d_cones, cs.d_sidx, x, y, out, cs.d_sdpws);
+    if (sd_set_lds_attr((const void *)k_sdp_div, cs.rmax, 2)) return -3;
+    hipLaunchKernelGGL(k_sdp_div, dim3(cs.ns), dim3(SD_T), sd_shmem(cs.rmax, 2), s, cs.d_cones, cs.d_sidx, x, y, out, cs.d_sdpws,
+                       sd_cap(cs.rmax, 2));
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 int cip_sdp_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const double *d, double scale, double *partial) {
-    if (sd_set_lds_attr((const void *)k_sdp_maxstep, cs.rmax)) return -3;
-    hipLaunchKernelGGL(k_sdp_maxstep, dim3(cs.ns), dim3(SD_T), sd_shmem(cs.rmax), s, cs.d_cones, cs.d_sidx, x, d, scale, partial,
-                       cs.d_sdpws);
+    // scratch of the tridiagonalisation + one matrix of pitch r + 1 when it fits
+    const long want = (long)cs.rmax * (cs.rmax + 1), room = SD_LDS_CAPMAX - SD_SCRATCH_TRI(cs.rmax);
+    const int cap = (int)(want < room ? want : (room > 0 ? room : 0));
+    const size_t shm = ((size_t)SD_SCRATCH_TRI(cs.rmax) + cap) * sizeof(double);
+    CIP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sdp_maxstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(k_sdp_maxstep, dim3(cs.ns), dim3(SD_T), shm, s, cs.d_cones, cs.d_sidx, x, d, scale, partial,
+                       cs.d_sdpws, cap);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
