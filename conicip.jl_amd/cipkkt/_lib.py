@@ -30,6 +30,21 @@ class CipProblem(C.Structure):
                 ("route", C.c_int), ("flags", C.c_int)]
 
 
+class CipOptions(C.Structure):
+    _fields_ = [("optTol", C.c_double), ("DTB", C.c_double), ("infeasTol", C.c_double),
+                ("refinementThreshold", C.c_double), ("maxRefinementSteps", C.c_int), ("maxIters", C.c_int),
+                ("verbose", C.c_int)]
+
+
+class CipResult(C.Structure):
+    _fields_ = [("status", C.c_int), ("iter", C.c_int), ("mu", C.c_double), ("prFeas", C.c_double),
+                ("duFeas", C.c_double), ("muFeas", C.c_double), ("pobj", C.c_double), ("dobj", C.c_double),
+                ("n_factor", C.c_int), ("n_solve", C.c_int), ("trace_rows", C.c_int), ("wall_s", C.c_double)]
+
+
+STATUS_NAMES = {0: "None", 1: "Optimal", 2: "Infeasible", 3: "Unbounded", 4: "Abandoned", 5: "Error"}
+TRACE_COLS = 9
+
 # name -> (restype, argtypes); every symbol include/cipkkt.h declares
 SIGNATURES = {
     "cip_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, C.c_void_p, C.c_void_p,
@@ -57,6 +72,8 @@ SIGNATURES = {
     "cip_dots_dev": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_int_p,
                                c_double_p]),
     "cip_axpby_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_double, C.c_void_p]),
+    "cip_conicip": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(CipOptions), C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.POINTER(CipResult), C.c_void_p, C.c_int]),
     "cip_ldlt_workspace_bytes": (C.c_int, [C.c_int, C.POINTER(C.c_size_t)]),
     "cip_ldlt_factor_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_int_p]),
     "cip_ldlt_solve_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -52,17 +52,50 @@ def _nrm(x2):
     return math.sqrt(x2) if x2 >= 0 else math.nan
 
 
+def _conicIP_native(ks, c_h, b_h, d_h, n, m, p, optTol, DTB, infeasTol, refinementThreshold, maxRefinementSteps,
+                    maxIters, verbose, t_start):
+    """The loop of src/ConicIP.jl:730-934 inside the library (csrc/driver.hip: cip_conicip)."""
+    import ctypes as C
+    opt = L.CipOptions(optTol, DTB, infeasTol, refinementThreshold, maxRefinementSteps, maxIters, int(bool(verbose)))
+    res = L.CipResult()
+    y, w, v = np.zeros(max(n, 1)), np.zeros(max(p, 1)), np.zeros(max(m, 1))
+    trace = np.zeros((max(maxIters, 1), L.TRACE_COLS))
+    c_h, b_h, d_h = (np.ascontiguousarray(x, dtype=np.float64) for x in (c_h, b_h, d_h))
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    with torch.cuda.device(ks.device):
+        L.check(ks.lib.cip_conicip(ks.h, ptr(c_h), ptr(b_h) if m else None, ptr(d_h) if p else None,
+                                    C.byref(opt), ptr(y), ptr(w), ptr(v), C.byref(res), ptr(trace), int(maxIters)))
+    sol = Solution(y[:n].copy(), w[:p].copy(), v[:m].copy())
+    sol.status = L.STATUS_NAMES[res.status]
+    sol.Iter, sol.Mu = res.iter, res.mu
+    sol.prFeas, sol.duFeas, sol.muFeas = res.prFeas, res.duFeas, res.muFeas
+    sol.pobj, sol.dobj = res.pobj, res.dobj
+    sol.n_factor, sol.n_solve = res.n_factor, res.n_solve
+    names = ("Iter", "mu", "rDu", "rPr", "rCp", "pobj", "dobj", "alpha", "sigma")
+    for row in trace[:res.trace_rows]:
+        d_ = dict(zip(names, row.tolist()))
+        d_["Iter"] = int(d_["Iter"])
+        if d_["alpha"] != d_["alpha"]:          # the terminating iteration takes no step
+            del d_["alpha"], d_["sigma"]
+        sol.trace.append(d_)
+    sol.wall_s = time.perf_counter() - t_start
+    return sol
+
+
 def conicIP(Q, c, A, b, cone_dims, G=None, d=None, *,
             kktsolver="schur",
             optTol=1e-6, DTB=0.01, verbose=False,
             maxRefinementSteps=3, maxIters=100, cache_nestodd=False,
             infeasTol=None, refinementThreshold=None,
-            device=None, system=None, keep_iterates=None):
+            device=None, system=None, keep_iterates=None, driver="native"):
     """minimize 1/2 y'Qy - c'y  s.t.  Ay - b in K,  Gy = d   (src/ConicIP.jl:411-430).
 
     `kktsolver` selects the elimination route of the HIP KKT path: "schur"
     (block elimination, ≙ pivot(kktsolver_2x2)) or "full3x3" (literal 3x3 assembly,
-    ≙ kktsolver_sparse).  `system` may carry an already-built KKTSystem (level 1)."""
+    ≙ kktsolver_sparse).  `system` may carry an already-built KKTSystem (level 1).
+
+    `driver`: "native" runs the loop in C++ inside libcipkkt (`cip_conicip`, csrc/driver.hip); "python" runs
+    the identical loop below through the per-operation C-ABI entry points (needed for `keep_iterates`)."""
     t_start = time.perf_counter()
     if infeasTol is None:
         infeasTol = optTol
@@ -87,6 +120,9 @@ def conicIP(Q, c, A, b, cone_dims, G=None, d=None, *,
         raise ValueError("Inconsistency in equalities/objective")
 
     ks = system if system is not None else KKTSystem(Q, A, G, cone_dims, route=kktsolver, device=device)
+    if driver == "native" and keep_iterates is None:
+        return _conicIP_native(ks, c_h, b_h, d_h, n, m, p, optTol, DTB, infeasTol, refinementThreshold,
+                               maxRefinementSteps, maxIters, verbose, t_start)
     dev = ks.device
     f64 = dict(dtype=torch.float64, device=dev)
     NT = n + p + 2 * m

@@ -137,6 +137,31 @@ int cip_dots_dev(cip_handle *h, int count, const double *const *x, const double 
                  const int *len, double *out_host);
 int cip_axpby_dev(cip_handle *h, int len, double alpha, const double *x, double beta, double *y); /* y = alpha x + beta y */
 
+/* ---- the whole interior-point loop of conicIP (src/ConicIP.jl:468-939) driven natively: every vector stays in
+ * HBM, the host sees scalars only.  Same options and defaults as the reference's keyword
+ * arguments (src/ConicIP.jl:498-509); a negative infeasTol / refinementThreshold selects the reference's derived
+ * default (optTol, optTol/1e7).  c[n], b[m], d[p] and the outputs y[n], w[p], v[m] are host pointers.
+ * trace (optional, trace_cap rows of CIP_TRACE_COLS doubles): Iter, mu, rDu, rPr, rCp, pobj, dobj, alpha, sigma. */
+#define CIP_STATUS_NONE       0
+#define CIP_STATUS_OPTIMAL    1   /* :Optimal    src/ConicIP.jl:786 */
+#define CIP_STATUS_INFEASIBLE 2   /* :Infeasible src/ConicIP.jl:815-818 */
+#define CIP_STATUS_UNBOUNDED  3   /* :Unbounded  src/ConicIP.jl:847-850 */
+#define CIP_STATUS_ABANDONED  4   /* :Abandoned  src/ConicIP.jl:936 */
+#define CIP_STATUS_ERROR      5   /* :Error      src/ConicIP.jl:870-873 */
+#define CIP_TRACE_COLS 9
+typedef struct cip_options {
+    double optTol, DTB, infeasTol, refinementThreshold;
+    int maxRefinementSteps, maxIters, verbose;
+} cip_options;
+typedef struct cip_result {          /* src/ConicIP.jl:384-398 (Solution) */
+    int status, iter;
+    double mu, prFeas, duFeas, muFeas, pobj, dobj;
+    int n_factor, n_solve, trace_rows;
+    double wall_s;
+} cip_result;
+int cip_conicip(cip_handle *h, const double *c, const double *b, const double *d, const cip_options *opt,
+                double *y, double *w, double *v, cip_result *res, double *trace, int trace_cap);
+
 /* ---- dense symmetric LDL' building blocks (device pointers), usable on their own.
  * K is N x N column-major with leading dimension ld; only the lower triangle is
  * referenced.  N and ld must be multiples of 128 (pad with an identity block). */

@@ -110,3 +110,32 @@ def test_dense_qp_2048_properties():
     s2 = cipkkt.conicIP(Q, c, A, b, [("R", n)], optTol=1e-6, kktsolver="full3x3")
     assert s2.status == "Optimal" and s2.Iter == s1.Iter
     assert np.linalg.norm(s1.y - s2.y) / (1 + np.linalg.norm(s1.y)) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["sphere", "combined", "simplex", "soc_direct", "lp_doc", "psd_projection",
+                                  "infeasible_box", "infeasible_eq", "unbounded"])
+def test_native_driver_matches_per_operation_driver(name):
+    """cip_conicip (csrc/driver.hip) and the Python loop over the per-operation entry points issue the same
+    kernels in the same order: statuses, iteration counts and the whole trajectory agree (1e-12 relative)."""
+    import cipkkt
+    Q, c, A, b, K, G, d = getattr(P, name)()[:7]
+    sols = [cipkkt.conicIP(Q, c, A, b, K, G, d, optTol=1e-7, driver=drv) for drv in ("native", "python")]
+    nat, py = sols
+    assert nat.status == py.status
+    assert (nat.Iter, nat.n_factor, nat.n_solve, len(nat.trace)) == (py.Iter, py.n_factor, py.n_solve, len(py.trace))
+    for tn, tp in zip(nat.trace, py.trace):
+        assert set(tn) == set(tp)
+        for key in tn:
+            assert tn[key] == pytest.approx(tp[key], rel=1e-12, abs=1e-300), (key, tn["Iter"])
+    for xn, xp in ((nat.y, py.y), (nat.w, py.w), (nat.v, py.v)):
+        np.testing.assert_allclose(xn, xp, rtol=1e-12, atol=0, equal_nan=True)
+    for f in ("Mu", "prFeas", "duFeas", "muFeas", "pobj", "dobj"):
+        assert getattr(nat, f) == pytest.approx(getattr(py, f), rel=1e-12)
+
+
+def test_native_driver_maxiters_abandoned():
+    """test/runtests.jl:246-269: maxIters = 2 -> :Abandoned, through the native loop."""
+    import cipkkt
+    Q, c, A, b, K, G, d = P.simplex()[:7]
+    sol = cipkkt.conicIP(Q, c, A, b, K, G, d, maxIters=2)
+    assert sol.status == "Abandoned" and len(sol.trace) == 2
