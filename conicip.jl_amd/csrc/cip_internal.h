@@ -23,7 +23,7 @@ void cip_set_error(const char *fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------- GEMM (gemm_f64.hip)
-enum { EPI_ACCUM = 0, EPI_TRSM = 1, EPI_SYRKQ = 2 };
+enum { EPI_ACCUM = 0, EPI_SYRKQ = 2 };
 
 struct GemmArgs {
     const double *A; long lda;   // M x K, element (i,k) at A[i + k*lda]
@@ -32,9 +32,6 @@ struct GemmArgs {
     int M, N, K;                 // M, N multiples of 128; K multiple of 16
     double alpha;
     int lower;                   // 1: only tiles with bi >= bj (M == N)
-    // EPI_TRSM: W = acc (ldw), C = acc * dinv[col]
-    double *W; long ldw;
-    const double *dinv;
     // EPI_SYRKQ: C = Qin + acc for i,j < nvalid (lower tiles)
     const double *Qin; long ldq; int nvalid;
     // batching (EPI_ACCUM only): grid.y x grid.z independent problems, pointer strides in doubles
@@ -42,9 +39,7 @@ struct GemmArgs {
     long sAy, sAz, sBy, sBz, sCy, sCz;
     int overwrite;               // EPI_ACCUM: C = alpha*acc instead of C += alpha*acc
     unsigned *queue_counter;     // non-NULL: persistent work-queue form (look-ahead trailing update)
-    int reserve;                 // 1: keep one CU per XCD free, 2: two
-    int stagger;                 // work-queue form: max random start delay in cycles (0 = none)
-    int t_first;                 // quarter-tile remainder launch: first 128-tile index it covers
+    int reserve;                 // work-queue form: CUs left free per (XCD, SE) pair for the panel chain (0, 1 or 2)
 };
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g);
 

@@ -2,7 +2,6 @@
 //
 // This one kernel carries every O(N^3) term of the KKT path:
 //   * LDL' trailing update   C -= (L21 D) L21'      (lower tiles only, K = outer block)
-//   * panel TRSM-as-GEMM     W21 = A21 inv(L11)'    (EPI_TRSM also writes L21 = W21 D^-1)
 //   * Schur formation        S  = Q + (A'F^-1)(A'F^-1)'   (EPI_SYRKQ)
 // i.e. the work the reference does in src/kktsolvers.jl:32-35 (dense GEMMs + QR)
 // and :289-295 (Schur + LU), re-designed for CDNA4.
@@ -134,10 +133,6 @@ __device__ __forceinline__ void gemm_tile_128(GemmArgs &g, double *lds, int bi, 
                     v2d c = g.overwrite ? (v2d){0.0, 0.0} : *(v2d *)cp;
                     c += g.alpha * val;
                     *(v2d *)cp = c;
-                } else if (EPI == EPI_TRSM) {
-                    *(v2d *)(g.W + row + col * g.ldw) = val;
-                    const double di = g.dinv[col];
-                    *(v2d *)(g.C + row + col * g.ldc) = val * di;
                 } else {   // EPI_SYRKQ
                     if (col < g.nvalid) {
                         if (row + 1 < g.nvalid) {
@@ -247,14 +242,14 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_64(GemmArgs g) {
 }
 
 // The LDL' trailing update C -= (L21 D) L21' on the lower triangle, in 64x64 quarter tiles (its own symbol so that
-// profiles separate it from the skinny in-block updates): block b -> 128-tile g.t_first + b/4, quadrant b%4.
+// profiles separate it from the skinny in-block updates): block b -> 128-tile b/4, quadrant b%4.
 // 5 workgroups (20 waves) per CU; measured against the 128x128-tile kernel at 2 workgroups per CU:
 // 55.0 vs 52.4 TFLOP/s at r = 8192, K = 512 and 53.1 vs 44.0 at K = 256 (tools/gemm_bench.hip, same session).
 __global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
     __builtin_amdgcn_s_setprio(3);       // measured: 58.0 vs 56.6 TFLOP/s without
     int bi, bj;
-    tile_coords(g.t_first + (int)(blockIdx.x >> 2), 1, g.M / CIP_NB, bi, bj);
+    tile_coords((int)(blockIdx.x >> 2), 1, g.M / CIP_NB, bi, bj);
     const int sub = blockIdx.x & 3;
     if (bi == bj && sub == 2) return;            // strictly-upper quadrant of a diagonal tile: never referenced
     gemm_tile_64(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB);
@@ -332,7 +327,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_64_queue(GemmArgs g, int nq,
     }
 }
 
-static int g_rem_mode = -1;
+static int g_tile = -1;
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.M % CIP_NB || g.N % CIP_NB || g.K % CIP_KT || g.K <= 0) {
@@ -354,9 +349,10 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    if (g_rem_mode < 0) g_rem_mode = getenv("CIP_GEMM_REM") ? atoi(getenv("CIP_GEMM_REM")) : 3;
-    if (epi == EPI_ACCUM && g.queue_counter && g_rem_mode == 3 && !g.overwrite) {
-        // persistent work-queue form; the caller hands over a zeroed counter
+    // CIP_GEMM_TILE=128: the lower-triangular update on the 128x128 kernel (kept for A/B runs of tools/gemm_bench.hip)
+    if (g_tile < 0) g_tile = (getenv("CIP_GEMM_TILE") && atoi(getenv("CIP_GEMM_TILE")) == 128) ? 128 : 64;
+    if (epi == EPI_ACCUM && g.queue_counter && !g.overwrite) {
+        // persistent work-queue form (look-ahead schedule); the caller hands over a zeroed counter
         static int ncu = 0;
         if (!ncu) {
             hipDeviceProp_t prop;
@@ -374,24 +370,9 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    if (epi == EPI_ACCUM && g.lower && !g.queue_counter && g_rem_mode && by * bz == 1) {
-        // Tile-count quantisation: 512 tiles are in flight (2 per CU); a last partial generation leaves most of
-        // the chip idle for a whole tile time (measured 62 % MFMA-busy at 1596 tiles = 3.12 generations).  The
-        // remainder is issued as quarter tiles (64x64), which spread over all CUs and finish in ~1/4 of the time.
-        const long slots = 512;
-        long nfull = (tiles / slots) * slots;
-        long rem = tiles - nfull;
-        if (rem * 4 > slots * 3) { nfull = tiles; rem = 0; }        // nearly full last generation: keep big tiles
-        if (tiles < slots && g_rem_mode == 1) { nfull = tiles; rem = 0; }   // mode >= 2: quarter tiles for small launches too
-        if (g_rem_mode == 3) { nfull = 0; rem = tiles; }                    // mode 3: quarter tiles only (experiment)
-        if (nfull > 0) {
-            hipLaunchKernelGGL(k_gemm_nt_128<EPI_ACCUM>, dim3((unsigned)nfull), dim3(256), 0, s, g);
-        }
-        if (rem > 0) {
-            GemmArgs gr = g;
-            gr.t_first = (int)nfull;
-            hipLaunchKernelGGL(k_ldlt_trailing_64, dim3((unsigned)(4 * rem)), dim3(256), 0, s, gr);
-        }
+    if (epi == EPI_ACCUM && g.lower && g_tile == 64) {
+        // the LDL' trailing update: every 128-tile of the lower triangle as four 64x64 quarter tiles
+        hipLaunchKernelGGL(k_ldlt_trailing_64, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -405,7 +386,6 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     dim3 grid((unsigned)tiles), block(256);
     switch (epi) {
         case EPI_ACCUM: hipLaunchKernelGGL(k_gemm_nt_128<EPI_ACCUM>, grid, block, 0, s, g); break;
-        case EPI_TRSM:  hipLaunchKernelGGL(k_gemm_nt_128<EPI_TRSM>, grid, block, 0, s, g); break;
         case EPI_SYRKQ: hipLaunchKernelGGL(k_gemm_nt_128<EPI_SYRKQ>, grid, block, 0, s, g); break;
         default: cip_set_error("gemm: bad epilogue"); return -1;
     }

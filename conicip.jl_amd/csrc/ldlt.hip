@@ -116,74 +116,6 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     ws->x_zeroed = nullptr;
 }
 
-// ---------------------------------------------------------------------------
-// Diagonal block: in-LDS LDL' of a 128x128 block + explicit inverse of its unit
-// lower factor.  One workgroup of 256 threads.
-//   in : K block (lower triangle), ld
-//   out: K block strictly-lower <- L, diagonal <- d ; dvec/dinv ; Linv, LinvT (128x128)
-#define DLDA 129
-__global__ __launch_bounds__(256) void k_ldlt_diag128(double *Kb, long ld, double *Linv, double *LinvT,
-                                                       double *dvec, double *dinv, int *info, int col0) {
-    extern __shared__ double a[];   // a[i + j*DLDA]
-    const int tid = threadIdx.x;
-    for (int e = tid; e < CIP_NB * CIP_NB; e += 256) {
-        const int i = e & 127, j = e >> 7;
-        a[i + j * DLDA] = (i >= j) ? Kb[i + (long)j * ld] : 0.0;
-    }
-    __syncthreads();
-
-    const int i = tid & 127, ty = tid >> 7;
-    for (int k = 0; k < CIP_NB; ++k) {
-        const double d = a[k + k * DLDA];
-        if (tid == 0 && !(fabs(d) > 0.0 && fabs(d) < 1.7e308)) atomicCAS(info, 0, col0 + k + 1);
-        const double di = 1.0 / d;
-        if (i > k) {
-            const double wi = a[i + k * DLDA];
-            for (int j = k + 1 + ty; j <= i; j += 2) a[i + j * DLDA] -= wi * (a[j + k * DLDA] * di);
-        }
-        __syncthreads();
-        // column k is final now and never read unscaled again: scale it (no extra barrier needed,
-        // later steps only touch columns > k).
-        if (ty == 0 && i > k) a[i + k * DLDA] *= di;
-    }
-    __syncthreads();
-
-    // write back L (strictly lower), d on the diagonal
-    for (int e = tid; e < CIP_NB * CIP_NB; e += 256) {
-        const int r = e & 127, c = e >> 7;
-        if (r >= c) Kb[r + (long)c * ld] = a[r + c * DLDA];
-    }
-    if (tid < CIP_NB) {
-        const double d = a[tid + tid * DLDA];
-        dvec[tid] = d;
-        dinv[tid] = 1.0 / d;
-    }
-    __syncthreads();
-
-    // X = inv(L) (unit lower).  X[r][c] (r > c) is kept at a[c + r*DLDA] (the unused upper
-    // triangle).  Column c is owned by lanes (2c, 2c+1) of one wave, which split the inner
-    // sum over k by parity and combine with one shuffle: no barrier in the whole phase.
-    {
-        const int c = tid >> 1, h = tid & 1;
-        for (int r = 1; r < CIP_NB; ++r) {
-            double s = 0.0;
-            if (r > c) {
-                for (int k = c + 1 + h; k < r; k += 2) s += a[r + k * DLDA] * a[c + k * DLDA];
-            }
-            s += __shfl_xor(s, 1);
-            if (r > c && h == 0) a[c + r * DLDA] = -(s + a[r + c * DLDA]);
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < CIP_NB * CIP_NB; e += 256) {
-        const int r = e & 127, c = e >> 7;
-        const double x = (r > c) ? a[c + r * DLDA] : (r == c ? 1.0 : 0.0);
-        Linv[r + c * CIP_NB] = x;
-        const double xt = (c > r) ? a[r + c * DLDA] : (r == c ? 1.0 : 0.0);   // LinvT[r][c] = X[c][r]
-        LinvT[r + c * CIP_NB] = xt;
-    }
-}
-
 // diag.hip
 int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0);
 int cip_launch_diag_inverse(hipStream_t s, const double *K, long ld, int nblk, const double *xm_all, double *Linv,
@@ -191,24 +123,6 @@ int cip_launch_diag_inverse(hipStream_t s, const double *K, long ld, int nblk, c
 int cip_launch_trsm_subst(hipStream_t s, double *Ap, long ld, int rows, const double *L11, const double *xm,
                           const double *dinv, double *W, long ldw);
 #include <stdlib.h>
-static bool g_diag_attr_set = false;
-static int g_diag_version = 0;                   // 0 = not decided yet; 1 = plain-LDS reference kernels (CIP_DIAG_V1)
-static int diag_version(void) {
-    if (g_diag_version == 0) g_diag_version = getenv("CIP_DIAG_V1") ? 1 : 2;
-    return g_diag_version;
-}
-static int launch_diag(hipStream_t s, double *Kb, long ld, double *Linv, double *LinvT, double *dvec,
-                       double *dinv, int *info, int col0) {
-    const size_t shm = (size_t)CIP_NB * DLDA * sizeof(double);
-    if (!g_diag_attr_set) {
-        CIP_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_diag128,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        g_diag_attr_set = true;
-    }
-    hipLaunchKernelGGL(k_ldlt_diag128, dim3(1), dim3(256), shm, s, Kb, ld, Linv, LinvT, dvec, dinv, info, col0);
-    CIP_HIP_CHECK(hipGetLastError());
-    return 0;
-}
 
 // right-looking update inside the outer block: after inner panel t, the remaining panel columns of the block
 //   K[c0+128:, c0+128 : C0+wblk] -= W_t[c0+128:, :] * L_t[c0+128 : C0+wblk, :]'        (K = 128, wide and short:
@@ -234,35 +148,17 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
         const int c0 = C0 + t * CIP_NB;
         const int jb = c0 / CIP_NB;
         const int r = Npad - c0 - CIP_NB;
-        if (diag_version() == 2) {
-            // MFMA micro-blocked diagonal kernel + substitution TRSM (the block inverses the solves
-            // need are produced by one batched launch after the factorisation)
-            if ((rc = cip_launch_diag_v2(s, K + c0 + (long)c0 * ld, ld, ws.Xm + (size_t)jb * 2048, ws.dvec + c0,
-                                         ws.dinv + c0, ws.info, c0)))
-                return rc;
-            if ((rc = cip_launch_trsm_subst(s, K + (c0 + CIP_NB) + (long)c0 * ld, ld, r, K + c0 + (long)c0 * ld,
-                                            ws.Xm + (size_t)jb * 2048, ws.dinv + c0,
-                                            Wb + (c0 + CIP_NB) + (long)(t * CIP_NB) * Npad, Npad)))
-                return rc;
-            // look-ahead: columns 128.. of this block are still receiving the previous block's update
-            if (t == 0 && rest_ready) CIP_HIP_CHECK(hipStreamWaitEvent(s, rest_ready, 0));
-            if ((rc = update_rest_of_block(s, K, Npad, ld, Wb, C0, wblk, t))) return rc;
-            continue;
-        }
-        if ((rc = launch_diag(s, K + c0 + (long)c0 * ld, ld, ws.Linv + (size_t)jb * CIP_NB * CIP_NB,
-                              ws.LinvT + (size_t)jb * CIP_NB * CIP_NB, ws.dvec + c0, ws.dinv + c0, ws.info, c0)))
+        // MFMA micro-blocked diagonal kernel + substitution TRSM (the block inverses the solves
+        // need are produced by one batched launch after the factorisation)
+        if ((rc = cip_launch_diag_v2(s, K + c0 + (long)c0 * ld, ld, ws.Xm + (size_t)jb * 2048, ws.dvec + c0,
+                                     ws.dinv + c0, ws.info, c0)))
             return rc;
-        if (r > 0) {
-            // W21 = A21 * inv(L11)'  ;  L21 = W21 * D^-1 (in place)
-            GemmArgs g = {};
-            g.A = K + (c0 + CIP_NB) + (long)c0 * ld; g.lda = ld;
-            g.B = ws.Linv + (size_t)jb * CIP_NB * CIP_NB; g.ldb = CIP_NB;
-            g.C = K + (c0 + CIP_NB) + (long)c0 * ld; g.ldc = ld;
-            g.W = Wb + (c0 + CIP_NB) + (long)(t * CIP_NB) * Npad; g.ldw = Npad;
-            g.dinv = ws.dinv + c0;
-            g.M = r; g.N = CIP_NB; g.K = CIP_NB; g.alpha = 1.0; g.lower = 0;
-            if ((rc = cip_launch_gemm(s, EPI_TRSM, g))) return rc;
-        }
+        if ((rc = cip_launch_trsm_subst(s, K + (c0 + CIP_NB) + (long)c0 * ld, ld, r, K + c0 + (long)c0 * ld,
+                                        ws.Xm + (size_t)jb * 2048, ws.dinv + c0,
+                                        Wb + (c0 + CIP_NB) + (long)(t * CIP_NB) * Npad, Npad)))
+            return rc;
+        // look-ahead: columns 128.. of this block are still receiving the previous block's update
+        if (t == 0 && rest_ready) CIP_HIP_CHECK(hipStreamWaitEvent(s, rest_ready, 0));
         if ((rc = update_rest_of_block(s, K, Npad, ld, Wb, C0, wblk, t))) return rc;
     }
     return 0;
@@ -272,7 +168,6 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
 // side stream while the big trailing update of the previous outer block runs on the caller's stream.
 // One process-wide side stream and event ring (factorisations of one process are issued from one thread).
 static hipStream_t g_side = nullptr;      // panel chain: high priority, all CUs
-static hipStream_t g_upd = nullptr;       // trailing updates: CU-masked so that a few CUs stay free for the panel chain
 static hipEvent_t g_evP[2] = {nullptr, nullptr}, g_evU[2] = {nullptr, nullptr}, g_evR[2] = {nullptr, nullptr};
 static hipEvent_t g_evStart = nullptr, g_evEnd = nullptr;
 static int g_lookahead = -1;
@@ -300,26 +195,6 @@ static int lookahead_init(void) {
     }
     CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evStart, hipEventDisableTiming));
     CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evEnd, hipEventDisableTiming));
-    // The diagonal kernel needs a whole CU's LDS (160 KB); the trailing-update GEMM keeps two 64 KB
-    // workgroups on every CU and refills each half as it frees, so without a reservation the panel
-    // chain only gets a CU in the GEMM's tail.  Keep CIP_RESERVED_CUS CUs out of the update stream.
-    if (getenv("CIP_RESERVED_CUS")) {      // off by default: measured to slow the masked GEMM far more than it helps
-        hipDeviceProp_t prop;
-        int dev = 0;
-        CIP_HIP_CHECK(hipGetDevice(&dev));
-        CIP_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        const int ncu = prop.multiProcessorCount;
-        int reserve = 16;
-        if (const char *e = getenv("CIP_RESERVED_CUS")) reserve = atoi(e);
-        if (reserve > 0 && reserve < ncu / 2) {
-            const int words = (ncu + 31) / 32;
-            uint32_t mask[32] = {0};
-            for (int c = 0; c < ncu; ++c) mask[c >> 5] |= (1u << (c & 31));
-            // leave out CUs spread over the mask (the bit -> physical CU map is not documented; any set works)
-            for (int k = 0; k < reserve; ++k) { const int c = (int)((long)k * ncu / reserve); mask[c >> 5] &= ~(1u << (c & 31)); }
-            if (hipExtStreamCreateWithCUMask(&g_upd, words, mask) != hipSuccess) { g_upd = nullptr; (void)hipGetLastError(); }
-        }
-    }
     return 0;
 }
 
@@ -427,7 +302,7 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
                 if (ws.prof && (rc = prof_event(ws.prof, s))) return rc;
             }
         }
-        if (diag_version() == 2 && (rc = cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.Linv, ws.LinvT)))
+        if ((rc = cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.Linv, ws.LinvT)))
             return rc;
         return build_solve_blocks(s, K, Npad, ld, ws);
     }
@@ -436,10 +311,6 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
     if (la) {
         CIP_HIP_CHECK(hipEventRecord(g_evStart, s));
         CIP_HIP_CHECK(hipStreamWaitEvent(sp, g_evStart, 0));
-        if (g_upd) {
-            CIP_HIP_CHECK(hipStreamWaitEvent(g_upd, g_evStart, 0));
-            s = g_upd;                                // trailing updates on the CU-masked stream
-        }
     }
     // panel of outer block 0
     {
@@ -513,111 +384,19 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
         CIP_HIP_CHECK(hipStreamWaitEvent(s_user, g_evEnd, 0));
         s = s_user;
     }
-    if (diag_version() == 2 && (rc = cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.Linv, ws.LinvT)))
+    if ((rc = cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.Linv, ws.LinvT)))
         return rc;
     return build_solve_blocks(s, K, Npad, ld, ws);
 }
 
 // ---------------------------------------------------------------------------
-// Solves.  y = M v for a 128x128 column-major M (ld ldm), v in LDS; 256 threads
-// (two per row, k split in halves); result returned to the threads with tid < 128.
-__device__ __forceinline__ double gemv128(const double *M, long ldm, const double *v_lds, double *red_lds, int tid) {
-    const int i = tid & 127, h = tid >> 7;
-    const double *Mp = M + i + (long)(h * 64) * ldm;
-    const double *vp = v_lds + h * 64;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll 4
-    for (int k = 0; k < 64; k += 4) {
-        s0 += Mp[(long)(k + 0) * ldm] * vp[k + 0];
-        s1 += Mp[(long)(k + 1) * ldm] * vp[k + 1];
-        s2 += Mp[(long)(k + 2) * ldm] * vp[k + 2];
-        s3 += Mp[(long)(k + 3) * ldm] * vp[k + 3];
-    }
-    double s = (s0 + s1) + (s2 + s3);
-    if (h == 1) red_lds[i] = s;
-    __syncthreads();
-    if (h == 0) s += red_lds[i];
-    return s;
-}
-
-// forward step for block column j:  y_j = inv(L_jj) b_j ;  b[R] -= L[R, j] y_j  (R = block row j+g, g >= 1)
-// workgroup 0 writes the D^-1-scaled y_j to yout; every workgroup recomputes y_j (128x128 gemv, L2-resident).
-__global__ __launch_bounds__(256) void k_solve_fwd(const double *K, long ld, const double *Linv, const double *dinv,
-                                                    double *b, double *yout, int j) {
-    __shared__ double v[CIP_NB], y[CIP_NB], red[CIP_NB];
-    const int tid = threadIdx.x;
-    const int g = blockIdx.x;
-    if (tid < CIP_NB) v[tid] = b[j * CIP_NB + tid];
-    __syncthreads();
-    const double yj = gemv128(Linv + (size_t)j * CIP_NB * CIP_NB, CIP_NB, v, red, tid);
-    if (tid < CIP_NB) {
-        y[tid] = yj;
-        if (g == 0) yout[j * CIP_NB + tid] = yj * dinv[j * CIP_NB + tid];
-    }
-    __syncthreads();
-    if (g == 0) return;
-    const long R = (long)(j + g) * CIP_NB;
-    const double u = gemv128(K + R + (long)j * CIP_NB * ld, ld, y, red, tid);
-    if (tid < CIP_NB) b[R + tid] -= u;
-}
-
-// backward step for block j:  x_j = inv(L_jj)' z_j ;  z[c] -= L[j-rows, c-cols]' x_j  for block c < j
-// (z = D^-1 y, updated in place; x written to xout).
-__global__ __launch_bounds__(256) void k_solve_bwd(const double *K, long ld, const double *LinvT, double *z,
-                                                    double *xout, int j) {
-    __shared__ double v[CIP_NB], x[CIP_NB], red[CIP_NB];
-    __shared__ double T[32 * DLDA];
-    const int tid = threadIdx.x;
-    const int g = blockIdx.x;
-    if (tid < CIP_NB) v[tid] = z[j * CIP_NB + tid];
-    __syncthreads();
-    const double xj = gemv128(LinvT + (size_t)j * CIP_NB * CIP_NB, CIP_NB, v, red, tid);
-    if (tid < CIP_NB) {
-        x[tid] = xj;
-        if (g == 0) xout[j * CIP_NB + tid] = xj;
-    }
-    __syncthreads();
-    if (g == 0) return;
-    const int c = g - 1;                       // column block c < j
-    const double *Lp = K + (long)j * CIP_NB + (long)c * CIP_NB * ld;
-    for (int q = 0; q < 4; ++q) {
-        for (int it = 0; it < 16; ++it) {
-            const int e = it * 256 + tid;
-            const int i = e & 127, cc = e >> 7;
-            T[cc * DLDA + i] = Lp[i + (long)(q * 32 + cc) * ld];
-        }
-        __syncthreads();
-        const int cc = tid >> 3, part = tid & 7;
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s += T[cc * DLDA + part * 16 + i] * x[part * 16 + i];
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        if (part == 0) z[c * CIP_NB + q * 32 + cc] -= s;
-        __syncthreads();
-    }
-}
-
+// Solves
 __global__ __launch_bounds__(256) void k_scale_vec(int n, const double *x, const double *d, double *y) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) y[i] = x[i] * d[i];
 }
 
-// L D L' x = b with the Bs-block inverses: every step is two coalesced, deterministic column-dot gemvs
-//   forward   y_J = X_J b_J            (gemv_t on XT_J)      b[below] -= U[J rows, below]' y_J   (U = L' mirrored)
-//   backward  x_J = X_J' z_J           (gemv_t on X_J)       z[above] -= L[J rows, above]' x_J
-// HBM-bound: L is read once per sweep (8 N^2/2 B) plus the block inverses (8 N Bs B).
 int cip_ldlt_solve(hipStream_t s, const double *K, int Npad, long ld, const LdltWorkspace &ws, double *rhs) {
-    if (getenv("CIP_SOLVE_V1")) {
-        const int nblk = Npad / CIP_NB;
-        for (int j = 0; j < nblk; ++j)
-            hipLaunchKernelGGL(k_solve_fwd, dim3(nblk - j), dim3(256), 0, s, K, ld, ws.Linv, ws.dinv, rhs, ws.tmp, j);
-        for (int j = nblk - 1; j >= 0; --j)
-            hipLaunchKernelGGL(k_solve_bwd, dim3(j + 1), dim3(256), 0, s, K, ld, ws.LinvT, ws.tmp, rhs, j);
-        CIP_HIP_CHECK(hipGetLastError());
-        return 0;
-    }
     const int Bs = ws.Bs;
     const int nbk = Npad / Bs;
     const double *X = (Bs == CIP_NB) ? ws.Linv : ws.X;

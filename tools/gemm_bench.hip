@@ -22,7 +22,7 @@ int main(int argc, char **argv) {
         const int r = sh[0], K = sh[1];
         GemmArgs g = {};
         unsigned *ctr = nullptr; if (dbg & 1) { static unsigned *c0 = nullptr; if (!c0) hipMalloc(&c0, 256); ctr = c0; }
-        g.queue_counter = ctr; g.stagger = (dbg & 2) ? K * 70 * 16 / 16 : 0;
+        g.queue_counter = ctr; if (ctr) hipMemsetAsync(ctr, 0, 4, 0);
         g.A = W; g.lda = Nmax; g.B = L; g.ldb = Nmax; g.C = C; g.ldc = Nmax; g.M = r; g.N = r; g.K = K; g.alpha = -1.0; g.lower = 1;
         for (int w = 0; w < 2; ++w) cip_launch_gemm(0, EPI_ACCUM, g);
         hipDeviceSynchronize();
