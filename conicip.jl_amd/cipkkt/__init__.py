@@ -10,5 +10,7 @@ from ._lib import (CONE_Q, CONE_R, CONE_S, MAT_A, MAT_G, MAT_Q, OP_F, OP_FINV, O
                    ROUTE_SCHUR, CipError)
 from .kkt import KKTSystem, kktsolver_hip, kktsolver_hip_full3x3
 from .driver import Solution, conicIP
+from .preprocess import imcols, preprocess_conicIP
 
-__all__ = ["KKTSystem", "kktsolver_hip", "kktsolver_hip_full3x3", "conicIP", "Solution", "CipError"]
+__all__ = ["KKTSystem", "kktsolver_hip", "kktsolver_hip_full3x3", "conicIP", "Solution", "CipError", "imcols",
+           "preprocess_conicIP"]

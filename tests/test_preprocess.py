@@ -1,0 +1,108 @@
+"""Pre-solve (src/preprocessor.jl): the reference's three preprocessor tests (test/runtests.jl:362-440) on the
+oracle restatement (CPU) and on the product's host-side pre-solve in front of the device solver (GPU), plus the
+rank logic of `imcols` itself.  The reference draws its data from Julia's RNG; the properties it asserts do not
+depend on the draw, so seeded numpy data of the same shape is used."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle.preprocess import imcols as o_imcols, preprocess_conicIP as o_pre
+
+TOL = 1e-3       # `tol` of test/runtests.jl:13
+OPT = 1e-7
+
+
+def redundant_equalities(seed=0, n=10):
+    rng = np.random.default_rng(seed)
+    h = rng.standard_normal(n)
+    H = np.outer(h, h)
+    c = np.arange(1.0, n + 1)
+    G = rng.random((6, n))
+    return H, H @ c, sp.identity(n, format="csr"), np.zeros(n), np.vstack([G, G]), np.zeros(12), G
+
+
+def check_imcols(imcols):
+    rng = np.random.default_rng(1)
+    G = rng.standard_normal((4, 9))
+    A = np.vstack([G, 2 * G[1:2], G[0:1] - G[3:4]])
+    rows, ok = imcols(A, A @ rng.standard_normal(9))
+    assert ok and len(rows) == 4 and np.linalg.matrix_rank(A[rows]) == 4
+    rows, ok = imcols(np.array([[1.0, 0, 0], [1.0, 0, 0]]), np.array([1.0, -1.0]))   # inconsistent duplicate
+    assert (rows, ok) == ([], False)
+    assert imcols(np.zeros((0, 5)), np.zeros(0)) == ([], True)
+
+
+def check_redundant(pre):
+    """test/runtests.jl:357-388: duplicated equality rows; the same problem with the equalities also stated as
+    inequalities has the same solution."""
+    H, Hc, A, b, G2, d2, G = redundant_equalities()
+    n = 10
+    s1 = pre(H, Hc, A, b, [("R", n)], G2, d2, optTol=OPT)
+    A2 = sp.vstack([A, sp.csr_matrix(G2), sp.csr_matrix(-G2)], format="csr")
+    s2 = pre(H, Hc, A2, np.concatenate([b, d2, -d2]), [("R", n + 24)], G2, d2, optTol=OPT)
+    assert s1.status == "Optimal" and s2.status == "Optimal"
+    assert np.linalg.norm(s1.y - s2.y) < TOL
+    assert s1.w.shape == (12,) and np.count_nonzero(s1.w) <= 6       # zeros re-inserted for the dropped rows
+    assert np.abs(G @ s1.y).max() < 1e-5
+
+
+def check_bad_dual(pre):
+    """test/runtests.jl:390-408: Q = 0 and A = [I I] leave n directions undetermined; the augmented Q picks y = 0."""
+    n = 10
+    Q = np.zeros((2 * n, 2 * n))
+    A = sp.hstack([sp.identity(n), sp.identity(n)], format="csr")
+    sol = pre(Q, -np.ones(2 * n), A, np.zeros(n), [("R", n)], optTol=OPT)
+    assert np.linalg.norm(sol.y) < TOL
+
+
+def check_infeasible(pre):
+    """test/runtests.jl:410-438: y1 = 1 and y1 = -1."""
+    H, Hc, A, b, _, _, _ = redundant_equalities()
+    G = np.zeros((2, 10))
+    G[:, 0] = 1.0
+    sol = pre(H, Hc, A, b, [("R", 10)], G, np.array([1.0, -1.0]), optTol=OPT)
+    assert sol.status == "Infeasible" and np.isnan(sol.y).all()
+
+
+def test_oracle_imcols():
+    check_imcols(o_imcols)
+
+
+def test_oracle_preprocess_redundant():
+    check_redundant(o_pre)
+
+
+def test_oracle_preprocess_bad_dual():
+    check_bad_dual(o_pre)
+
+
+def test_oracle_preprocess_infeasible():
+    check_infeasible(o_pre)
+
+
+def test_product_imcols_matches_oracle():
+    from cipkkt.preprocess import imcols
+    check_imcols(imcols)
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((7, 5)) @ rng.standard_normal((5, 12))          # rank 5
+    b = A @ rng.standard_normal(12)
+    (r1, ok1), (r2, ok2) = imcols(A, b), o_imcols(A, b)
+    assert ok1 and ok2 and len(r1) == len(r2) == 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("check", [check_redundant, check_bad_dual, check_infeasible],
+                         ids=["redundant", "bad_dual", "infeasible"])
+def test_product_preprocess(check):
+    import cipkkt
+    check(cipkkt.preprocess_conicIP)
+
+
+@pytest.mark.gpu
+def test_product_preprocess_matches_oracle():
+    import cipkkt
+    H, Hc, A, b, G2, d2, _ = redundant_equalities(seed=3)
+    got = cipkkt.preprocess_conicIP(H, Hc, A, b, [("R", 10)], G2, d2, optTol=OPT)
+    ref = o_pre(H, Hc, A, b, [("R", 10)], G2, d2, optTol=OPT)
+    assert got.status == ref.status == "Optimal" and got.Iter == ref.Iter
+    np.testing.assert_allclose(got.y, ref.y, rtol=1e-6, atol=1e-8)
