@@ -17,7 +17,13 @@
 #include "../../include/cipkkt.h"
 #include <math.h>
 
-#define SD_T 256
+// Threads per workgroup: 1024 (16 waves) for cones of order > 48, 256 otherwise.  The serial chains below are
+// instruction-issue bound with one wave per SIMD (a wave issues ~1 instruction per 4-5 cycles; measured 11 k cycles
+// per triangular-solve step at r = 128 with 4 waves for ~2000 instructions per wave), so the large cones get four
+// waves per SIMD.  Device code uses the launch's own block size.
+#define SD_T ((int)blockDim.x)
+#define SD_TMAX 1024
+#define SD_NW (SD_T / 64)
 #ifdef SD_PROFILE
 #include <stdio.h>
 // development timers: s_memtime stamps collected in LDS, printed once at the end of the kernel
@@ -40,6 +46,27 @@
 __device__ __forceinline__ void sd_sync(bool lds_only) {
     if (lds_only) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else __syncthreads();
+}
+// Newton-refined hardware reciprocal / reciprocal square root (v_rcp_f64, v_rsq_f64 give ~2^-26; two steps reach
+// the last bits): a handful of instructions where the IEEE division / sqrt expansions cost 30-40 each.  Used where the
+// value feeds a rotation or a multiplier of a serial chain that every lane recomputes (the chains are issue-bound).
+__device__ __forceinline__ double sd_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(r, fma(-d, r, 1.0), r);
+    r = fma(r, fma(-d, r, 1.0), r);
+    return r;
+}
+__device__ __forceinline__ double sd_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
+    r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
+    return r;
+}
+// guarded load without a branch: the address is clamped into range (so the load can be issued unconditionally and
+// the unrolled loops below stay straight-line code), the value is masked afterwards
+__device__ __forceinline__ double sd_ld(const double *p, long stride, int i, int n) {
+    const double x = p[(long)(i < n ? i : n - 1) * stride];
+    return i < n ? x : 0.0;
 }
 __device__ __forceinline__ int vidx(int i, int j, int r) { return i * r - i * (i - 1) / 2 + (j - i); }   // i <= j
 
@@ -83,8 +110,8 @@ __device__ void sd_gemm(double *C, const double *A, bool ta, const double *B, bo
         v4d acc00 = {0, 0, 0, 0}, acc01 = acc00, acc10 = acc00, acc11 = acc00;     // acc[x][y]: rows i0+16x, cols j0+16y
 #pragma unroll 4
         for (int k0 = 0; k0 < kfull; k0 += 4) {
-            const double a0 = via ? pa0[k0 * sa_k] : 0.0, a1 = vib ? pa1[k0 * sa_k] : 0.0;
-            const double b0 = vja ? pb0[k0 * sb_k] : 0.0, b1 = vjb ? pb1[k0 * sb_k] : 0.0;
+            double a0 = pa0[k0 * sa_k], a1 = pa1[k0 * sa_k], b0 = pb0[k0 * sb_k], b1 = pb1[k0 * sb_k];   // clamped rows: always valid
+            a0 = via ? a0 : 0.0; a1 = vib ? a1 : 0.0; b0 = vja ? b0 : 0.0; b1 = vjb ? b1 : 0.0;
             acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc00, 0, 0, 0);
             acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc01, 0, 0, 0);
             acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc10, 0, 0, 0);
@@ -166,10 +193,10 @@ __device__ void sd_jacobi_core(double *A, double *V, int r, double *sh /* >= 4*(
         }
         for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o); tot += __shfl_xor(tot, o); }
         __syncthreads();
-        if ((tid & 63) == 0) { red[tid >> 6] = off; red[4 + (tid >> 6)] = tot; }
+        if ((tid & 63) == 0) { red[tid >> 6] = off; red[16 + (tid >> 6)] = tot; }
         __syncthreads();
-        off = red[0] + red[1] + red[2] + red[3];
-        tot = red[4] + red[5] + red[6] + red[7];
+        off = 0.0; tot = 0.0;
+        for (int q = 0; q < SD_NW; ++q) { off += red[q]; tot += red[16 + q]; }
         if (off <= 1e-30 * tot || tot == 0.0) break;
         for (int t = 0; t < m - 1; ++t) {
             for (int k = tid; k < np; k += SD_T) {
@@ -226,7 +253,7 @@ __device__ void sd_jacobi_core(double *A, double *V, int r, double *sh /* >= 4*(
 // vectors are wanted, A and V otherwise): the sweep is a chain of ~3 (r-1) barrier-separated passes per sweep,
 // each a handful of dependent accesses per thread, so LDS latency instead of global-memory latency is a ~10x
 // difference (r = 128, values only: 80 ms -> ~1 ms).
-#define SD_SCRATCH(r) (4 * (((r) + 2) / 2 + 1) + 16)
+#define SD_SCRATCH(r) (4 * (((r) + 2) / 2 + 1) + 40)
 #define SD_LDS_CAPMAX ((160 * 1024 - 1024) / 8)          // doubles of dynamic LDS a kernel may ask for
 __device__ void sd_jacobi(double *A, double *V, int r, double *sh, int cap) {
     if ((V ? 2 : 1) * r * r > cap) { sd_jacobi_core(A, V, r, sh); return; }
@@ -252,32 +279,32 @@ __device__ __forceinline__ void sd_trsm_l(const double *L, double *B, int r, int
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double lcol[SD_RPL];
 #pragma unroll
-    for (int q = 0; q < SD_RPL; ++q) { const int i = lane + 64 * q; lcol[q] = (i < r) ? L[i] : 0.0; }      // column 0
+    for (int q = 0; q < SD_RPL; ++q) lcol[q] = sd_ld(L, 1, lane + 64 * q, r);      // column 0
     for (int j = 0; j < r; ++j) {
         double ljj = 0.0;
 #pragma unroll
         for (int q = 0; q < SD_RPL; ++q) if (lane + 64 * q == j) ljj = lcol[q];
         ljj = __shfl(ljj, j & 63);                           // the diagonal entry sits in lane j % 64
-        const double inv = 1.0 / ljj;
+        const double inv = sd_rcp(ljj);
         double lcur[SD_RPL];
 #pragma unroll
         for (int q = 0; q < SD_RPL; ++q) lcur[q] = lcol[q];
         if (j + 1 < r) {
 #pragma unroll
-            for (int q = 0; q < SD_RPL; ++q) { const int i = lane + 64 * q; lcol[q] = (i < r) ? L[i + (long)(j + 1) * ldl] : 0.0; }
+            for (int q = 0; q < SD_RPL; ++q) lcol[q] = sd_ld(L + (long)(j + 1) * ldl, 1, lane + 64 * q, r);
         }
         // four columns of B per pass: their LDS reads are issued together (the loop is latency-, not bandwidth-bound)
         for (int c0 = wave * 4; c0 < r; c0 += (SD_T / 64) * 4) {
             double bj[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) bj[u] = (c0 + u < r) ? B[j + (long)(c0 + u) * ldb] * inv : 0.0;
+            for (int u = 0; u < 4; ++u) bj[u] = sd_ld(B + j, ldb, c0 + u, r) * inv;
 #pragma unroll
             for (int q = 0; q < SD_RPL; ++q) {
                 const int i = lane + 64 * q;
                 if (i > j && i < r) {
                     double t[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) t[u] = (c0 + u < r) ? B[i + (long)(c0 + u) * ldb] : 0.0;
+                    for (int u = 0; u < 4; ++u) t[u] = sd_ld(B + i, ldb, c0 + u, r);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) if (c0 + u < r) B[i + (long)(c0 + u) * ldb] = t[u] - lcur[q] * bj[u];
                 }
@@ -298,32 +325,32 @@ __device__ __forceinline__ void sd_trsm_lt(const double *L, double *B, int r, in
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double lrow[SD_RPL];
 #pragma unroll
-    for (int q = 0; q < SD_RPL; ++q) { const int i = lane + 64 * q; lrow[q] = (i < r) ? L[(r - 1) + (long)i * ldl] : 0.0; }
+    for (int q = 0; q < SD_RPL; ++q) lrow[q] = sd_ld(L + (r - 1), ldl, lane + 64 * q, r);
     for (int j = r - 1; j >= 0; --j) {
         double ljj = 0.0;
 #pragma unroll
         for (int q = 0; q < SD_RPL; ++q) if (lane + 64 * q == j) ljj = lrow[q];
         ljj = __shfl(ljj, j & 63);
-        const double inv = 1.0 / ljj;
+        const double inv = sd_rcp(ljj);
         double lcur[SD_RPL];
 #pragma unroll
         for (int q = 0; q < SD_RPL; ++q) lcur[q] = lrow[q];
         if (j > 0) {
 #pragma unroll
-            for (int q = 0; q < SD_RPL; ++q) { const int i = lane + 64 * q; lrow[q] = (i < j) ? L[(j - 1) + (long)i * ldl] : 0.0; }
+            for (int q = 0; q < SD_RPL; ++q) lrow[q] = sd_ld(L + (j - 1), ldl, lane + 64 * q, j);
         }
         // four columns of B per pass: their LDS reads are issued together (the loop is latency-, not bandwidth-bound)
         for (int c0 = wave * 4; c0 < r; c0 += (SD_T / 64) * 4) {
             double bj[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) bj[u] = (c0 + u < r) ? B[j + (long)(c0 + u) * ldb] * inv : 0.0;
+            for (int u = 0; u < 4; ++u) bj[u] = sd_ld(B + j, ldb, c0 + u, r) * inv;
 #pragma unroll
             for (int q = 0; q < SD_RPL; ++q) {
                 const int i = lane + 64 * q;
                 if (i < j) {
                     double t[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) t[u] = (c0 + u < r) ? B[i + (long)(c0 + u) * ldb] : 0.0;
+                    for (int u = 0; u < 4; ++u) t[u] = sd_ld(B + i, ldb, c0 + u, r);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) if (c0 + u < r) B[i + (long)(c0 + u) * ldb] = t[u] - lcur[q] * bj[u];
                 }
@@ -348,18 +375,20 @@ __device__ __forceinline__ void sd_transpose(double *A, int r, int ld = 0, bool 
 // ---- extreme eigenvalue of a symmetric matrix: Householder tridiagonalisation + multisection on the Sturm count.
 // maxstep_sdc needs only the largest eigenvalue of X^-1/2 D X^-1/2 (or the smallest of X) (:272-303): r^3 4/3 flops
 // and r barrier-separated steps instead of ~10 Jacobi sweeps of 3 (r - 1) steps each.
-#define SD_SCRATCH_TRI(r) (4 * (r) + SD_T + 32)
+#define SD_SCRATCH_TRI(r) (4 * (r) + SD_TMAX + 48)
 __device__ __forceinline__ double sd_block_sum(double x, double *red) {
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
     sd_sync(true);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
     sd_sync(true);
-    return red[0] + red[1] + red[2] + red[3];
+    double sum = 0.0;
+    for (int q = 0; q < SD_NW; ++q) sum += red[q];
+    return sum;
 }
 // A (full symmetric storage, pitch ld, destroyed).  sc: SD_SCRATCH_TRI(r) doubles of LDS.  Result returned to all threads.
 __device__ __forceinline__ double sd_extreme_eig(double *A, int r, int ld, double *sc, bool want_max, bool lds = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *dg = sc, *of = sc + r, *v = sc + 2 * r, *w = sc + 3 * r, *pb = sc + 4 * r, *red = sc + 4 * r + SD_T;
+    double *dg = sc, *of = sc + r, *v = sc + 2 * r, *w = sc + 3 * r, *pb = sc + 4 * r, *red = sc + 4 * r + SD_TMAX;
     for (int k = 0; k + 1 < r; ++k) {
         const int m = r - k - 1;
         double *x = A + (k + 1) + (long)k * ld;                 // column k below the diagonal
@@ -391,7 +420,7 @@ __device__ __forceinline__ double sd_extreme_eig(double *A, int r, int ld, doubl
                 for (int j0 = jpart; j0 < m; j0 += 8 * nparts) {
                     double av[8], vv[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { const int j = j0 + u * nparts; av[u] = (j < m) ? A22[i + (long)j * ld] : 0.0; vv[u] = (j < m) ? v[j] : 0.0; }
+                    for (int u = 0; u < 8; ++u) { const int j = j0 + u * nparts; av[u] = sd_ld(A22 + i, ld, j, m); vv[u] = sd_ld(v, 1, j, m); }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) acc += av[u] * vv[u];
                 }
@@ -413,18 +442,18 @@ __device__ __forceinline__ double sd_extreme_eig(double *A, int r, int ld, doubl
         {                                                       // A22 -= v w' + w v': lanes own rows, four columns per pass
             double vi[SD_RPL], wi[SD_RPL];
 #pragma unroll
-            for (int q = 0; q < SD_RPL; ++q) { const int i = lane + 64 * q; vi[q] = (i < m) ? v[i] : 0.0; wi[q] = (i < m) ? w[i] : 0.0; }
+            for (int q = 0; q < SD_RPL; ++q) { const int i = lane + 64 * q; vi[q] = sd_ld(v, 1, i, m); wi[q] = sd_ld(w, 1, i, m); }
             for (int j0 = wave * 4; j0 < m; j0 += (SD_T / 64) * 4) {
                 double vj[4], wj[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { vj[u] = (j0 + u < m) ? v[j0 + u] : 0.0; wj[u] = (j0 + u < m) ? w[j0 + u] : 0.0; }
+                for (int u = 0; u < 4; ++u) { vj[u] = sd_ld(v, 1, j0 + u, m); wj[u] = sd_ld(w, 1, j0 + u, m); }
 #pragma unroll
                 for (int q = 0; q < SD_RPL; ++q) {
                     const int i = lane + 64 * q;
                     if (i < m) {
                         double t[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) t[u] = (j0 + u < m) ? A22[i + (long)(j0 + u) * ld] : 0.0;
+                        for (int u = 0; u < 4; ++u) t[u] = sd_ld(A22 + i, ld, j0 + u, m);
 #pragma unroll
                         for (int u = 0; u < 4; ++u) if (j0 + u < m) A22[i + (long)(j0 + u) * ld] = t[u] - (vi[q] * wj[u] + wi[q] * vj[u]);
                     }
@@ -444,14 +473,14 @@ __device__ __forceinline__ double sd_extreme_eig(double *A, int r, int ld, doubl
     }
     for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
     sd_sync(lds);
-    if (lane == 0) { red[wave] = lo; red[4 + wave] = hi; }
+    if (lane == 0) { red[wave] = lo; red[16 + wave] = hi; }
     sd_sync(lds);
-    lo = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
-    hi = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+    lo = red[0]; hi = red[16];
+    for (int q = 1; q < SD_NW; ++q) { lo = fmin(lo, red[q]); hi = fmax(hi, red[16 + q]); }
     const double span = fmax(fabs(lo), fabs(hi));
     hi += 1e-15 * span + 1e-300;                               // the count at hi must be r, at lo 0
     lo -= 1e-15 * span + 1e-300;
-    int *first = (int *)(red + 8);
+    int *first = (int *)(red + 40);
     for (int round = 0; round < 12; ++round) {
         if (!(hi - lo > 4.4e-16 * fmax(fabs(lo), fabs(hi)))) break;
         const double step = (hi - lo) / (SD_T + 1);
@@ -505,25 +534,25 @@ __device__ __forceinline__ void sd_jacobi_onesided(double *G, int r, int ld, int
                 const bool live = p < r && q < r;              // dummy player (index r) when r is odd
                 double *gp = G + (long)(live ? p : 0) * ld, *gq = G + (long)(live ? q : 0) * ld;
                 double a = 0.0, b = 0.0, c = 0.0;
-                if (r <= 32 * tpp) {
+                if (r <= 8 * tpp) {
                     // both columns stay in registers between the dot products and the rotation
-                    double xv[32], yv[32];
+                    double xv[8], yv[8];
 #pragma unroll
-                    for (int u = 0; u < 32; ++u) {
+                    for (int u = 0; u < 8; ++u) {
                         const int i = part + u * tpp;
-                        const bool in = live && i < r;
-                        xv[u] = in ? gp[i] : 0.0;
-                        yv[u] = in ? gq[i] : 0.0;
+                        xv[u] = sd_ld(gp, 1, i, r);
+                        yv[u] = sd_ld(gq, 1, i, r);
                     }
 #pragma unroll
-                    for (int u = 0; u < 32; ++u) { a += xv[u] * xv[u]; b += yv[u] * yv[u]; c += xv[u] * yv[u]; }
+                    for (int u = 0; u < 8; ++u) { a += xv[u] * xv[u]; b += yv[u] * yv[u]; c += xv[u] * yv[u]; }
                     for (int o = tpp >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
-                    if (live && fabs(c) > 1e-15 * sqrt(a * b) && c != 0.0) {
-                        const double zeta = (b - a) / (2.0 * c);
-                        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                        const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+                    if (live && c * c > 1e-30 * (a * b) && c != 0.0) {
+                        const double zeta = (b - a) * 0.5 * sd_rcp(c);
+                        const double h2 = 1.0 + zeta * zeta;
+                        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * sd_rcp(fabs(zeta) + h2 * sd_rsqrt(h2));
+                        const double cs = sd_rsqrt(1.0 + tt * tt), sn = cs * tt;
 #pragma unroll
-                        for (int u = 0; u < 32; ++u) {
+                        for (int u = 0; u < 8; ++u) {
                             const int i = part + u * tpp;
                             if (i < r) { gp[i] = cs * xv[u] - sn * yv[u]; gq[i] = sn * xv[u] + cs * yv[u]; }
                         }
@@ -535,20 +564,21 @@ __device__ __forceinline__ void sd_jacobi_onesided(double *G, int r, int ld, int
                     for (int i0 = part; i0 < r; i0 += 8 * tpp) {       // 16 LDS reads in flight per pass
                         double xv[8], yv[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) { const int i = i0 + u * tpp; xv[u] = (i < r) ? gp[i] : 0.0; yv[u] = (i < r) ? gq[i] : 0.0; }
+                        for (int u = 0; u < 8; ++u) { const int i = i0 + u * tpp; xv[u] = sd_ld(gp, 1, i, r); yv[u] = sd_ld(gq, 1, i, r); }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) { a += xv[u] * xv[u]; b += yv[u] * yv[u]; c += xv[u] * yv[u]; }
                     }
                 }
                 for (int o = tpp >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
-                if (live && fabs(c) > 1e-15 * sqrt(a * b) && c != 0.0) {
-                    const double zeta = (b - a) / (2.0 * c);
-                    const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+                if (live && c * c > 1e-30 * (a * b) && c != 0.0) {
+                    const double zeta = (b - a) * 0.5 * sd_rcp(c);
+                    const double h2 = 1.0 + zeta * zeta;
+                    const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * sd_rcp(fabs(zeta) + h2 * sd_rsqrt(h2));
+                    const double cs = sd_rsqrt(1.0 + tt * tt), sn = cs * tt;
                     for (int i0 = part; i0 < r; i0 += 8 * tpp) {
                         double xv[8], yv[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) { const int i = i0 + u * tpp; xv[u] = (i < r) ? gp[i] : 0.0; yv[u] = (i < r) ? gq[i] : 0.0; }
+                        for (int u = 0; u < 8; ++u) { const int i = i0 + u * tpp; xv[u] = sd_ld(gp, 1, i, r); yv[u] = sd_ld(gq, 1, i, r); }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             const int i = i0 + u * tpp;
@@ -629,7 +659,7 @@ __device__ __forceinline__ void sd_nt_body(const ConeDesc &cd, const double *v, 
         for (int i = threadIdx.x; i < r; i += SD_T) lambda[cd.off + vidx(i, i, r)] = lam[i];
     }
 }
-__global__ __launch_bounds__(SD_T) void k_sdp_nt_scaling(const ConeDesc *cones, const int *sidx, const double *v,
+__global__ __launch_bounds__(SD_TMAX) void k_sdp_nt_scaling(const ConeDesc *cones, const int *sidx, const double *v,
                                                           const double *s, double *scal, double *lambda, double *wsb,
                                                           int *flag, int cap) {
     extern __shared__ double sh[];
@@ -656,7 +686,7 @@ __device__ void sd_congruence(const double *R, const double *Ri, int mode, const
     sd_vecm(Y, out, os, r, 1.0);
 }
 
-__global__ __launch_bounds__(SD_T) void k_sdp_apply(const ConeDesc *cones, const int *sidx, const double *scal, int mode,
+__global__ __launch_bounds__(SD_TMAX) void k_sdp_apply(const ConeDesc *cones, const int *sidx, const double *scal, int mode,
                                                      const double *x, double *out, double *wsb) {
     const ConeDesc cd = cones[sidx[blockIdx.x]];
     const int r = cd.r;
@@ -666,7 +696,7 @@ __global__ __launch_bounds__(SD_T) void k_sdp_apply(const ConeDesc *cones, const
 }
 
 // Wt[i, off+e] = (F^-T a_i)_e for rows i of At (grid.x loops over i, grid.y = S cone)
-__global__ __launch_bounds__(SD_T) void k_sdp_scale_At(const ConeDesc *cones, const int *sidx, const double *scal, int n,
+__global__ __launch_bounds__(SD_TMAX) void k_sdp_scale_At(const ConeDesc *cones, const int *sidx, const double *scal, int n,
                                                         const double *At, long ldat, double *Wt, long ldwt, double *wsb) {
     const ConeDesc cd = cones[sidx[blockIdx.y]];
     const int r = cd.r;
@@ -678,7 +708,7 @@ __global__ __launch_bounds__(SD_T) void k_sdp_scale_At(const ConeDesc *cones, co
 }
 
 // column c of -(F'F) for the literal 3x3 assembly: K[off+e, off+c] = -(F'(F e_c))_e  (lower part)
-__global__ __launch_bounds__(SD_T) void k_sdp_fill_ftf(const ConeDesc *cones, const int *sidx, const double *scal, double *K,
+__global__ __launch_bounds__(SD_TMAX) void k_sdp_fill_ftf(const ConeDesc *cones, const int *sidx, const double *scal, double *K,
                                                         long ldk, double *wsb, double *vtmp) {
     const ConeDesc cd = cones[sidx[blockIdx.y]];
     const int r = cd.r, k = cd.dim;
@@ -698,7 +728,7 @@ __global__ __launch_bounds__(SD_T) void k_sdp_fill_ftf(const ConeDesc *cones, co
 }
 
 // ---------------------------------------------------------------------------------- Jordan product / division
-__global__ __launch_bounds__(SD_T) void k_sdp_prod(const ConeDesc *cones, const int *sidx, const double *x, const double *y,
+__global__ __launch_bounds__(SD_TMAX) void k_sdp_prod(const ConeDesc *cones, const int *sidx, const double *x, const double *y,
                                                     double *out, double *wsb) {
     const ConeDesc cd = cones[sidx[blockIdx.x]];
     const int r = cd.r;
@@ -712,7 +742,7 @@ __global__ __launch_bounds__(SD_T) void k_sdp_prod(const ConeDesc *cones, const 
 }
 
 // out: Y O + O Y = X  (dsdc! = vecm(lyap(Y, -X)) src/ConicIP.jl:347-353)
-__global__ __launch_bounds__(SD_T) void k_sdp_div(const ConeDesc *cones, const int *sidx, const double *x, const double *y,
+__global__ __launch_bounds__(SD_TMAX) void k_sdp_div(const ConeDesc *cones, const int *sidx, const double *x, const double *y,
                                                    double *out, double *wsb, int cap) {
     extern __shared__ double sh[];
     const ConeDesc cd = cones[sidx[blockIdx.x]];
@@ -774,7 +804,7 @@ __device__ __forceinline__ void sd_maxstep_body(const ConeDesc &cd, const double
     SD_TICK_DUMP;
     if (threadIdx.x == 0) partial[cd.item] = (mx < 0.0) ? INF : 1.0 / mx;
 }
-__global__ __launch_bounds__(SD_T) void k_sdp_maxstep(const ConeDesc *cones, const int *sidx, const double *x, const double *d,
+__global__ __launch_bounds__(SD_TMAX) void k_sdp_maxstep(const ConeDesc *cones, const int *sidx, const double *x, const double *d,
                                                        double scale, double *partial, double *wsb, int cap) {
     extern __shared__ double sh[];
     __shared__ int sflag;
@@ -786,6 +816,7 @@ __global__ __launch_bounds__(SD_T) void k_sdp_maxstep(const ConeDesc *cones, con
 }
 
 // ---------------------------------------------------------------------------------- host launchers
+static int sd_threads(int rmax) { return rmax > 48 ? 1024 : 256; }
 // dynamic LDS: rotation scratch + up to `nmat` matrices of the largest cone (pitch r+1 allowed for), capped
 static int sd_cap(int rmax, int nmat) {
     const int pitch = sd_pitch(rmax) > rmax + 1 ? sd_pitch(rmax) : rmax + 1;
@@ -801,24 +832,24 @@ static int sd_set_lds_attr(const void *fn, int rmax, int nmat) {
 
 int cip_sdp_nt_scaling(hipStream_t s, const ConeSet &cs, const double *v, const double *sv, double *lambda) {
     if (sd_set_lds_attr((const void *)k_sdp_nt_scaling, cs.rmax, 1)) return -3;
-    hipLaunchKernelGGL(k_sdp_nt_scaling, dim3(cs.ns), dim3(SD_T), sd_shmem(cs.rmax, 1), s, cs.d_cones, cs.d_sidx, v, sv,
+    hipLaunchKernelGGL(k_sdp_nt_scaling, dim3(cs.ns), dim3(sd_threads(cs.rmax)), sd_shmem(cs.rmax, 1), s, cs.d_cones, cs.d_sidx, v, sv,
                        cs.d_scal, lambda, cs.d_sdpws, cs.d_sdpflag, sd_cap(cs.rmax, 1) + SD_SCRATCH(cs.rmax));
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 int cip_sdp_apply(hipStream_t s, const ConeSet &cs, int mode, const double *x, double *out) {
-    hipLaunchKernelGGL(k_sdp_apply, dim3(cs.ns), dim3(SD_T), 0, s, cs.d_cones, cs.d_sidx, cs.d_scal, mode, x, out, cs.d_sdpws);
+    hipLaunchKernelGGL(k_sdp_apply, dim3(cs.ns), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx, cs.d_scal, mode, x, out, cs.d_sdpws);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 int cip_sdp_prod(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out) {
-    hipLaunchKernelGGL(k_sdp_prod, dim3(cs.ns), dim3(SD_T), 0, s, cs.d_cones, cs.d_sidx, x, y, out, cs.d_sdpws);
+    hipLaunchKernelGGL(k_sdp_prod, dim3(cs.ns), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx, x, y, out, cs.d_sdpws);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 int cip_sdp_div(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out) {
     if (sd_set_lds_attr((const void *)k_sdp_div, cs.rmax, 2)) return -3;
-    hipLaunchKernelGGL(k_sdp_div, dim3(cs.ns), dim3(SD_T), sd_shmem(cs.rmax, 2), s, cs.d_cones, cs.d_sidx, x, y, out, cs.d_sdpws,
+    hipLaunchKernelGGL(k_sdp_div, dim3(cs.ns), dim3(sd_threads(cs.rmax)), sd_shmem(cs.rmax, 2), s, cs.d_cones, cs.d_sidx, x, y, out, cs.d_sdpws,
                        sd_cap(cs.rmax, 2));
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
@@ -829,21 +860,21 @@ int cip_sdp_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const dou
     const int cap = (int)(want < room ? want : (room > 0 ? room : 0));
     const size_t shm = ((size_t)SD_SCRATCH_TRI(cs.rmax) + cap) * sizeof(double);
     CIP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sdp_maxstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(k_sdp_maxstep, dim3(cs.ns), dim3(SD_T), shm, s, cs.d_cones, cs.d_sidx, x, d, scale, partial,
+    hipLaunchKernelGGL(k_sdp_maxstep, dim3(cs.ns), dim3(sd_threads(cs.rmax)), shm, s, cs.d_cones, cs.d_sidx, x, d, scale, partial,
                        cs.d_sdpws, cap);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 int cip_sdp_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, long ldat, double *Wt, long ldwt) {
     const int gx = n < cs.sdp_slots / cs.ns ? n : cs.sdp_slots / cs.ns;
-    hipLaunchKernelGGL(k_sdp_scale_At, dim3(gx, cs.ns), dim3(SD_T), 0, s, cs.d_cones, cs.d_sidx, cs.d_scal, n, At, ldat, Wt, ldwt,
+    hipLaunchKernelGGL(k_sdp_scale_At, dim3(gx, cs.ns), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx, cs.d_scal, n, At, ldat, Wt, ldwt,
                        cs.d_sdpws);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 int cip_sdp_fill_ftf(hipStream_t s, const ConeSet &cs, double *K, long ldk) {
     const int gx = cs.sdp_slots / cs.ns;
-    hipLaunchKernelGGL(k_sdp_fill_ftf, dim3(gx, cs.ns), dim3(SD_T), 0, s, cs.d_cones, cs.d_sidx, cs.d_scal, K, ldk, cs.d_sdpws,
+    hipLaunchKernelGGL(k_sdp_fill_ftf, dim3(gx, cs.ns), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx, cs.d_scal, K, ldk, cs.d_sdpws,
                        cs.d_sdpvec);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
