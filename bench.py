@@ -163,7 +163,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("CIP_BENCH_FORCE_DIST"):     # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=device)   # nccl == RCCL on ROCm
 
