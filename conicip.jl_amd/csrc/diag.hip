@@ -43,6 +43,14 @@ __device__ __forceinline__ double fast_rcp(double d) {
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ double shfl_d(double x, int src) { return __shfl(x, src, 64); }
+// x of lane (byte_addr / 4): ds_bpermute with a precomputed byte address (the per-pivot part of the source lane is a
+// multiple of 16 lanes = 64 bytes and folds into the instruction's offset field)
+__device__ __forceinline__ double bperm_d(double x, int byte_addr) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_ds_bpermute(byte_addr, lo);
+    hi = __builtin_amdgcn_ds_bpermute(byte_addr, hi);
+    return __hiloint2double(hi, lo);
+}
 
 // Step A: LDL' of the 16x16 diagonal micro-block kb and the inverse X of its unit-lower factor, by one wave.
 // The tile is held in the f64-MFMA accumulator layout -- lane (row i = l15, group g) owns columns g, g+4, g+8,
@@ -53,23 +61,26 @@ __device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int l
     const int l15 = lane & 15, g = lane >> 4;
     const int c = kb * 16;
     double u[4], x[4];
+    int addr_c[4];                                             // byte address of lane ((g + 4q) & 15) of lane group 0
+    const int addr_r = l15 * 4;                                // ... of lane l15 of lane group 0
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         u[q] = a[(c + l15) + (c + g + 4 * q) * DP];
         x[q] = (g + 4 * q == l15) ? 1.0 : 0.0;
+        addr_c[q] = ((g + 4 * q) & 15) * 4;
     }
 #pragma unroll
     for (int j = 0; j < ((DIAG_SKIP & 8) ? 0 : 16); ++j) {
         const int gj = j & 3, qj = j >> 2;
         const double d = rlane(u[qj], 16 * gj + j);
         const double di = fast_rcp(d);
-        const double wi = shfl_d(u[qj], 16 * gj + l15);        // a[i][j], own row
-        const double xj = shfl_d(x[qj], 16 * gj + l15);        // X[j][cc], own column
+        const double wi = bperm_d(u[qj], addr_r + 64 * gj);    // a[i][j], own row
+        const double xj = bperm_d(x[qj], addr_r + 64 * gj);    // X[j][cc], own column
         const double ti = wi * di;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (4 * q + 3 > j) {                               // some lane group still has column g+4q > j
-                const double cj = shfl_d(u[qj], 16 * gj + ((g + 4 * q) & 15));   // a[g+4q][j]
+                const double cj = bperm_d(u[qj], addr_c[q] + 64 * gj);           // a[g+4q][j]
                 if (g + 4 * q > j) {
                     u[q] -= ti * cj;
                     x[q] -= (cj * di) * xj;
