@@ -255,6 +255,24 @@ __global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64(GemmArgs g) {
     gemm_tile_64(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB);
 }
 
+// XCD-aware order (optional, CIP_TRAIL_PATCH): workgroups are dealt round-robin to the 8 XCDs, so XCD x is handed whole
+// p x p patches of quarter tiles (patches x, x+8, ...): the 2p half-panels of a patch are then fetched into that
+// XCD's L2 once for p^2 tiles instead of once per tile.
+__global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64p(GemmArgs g, int psz, int npatch, int P) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.x, x = b & 7, sq = b >> 3, per = psz * psz;
+    const int patch = x + 8 * (sq / per), w = sq % per;
+    if (patch >= npatch) return;
+    int pi, pj;
+    tile_coords(patch, 1, P, pi, pj);
+    const int nq = g.M / SB;
+    const int qi = pi * psz + w % psz, qj = pj * psz + w / psz;
+    if (qi >= nq || qj >= nq) return;
+    if ((qi >> 1) < (qj >> 1) || ((qi >> 1) == (qj >> 1) && qi < qj)) return;      // above the (128-tile) diagonal
+    gemm_tile_64(g, lds, (long)qi * SB, (long)qj * SB);
+}
+
 // Persistent form of the lower-triangular trailing update for the look-ahead schedule: 5 workgroups per CU pull
 // quarter tiles from an atomic counter, and workgroups that find themselves on a RESERVED CU exit at once, so the
 // reserved CUs stay empty for the whole launch.  The serial panel chain of the next outer block -- whose diagonal
@@ -372,6 +390,20 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     }
     if (epi == EPI_ACCUM && g.lower && g_tile == 64) {
         // the LDL' trailing update: every 128-tile of the lower triangle as four 64x64 quarter tiles
+        // Optional XCD-aware patch order (CIP_TRAIL_PATCH=4 or 8).  PMC at r = 8192, K = 512: 1.52 GB of L2-miss
+        // fetches per launch in plain tile order, 0.94 GB with 4x4 patches, 0.75 GB with 8x8 -- but the launch is not
+        // faster (standalone +1.5 % at r = 8192, -1 % at r = 2048) and the factorisation is 1-2 % SLOWER (same-session
+        // A/B: 52.6 / 51.9 vs 51.0 / 50.4 TFLOP/s): the misses are served by the Infinity Cache and hidden by the 20
+        // waves per CU, while a patch granularity costs load balance over the 8 XCDs.  Off by default.
+        static int psz = -1;
+        if (psz < 0) psz = getenv("CIP_TRAIL_PATCH") ? atoi(getenv("CIP_TRAIL_PATCH")) : 0;
+        if (psz > 0) {
+            const int nq = g.M / SB, P = (nq + psz - 1) / psz, npatch = P * (P + 1) / 2;
+            const long grid = (long)((npatch + 7) / 8) * 8 * psz * psz;
+            hipLaunchKernelGGL(k_ldlt_trailing_64p, dim3((unsigned)grid), dim3(256), 0, s, g, psz, npatch, P);
+            CIP_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
         hipLaunchKernelGGL(k_ldlt_trailing_64, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
