@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_128(GemmArgs g) {
 // 4x the workgroups and a quarter of the per-tile latency of the 128x128 kernel, at twice the LDS
 // traffic per flop -- these launches carry < 10 % of the flops.  Accumulate epilogue only.
 #define SB 64
+template <int EPI = EPI_ACCUM>
 __device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, long i0, long j0) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -227,9 +228,19 @@ __device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, lon
             const long col = j0 + wn * 32 + 2 * (l4 + 4 * q) + tj;
             const long row = i0 + wm * 32 + 2 * l15;
             double *cp = g.C + row + col * g.ldc;
-            v2d c = *(v2d *)cp;
-            c += g.alpha * (v2d){acc[0][tj][q], acc[1][tj][q]};
-            *(v2d *)cp = c;
+            const v2d val = (v2d){acc[0][tj][q], acc[1][tj][q]};
+            if (EPI == EPI_ACCUM) {
+                v2d c = *(v2d *)cp;
+                c += g.alpha * val;
+                *(v2d *)cp = c;
+            } else if (col < g.nvalid) {      // EPI_SYRKQ: C = Qin + alpha acc inside the valid n x n corner
+                if (row + 1 < g.nvalid) {
+                    const double *qp = g.Qin + row + col * g.ldq;       // Q keeps the caller's (possibly odd) pitch
+                    *(v2d *)cp = (v2d){qp[0], qp[1]} + g.alpha * val;
+                } else if (row < g.nvalid) {
+                    *cp = g.Qin[row + col * g.ldq] + g.alpha * val.x;
+                }
+            }
         }
 }
 
@@ -253,6 +264,16 @@ __global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64(GemmArgs g) {
     const int sub = blockIdx.x & 3;
     if (bi == bj && sub == 2) return;            // strictly-upper quadrant of a diagonal tile: never referenced
     gemm_tile_64(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB);
+}
+
+// Schur formation S = Q + Wt Wt' (lower tiles) in quarter tiles: the long-K (K = m) counterpart of the trailing update
+__global__ __launch_bounds__(256, 4) void k_syrkq_64(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
+    int bi, bj;
+    tile_coords((int)(blockIdx.x >> 2), 1, g.M / CIP_NB, bi, bj);
+    const int sub = blockIdx.x & 3;
+    if (bi == bj && sub == 2) return;
+    gemm_tile_64<EPI_SYRKQ>(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB);
 }
 
 // XCD-aware order (optional, CIP_TRAIL_PATCH): workgroups are dealt round-robin to the 8 XCDs, so XCD x is handed whole
@@ -405,6 +426,11 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
             return 0;
         }
         hipLaunchKernelGGL(k_ldlt_trailing_64, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
+        CIP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    if (epi == EPI_SYRKQ && g.lower && g_tile == 64) {
+        hipLaunchKernelGGL(k_syrkq_64, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
