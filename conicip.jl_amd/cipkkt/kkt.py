@@ -71,26 +71,19 @@ class KKTSystem:
         ct = (C.c_int * max(1, len(self.cone_dims)))(*[_CONE_CODE[t] for t, _ in self.cone_dims])
         cdm = (C.c_int * max(1, len(self.cone_dims)))(*[k for _, k in self.cone_dims])
         pr.cone_type, pr.cone_dim = ct, cdm
-        on_dev = isinstance(Q, torch.Tensor) and Q.is_cuda
-        if on_dev:
-            flags |= L.FLAG_DEVICE_PTRS
+        # Every matrix is handed over as a device pointer: host arrays are uploaded in whatever (row-major) layout
+        # they have and re-laid out column-major by a device transpose -- numpy.asfortranarray of a 2048 x 2048 Q
+        # alone cost 33 ms of the 42 ms this constructor took, cip_create_ex itself 3 ms.
+        on_dev = True
+        flags |= L.FLAG_DEVICE_PTRS
 
         def dense(M, rows, cols):
-            """column-major fp64 buffer (host numpy, or device torch when Q is on the device)"""
-            if on_dev:
-                if not isinstance(M, torch.Tensor):
-                    M = torch.as_tensor(np.asarray(M.toarray() if _is_sparse(M) else M, dtype=np.float64),
-                                        device=self.device)
-                Mt = M.to(dtype=torch.float64, device=self.device).reshape(rows, cols).t().contiguous()
-                keep.append(Mt)        # row-major of M' == column-major of M
-                return C.c_void_p(Mt.data_ptr())
-            if isinstance(M, torch.Tensor):
-                M = M.cpu().numpy()
-            if _is_sparse(M):
-                M = M.toarray()
-            Mf = np.asfortranarray(np.asarray(M, dtype=np.float64).reshape(rows, cols))
-            keep.append(Mf)
-            return C.c_void_p(Mf.ctypes.data)
+            """column-major fp64 device buffer"""
+            if not isinstance(M, torch.Tensor):
+                M = torch.from_numpy(np.ascontiguousarray(M.toarray() if _is_sparse(M) else M, dtype=np.float64))
+            Mt = M.to(dtype=torch.float64, device=self.device).reshape(rows, cols).t().contiguous()
+            keep.append(Mt)            # row-major of M' == column-major of M
+            return C.c_void_p(Mt.data_ptr())
 
         pr.Q, pr.ldq = dense(Q, n, n), n
         if m > 0 and _is_sparse(A) and not any(t == "S" for t, _ in self.cone_dims):
