@@ -38,6 +38,7 @@ struct GemmArgs {
     int by, bz;
     long sAy, sAz, sBy, sBz, sCy, sCz;
     int overwrite;               // EPI_ACCUM: C = alpha*acc instead of C += alpha*acc
+    double *Ct; long ldct, sCty, sCtz;   // 128-tile EPI_ACCUM only, optional: the result is also stored transposed, Ct[j + i*ldct]
     unsigned *queue_counter;     // non-NULL: persistent work-queue form (look-ahead trailing update)
     int reserve;                 // work-queue form: CUs left free per (XCD, SE) pair for the panel chain (0, 1 or 2)
 };

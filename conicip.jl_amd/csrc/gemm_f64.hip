@@ -58,6 +58,7 @@ __device__ __forceinline__ void gemm_tile_128(GemmArgs &g, double *lds, int bi, 
         g.A += blockIdx.y * g.sAy + blockIdx.z * g.sAz;
         g.B += blockIdx.y * g.sBy + blockIdx.z * g.sBz;
         g.C += blockIdx.y * g.sCy + blockIdx.z * g.sCz;
+        if (g.Ct) g.Ct += blockIdx.y * g.sCty + blockIdx.z * g.sCtz;
     }
 
     const double *Ap = g.A + i0 + 2 * lane;
@@ -133,6 +134,7 @@ __device__ __forceinline__ void gemm_tile_128(GemmArgs &g, double *lds, int bi, 
                     v2d c = g.overwrite ? (v2d){0.0, 0.0} : *(v2d *)cp;
                     c += g.alpha * val;
                     *(v2d *)cp = c;
+                    if (g.Ct) { g.Ct[col + row * g.ldct] = c.x; g.Ct[col + (row + 1) * g.ldct] = c.y; }
                 } else {   // EPI_SYRKQ
                     if (col < g.nvalid) {
                         if (row + 1 < g.nvalid) {

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k_seed_block_inverse(const double *Linv, 
 
 // After the factorisation: inverses of the Bs x Bs unit-lower diagonal blocks by doubling,
 //   inv([L11 0; L21 L22]) = [X11 0; -X22 L21 X11  X22],
-// three batched MFMA GEMMs per level (Tt = X11' L21', X21 = -X22 Tt', X21' = -Tt X22'), so that a
+// two batched MFMA GEMMs per level (Tt = X11' L21', then X21 = -X22 Tt' together with its transpose), so that a
 // triangular solve is Npad/Bs block steps (8 at n = 8192) instead of Npad/128 (64).
 static int build_solve_blocks(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws) {
     const int Bs = ws.Bs;
@@ -258,17 +258,14 @@ static int build_solve_blocks(hipStream_t s, double *K, int Npad, long ld, const
         g.B = K + h; g.ldb = ld; g.sBy = (long)Bs * (ld + 1); g.sBz = pK;
         g.C = ws.Tt; g.ldc = h; g.sCy = tt2; g.sCz = (long)h * h;
         if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
-        // X21 = -X22 * Tt'
+        // X21 = -X22 * Tt'  and, from the same accumulators, XT12 = X21' (stored transposed by the epilogue)
         g.alpha = -1.0;
         g.A = ws.X + h + (long)h * Bs; g.lda = Bs; g.sAy = bs2; g.sAz = pX;
         g.B = ws.Tt; g.ldb = h; g.sBy = tt2; g.sBz = (long)h * h;
         g.C = ws.X + h; g.ldc = Bs; g.sCy = bs2; g.sCz = pX;
+        g.Ct = ws.XT + (long)h * Bs; g.ldct = Bs; g.sCty = bs2; g.sCtz = pX;
         if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
-        // XT12 = X21' = -Tt * X22'
-        g.A = ws.Tt; g.lda = h; g.sAy = tt2; g.sAz = (long)h * h;
-        g.B = ws.X + h + (long)h * Bs; g.ldb = Bs; g.sBy = bs2; g.sBz = pX;
-        g.C = ws.XT + (long)h * Bs; g.ldc = Bs; g.sCy = bs2; g.sCz = pX;
-        if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
+        g.Ct = nullptr;
     }
     return 0;
 }
