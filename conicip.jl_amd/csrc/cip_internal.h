@@ -23,7 +23,7 @@ void cip_set_error(const char *fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------- GEMM (gemm_f64.hip)
-enum { EPI_ACCUM = 0, EPI_SYRKQ = 2 };
+enum { EPI_ACCUM = 0, EPI_SYRKQ = 2, EPI_STORE = 3 };
 
 struct GemmArgs {
     const double *A; long lda;   // M x K, element (i,k) at A[i + k*lda]

@@ -235,6 +235,10 @@ __device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, lon
                 v2d c = *(v2d *)cp;
                 c += g.alpha * val;
                 *(v2d *)cp = c;
+            } else if (EPI == EPI_STORE) {    // C = alpha acc, optionally also stored transposed
+                const v2d c = g.alpha * val;
+                *(v2d *)cp = c;
+                if (g.Ct) { g.Ct[col + row * g.ldct] = c.x; g.Ct[col + (row + 1) * g.ldct] = c.y; }
             } else if (col < g.nvalid) {      // EPI_SYRKQ: C = Qin + alpha acc inside the valid n x n corner
                 if (row + 1 < g.nvalid) {
                     const double *qp = g.Qin + row + col * g.ldq;       // Q keeps the caller's (possibly odd) pitch
@@ -266,6 +270,17 @@ __global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64(GemmArgs g) {
     const int sub = blockIdx.x & 3;
     if (bi == bj && sub == 2) return;            // strictly-upper quadrant of a diagonal tile: never referenced
     gemm_tile_64(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB);
+}
+
+// Batched small products (block-inverse doubling): grid.y x grid.z independent problems, C = alpha A B' (overwrite)
+__global__ __launch_bounds__(256, 4) void k_gemm_nt_64_batched(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
+    g.A += blockIdx.y * g.sAy + blockIdx.z * g.sAz;
+    g.B += blockIdx.y * g.sBy + blockIdx.z * g.sBz;
+    g.C += blockIdx.y * g.sCy + blockIdx.z * g.sCz;
+    if (g.Ct) g.Ct += blockIdx.y * g.sCty + blockIdx.z * g.sCtz;
+    const int tm = g.M / SB;
+    gemm_tile_64<EPI_STORE>(g, lds, (long)(blockIdx.x % tm) * SB, (long)(blockIdx.x / tm) * SB);
 }
 
 // Schur formation S = Q + Wt Wt' (lower tiles) in quarter tiles: the long-K (K = m) counterpart of the trailing update
@@ -386,6 +401,11 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     const int by = g.by > 0 ? g.by : 1, bz = g.bz > 0 ? g.bz : 1;
     if (by * bz > 1) {
         if (epi != EPI_ACCUM || g.lower) { cip_set_error("gemm: batching needs the plain accumulate form"); return -1; }
+        if (g.overwrite) {
+            hipLaunchKernelGGL(k_gemm_nt_64_batched, dim3((unsigned)(4 * tiles), by, bz), dim3(256), 0, s, g);
+            CIP_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
         hipLaunchKernelGGL(k_gemm_nt_128<EPI_ACCUM>, dim3((unsigned)tiles, by, bz), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
