@@ -74,6 +74,14 @@ SIGNATURES = {
     "cip_axpby_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_double, C.c_void_p]),
     "cip_conicip": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(CipOptions), C.c_void_p,
                               C.c_void_p, C.c_void_p, C.POINTER(CipResult), C.c_void_p, C.c_int]),
+    "cip_batch_create": (C.c_int, [C.c_int, C.POINTER(CipProblem), C.POINTER(C.c_void_p)]),
+    "cip_batch_destroy": (C.c_int, [C.c_void_p]),
+    "cip_batch_size": (C.c_int, [C.c_void_p]),
+    "cip_batch_handle": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "cip_batch_conicip": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(CipOptions)] +
+                          [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(CipResult), C.c_int]),
+    "cip_conicip_many": (C.c_int, [C.POINTER(C.c_void_p), C.c_int] + [C.POINTER(C.c_void_p)] * 3 +
+                         [C.POINTER(CipOptions)] + [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(CipResult), C.c_int]),
     "cip_ldlt_workspace_bytes": (C.c_int, [C.c_int, C.POINTER(C.c_size_t)]),
     "cip_ldlt_factor_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_int_p]),
     "cip_ldlt_solve_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

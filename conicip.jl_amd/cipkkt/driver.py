@@ -52,6 +52,26 @@ def _nrm(x2):
     return math.sqrt(x2) if x2 >= 0 else math.nan
 
 
+def solution_from_result(res, y, w, v, trace=None):
+    """cip_result (+ output vectors, optional trace rows) -> Solution."""
+    sol = Solution(np.array(y, copy=True), np.array(w, copy=True), np.array(v, copy=True))
+    sol.status = L.STATUS_NAMES[res.status]
+    sol.Iter, sol.Mu = res.iter, res.mu
+    sol.prFeas, sol.duFeas, sol.muFeas = res.prFeas, res.duFeas, res.muFeas
+    sol.pobj, sol.dobj = res.pobj, res.dobj
+    sol.n_factor, sol.n_solve = res.n_factor, res.n_solve
+    sol.wall_s = res.wall_s
+    names = ("Iter", "mu", "rDu", "rPr", "rCp", "pobj", "dobj", "alpha", "sigma")
+    if trace is not None:
+        for row in trace[:res.trace_rows]:
+            d_ = dict(zip(names, row.tolist()))
+            d_["Iter"] = int(d_["Iter"])
+            if d_["alpha"] != d_["alpha"]:          # the terminating iteration takes no step
+                del d_["alpha"], d_["sigma"]
+            sol.trace.append(d_)
+    return sol
+
+
 def _conicIP_native(ks, c_h, b_h, d_h, n, m, p, optTol, DTB, infeasTol, refinementThreshold, maxRefinementSteps,
                     maxIters, verbose, t_start):
     """The loop of src/ConicIP.jl:730-934 inside the library (csrc/driver.hip: cip_conicip)."""
@@ -65,19 +85,7 @@ def _conicIP_native(ks, c_h, b_h, d_h, n, m, p, optTol, DTB, infeasTol, refineme
     with torch.cuda.device(ks.device):
         L.check(ks.lib.cip_conicip(ks.h, ptr(c_h), ptr(b_h) if m else None, ptr(d_h) if p else None,
                                     C.byref(opt), ptr(y), ptr(w), ptr(v), C.byref(res), ptr(trace), int(maxIters)))
-    sol = Solution(y[:n].copy(), w[:p].copy(), v[:m].copy())
-    sol.status = L.STATUS_NAMES[res.status]
-    sol.Iter, sol.Mu = res.iter, res.mu
-    sol.prFeas, sol.duFeas, sol.muFeas = res.prFeas, res.duFeas, res.muFeas
-    sol.pobj, sol.dobj = res.pobj, res.dobj
-    sol.n_factor, sol.n_solve = res.n_factor, res.n_solve
-    names = ("Iter", "mu", "rDu", "rPr", "rCp", "pobj", "dobj", "alpha", "sigma")
-    for row in trace[:res.trace_rows]:
-        d_ = dict(zip(names, row.tolist()))
-        d_["Iter"] = int(d_["Iter"])
-        if d_["alpha"] != d_["alpha"]:          # the terminating iteration takes no step
-            del d_["alpha"], d_["sigma"]
-        sol.trace.append(d_)
+    sol = solution_from_result(res, y[:n], w[:p], v[:m], trace)
     sol.wall_s = time.perf_counter() - t_start
     return sol
 

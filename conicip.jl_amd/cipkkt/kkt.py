@@ -107,6 +107,7 @@ class KKTSystem:
         pr.G, pr.ldg = (dense(G, p, n) if p > 0 else None), max(p, 1)
         pr.route, pr.flags = self.route, flags
         h = C.c_void_p()
+        torch.cuda.current_stream(self.device).synchronize()    # staging transposes ran on torch's current stream
         L.check(self.lib.cip_create_ex(C.byref(pr), C.byref(h)))
         self.h = h
         N, Np = C.c_int(), C.c_int()

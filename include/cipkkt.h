@@ -162,6 +162,22 @@ typedef struct cip_result {          /* src/ConicIP.jl:384-398 (Solution) */
 int cip_conicip(cip_handle *h, const double *c, const double *b, const double *d, const cip_options *opt,
                 double *y, double *w, double *v, cip_result *res, double *trace, int trace_cap);
 
+/* ---- batches of independent problems on one GPU (BASELINE config 5).  A batch is an array of ordinary handles,
+ * each on its own HIP stream; cip_batch_handle(b, i) is the "leading problem index": every entry point above works
+ * on it.  cip_conicip_many / cip_batch_conicip keep `in_flight` interior-point loops running at once (one host
+ * thread each); pointer arrays have one entry per problem (b / d / w / v arrays may be NULL when m or p is 0). */
+typedef struct cip_batch cip_batch;
+int cip_batch_create(int count, const cip_problem *probs, cip_batch **out);
+int cip_batch_destroy(cip_batch *b);
+int cip_batch_size(const cip_batch *b);
+cip_handle *cip_batch_handle(cip_batch *b, int i);
+int cip_batch_conicip(cip_batch *b, const double *const *c, const double *const *bvec, const double *const *d,
+                      const cip_options *opt, double *const *y, double *const *w, double *const *v, cip_result *res,
+                      int in_flight);
+int cip_conicip_many(cip_handle *const *handles, int count, const double *const *c, const double *const *bvec,
+                     const double *const *d, const cip_options *opt, double *const *y, double *const *w,
+                     double *const *v, cip_result *res, int in_flight);
+
 /* ---- dense symmetric LDL' building blocks (device pointers), usable on their own.
  * K is N x N column-major with leading dimension ld; only the lower triangle is
  * referenced.  N and ld must be multiples of 128 (pad with an identity block). */

@@ -105,3 +105,26 @@ def test_config5_batch_of_qps():
     assert stats["n_problems"] == 3 and stats["n_optimal"] == 3
     for i, pr in enumerate(probs):
         check_optimality(pr["Q"], pr["c"], pr["A"], pr["b"], pr["cone_dims"], np.zeros((0, n)), np.zeros(0), sols[i], 1e-5)
+
+
+@pytest.mark.parametrize("native", [True, False], ids=["cip_conicip_many", "python-threads"])
+def test_config5_batch_in_flight(native):
+    """The same batch with several problems in flight on separate HIP streams: through the library's batch entry
+    point (csrc/batch.hip) and through Python threads; both must reproduce the one-at-a-time solutions exactly
+    (independent problems share nothing)."""
+    from cipkkt.batch import solve_batch
+    probs = []
+    n = 512
+    for i in range(5):
+        rng = np.random.default_rng(700 + i)
+        M = rng.standard_normal((n, n))
+        G = rng.standard_normal((3, n)) if i % 2 else None
+        probs.append(dict(Q=M.T @ M / n, c=rng.standard_normal(n), A=sp.identity(n, format="csr"), b=np.zeros(n),
+                          cone_dims=[("R", n)], G=G, d=None if G is None else np.zeros(3), kwargs=dict(optTol=1e-7)))
+    ref, st0 = solve_batch(probs)
+    got, st1 = solve_batch(probs, concurrency=3, native=native)
+    assert st1["n_optimal"] == 5 and st1["n_factor"] == st0["n_factor"] and st1["n_solve"] == st0["n_solve"]
+    for i in range(5):
+        assert got[i].status == ref[i].status == "Optimal" and got[i].Iter == ref[i].Iter
+        np.testing.assert_allclose(got[i].y, ref[i].y, rtol=1e-12, atol=0)
+        np.testing.assert_allclose(got[i].w, ref[i].w, rtol=1e-12, atol=1e-300)

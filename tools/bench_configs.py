@@ -77,7 +77,15 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         st["wall_s"] = dt
-        print(json.dumps(dict(config="C5 batch 8 x dense QP n=2048, %d streams in flight" % conc, **st,
+        print(json.dumps(dict(config="C5 batch 8 x dense QP n=2048, %d in flight (cip_conicip_many)" % conc, **st,
+                              kkt_solves_per_s=st["n_factor"] / dt)), flush=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sols, st = solve_batch(probs, concurrency=conc, native=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st["wall_s"] = dt
+        print(json.dumps(dict(config="C5 batch 8 x dense QP n=2048, %d in flight (Python threads)" % conc, **st,
                               kkt_solves_per_s=st["n_factor"] / dt)), flush=True)
 
 
