@@ -29,7 +29,7 @@ static int rup(int x, int q) { return ((x + q - 1) / q) * q; }
 static void free_all(cip_handle *h) {
     void *ptrs[] = {h->cs.d_sidx, h->cs.d_sdpws, h->cs.d_sdpvec, h->cs.d_sdpflag, h->Q, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->row_cone, h->G, h->Gt,
                     h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->cs.d_partial, h->cs.d_scalar, h->K, h->Wt, h->Gm,
-                    h->ws_base, h->rhs, h->mt1, h->mt2, h->mt3, h->nt1, h->pt1, h->dot_scratch, h->dot_ptrs, h->stage};
+                    h->ws_base, h->rhs, h->mt1, h->mt2, h->mt3, h->nt1, h->pt1, h->dot_scratch, h->dot_ptrs, h->stage, h->drv};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);

@@ -43,6 +43,7 @@ struct cip_handle {
     double *pt1 = nullptr;          // p-vector
     double *dot_scratch = nullptr; void *dot_ptrs = nullptr;
     double *stage = nullptr;        // device staging for the host-pointer entry points: 2*(n+p+m) doubles
+    double *drv = nullptr;          // vectors of the native interior-point loop (cip_conicip), allocated on first use
 
     // ---- stats
     double n_factor = 0, n_solve = 0, ms_assemble = 0, ms_ldlt = 0, flops_ldlt = 0;

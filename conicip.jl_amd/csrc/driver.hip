@@ -28,23 +28,34 @@ struct Vec4 {          // (y[n], w[p], v[m], s[m]) stored contiguously
 struct Driver {
     cip_handle *h;
     int n, m, p, NT;
-    std::vector<void *> allocs;
+    double *next = nullptr;      // bump pointer into h->drv (one allocation per handle, kept for later calls)
     int rc = 0;
 
+    static size_t pad(size_t c) { return (c + 31) & ~(size_t)31; }      // 256-byte alignment of every vector
+    size_t total() const {
+        return 9 * pad(NT) + pad(n) + pad(m) + pad(p) + 5 * pad(m) + 2 * pad(n) + pad(m) + pad(p) + 32;
+    }
+    int init() {
+        if (!h->drv) {
+            void *ptr = nullptr;
+            if (hipMalloc(&ptr, sizeof(double) * total()) != hipSuccess) { rc = CIP_E_HIP; return rc; }
+            h->drv = (double *)ptr;
+        }
+        if (hipMemsetAsync(h->drv, 0, sizeof(double) * total(), h->stream) != hipSuccess) { rc = CIP_E_HIP; return rc; }
+        next = h->drv;
+        return 0;
+    }
     double *dalloc(size_t count) {
-        void *ptr = nullptr;
-        if (hipMalloc(&ptr, sizeof(double) * (count ? count : 1)) != hipSuccess) { rc = CIP_E_HIP; return nullptr; }
-        (void)hipMemsetAsync(ptr, 0, sizeof(double) * (count ? count : 1), h->stream);
-        allocs.push_back(ptr);
-        return (double *)ptr;
+        double *ptr = next;
+        next += pad(count);
+        return ptr;
     }
     Vec4 vec4() {
         Vec4 v;
         v.base = dalloc(NT);
-        if (v.base) { v.y = v.base; v.w = v.y + n; v.v = v.w + p; v.s = v.v + m; }
+        v.y = v.base; v.w = v.y + n; v.v = v.w + p; v.s = v.v + m;
         return v;
     }
-    ~Driver() { for (void *q : allocs) (void)hipFree(q); }
 
     // y <- alpha x + beta y
     int axpby(int len, double alpha, const double *x, double beta, double *y) { return len > 0 ? cip_axpby_dev(h, len, alpha, x, beta, y) : 0; }
@@ -83,12 +94,12 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
 
     Driver D{h, h->n, h->m, h->p, h->n + h->p + 2 * h->m};
     const int n = D.n, m = D.m, p = D.p;
+    if (D.init()) { cip_set_error("cip_conicip: device allocation failed"); return CIP_E_HIP; }
     double *c_d = D.dalloc(n), *b_d = D.dalloc(m), *d_d = D.dalloc(p);
     Vec4 z = D.vec4(), r0 = D.vec4(), rleft = D.vec4(), r = D.vec4(), daff = D.vec4(), dz = D.vec4(), dzr = D.vec4(),
          rIr = D.vec4(), rkkt = D.vec4();
     double *e = D.dalloc(m), *lam = D.dalloc(m), *mb1 = D.dalloc(m), *mb2 = D.dalloc(m), *mb3 = D.dalloc(m);
     double *Qy = D.dalloc(n), *pinf = D.dalloc(n), *Ays = D.dalloc(m), *Gy = D.dalloc(p);
-    if (D.rc) { cip_set_error("cip_conicip: device allocation failed"); return CIP_E_HIP; }
     CIP_HIP_CHECK(hipMemcpyAsync(c_d, c_host, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
     if (m > 0) CIP_HIP_CHECK(hipMemcpyAsync(b_d, b_host, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
     if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(d_d, d_host, sizeof(double) * p, hipMemcpyHostToDevice, h->stream));
