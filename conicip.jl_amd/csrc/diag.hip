@@ -190,6 +190,16 @@ __device__ __forceinline__ void diag_load_block(double *a, const double *Kb, lon
     }
 }
 
+// columns [c, c+16) of the LDS image -> K (L strictly lower, d on the diagonal), 16-byte stores where aligned pairs
+// lie below the diagonal; `t` of `nt` threads
+__device__ __forceinline__ void diag_store_panel(const double *a, double *Kb, long ld, int c, int t, int nt) {
+    for (int e = t; e < 16 * 64; e += nt) {
+        const int i = 2 * (e & 63), j = c + (e >> 6);
+        if (i >= j) *(v2d *)(Kb + i + (long)j * ld) = *(const v2d *)(a + i + j * DP);
+        else if (i + 1 == j) Kb[i + 1 + (long)j * ld] = a[i + 1 + j * DP];
+    }
+}
+
 // Factor-only diagonal kernel: L (strictly lower) and d back into K, d / 1/d vectors, and the 8 micro
 // inverses Xm (xm_out[kb][k*16 + jj] = inv(L11_kb)[jj][k]) for the TRSM and the block-inverse kernels.
 __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
@@ -228,6 +238,9 @@ __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, do
             if (!(DIAG_SKIP & 4)) diag_step_c(a, kb + 1, kb + 1, c, l15, g, d4);
             diag_step_a(a, xm, kb + 1, lane, info, col0);
         } else if (!(DIAG_SKIP & 4)) {
+            // micro-panel kb is final (A(kb) and B(kb) are behind the barrier): waves 1-3 write it back now, under
+            // wave 0's serial step, instead of in a store phase at the end of the kernel
+            if (!(DIAG_SKIP & 16)) diag_store_panel(a, Kb, ld, c, tid - 64, 192);
             int idx = 0;
             for (int it = kb + 1; it < 8; ++it)
                 for (int jt = kb + 1; jt <= it; ++jt) {
@@ -239,14 +252,8 @@ __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, do
         __syncthreads();
     }
 
-    // ---- L (strictly lower) and d out, 16-byte stores; the strictly upper part of K is left untouched
-#pragma unroll 8
-    for (int q = 0; q < ((DIAG_SKIP & 16) ? 0 : 32); ++q) {
-        const int e = q * 256 + tid;
-        const int i = 2 * (e & 63), j = e >> 6;
-        if (i >= j) *(v2d *)(Kb + i + (long)j * ld) = *(const v2d *)(a + i + j * DP);
-        else if (i + 1 == j) Kb[i + 1 + (long)j * ld] = a[i + 1 + j * DP];
-    }
+    // ---- last micro-panel, d and the micro inverses out; the strictly upper part of K is left untouched
+    if (!(DIAG_SKIP & 16)) diag_store_panel(a, Kb, ld, 112, tid, 256);
     if (tid < CIP_NB) {
         dvec[tid] = a[128 + tid * DP];
         dinv[tid] = a[129 + tid * DP];
