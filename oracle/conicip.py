@@ -235,7 +235,7 @@ def conicIP(Q, c, A, b, cone_dims, G=None, d=None, *,
         r0 = V4(rleft.y - c, rleft.w - d, rleft.v - b, rleft.s)               # :753
 
         mubar = float(np.dot(z.v, z.s))                       # :756
-        mu = mubar / conedim                                  # :757
+        mu = mubar / conedim if conedim > 0 else np.nan      # :757 (Julia: 0.0/0 = NaN, no exception)
 
         cTy = float(np.dot(c, z.y))                           # :763
         rDu = float(np.linalg.norm(r0.y)) / (1 + normc)       # :764

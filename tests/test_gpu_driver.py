@@ -139,3 +139,27 @@ def test_native_driver_maxiters_abandoned():
     Q, c, A, b, K, G, d = P.simplex()[:7]
     sol = cipkkt.conicIP(Q, c, A, b, K, G, d, maxIters=2)
     assert sol.status == "Abandoned" and len(sol.trace) == 2
+
+
+@pytest.mark.parametrize("drv", ["native", "python"])
+def test_degenerate_shapes(drv):
+    """No inequality rows / no cones (m = 0), with and without equalities, and a 1 x 1 problem: the reference's loop
+    handles them (the first Newton solve is the answer); so do both drivers, in agreement with the oracle."""
+    import cipkkt
+    rng = np.random.default_rng(0)
+    n = 7
+    M = rng.standard_normal((n, n))
+    Q, c = M.T @ M + np.eye(n), rng.standard_normal(n)
+    A0, b0 = np.zeros((0, n)), np.zeros(0)
+    s = cipkkt.conicIP(Q, c, A0, b0, [], driver=drv)
+    r = oracle_conicIP(Q, c, A0, b0, [])
+    assert s.status == r.status == "Optimal"
+    np.testing.assert_allclose(s.y, np.linalg.solve(Q, c), rtol=1e-12)
+    G, d = rng.standard_normal((2, n)), rng.standard_normal(2)
+    s = cipkkt.conicIP(Q, c, A0, b0, [], G, d, driver=drv)
+    r = oracle_conicIP(Q, c, A0, b0, [], G, d)
+    assert s.status == r.status == "Optimal"
+    np.testing.assert_allclose(s.y, r.y, rtol=1e-10, atol=1e-12)
+    assert np.abs(G @ s.y - d).max() < 1e-12
+    s = cipkkt.conicIP(np.array([[2.0]]), np.array([-1.0]), np.array([[1.0]]), np.array([0.0]), [("R", 1)], driver=drv)
+    assert s.status == "Optimal" and abs(s.y[0]) < 1e-5

@@ -274,3 +274,15 @@ def test_solvers_agree_on_mixed():
     for s in sols[1:]:
         assert s.Iter == sols[0].Iter
         np.testing.assert_allclose(s.y, sols[0].y, rtol=1e-6, atol=1e-8)
+
+
+def test_oracle_no_cones():
+    """m = 0 (no inequality rows): mu = 0/0 is NaN in Julia, not an exception (src/ConicIP.jl:757); the first Newton
+    solve already satisfies the stopping test."""
+    rng = np.random.default_rng(0)
+    n = 6
+    M = rng.standard_normal((n, n))
+    Q, c = M.T @ M + np.eye(n), rng.standard_normal(n)
+    sol = conicIP(Q, c, np.zeros((0, n)), np.zeros(0), [])
+    assert sol.status == "Optimal"
+    np.testing.assert_allclose(sol.y, np.linalg.solve(Q, c), rtol=1e-12)
