@@ -60,6 +60,8 @@ SIGNATURES = {
     "cip_get_scaling_packed": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cip_factor": (C.c_int, [C.c_void_p]),
     "cip_check_factor": (C.c_int, [C.c_void_p]),
+    "cip_set_regularization": (C.c_int, [C.c_void_p, C.c_double, C.c_int]),
+    "cip_get_regularization": (C.c_int, [C.c_void_p, c_double_p, c_int_p]),
     "cip_solve3x3": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6),
     "cip_solve3x3_dev": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6),
     "cip_solve4x4_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

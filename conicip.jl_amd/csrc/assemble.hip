@@ -190,8 +190,43 @@ static int assemble_full(cip_handle *h) {
     return 0;
 }
 
+// Static regularisation, scaled per row: K_ii += s_i * rel * max_j |K_ij| (the symmetric matrix' full row i: its stored
+// row part j <= i and its column part below the diagonal), s_i = +1 on the positive-pivot block [p0, p1), -1 elsewhere.
+// Late interior-point iterates spread the diagonal of S over 20 orders of magnitude; one global delta either drowns
+// the small rows or does nothing for the large ones.
+__global__ __launch_bounds__(256) void k_rowmax_lower(const double *K, long ldk, int N, double *rowmax) {
+    // thread <-> row i: the row part K[i, 0..i] (coalesced across the threads of a workgroup)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    double mx = 0.0;
+    for (int j = 0; j <= i; ++j) mx = fmax(mx, fabs(K[i + (long)j * ldk]));
+    rowmax[i] = mx;
+}
+__global__ __launch_bounds__(256) void k_regularize_rows(double *K, long ldk, int N, int p0, int p1, double rel, const double *rowmax) {
+    // workgroup <-> column i: the column part K[i+1.., i], then the diagonal update
+    __shared__ double red[4];
+    const int i = blockIdx.x;
+    double mx = 0.0;
+    for (int r = i + 1 + threadIdx.x; r < N; r += 256) mx = fmax(mx, fabs(K[r + (long)i * ldk]));
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double delta = rel * fmax(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])), rowmax[i]);
+        K[i + (long)i * ldk] += (i >= p0 && i < p1) ? delta : -delta;
+    }
+}
+
 int cip_assemble(cip_handle *h) {
     int rc = (h->route == CIP_ROUTE_SCHUR) ? assemble_schur(h) : assemble_full(h);
+    if (rc == 0 && h->reg_rel > 0.0) {
+        // (the diagonal is modified only after every row / column maximum has been read: the second kernel reads
+        //  column i strictly below the diagonal, the first one has finished before it starts)
+        hipLaunchKernelGGL(k_rowmax_lower, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->K, h->ldk, h->N, h->rhs);
+        hipLaunchKernelGGL(k_regularize_rows, dim3(h->N), dim3(256), 0, h->stream, h->K, h->ldk, h->N, h->ws.signs.p0,
+                           h->ws.signs.p1, h->reg_rel, h->rhs);
+        CIP_HIP_CHECK(hipGetLastError());
+    }
     if (rc == 0) { h->assembled = true; h->factored = false; }
     return rc;
 }

@@ -34,6 +34,11 @@ struct cip_handle {
     double *Gm = nullptr;           // npad x nqpad  rank-1 columns of the Q cones (sparse-A Schur route)
     void *ws_base = nullptr; LdltWorkspace ws = {};
     bool assembled = false, factored = false;
+    // static regularisation K + delta diag(+1 .. -1 ..), delta = reg_rel * max|K_ii|: 0 until a factorisation meets a
+    // bad pivot (auto_reg), then kept for the lifetime of the handle; the loops' iterative refinement absorbs it
+    double reg_rel = 0.0;
+    bool auto_reg = true;
+    int n_regularized = 0;
     int x_zeroed = 0;               // block-inverse storage zero-initialised
 
     // ---- scratch
@@ -43,6 +48,7 @@ struct cip_handle {
     double *pt1 = nullptr;          // p-vector
     double *dot_scratch = nullptr; void *dot_ptrs = nullptr;
     double *stage = nullptr;        // device staging for the host-pointer entry points: 2*(n+p+m) doubles
+    double *ref = nullptr;          // right-hand side / residual / correction of the refinement inside solve3x3 (regularised factor only)
     double *drv = nullptr;          // vectors of the native interior-point loop (cip_conicip), allocated on first use
 
     // ---- stats

@@ -51,6 +51,10 @@ void cip_ldlt_profile_destroy(LdltProfile *p);
 // synchronises; adds the elapsed time of every recorded trailing-update launch to the totals
 int cip_ldlt_profile_collect(LdltProfile *p, double *launches, double *ms, double *flops);
 
+// Expected pivot signs of a quasi-definite matrix in its static order: positive for columns in [p0, p1) and for the
+// identity padding (>= N), negative elsewhere; p0 < 0: unknown, no sign check (stand-alone LDL' entry points)
+struct PivotSigns { int p0, p1, N; };
+
 struct LdltWorkspace {        // carved out of one device allocation
     double *Wbuf;             // Npad x NBO      (W = L*D panels of the current outer block)
     double *Linv;             // (Npad/128) x 128 x 128   inverse of each unit-lower diagonal block
@@ -64,7 +68,8 @@ struct LdltWorkspace {        // carved out of one device allocation
     double *dinv;             // Npad   1/d
     double *dvec;             // Npad   d
     double *tmp;              // Npad   scratch vector for the solves
-    int *info;                // device int: 0 ok, >0 = 1-based column of a bad pivot
+    int *info;                // device int: 0 ok, >0 = 1-based column of a bad pivot (zero, non-finite, or of the wrong sign)
+    PivotSigns signs;
     unsigned *qcounter;       // device tile counter of the work-queue trailing update
     LdltProfile *prof;        // host object or NULL
 };

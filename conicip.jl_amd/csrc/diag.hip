@@ -57,7 +57,7 @@ __device__ __forceinline__ double bperm_d(double x, int byte_addr) {
 // g+12 -- so each of the 16 pivot steps costs a quarter of the column updates per lane; the pivot is broadcast
 // with v_readlane, the pivot column / pivot row entries move between lane groups with ds_bpermute.  X is updated
 // right-looking by the same multipliers (lane (cc = l15, g) owns rows g+4q of column cc).
-__device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int lane, int *info, int col0) {
+__device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int lane, int *info, int col0, PivotSigns sg) {
     const int l15 = lane & 15, g = lane >> 4;
     const int c = kb * 16;
     double u[4], x[4];
@@ -98,7 +98,10 @@ __device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int l
         xm[kb * 256 + l15 * 16 + col] = x[q];                  // xm[k = cc][jj = r] = X[r][cc]
     }
     if (g == (l15 & 3)) {
-        if (!(fabs(dsel) > 0.0 && fabs(dsel) < 1.7e308)) atomicCAS(info, 0, col0 + c + l15 + 1);
+        // a bad pivot: zero, non-finite, or -- the matrix is quasi-definite in this static order -- of the wrong sign
+        const int col = col0 + c + l15;
+        const bool want_pos = (col >= sg.p0 && col < sg.p1) || col >= sg.N;
+        if (!(fabs(dsel) > 0.0 && fabs(dsel) < 1.7e308) || (sg.p0 >= 0 && (dsel > 0.0) != want_pos)) atomicCAS(info, 0, col + 1);
         a[128 + (c + l15) * DP] = dsel;
         a[129 + (c + l15) * DP] = fast_rcp(dsel);
     }
@@ -203,7 +206,7 @@ __device__ __forceinline__ void diag_store_panel(const double *a, double *Kb, lo
 // Factor-only diagonal kernel: L (strictly lower) and d back into K, d / 1/d vectors, and the 8 micro
 // inverses Xm (xm_out[kb][k*16 + jj] = inv(L11_kb)[jj][k]) for the TRSM and the block-inverse kernels.
 __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
-                                                          int *info, int col0) {
+                                                          int *info, int col0, PivotSigns sg) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *a = sm;
     double *xm = sm + XM_OFF;
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, do
     //   wave 0              : trailing update of the NEXT diagonal micro-block, then A(kb+1)      } overlapped
     //   waves 1-3           : all other trailing tiles of step kb (any tile, operands from LDS)   }
     //   barrier
-    if (wave == 0) diag_step_a(a, xm, 0, lane, info, col0);
+    if (wave == 0) diag_step_a(a, xm, 0, lane, info, col0, sg);
     __syncthreads();
     for (int kb = 0; kb < 7; ++kb) {
         const int c = kb * 16;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, do
         __syncthreads();
         if (wave == 0) {
             if (!(DIAG_SKIP & 4)) diag_step_c(a, kb + 1, kb + 1, c, l15, g, d4);
-            diag_step_a(a, xm, kb + 1, lane, info, col0);
+            diag_step_a(a, xm, kb + 1, lane, info, col0, sg);
         } else if (!(DIAG_SKIP & 4)) {
             // micro-panel kb is final (A(kb) and B(kb) are behind the barrier): waves 1-3 write it back now, under
             // wave 0's serial step, instead of in a store phase at the end of the kernel
@@ -342,13 +345,14 @@ __global__ __launch_bounds__(256) void k_trsm_subst(double *__restrict__ Ap, lon
 }
 
 static bool g_attr_diag = false, g_attr_inv = false;
-int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0) {
+int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
+                       PivotSigns sg) {
     if (!g_attr_diag) {
         CIP_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_diag128_v2, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           DIAG2_LDS_BYTES));
         g_attr_diag = true;
     }
-    hipLaunchKernelGGL(k_ldlt_diag128_v2, dim3(1), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0);
+    hipLaunchKernelGGL(k_ldlt_diag128_v2, dim3(1), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }

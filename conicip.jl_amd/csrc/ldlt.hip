@@ -113,11 +113,13 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     ws->info = (int *)p;
     ws->qcounter = (unsigned *)(p + 64);
     ws->prof = nullptr;
+    ws->signs = PivotSigns{-1, 0, 0};
     ws->x_zeroed = nullptr;
 }
 
 // diag.hip
-int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0);
+int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
+                       PivotSigns sg);
 int cip_launch_diag_inverse(hipStream_t s, const double *K, long ld, int nblk, const double *xm_all, double *Linv,
                             double *LinvT);
 int cip_launch_trsm_subst(hipStream_t s, double *Ap, long ld, int rows, const double *L11, const double *xm,
@@ -151,7 +153,7 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
         // MFMA micro-blocked diagonal kernel + substitution TRSM (the block inverses the solves
         // need are produced by one batched launch after the factorisation)
         if ((rc = cip_launch_diag_v2(s, K + c0 + (long)c0 * ld, ld, ws.Xm + (size_t)jb * 2048, ws.dvec + c0,
-                                     ws.dinv + c0, ws.info, c0)))
+                                     ws.dinv + c0, ws.info, c0, ws.signs)))
             return rc;
         if ((rc = cip_launch_trsm_subst(s, K + (c0 + CIP_NB) + (long)c0 * ld, ld, r, K + c0 + (long)c0 * ld,
                                         ws.Xm + (size_t)jb * 2048, ws.dinv + c0,

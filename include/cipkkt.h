@@ -111,6 +111,13 @@ int cip_get_scaling_packed(cip_handle *h, double *packedF);             /* host 
 int cip_factor(cip_handle *h);
 /* synchronise and report the factorisation status: CIP_OK or CIP_E_SINGULAR */
 int cip_check_factor(cip_handle *h);
+/* Static regularisation of the quasi-definite LDL' (K + delta diag(+1.. -1..), delta = rel * max|K_ii|).  Default:
+ * rel = 0 and automatic = 1 -- the first factorisation that meets a zero / non-finite / wrong-sign pivot (singular S:
+ * LPs, free variables with singular Q; the reference's pivoting LU / QR, src/kktsolvers.jl:24,:231,:295, has no such
+ * restriction) is redone with rel = 1e-13 per row (delta_i = rel * max_j |K_ij|), which then stays on; solve3x3 then
+ * refines against the true operator (a few extra back-solves) so that callers see the unregularised solution. */
+int cip_set_regularization(cip_handle *h, double rel, int automatic);
+int cip_get_regularization(cip_handle *h, double *rel, int *times_switched_on);
 
 /* ---- level 3: solve3x3(x, y, z) -> (a, b, c)  (src/ConicIP.jl:688; src/kktsolvers.jl:37-50, :324-330)
  *   Q a + G' b - A' c = x ;  G a = y ;  A a + F'F c = z */

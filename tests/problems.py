@@ -141,3 +141,56 @@ def random_mixed(n=40, nq=3, kq=6, p=4, seed=1, dense_A=True):
     if not dense_A:
         A = sp.csr_matrix(A)
     return Q, c, A, b, cone_dims, G, d, None
+
+
+# ------------------------------------------------------------------------------------------------------------
+# "Miles's counterexamples" (test/runtests.jl:592-651).  The numeric data is the reference's own fixture
+# (test/testdata.jl:109-150, extracted to tests/golden/miles_problems.json by tests/golden/make_miles_fixture.py);
+# the conversion from the MathProgBase conic form to ConicIP's form restates what the reference's test helper
+# documents (test/testdata.jl:5-15):   MPB:  min c'x  s.t.  b - Ax in K_con,  x in K_var
+#                                      here: min 1/2 y'Qy - c'y  s.t.  Ay - b in K,  Gy = d
+def miles_problem(k):
+    import json
+    import os
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "miles_problems.json")))[
+        "miles_problem_%d" % k]
+    c, b = np.array(rec["c"]), np.array(rec["b"])
+    A = sp.csr_matrix((rec["V"], (np.array(rec["I"]) - 1, np.array(rec["J"]) - 1)), shape=(b.size, c.size))
+    cones = lambda lst: [(t, np.array(idx) - 1) for t, idx in lst]            # 1-based -> 0-based
+    return c, A, b, cones(rec["con_cones"]), cones(rec["var_cones"])
+
+
+def mpb_to_conicip(c, A, b, con_cones, var_cones):
+    """(Q, c, A, b, cone_dims, G, d) of the ConicIP form.  Zero cones become equality rows; NonPos rows are kept
+    (b - Ax <= 0  <=>  Ax - b >= 0); NonNeg / SOC / SDP rows are negated (b - Ax in K  <=>  (-A)x - (-b) in K);
+    variable cones add rows nA * I (nA = ||A||_F, the reference's conditioning scale) with zero right-hand side;
+    the objective sign flips because ConicIP minimises -c'y."""
+    A = sp.csr_matrix(A)
+    n = c.size
+    nA = np.sqrt(A.multiply(A).sum())
+    eq = [idx for t, idx in con_cones if t == "Zero"]
+    rows, rhs, dims = [], [], []
+    kind = {"NonPos": ("R", 1.0), "NonNeg": ("R", -1.0), "SOC": ("Q", -1.0), "SDP": ("S", -1.0)}
+    for t, idx in con_cones:
+        if t == "Zero":
+            continue
+        cone, sign = kind[t]
+        rows.append(sign * A[idx, :])
+        rhs.append(sign * b[idx])
+        dims.append((cone, len(idx)))
+    vkind = {"NonNeg": ("R", 1.0), "NonPos": ("R", -1.0), "SOC": ("Q", 1.0), "SDP": ("S", 1.0)}
+    for t, idx in var_cones:
+        if t == "Free":
+            continue
+        cone, sign = vkind[t]
+        rows.append(sp.csr_matrix((np.full(len(idx), sign * nA), (np.arange(len(idx)), idx)), shape=(len(idx), n)))
+        rhs.append(np.zeros(len(idx)))
+        dims.append((cone, len(idx)))
+    Ai = sp.vstack(rows, format="csr") if rows else sp.csr_matrix((0, n))
+    bi = np.concatenate(rhs) if rhs else np.zeros(0)
+    if eq:
+        e = np.concatenate(eq)
+        G, d = A[e, :], b[e]
+    else:
+        G, d = sp.csr_matrix((0, n)), np.zeros(0)
+    return sp.csr_matrix((n, n)), -c, Ai, bi, dims, G, d

@@ -422,3 +422,32 @@ def test_plain_c_abi_sequence_as_the_julia_shim_calls_it(lib):
                         C.byref(bad))
     assert rc != 0 and b"cone_dims" in lib.cip_last_error()
     L.check(lib.cip_destroy(h))
+
+
+def test_singular_schur_block_is_regularised_and_refined():
+    """Q = 0 and free variables that only the equalities pin: S = A'(F'F)^-1 A is singular although the KKT matrix is
+    not, so the static-order LDL' meets a zero pivot.  The handle switches to the regularised factorisation and
+    solve3x3 refines against the true operator: the answer must match the reference-faithful null-space QR solver."""
+    import cipkkt
+    rng = np.random.default_rng(12)
+    n, p, k = 30, 12, 14                                  # 14 bounded variables, 16 free ones, 12 equalities
+    Q = np.zeros((n, n))
+    A = np.zeros((k, n))
+    A[np.arange(k), np.arange(k)] = 1.0
+    G = rng.standard_normal((p, n))
+    cone_dims = [("R", k)]
+    _, nt_scaling, _, _ = make_cone_ops(cone_dims)
+    F = nt_scaling(rng.random(k) + 0.1, rng.random(k) + 0.1)
+    x, y, z = rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(k)
+    # (the 16 free directions need 16 <= ... pinned: G has 12 rows, so add curvature on 4 of them to keep K non-singular)
+    Q[k:k + 4, k:k + 4] = np.eye(4)
+    ref = np.concatenate(kktsolver_qr(Q, A, G, cone_dims)(F, F.inv_adjoint())(x, y, z))
+    for route in ("schur", "full3x3"):
+        gen = cipkkt.kktsolver_hip(Q, A, G, cone_dims) if route == "schur" else cipkkt.kktsolver_hip_full3x3(Q, A, G, cone_dims)
+        got = np.concatenate(gen(F, F.inv_adjoint())(x, y, z))
+        rel = C.c_double()
+        times = C.c_int()
+        gen.system.lib.cip_get_regularization(gen.system.h, C.byref(rel), C.byref(times))
+        assert times.value == 1 and rel.value > 0, "the factorisation should have switched to the regularised form"
+        np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-9)
+        gen.system.close()

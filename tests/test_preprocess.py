@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
+import problems as P
 from oracle.preprocess import imcols as o_imcols, preprocess_conicIP as o_pre
 
 TOL = 1e-3       # `tol` of test/runtests.jl:13
@@ -106,3 +107,28 @@ def test_product_preprocess_matches_oracle():
     ref = o_pre(H, Hc, A, b, [("R", 10)], G2, d2, optTol=OPT)
     assert got.status == ref.status == "Optimal" and got.Iter == ref.Iter
     np.testing.assert_allclose(got.y, ref.y, rtol=1e-6, atol=1e-8)
+
+
+# ---- Miles's counterexamples (test/runtests.jl:592-651) through the pre-solve: reference data, reference verdicts
+def _miles(k, kc=1.0, ka=1.0):
+    c, A, b, con, var = P.miles_problem(k)
+    return P.mpb_to_conicip(kc * c, ka * A, ka * b, con, var)
+
+
+def check_miles(pre):
+    assert pre(*_miles(1)).status == "Optimal"                       # :598-606
+    assert pre(*_miles(2)).status == "Infeasible"                    # :608-616
+    for kappa in (1e-8, 1e-6, 1e-4, 1.0, 1e4, 1e6, 1e8):             # :621-628  (c, A, b all scaled)
+        assert pre(*_miles(3, kappa, kappa)).status == "Optimal", kappa
+    for kappa in (1e-4, 1.0, 1e4, 1e6):                              # :630-637  (A, b scaled)
+        assert pre(*_miles(3, 1.0, kappa)).status == "Optimal", kappa
+
+
+def test_oracle_miles_counterexamples():
+    check_miles(o_pre)
+
+
+@pytest.mark.gpu
+def test_product_miles_counterexamples():
+    import cipkkt
+    check_miles(cipkkt.preprocess_conicIP)

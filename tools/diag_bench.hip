@@ -18,10 +18,10 @@ int main() {
     hipMemset(dinfo, 0, 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int reps = 200;
-    for (int w = 0; w < 3; ++w) { hipMemcpy(dK, dK0, N * N * 8, hipMemcpyDeviceToDevice); cip_launch_diag_v2(0, dK, N, dLi, dd, ddi, dinfo, 0); }
+    for (int w = 0; w < 3; ++w) { hipMemcpy(dK, dK0, N * N * 8, hipMemcpyDeviceToDevice); cip_launch_diag_v2(0, dK, N, dLi, dd, ddi, dinfo, 0, PivotSigns{-1, 0, 0}); }
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);
-    for (int r = 0; r < reps; ++r) cip_launch_diag_v2(0, dK, N, dLi, dd, ddi, dinfo, 0);
+    for (int r = 0; r < reps; ++r) cip_launch_diag_v2(0, dK, N, dLi, dd, ddi, dinfo, 0, PivotSigns{-1, 0, 0});
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("DIAG_SKIP=%d avg %.2f us per launch\n",
