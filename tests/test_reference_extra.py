@@ -92,3 +92,29 @@ def test_product_matches_oracle_on_rank_one_hessian():
     ref = oracle_conicIP(H, Hc, A, b, [("R", 10)], G, d, optTol=OPT)
     assert got.status == ref.status == "Optimal" and got.Iter == ref.Iter
     np.testing.assert_allclose(got.y, ref.y, rtol=1e-6, atol=1e-8)
+
+
+# ---- the documentation's worked examples with known answers (docs/src/tutorials/qp.jl:21-41, socp.jl:32-53)
+def check_doc_examples(solve):
+    n = 5
+    p = np.arange(1.0, n + 1)                       # nearest point of the simplex to (1..5) is e_5
+    sol = solve(sp.identity(n, format="csr"), p, sp.identity(n, format="csr"), np.zeros(n), [("R", n)], np.ones((1, n)),
+                np.array([1.0]), optTol=1e-7)
+    assert sol.status == "Optimal"
+    np.testing.assert_allclose(sol.y, [0, 0, 0, 0, 1], atol=1e-4)
+    n = 3
+    a = np.ones(n)                                  # projection of (1,1,1) onto the unit ball: a / ||a||
+    A = sp.vstack([sp.csr_matrix((1, n)), sp.identity(n)], format="csr")
+    sol = solve(sp.identity(n, format="csr"), a, A, np.array([-1.0, 0, 0, 0]), [("Q", n + 1)], optTol=1e-7)
+    assert sol.status == "Optimal"
+    np.testing.assert_allclose(sol.y, a / np.linalg.norm(a), atol=1e-4)
+
+
+def test_oracle_doc_examples():
+    check_doc_examples(oracle_conicIP)
+
+
+@pytest.mark.gpu
+def test_product_doc_examples():
+    import cipkkt
+    check_doc_examples(cipkkt.conicIP)
