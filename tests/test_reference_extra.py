@@ -101,7 +101,9 @@ def check_doc_examples(solve):
     sol = solve(sp.identity(n, format="csr"), p, sp.identity(n, format="csr"), np.zeros(n), [("R", n)], np.ones((1, n)),
                 np.array([1.0]), optTol=1e-7)
     assert sol.status == "Optimal"
-    np.testing.assert_allclose(sol.y, [0, 0, 0, 0, 1], atol=1e-4)
+    # (y_4 sits exactly on its bound with a zero multiplier: no strict complementarity, so the interior-point iterate is
+    #  only O(sqrt(optTol)) close there)
+    np.testing.assert_allclose(sol.y, [0, 0, 0, 0, 1], atol=2e-3)
     n = 3
     a = np.ones(n)                                  # projection of (1,1,1) onto the unit ball: a / ||a||
     A = sp.vstack([sp.csr_matrix((1, n)), sp.identity(n)], format="csr")
