@@ -242,6 +242,31 @@ def main():
     ks.profile_trailing(False)
     ks.check_factor()
 
+    # the same steps under the opt-in look-ahead schedule (reported beside the headline, not as the headline: it
+    # trades trailing-update efficiency for overlap with the latency-bound panel chain -- DESIGN.md section 5)
+    la = None
+    if world == 1 and not os.environ.get("CIP_LOOKAHEAD"):
+        lib = cipkkt._lib.load()
+        lib.cip_set_ldlt_lookahead(1)
+        for _ in range(max(1, args.warmup)):
+            step()
+        ks.profile_trailing(True)
+        torch.cuda.synchronize()
+        t_la = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        e_la = time.perf_counter() - t_la
+        p_la = ks.profile_get()
+        ks.profile_trailing(False)
+        lib.cip_set_ldlt_lookahead(0)
+        step()
+        torch.cuda.synchronize()
+        la = {"value": args.steps / e_la, "ms_per_step": e_la / args.steps * 1e3,
+              "trailing_update_tflops": p_la["flops"] / (p_la["ms"] * 1e-3) / 1e12 if p_la["ms"] > 0 else None,
+              "note": "cip_set_ldlt_lookahead(1): panel chain of the next outer block on a side stream beside a persistent "
+                      "trailing update that leaves 64 CUs free; same steps, same process"}
+
     # separate factor / solve split (untimed region, for the report)
     ks.set_timing(True)
     ks.factor()
@@ -268,6 +293,7 @@ def main():
                                    "step = NT scaling + assembly + LDL' + %d solve4x4" % (n, n, spf),
                        "route": args.route, "kkt_order": N, "solves_per_factor": spf,
                        "ldlt_outer_block": int(st["nbo"]), "parallelism": "problem-per-GPU x%d" % world},
+            "lookahead_schedule": la,
             "converge": {"wall_s": converge_s, "iters": iters, "status": status, "n_factor": n_factor,
                          "n_solve": n_solve},
             "breakdown_ms": {"assemble": st["ms_assemble"], "ldlt_factor": st["ms_ldlt"], "solve4x4": solve_ms,

@@ -657,4 +657,5 @@ extern "C" int cip_profile_get(cip_handle *h, double *out3) {
     if (!h || !out3 || !h->ws.prof) { cip_set_error("profiling not enabled"); return CIP_E_INVALID; }
     return cip_ldlt_profile_collect(h->ws.prof, &out3[0], &out3[1], &out3[2]);
 }
+extern "C" int cip_set_ldlt_lookahead(int on) { return cip_ldlt_set_lookahead(on); }
 extern "C" int cip_set_ldlt_outer_block(int nbo) { cip_ldlt_set_outer_block(nbo); return cip_ldlt_outer_block(); }

@@ -73,6 +73,7 @@ struct LdltWorkspace {        // carved out of one device allocation
     unsigned *qcounter;       // device tile counter of the work-queue trailing update
     LdltProfile *prof;        // host object or NULL
 };
+int cip_ldlt_set_lookahead(int on);
 int cip_solve_block(int Npad);
 size_t cip_ldlt_ws_bytes(int Npad);
 void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws);

@@ -143,7 +143,7 @@ static int update_rest_of_block(hipStream_t s, double *K, int Npad, long ld, dou
 
 // one inner-panel sweep of an outer block: [strip update] -> diagonal kernel -> TRSM, for each 128 columns
 static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws, double *Wb, int C0,
-                               int wblk, hipEvent_t rest_ready = nullptr) {
+                               int wblk) {
     int rc;
     const int T = wblk / CIP_NB;
     for (int t = 0; t < T; ++t) {
@@ -159,8 +159,6 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
                                         ws.Xm + (size_t)jb * 2048, ws.dinv + c0,
                                         Wb + (c0 + CIP_NB) + (long)(t * CIP_NB) * Npad, Npad)))
             return rc;
-        // look-ahead: columns 128.. of this block are still receiving the previous block's update
-        if (t == 0 && rest_ready) CIP_HIP_CHECK(hipStreamWaitEvent(s, rest_ready, 0));
         if ((rc = update_rest_of_block(s, K, Npad, ld, Wb, C0, wblk, t))) return rc;
     }
     return 0;
@@ -169,34 +167,43 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
 // Look-ahead plumbing: the panel chain (diag -> TRSM -> strip, serial, tiny grids) runs on a high-priority
 // side stream while the big trailing update of the previous outer block runs on the caller's stream.
 // One process-wide side stream and event ring (factorisations of one process are issued from one thread).
-static hipStream_t g_side = nullptr;      // panel chain: high priority, all CUs
-static hipEvent_t g_evP[2] = {nullptr, nullptr}, g_evU[2] = {nullptr, nullptr}, g_evR[2] = {nullptr, nullptr};
-static hipEvent_t g_evStart = nullptr, g_evEnd = nullptr;
+static thread_local hipStream_t g_side = nullptr;      // panel chain: high priority (one per host thread: handles of a batch factor concurrently)
+static thread_local hipEvent_t g_evP[2] = {nullptr, nullptr}, g_evU[2] = {nullptr, nullptr};
+static thread_local hipEvent_t g_evStart = nullptr;
 static int g_lookahead = -1;
 static int g_queue = 0;                   // CIP_GEMM_QUEUE=1: persistent work-queue trailing update
-static int g_split = 1;                   // look-ahead: update the next block's first 128 columns separately
+static int g_la_min = 3072;               // look-ahead only while the trailing matrix has at least this many rows
 static int g_reserve = 0;                 // CUs per XCD kept free by the work-queue trailing update (0 = plain launch)
+// run-time switch of the schedule (bench.py measures both in one process); -1 = not decided yet (environment)
+int cip_ldlt_set_lookahead(int on) {
+    const int prev = g_lookahead;
+    g_lookahead = on ? 1 : 0;
+    g_reserve = on ? 2 : 0;
+    if (const char *e = getenv("CIP_RESERVE")) { if (on) g_reserve = atoi(e); }
+    if (const char *e = getenv("CIP_LA_MIN")) g_la_min = atoi(e);
+    g_queue = g_reserve ? 1 : 0;
+    return prev;
+}
 static int lookahead_init(void) {
-    if (g_lookahead >= 0) return 0;
-    // Off by default.  Same-session A/B at n = 8192 (3 alternations): look-ahead 117.4 vs serial 115.7 KKT
-    // solves/s (+1.5 %), but the trailing-update kernel runs at 43.3 vs 47.2 TFLOP/s because it shares the chip
-    // with the panel chain, and the chain kernels themselves run 1.5-2x slower under that load.  The serial
-    // single-stream schedule is the default; CIP_LOOKAHEAD=1 selects the two-stream look-ahead.
-    g_lookahead = getenv("CIP_LOOKAHEAD") ? 1 : 0;
-    g_reserve = g_lookahead ? 1 : 0;          // CUs per (XCD, SE) the persistent trailing update keeps free: 32 or 64 in all
-    if (const char *e = getenv("CIP_RESERVE")) g_reserve = atoi(e);
-    if (const char *e = getenv("CIP_LA_SPLIT")) g_split = atoi(e);
-    g_queue = getenv("CIP_GEMM_QUEUE") ? atoi(getenv("CIP_GEMM_QUEUE")) : (g_reserve ? 1 : 0);
+    // Opt-in (CIP_LOOKAHEAD=1); the serial single-stream schedule is the default.  Same-session A/B at n = 8192:
+    // 133.2 vs 125.3 KKT solves/s (factorisation 6.56 vs 7.0 ms) with CIP_RESERVE=2, but the trailing-update kernel
+    // then runs at 38 instead of 51 TFLOP/s because it gives 64 CUs to the panel chain -- see DESIGN.md.
+    if (g_lookahead < 0) {
+        g_lookahead = getenv("CIP_LOOKAHEAD") ? 1 : 0;
+        g_reserve = g_lookahead ? 2 : 0;      // CUs per (XCD, SE) the persistent trailing update keeps free: 32 or 64 in all
+        if (const char *e = getenv("CIP_RESERVE")) g_reserve = atoi(e);
+        if (const char *e = getenv("CIP_LA_MIN")) g_la_min = atoi(e);
+        g_queue = getenv("CIP_GEMM_QUEUE") ? atoi(getenv("CIP_GEMM_QUEUE")) : (g_reserve ? 1 : 0);
+    }
+    if (!g_lookahead || g_side) return 0;     // the stream and the events are per host thread
     int lo = 0, hi = 0;
     CIP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     CIP_HIP_CHECK(hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, hi));
     for (int i = 0; i < 2; ++i) {
         CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evP[i], hipEventDisableTiming));
         CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evU[i], hipEventDisableTiming));
-        CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evR[i], hipEventDisableTiming));
     }
     CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evStart, hipEventDisableTiming));
-    CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evEnd, hipEventDisableTiming));
     return 0;
 }
 
@@ -279,7 +286,7 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
     if ((rc = lookahead_init())) return rc;
     CIP_HIP_CHECK(hipMemsetAsync(ws.info, 0, g_lookahead ? 64 + 4 * (2 * (size_t)(Npad / CIP_NB) + 8) : sizeof(int), s));
     const size_t wstride = (size_t)Npad * CIP_NBO_MAX;
-    const bool la = g_lookahead && Npad > NBO;
+    const bool la = g_lookahead && Npad - NBO >= g_la_min;
     if (!la) {
         // serial right-looking schedule: panels of the outer block, then ONE trailing update
         for (int C0 = 0; C0 < Npad; C0 += NBO) {
@@ -305,17 +312,17 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
             return rc;
         return build_solve_blocks(s, K, Npad, ld, ws);
     }
-    hipStream_t sp = la ? g_side : s;                 // panel stream
-    hipStream_t s_user = s;
-    if (la) {
-        CIP_HIP_CHECK(hipEventRecord(g_evStart, s));
-        CIP_HIP_CHECK(hipStreamWaitEvent(sp, g_evStart, 0));
-    }
-    // panel of outer block 0
+    // Look-ahead schedule: the panel chain of outer block J+1 runs on the high-priority side stream beside the
+    // trailing update of block J (persistent form, reserved CUs), for as long as the trailing matrix is large enough
+    // for that update to cover the chain; below g_la_min rows the blocks are chain-bound either way and the plain
+    // serial order is faster (measured per-block periods).
+    hipStream_t sp = g_side;
+    CIP_HIP_CHECK(hipEventRecord(g_evStart, s));
+    CIP_HIP_CHECK(hipStreamWaitEvent(sp, g_evStart, 0));
     {
         const int wblk = (Npad < NBO) ? Npad : NBO;
         if ((rc = factor_outer_panels(sp, K, Npad, ld, ws, ws.Wbuf, 0, wblk))) return rc;
-        if (la) CIP_HIP_CHECK(hipEventRecord(g_evP[0], sp));
+        CIP_HIP_CHECK(hipEventRecord(g_evP[0], sp));
     }
     int J = 0;
     for (int C0 = 0; C0 < Npad; C0 += NBO, ++J) {
@@ -325,64 +332,49 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
         const int w1 = (Npad - r0 < NBO) ? (Npad - r0) : NBO;       // width of the next outer block
         double *Wcur = ws.Wbuf + (size_t)(J & 1) * wstride;
         double *Wnext = ws.Wbuf + (size_t)((J + 1) & 1) * wstride;
-        if (la) CIP_HIP_CHECK(hipStreamWaitEvent(s, g_evP[J & 1], 0));
-        unsigned *qc = ws.qcounter + 2 * J;                         // zeroed at the start of the factorisation
+        CIP_HIP_CHECK(hipStreamWaitEvent(s, g_evP[J & 1], 0));      // panel J (wherever it was factored)
+        const bool ahead = Npad - r0 >= g_la_min;
+        auto trailing = [&](int from, unsigned *qc) -> int {        // K[from:, from:] -= W[from:, :] L[from:, C0:C0+wblk]'
+            GemmArgs g = {};
+            g.A = Wcur + from; g.lda = Npad;
+            g.B = K + from + (long)C0 * ld; g.ldb = ld;
+            g.C = K + from + (long)from * ld; g.ldc = ld;
+            g.M = Npad - from; g.N = Npad - from; g.K = wblk; g.alpha = -1.0; g.lower = 1;
+            if (qc) { g.queue_counter = qc; g.reserve = g_reserve; }
+            int e;
+            if (ws.prof) {
+                if ((e = prof_event(ws.prof, s))) return e;
+                const double r = (double)(Npad - from);
+                ws.prof->flops.push_back(r * (r + 1.0) * (double)wblk);   // 2 flop/MAC on the lower triangle
+            }
+            if ((e = cip_launch_gemm(s, EPI_ACCUM, g))) return e;
+            return ws.prof ? prof_event(ws.prof, s) : 0;
+        };
+        if (!ahead) {
+            // serial order from here on: whole trailing update, then the next panel, both on the caller's stream
+            if ((rc = trailing(r0, nullptr))) return rc;
+            if ((rc = factor_outer_panels(s, K, Npad, ld, ws, Wnext, r0, w1))) return rc;
+            CIP_HIP_CHECK(hipEventRecord(g_evP[(J + 1) & 1], s));
+            continue;
+        }
         {
-            // U1a: the first 128 columns of the NEXT outer block (all its rows), so that its first diagonal block
-            // and TRSM can start at once
+            // U1: the column strip of the NEXT outer block first (all its rows), so that its panel factorisation can
+            // start while the rest of the trailing matrix is still being updated
             GemmArgs g = {};
             g.A = Wcur + r0; g.lda = Npad;
             g.B = K + r0 + (long)C0 * ld; g.ldb = ld;
             g.C = K + r0 + (long)r0 * ld; g.ldc = ld;
-            g.M = Npad - r0; g.N = (g_queue && g_split) ? CIP_NB : w1; g.K = wblk; g.alpha = -1.0; g.lower = 0;
+            g.M = Npad - r0; g.N = w1; g.K = wblk; g.alpha = -1.0; g.lower = 0;
             if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
         }
-        if (la) {
-            CIP_HIP_CHECK(hipEventRecord(g_evU[J & 1], s));
-            CIP_HIP_CHECK(hipStreamWaitEvent(sp, g_evU[J & 1], 0));
-        }
-        hipEvent_t rest_ready = nullptr;
-        if (g_queue && g_split && w1 > CIP_NB && Npad - r0 - CIP_NB > 0) {
-            // U1b: the other columns of the next block, concurrently with its first diagonal block / TRSM
-            // (persistent form: leaves the reserved CUs to the panel chain)
-            GemmArgs g = {};
-            const int r1 = r0 + CIP_NB;
-            g.A = Wcur + r1; g.lda = Npad;
-            g.B = K + r1 + (long)C0 * ld; g.ldb = ld;
-            g.C = K + r1 + (long)r1 * ld; g.ldc = ld;
-            g.M = Npad - r1; g.N = w1 - CIP_NB; g.K = wblk; g.alpha = -1.0; g.lower = 0;
-            g.queue_counter = qc; g.reserve = g_reserve;
-            if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
-            CIP_HIP_CHECK(hipEventRecord(g_evR[J & 1], s));
-            rest_ready = g_evR[J & 1];
-        }
-        if ((rc = factor_outer_panels(sp, K, Npad, ld, ws, Wnext, r0, w1, rest_ready))) return rc;
-        if (la) CIP_HIP_CHECK(hipEventRecord(g_evP[(J + 1) & 1], sp));
-        const int r2 = r0 + w1;
-        if (r2 < Npad) {
-            // U2: the rest of the trailing matrix, K[r2:, r2:] -= W[r2:, :] L[r2:, C0:C0+wblk]'  (lower tiles)
-            GemmArgs g = {};
-            g.A = Wcur + r2; g.lda = Npad;
-            g.B = K + r2 + (long)C0 * ld; g.ldb = ld;
-            g.C = K + r2 + (long)r2 * ld; g.ldc = ld;
-            g.M = Npad - r2; g.N = Npad - r2; g.K = wblk; g.alpha = -1.0; g.lower = 1;
-            // optional persistent work-queue form (CIP_GEMM_QUEUE=1: +5 % standalone, no gain measured in situ)
-            if (g_queue) { g.queue_counter = qc + 1; g.reserve = g_reserve; }
-            if (ws.prof) {
-                if ((rc = prof_event(ws.prof, s))) return rc;
-                const double r = (double)(Npad - r2);
-                ws.prof->flops.push_back(r * (r + 1.0) * (double)wblk);   // 2 flop/MAC on the lower triangle
-            }
-            if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
-            if (ws.prof && (rc = prof_event(ws.prof, s))) return rc;
-        }
+        CIP_HIP_CHECK(hipEventRecord(g_evU[J & 1], s));
+        CIP_HIP_CHECK(hipStreamWaitEvent(sp, g_evU[J & 1], 0));
+        if ((rc = factor_outer_panels(sp, K, Npad, ld, ws, Wnext, r0, w1))) return rc;
+        CIP_HIP_CHECK(hipEventRecord(g_evP[(J + 1) & 1], sp));
+        // U2: the rest of the trailing matrix beside the chain (persistent form: leaves the reserved CUs to it)
+        if (r0 + w1 < Npad && (rc = trailing(r0 + w1, g_queue ? ws.qcounter + J : nullptr))) return rc;
     }
-    if (la) CIP_HIP_CHECK(hipStreamWaitEvent(s, g_evP[J & 1], 0));
-    if (s != s_user) {
-        CIP_HIP_CHECK(hipEventRecord(g_evEnd, s));
-        CIP_HIP_CHECK(hipStreamWaitEvent(s_user, g_evEnd, 0));
-        s = s_user;
-    }
+    CIP_HIP_CHECK(hipStreamWaitEvent(s, g_evP[J & 1], 0));
     if ((rc = cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.Linv, ws.LinvT)))
         return rc;
     return build_solve_blocks(s, K, Npad, ld, ws);

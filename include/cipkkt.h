@@ -203,6 +203,9 @@ int cip_assemble_only(cip_handle *h);                                   /* level
 int cip_stats(cip_handle *h, double *out8);
 int cip_set_timing(cip_handle *h, int enabled);
 int cip_set_ldlt_outer_block(int nbo);
+/* schedule of the blocked LDL': 0 = serial single-stream (default), 1 = look-ahead (panel chain of the next outer block on a
+ * side stream beside the trailing update; also CIP_LOOKAHEAD=1).  Process-wide; returns the previous setting. */
+int cip_set_ldlt_lookahead(int on);
 /* HIP-event timing of every LDL' trailing-update launch (bench.py roofline): enable, then read
  * out3 = [launches, total ms, total algorithmic flops (r(r+1)K per launch)] */
 int cip_profile_trailing(cip_handle *h, int enabled);
