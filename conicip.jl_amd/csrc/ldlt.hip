@@ -172,6 +172,7 @@ static thread_local hipEvent_t g_evP[2] = {nullptr, nullptr}, g_evU[2] = {nullpt
 static thread_local hipEvent_t g_evStart = nullptr;
 static int g_lookahead = -1;
 static int g_queue = 0;                   // CIP_GEMM_QUEUE=1: persistent work-queue trailing update
+static int g_reserve_fixed = 0;           // CIP_RESERVE given: use it for every block
 static int g_la_min = 3072;               // look-ahead only while the trailing matrix has at least this many rows
 static int g_reserve = 0;                 // CUs per XCD kept free by the work-queue trailing update (0 = plain launch)
 // run-time switch of the schedule (bench.py measures both in one process); -1 = not decided yet (environment)
@@ -179,7 +180,7 @@ int cip_ldlt_set_lookahead(int on) {
     const int prev = g_lookahead;
     g_lookahead = on ? 1 : 0;
     g_reserve = on ? 2 : 0;
-    if (const char *e = getenv("CIP_RESERVE")) { if (on) g_reserve = atoi(e); }
+    if (const char *e = getenv("CIP_RESERVE")) { if (on) { g_reserve = atoi(e); g_reserve_fixed = 1; } }
     if (const char *e = getenv("CIP_LA_MIN")) g_la_min = atoi(e);
     g_queue = g_reserve ? 1 : 0;
     return prev;
@@ -191,7 +192,7 @@ static int lookahead_init(void) {
     if (g_lookahead < 0) {
         g_lookahead = getenv("CIP_LOOKAHEAD") ? 1 : 0;
         g_reserve = g_lookahead ? 2 : 0;      // CUs per (XCD, SE) the persistent trailing update keeps free: 32 or 64 in all
-        if (const char *e = getenv("CIP_RESERVE")) g_reserve = atoi(e);
+        if (const char *e = getenv("CIP_RESERVE")) { g_reserve = atoi(e); g_reserve_fixed = 1; }
         if (const char *e = getenv("CIP_LA_MIN")) g_la_min = atoi(e);
         g_queue = getenv("CIP_GEMM_QUEUE") ? atoi(getenv("CIP_GEMM_QUEUE")) : (g_reserve ? 1 : 0);
     }
@@ -340,7 +341,9 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
             g.B = K + from + (long)C0 * ld; g.ldb = ld;
             g.C = K + from + (long)from * ld; g.ldc = ld;
             g.M = Npad - from; g.N = Npad - from; g.K = wblk; g.alpha = -1.0; g.lower = 1;
-            if (qc) { g.queue_counter = qc; g.reserve = g_reserve; }
+            // reserved CUs per (XCD, SE): one while the update is long enough to cover a chain squeezed onto 32 CUs
+            // (top blocks), two below (CIP_RESERVE fixes the number)
+            if (qc) { g.queue_counter = qc; g.reserve = g_reserve_fixed ? g_reserve : (Npad - from >= 6144 ? 1 : 2); }
             int e;
             if (ws.prof) {
                 if ((e = prof_event(ws.prof, s))) return e;
