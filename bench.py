@@ -153,6 +153,8 @@ def main():
     ap.add_argument("--nbo", type=int, default=0, help="LDL' outer block (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true")
+    ap.add_argument("--compare-lookahead", action="store_true",
+                    help="also time the same steps under the opt-in look-ahead schedule (adds its kernels to a profile)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -245,7 +247,7 @@ def main():
     # the same steps under the opt-in look-ahead schedule (reported beside the headline, not as the headline: it
     # trades trailing-update efficiency for overlap with the latency-bound panel chain -- DESIGN.md section 5)
     la = None
-    if world == 1 and not os.environ.get("CIP_LOOKAHEAD"):
+    if args.compare_lookahead and world == 1 and not os.environ.get("CIP_LOOKAHEAD"):
         lib = cipkkt._lib.load()
         lib.cip_set_ldlt_lookahead(1)
         for _ in range(max(1, args.warmup)):
