@@ -33,6 +33,17 @@ __global__ __launch_bounds__(256) void k_copy_block(double *K, long ldk, int r0,
         K[(r0 + i) + (long)(c0 + j) * ldk] = sign * M[i + (long)j * ldm];
 }
 
+// The same for a square block on the diagonal (r0 == c0), restricted to the 128x128 tiles of K on or below the
+// diagonal: the factorisation never references a tile above it, and Q is half of the assembly's HBM traffic
+// (n = 8192: 1.07 GB -> 0.56 GB per factorisation).
+__global__ __launch_bounds__(256) void k_copy_block_lower(double *K, long ldk, int r0, const double *M, long ldm, int n, double sign) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int jend = min(n, (((r0 + i) >> 7) + 1) * 128 - r0);      // columns up to the end of this row's diagonal tile
+    for (int j = blockIdx.y; j < jend; j += gridDim.y)
+        K[(r0 + i) + (long)(r0 + j) * ldk] = sign * M[i + (long)j * ldm];
+}
+
 // ---------------------------------------------------------------- sparse-A Schur terms (R and Q cones)
 // per row r of A:  K[i,j] += w_r a_ri a_rj  (i >= j), w_r = 1/d_r^2 (R),  -J_rr/beta^2 (Q)
 __global__ __launch_bounds__(256) void k_schur_rows(int m, const int *rp, const int *ci, const double *av,
@@ -132,8 +143,8 @@ static int assemble_schur(cip_handle *h) {
         if ((rc = cip_launch_gemm(s, EPI_SYRKQ, g))) return rc;
     } else {
         if (n > 0) {
-            hipLaunchKernelGGL(k_copy_block, dim3((n + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, 0, 0, h->Q,
-                               (long)n, n, n, 1.0);
+            hipLaunchKernelGGL(k_copy_block_lower, dim3((n + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, 0, h->Q,
+                               (long)n, n, 1.0);
         }
         if (h->m > 0) {
             hipLaunchKernelGGL(k_schur_rows, dim3((h->m + 255) / 256), dim3(256), 0, s, h->m, h->A_rp, h->A_ci, h->A_v,
@@ -179,7 +190,7 @@ static int assemble_full(cip_handle *h) {
                                h->K, h->ldk, m);
     }
     if (n > 0)
-        hipLaunchKernelGGL(k_copy_block, dim3((n + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, m, m, h->Q, (long)n, n,
+        hipLaunchKernelGGL(k_copy_block_lower, dim3((n + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, m, h->Q, (long)n,
                            n, 1.0);
     if (p > 0)
         hipLaunchKernelGGL(k_copy_block, dim3((p + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, m + n, m, h->G,
