@@ -194,3 +194,41 @@ def mpb_to_conicip(c, A, b, con_cones, var_cones):
     else:
         G, d = sp.csr_matrix((0, n)), np.zeros(0)
     return sp.csr_matrix((n, n)), -c, Ai, bi, dims, G, d
+
+
+def random_degenerate(seed):
+    """A small conic program with the structures that stress the static-order LDL' and the pre-solve: rank-deficient Q
+    (down to Q = 0), free variables, SOC / small PSD blocks, redundant equality rows, objective scales 1e-2..1e2.
+    Returns (Q, c, A, b, cone_dims, G, d); about two thirds are solvable, the rest unbounded or infeasible."""
+    from oracle import cones as oc
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(4, 30))
+    rankq = int(rng.integers(0, n + 1))
+    B = rng.standard_normal((rankq, n))
+    Q = B.T @ B if rankq else np.zeros((n, n))
+    c = rng.standard_normal(n) * (10.0 ** rng.integers(-2, 3))
+    cone_dims, rows, rhs = [], [], []
+    nb = int(rng.integers(0, n + 1))                              # bounded variables (the rest are free)
+    if nb:
+        A0 = np.zeros((nb, n))
+        A0[np.arange(nb), rng.permutation(n)[:nb]] = 1.0
+        rows.append(A0); rhs.append(-rng.random(nb)); cone_dims.append(("R", nb))
+    for _ in range(int(rng.integers(0, 3))):
+        k = int(rng.integers(2, 6))
+        b = rng.standard_normal(k)
+        b[0] = -abs(b[0]) - np.linalg.norm(b[1:]) - 1
+        rows.append(rng.standard_normal((k, n))); rhs.append(b); cone_dims.append(("Q", k))
+    if rng.random() < 0.3:                                        # a small semidefinite block: mat(A y - b) >= 0
+        r_ = int(rng.integers(2, 5))
+        k = r_ * (r_ + 1) // 2
+        rows.append(rng.standard_normal((k, n)) * 0.3); rhs.append(-oc.vecm(np.eye(r_) * (1 + rng.random())))
+        cone_dims.append(("S", k))
+    if not rows:
+        rows.append(np.eye(n)[:1]); rhs.append(np.array([-1.0])); cone_dims.append(("R", 1))
+    A, b = np.vstack(rows), np.concatenate(rhs)
+    p = int(rng.integers(0, max(1, n // 2)))
+    G = rng.standard_normal((p, n))
+    d = G @ rng.standard_normal(n)
+    if p and rng.random() < 0.3:                                  # a redundant (consistent) equality row
+        G, d = np.vstack([G, G[:1]]), np.concatenate([d, d[:1]])
+    return Q, c, A, b, cone_dims, G, d
