@@ -64,6 +64,8 @@ SIGNATURES = {
     "cip_get_regularization": (C.c_int, [C.c_void_p, c_double_p, c_int_p]),
     "cip_solve3x3": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6),
     "cip_solve3x3_dev": (C.c_int, [C.c_void_p] + [C.c_void_p] * 6),
+    "cip_solve2x2": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4),
+    "cip_solve2x2_dev": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4),
     "cip_solve4x4_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cip_apply_F_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "cip_cone_prod_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -102,6 +102,14 @@ def conicIP(Q, c, A, b, cone_dims, G=None, d=None, *,
     (block elimination, ≙ pivot(kktsolver_2x2)) or "full3x3" (literal 3x3 assembly,
     ≙ kktsolver_sparse).  `system` may carry an already-built KKTSystem (level 1).
 
+    `kktsolver` may also be a CALLABLE with the reference's plugin signature
+    (src/ConicIP.jl:432-466): `kktsolver(Q, A, G, cone_dims) -> solve3x3gen`,
+    `solve3x3gen(F, F_invT) -> solve3x3`, `solve3x3(x, y, z) -> (a, b, c)` -- e.g.
+    `cipkkt.pivot(user_2x2)` as in test/runtests.jl:90-131.  The loop then stays on the
+    device (scaling, cone algebra, residuals), the plugin receives host `cipkkt.blocks.Block`
+    objects with the reference's element fields rebuilt from the device's packed scaling, and
+    every 3x3 right-hand side / solution crosses PCIe (that is the reference's own boundary).
+
     `driver`: "native" runs the loop in C++ inside libcipkkt (`cip_conicip`, csrc/driver.hip); "python" runs
     the identical loop below through the per-operation C-ABI entry points (needed for `keep_iterates`)."""
     t_start = time.perf_counter()
@@ -127,8 +135,17 @@ def conicIP(Q, c, A, b, cone_dims, G=None, d=None, *,
     if p > 0 and G.shape[1] != n:
         raise ValueError("Inconsistency in equalities/objective")
 
+    from . import kkt as _kkt
+    plugin = None
+    if callable(kktsolver):
+        if kktsolver is _kkt.kktsolver_hip:
+            kktsolver = "schur"
+        elif kktsolver is _kkt.kktsolver_hip_full3x3:
+            kktsolver = "full3x3"
+        else:
+            plugin, kktsolver = kktsolver, "schur"
     ks = system if system is not None else KKTSystem(Q, A, G, cone_dims, route=kktsolver, device=device)
-    if driver == "native" and keep_iterates is None:
+    if driver == "native" and keep_iterates is None and plugin is None:
         return _conicIP_native(ks, c_h, b_h, d_h, n, m, p, optTol, DTB, infeasTol, refinementThreshold,
                                maxRefinementSteps, maxIters, verbose, t_start)
     dev = ks.device
@@ -167,9 +184,50 @@ def conicIP(Q, c, A, b, cone_dims, G=None, d=None, *,
     Gy = torch.zeros(max(p, 1), **f64)[:p]
     counts = dict(factor=0, solve=0)
 
+    user = dict(gen=None, solve=None)
+    if plugin is not None:
+        from .blocks import Block as _Block, Diagonal as _Diagonal, blocks_from_packed
+        Gh = G if G is not None else np.zeros((0, n))
+        user["gen"] = plugin(Q, A, Gh, ks.cone_dims)                       # level 1 (:667)
+        t1_d = torch.zeros(max(m, 1), **f64)[:m]
+        zin_d = torch.zeros(max(m, 1), **f64)[:m]
+        t2_d = torch.zeros(max(m, 1), **f64)[:m]
+
+    def factor(identity=False):                   # level 2 (:682)
+        counts["factor"] += 1
+        if plugin is None:
+            ks.factor()
+            return
+        if identity:
+            I = _Block([_Diagonal(np.ones(k)) for _, k in ks.cone_dims])   # :704
+            user["solve"] = user["gen"](I, I)
+        else:
+            F, FiT = blocks_from_packed(ks.cone_dims, ks.get_scaling_packed())
+            user["solve"] = user["gen"](F, FiT)
+
     def solve4x4(lam_, rhs, out):                 # src/ConicIP.jl:684-692
-        ks.solve4x4_dev(lam_, rhs, out)
         counts["solve"] += 1
+        if plugin is None:
+            ks.solve4x4_dev(lam_, rhs, out)
+            return
+        ry_, rw_, rv_, rs_ = parts(rhs)
+        oy, ow, ov, os_ = parts(out)
+        if m > 0:
+            ks.cone_div(rs_, lam_, t1_d)                                   # q = r.s / lambda          (:686)
+            ks.apply_F(L.OP_FT, t1_d, t1_d)                                # t1 = F'q                  (:687)
+            zin_d.copy_(rv_)
+            ks.axpby(1.0, t1_d, 1.0, zin_d)
+        torch.cuda.synchronize(dev)
+        a_, b_, c_ = user["solve"](ry_.cpu().numpy(), rw_.cpu().numpy(), zin_d.cpu().numpy())   # level 3 (:688)
+        oy.copy_(torch.as_tensor(np.asarray(a_, dtype=np.float64).reshape(n)))
+        if p > 0:
+            ow.copy_(torch.as_tensor(np.asarray(b_, dtype=np.float64).reshape(p)))
+        if m > 0:
+            ov.copy_(torch.as_tensor(np.asarray(c_, dtype=np.float64).reshape(m)))
+            ks.apply_F(L.OP_F, ov, t2_d)
+            ks.apply_F(L.OP_FT, t2_d, t2_d)
+            os_.copy_(t1_d)
+            ks.axpby(-1.0, t2_d, 1.0, os_)                                  # ds = t1 - F'(F dv)         (:689)
 
     def kkt_apply(x, out):
         """out.y = Q x.y + G' x.w - A' x.v ; out.w = G x.y ; out.v = A x.y - x.s   (:747-749, :912-914)"""
@@ -186,8 +244,9 @@ def conicIP(Q, c, A, b, cone_dims, G=None, d=None, *,
 
     # ---------------------------------------------------------------- initial point (:704-713)
     ks.set_scaling_identity()
-    ks.factor()
-    counts["factor"] += 1
+    factor(identity=True)
+    if plugin is None:
+        ks.check_factor()            # the solve below would otherwise run on an unverified factor (LPs fail here)
     r0y, r0w, r0v, r0s = parts(r0)
     r0y.copy_(c_d)
     r0w.copy_(d_d)
@@ -219,8 +278,7 @@ def conicIP(Q, c, A, b, cone_dims, G=None, d=None, *,
             keep_iterates.append(z.clone())
         if m > 0:
             ks.set_scaling_from_iterate(zv, zs, lam)                       # :732-735 (F, lambda = F v)
-        ks.factor()                                                        # :737 -> :682
-        counts["factor"] += 1
+        factor()                                                           # :737 -> :682
 
         if m > 0:
             ks.cone_prod(lam, lam, rls)                                    # :746

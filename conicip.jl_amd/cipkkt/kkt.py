@@ -40,6 +40,51 @@ def _require_gpu():
         raise RuntimeError("cipkkt: no HIP device visible -- the KKT path is GPU-only (no CPU fallback)")
 
 
+def pack_scaling(cone_dims, F, FinvT=None):
+    """Read the packed scaling off Block elements shaped like the reference's
+    (src/ConicIP.jl:189-192 SymWoodbury(.A.diag,.B,.D); :208 VecCongurance(.R); :598 Diagonal(.diag))."""
+    blocks = F.Blocks if hasattr(F, "Blocks") else list(F)
+    iblocks = (FinvT.Blocks if hasattr(FinvT, "Blocks") else list(FinvT)) if FinvT is not None else [None] * len(blocks)
+    out = []
+    for (t, k), blk, iblk in zip(cone_dims, blocks, iblocks):
+        # The reference's initial point is computed with F = F^-T = Block([Diagonal(ones(k)) ...]) for EVERY cone
+        # type (src/ConicIP.jl:704-706): a (uniform) Diagonal element must be accepted for Q and S cones too.
+        uniform = None
+        if t != "R" and hasattr(blk, "diag") and not hasattr(blk, "B") and not hasattr(blk, "R"):
+            dg = np.asarray(blk.diag, dtype=np.float64).reshape(-1)
+            if dg.size != k or not np.all(dg == dg[0]) or not dg[0] > 0:
+                raise ValueError("a Diagonal scaling element of a %s cone must be a positive multiple of the identity" % t)
+            uniform = float(dg[0])
+        if t == "R":
+            out.append(np.asarray(blk.diag, dtype=np.float64).reshape(k))
+        elif t == "Q":
+            if uniform is not None:
+                # d I = diag(-beta, beta, ...) + w w'  with beta = d, w = sqrt(2 d) e1
+                w = np.zeros(k)
+                w[0] = np.sqrt(2.0 * uniform)
+                out.append(np.concatenate([[uniform], w]))
+                continue
+            Ad = blk.A.diag if hasattr(blk.A, "diag") else blk.A
+            Ad = np.asarray(Ad, dtype=np.float64)
+            B = np.asarray(blk.B, dtype=np.float64).reshape(k, -1)
+            D = np.asarray(blk.D, dtype=np.float64).reshape(B.shape[1], B.shape[1])
+            if B.shape[1] != 1:
+                raise ValueError("Q-cone scaling must be rank one (diag + w w')")
+            out.append(np.concatenate([[-Ad[0]], B[:, 0] * np.sqrt(D[0, 0])]))
+        else:
+            if uniform is not None:
+                # vecm(R' X R) = d vecm(X)  <=>  R = sqrt(d) I
+                r = int(round((np.sqrt(1 + 8 * k) - 1) / 2))
+                R = np.sqrt(uniform) * np.eye(r)
+                out.append(np.concatenate([R.reshape(-1), (R / uniform).reshape(-1)]))
+                continue
+            R = np.asarray(blk.R, dtype=np.float64)
+            Rinv = np.asarray(iblk.R, dtype=np.float64).T if iblk is not None and hasattr(iblk, "R") else np.linalg.inv(R)
+            out.append(np.concatenate([R.reshape(-1, order="F"), Rinv.reshape(-1, order="F")]))
+    return np.ascontiguousarray(np.concatenate(out)) if out else np.zeros(0)
+
+
+
 class KKTSystem:
     """Level-1 object: problem matrices resident in HBM, cone layout, workspaces.
     ≙ what `kktsolver(Q,A,G,cone_dims)` captures (src/kktsolvers.jl:18-28, :180-190, :281-285)."""
@@ -129,27 +174,7 @@ class KKTSystem:
 
     # ---------------------------------------------------------------- level 2
     def pack_scaling(self, F, FinvT=None):
-        """Read the packed scaling off Block elements shaped like the reference's
-        (src/ConicIP.jl:189-192 SymWoodbury(.A.diag,.B,.D); :208 VecCongurance(.R); :598 Diagonal(.diag))."""
-        blocks = F.Blocks if hasattr(F, "Blocks") else list(F)
-        iblocks = (FinvT.Blocks if hasattr(FinvT, "Blocks") else list(FinvT)) if FinvT is not None else [None] * len(blocks)
-        out = []
-        for (t, k), blk, iblk in zip(self.cone_dims, blocks, iblocks):
-            if t == "R":
-                out.append(np.asarray(blk.diag, dtype=np.float64).reshape(k))
-            elif t == "Q":
-                Ad = blk.A.diag if hasattr(blk.A, "diag") else blk.A
-                Ad = np.asarray(Ad, dtype=np.float64)
-                B = np.asarray(blk.B, dtype=np.float64).reshape(k, -1)
-                D = np.asarray(blk.D, dtype=np.float64).reshape(B.shape[1], B.shape[1])
-                if B.shape[1] != 1:
-                    raise ValueError("Q-cone scaling must be rank one (diag + w w')")
-                out.append(np.concatenate([[-Ad[0]], B[:, 0] * np.sqrt(D[0, 0])]))
-            else:
-                R = np.asarray(blk.R, dtype=np.float64)
-                Rinv = np.asarray(iblk.R, dtype=np.float64).T if iblk is not None else np.linalg.inv(R)
-                out.append(np.concatenate([R.reshape(-1, order="F"), Rinv.reshape(-1, order="F")]))
-        return np.ascontiguousarray(np.concatenate(out)) if out else np.zeros(0)
+        return pack_scaling(self.cone_dims, F, FinvT)
 
     def set_scaling_packed(self, packed):
         packed = np.ascontiguousarray(packed, dtype=np.float64)
@@ -189,6 +214,17 @@ class KKTSystem:
         a, b, c = np.empty(self.n), np.empty(self.p), np.empty(self.m)
         L.check(self.lib.cip_solve3x3(self.h, _ptr(x), _ptr(y), _ptr(z), _ptr(a), _ptr(b), _ptr(c)))
         return a, b, c
+
+    def solve2x2(self, y, w):
+        """The 2x2 form (src/ConicIP.jl:450-466): [Q + A'(F'F)^-1 A, G'; G, 0][dy; dw] = [y; w]; fresh host arrays."""
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(self.n)
+        w = np.ascontiguousarray(w, dtype=np.float64).reshape(self.p)
+        dy, dw = np.empty(self.n), np.empty(self.p)
+        L.check(self.lib.cip_solve2x2(self.h, _ptr(y), _ptr(w), _ptr(dy), _ptr(dw)))
+        return dy, dw
+
+    def solve2x2_dev(self, y, w, dy, dw):
+        L.check(self.lib.cip_solve2x2_dev(self.h, _ptr(y), _ptr(w), _ptr(dy), _ptr(dw)))
 
     def solve3x3_dev(self, x, y, z, a, b, c):
         L.check(self.lib.cip_solve3x3_dev(self.h, _ptr(x), _ptr(y), _ptr(z), _ptr(a), _ptr(b), _ptr(c)))
@@ -278,6 +314,53 @@ def kktsolver_hip(Q, A, G, cone_dims, route="schur", device=None):
 
     solve3x3gen.system = sysm
     return solve3x3gen
+
+
+def kktsolver_2x2_hip(Q, A, G, cone_dims, device=None):
+    """The reference's 2x2 plugin form (src/ConicIP.jl:450-466; src/kktsolvers.jl:281-310) on the device:
+
+        solve2x2gen = kktsolver_2x2_hip(Q, A, G, cone_dims)
+        solve2x2    = solve2x2gen(F, F_invT)
+        dy, dw      = solve2x2(y, w)          # [Q + A'(F'F)^-1 A, G'; G, 0][dy; dw] = [y; w]
+
+    to be wrapped by `pivot` exactly as `pivot(ConicIP.kktsolver_2x2)`."""
+    sysm = KKTSystem(Q, A, G, cone_dims, route="schur", device=device)
+
+    def solve2x2gen(F, FinvT=None):
+        sysm.set_scaling_packed(sysm.pack_scaling(F, FinvT))
+        sysm.factor()
+        return lambda y, w: sysm.solve2x2(y, w)
+
+    solve2x2gen.system = sysm
+    return solve2x2gen
+
+
+def pivot(kktsolver_2x2):
+    """`pivot` of the reference (src/kktsolvers.jl:316-349): wraps a 2x2 solver -- `kktsolver_2x2_hip` or any
+    user-written one with the same three-level shape -- into the 3x3 plugin interface by eliminating the third
+    block row:  t = F^-T(F^-T v);  (dy, dw) = solve2x2(y + A't, w);  dv = t - F^-T(F^-T(A dy)).
+    F^-T is the host Block the caller hands over (its `mul`), A any matrix with `@`/`.T`."""
+
+    def kktsolver(Q, A, G, cone_dims):
+        solve2x2gen = kktsolver_2x2(Q, A, G, cone_dims)
+        At = A.T
+
+        def solve3x3gen(F, FinvT):
+            solve2x2 = solve2x2gen(F, FinvT)
+
+            def solve3x3(y, w, v):
+                t1 = FinvT.mul(FinvT.mul(np.asarray(v, dtype=np.float64)))          # :326
+                dy, dw = solve2x2(np.asarray(y, dtype=np.float64) + At @ t1, w)     # :327
+                t1 = t1 - FinvT.mul(FinvT.mul(A @ dy))                              # :328
+                return np.asarray(dy), np.asarray(dw), t1
+
+            return solve3x3
+
+        if hasattr(solve2x2gen, "system"):
+            solve3x3gen.system = solve2x2gen.system
+        return solve3x3gen
+
+    return kktsolver
 
 
 def kktsolver_hip_full3x3(Q, A, G, cone_dims, device=None):

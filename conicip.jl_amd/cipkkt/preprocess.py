@@ -27,6 +27,10 @@ def imcols(A, b, eps=1e-8):
     if A.size == 0:
         return [], True
     scale = np.linalg.norm(A)
+    if scale == 0.0:
+        # an all-zero matrix: the reference divides only the STORED entries of its sparse A by zero (none), the QR has
+        # no pivot above eps and the empty-R branch answers ([], true) (src/preprocessor.jl:14, :25)
+        return [], True
     A, b = A / scale, b / scale
     _, R, piv = sla.qr(A.T, mode="economic", pivoting=True)
     k = min(R.shape)

@@ -30,12 +30,14 @@ static int rup(int x, int q) { return ((x + q - 1) / q) * q; }
 static void free_all(cip_handle *h) {
     void *ptrs[] = {h->cs.d_sidx, h->cs.d_sdpws, h->cs.d_sdpvec, h->cs.d_sdpflag, h->Q, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->row_cone, h->G, h->Gt,
                     h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->cs.d_partial, h->cs.d_scalar, h->K, h->Wt, h->Gm,
-                    h->ws_base, h->rhs, h->mt1, h->mt2, h->mt3, h->nt1, h->pt1, h->dot_scratch, h->dot_ptrs, h->stage, h->drv, h->ref};
+                    h->ws_base, h->rhs, h->mt1, h->mt2, h->mt3, h->nt1, h->pt1, h->dot_scratch, h->dot_ptrs, h->stage, h->drv, h->ref, h->c2x2};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
+    if (h->ev_info) (void)hipEventDestroy(h->ev_info);
+    if (h->info_host) (void)hipHostFree(h->info_host);
     if (h->ws.prof) { cip_ldlt_profile_destroy(h->ws.prof); h->ws.prof = nullptr; }
 }
 
@@ -238,6 +240,9 @@ static int create_impl(const cip_problem *pr, cip_handle *h) {
     DMALLOC(h->dot_ptrs, 32 * 32);
     DMALLOC(h->stage, sizeof(double) * 2 * (size_t)(n + p + m));
     CIP_HIP_CHECK(hipEventCreate(&h->ev0)); CIP_HIP_CHECK(hipEventCreate(&h->ev1)); CIP_HIP_CHECK(hipEventCreate(&h->ev2));
+    CIP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_info, hipEventDisableTiming));
+    CIP_HIP_CHECK(hipHostMalloc((void **)&h->info_host, sizeof(int), hipHostMallocDefault));
+    *h->info_host = 0;
     if ((rc = cip_cones_identity_scaling(s, h->cs))) return rc;
     CIP_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
@@ -316,27 +321,71 @@ extern "C" int cip_assemble_only(cip_handle *h) {
 // 15 21 26 24 | 20 28 27; 1e-13 -> 16 16 16 15 21 29 29 | 21 29 32.  The refinement inside solve3x3 is what makes the
 // small value work.  CIP_AUTO_REG overrides.
 #define CIP_AUTO_REG 1e-13
+
+// assembly + LDL' + an asynchronous read-back of the pivot flag into pinned host memory; nothing here waits for the GPU
+static int factor_enqueue(cip_handle *h) {
+    int rc;
+    if ((rc = cip_assemble(h))) return rc;
+    if (h->timing) CIP_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+    if ((rc = cip_ldlt_factor(h->stream, h->K, h->Npad, h->ldk, h->ws))) return rc;
+    h->n_factor += 1;
+    CIP_HIP_CHECK(hipMemcpyAsync(h->info_host, h->ws.info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    CIP_HIP_CHECK(hipEventRecord(h->ev_info, h->stream));
+    h->info_pending = true;
+    h->spec_solves = 0;
+    return 0;
+}
+
+// Resolve the pivot flag of the last factorisation.  wait = false: only if the read-back has already landed (no host
+// wait; the caller goes ahead speculatively otherwise).  A zero / non-finite / wrong-sign pivot means [S G'; G 0] is not
+// quasi-definite in the static order (typically an LP or a QP with singular Q and free variables: S is singular although
+// the KKT matrix is not).  The reference's pivoting LU / QR does not care; the static-order LDL' switches to a
+// regularised factorisation, once, for good -- and if that one fails too the error is reported (CIP_E_SINGULAR).
+static int factor_resolve(cip_handle *h, bool wait);
+int cip_factor_resolve(cip_handle *h, int wait) { return factor_resolve(h, wait != 0); }
+static int factor_resolve(cip_handle *h, bool wait) {
+    if (!h->info_pending) return 0;
+    if (!wait) {
+        const hipError_t q = hipEventQuery(h->ev_info);
+        if (q == hipErrorNotReady) return 0;
+        if (q != hipSuccess) { cip_set_error("hipEventQuery failed: %s", hipGetErrorString(q)); return CIP_E_HIP; }
+    } else {
+        CIP_HIP_CHECK(hipEventSynchronize(h->ev_info));
+    }
+    h->info_pending = false;
+    int info = *h->info_host;
+    if (info == 0) return 0;
+    const int spec = h->spec_solves;
+    if (h->auto_reg && h->reg_rel <= 0.0) {
+        h->reg_rel = getenv("CIP_AUTO_REG") ? atof(getenv("CIP_AUTO_REG")) : CIP_AUTO_REG;
+        h->n_regularized += 1;
+        int rc;
+        if ((rc = factor_enqueue(h))) return rc;
+        CIP_HIP_CHECK(hipEventSynchronize(h->ev_info));
+        h->info_pending = false;
+        info = *h->info_host;
+        if (info == 0) {
+            if (spec > 0) {
+                cip_set_error("LDL': %d solve(s) were enqueued on a factorisation that met a bad pivot; the handle has switched "
+                              "to the regularised factorisation -- repeat them", spec);
+                return CIP_E_SINGULAR;
+            }
+            return 0;
+        }
+    }
+    h->factored = false;
+    cip_set_error("LDL': zero, non-finite or wrong-sign pivot at column %d%s", info,
+                  h->reg_rel > 0.0 ? " (regularised factorisation)" : "");
+    return CIP_E_SINGULAR;
+}
+
 extern "C" int cip_factor(cip_handle *h) {
     if (!h) return CIP_E_INVALID;
     int rc;
     if (h->timing) CIP_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
-    for (int attempt = 0;; ++attempt) {
-        if ((rc = cip_assemble(h))) return rc;
-        if (h->timing && attempt == 0) CIP_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
-        if ((rc = cip_ldlt_factor(h->stream, h->K, h->Npad, h->ldk, h->ws))) return rc;
-        h->n_factor += 1;
-        if (!h->auto_reg || h->reg_rel > 0.0 || attempt > 0) break;
-        // A zero / non-finite / wrong-sign pivot means [S G'; G 0] is not quasi-definite in this order (typically an LP
-        // or a QP with singular Q and free variables: S is singular although the KKT matrix is not).  The reference's
-        // pivoting LU / QR does not care; the static-order LDL' switches to a regularised factorisation, once, for good.
-        int info = 0;
-        CIP_HIP_CHECK(hipMemcpyAsync(&info, h->ws.info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        CIP_HIP_CHECK(hipStreamSynchronize(h->stream));
-        if (info == 0) break;
-        h->reg_rel = getenv("CIP_AUTO_REG") ? atof(getenv("CIP_AUTO_REG")) : CIP_AUTO_REG;
-        h->n_regularized += 1;
-    }
+    if ((rc = factor_enqueue(h))) return rc;
     h->flops_ldlt = (double)h->N * h->N * h->N / 3.0;
+    h->factored = true;
     if (h->timing) {
         CIP_HIP_CHECK(hipEventRecord(h->ev2, h->stream));
         CIP_HIP_CHECK(hipEventSynchronize(h->ev2));
@@ -344,11 +393,8 @@ extern "C" int cip_factor(cip_handle *h) {
         CIP_HIP_CHECK(hipEventElapsedTime(&a, h->ev0, h->ev1));
         CIP_HIP_CHECK(hipEventElapsedTime(&b, h->ev1, h->ev2));
         h->ms_assemble = a; h->ms_ldlt = b;
-        int info = 0;
-        CIP_HIP_CHECK(hipMemcpy(&info, h->ws.info, sizeof(int), hipMemcpyDeviceToHost));
-        if (info) { cip_set_error("LDL': zero, non-finite or wrong-sign pivot at column %d", info); return CIP_E_SINGULAR; }
+        return factor_resolve(h, true);
     }
-    h->factored = true;
     return 0;
 }
 extern "C" int cip_set_regularization(cip_handle *h, double rel, int automatic) {
@@ -367,10 +413,9 @@ extern "C" int cip_get_regularization(cip_handle *h, double *rel, int *times_swi
 extern "C" int cip_check_factor(cip_handle *h) {
     if (!h) return CIP_E_INVALID;
     if (!h->factored) { cip_set_error("no factorisation"); return CIP_E_NOTFACTORED; }
-    int info = 0;
-    CIP_HIP_CHECK(hipMemcpyAsync(&info, h->ws.info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    int rc;
+    if ((rc = factor_resolve(h, true))) return rc;
     CIP_HIP_CHECK(hipStreamSynchronize(h->stream));
-    if (info) { cip_set_error("LDL': zero, non-finite or wrong-sign pivot at column %d", info); return CIP_E_SINGULAR; }
     return 0;
 }
 
@@ -394,9 +439,11 @@ static int apply_FtF_inv(cip_handle *h, const double *z, double *tmp, double *ou
 }
 
 // ------------------------------------------------------------------ level 3
+// z == NULL (Schur route only): the 2x2 form [S G'; G 0][a; b] = [x; y] (src/kktsolvers.jl:297-302), c is not written
 static int solve3x3_once(cip_handle *h, const double *x, const double *y, const double *z, double *a, double *b, double *c) {
     hipStream_t s = h->stream;
-    const int n = h->n, m = h->m, p = h->p;
+    const int n = h->n, p = h->p;
+    const int m = z ? h->m : 0;
     int rc;
     if (h->route == CIP_ROUTE_SCHUR) {
         // algebra of pivotgen, src/kktsolvers.jl:324-330, with the exact (F'F)^-1 = F^-1 F^-T:
@@ -461,6 +508,8 @@ extern "C" int cip_solve3x3_dev(cip_handle *h, const double *x, const double *y,
     if (!h->factored) { cip_set_error("cip_solve3x3: no factorisation (call cip_factor first)"); return CIP_E_NOTFACTORED; }
     const int n = h->n, m = h->m, p = h->p;
     int rc;
+    if ((rc = factor_resolve(h, false))) return rc;      // no host wait: resolved only if the flag has already landed
+    if (h->info_pending) h->spec_solves += 1;
     h->n_solve += 1;
     if (h->reg_rel <= 0.0) return solve3x3_once(h, x, y, z, a, b, c);
     // Regularised factor: iterative refinement against the true operator (the factor is of K + E, |E_ii| = reg_rel
@@ -502,15 +551,48 @@ extern "C" int cip_solve3x3(cip_handle *h, const double *x, const double *y, con
     CIP_HIP_CHECK(hipMemcpyAsync(in, x, sizeof(double) * n, hipMemcpyHostToDevice, s));
     if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(in + n, y, sizeof(double) * p, hipMemcpyHostToDevice, s));
     if (m > 0) CIP_HIP_CHECK(hipMemcpyAsync(in + n + p, z, sizeof(double) * m, hipMemcpyHostToDevice, s));
-    const int rc = cip_solve3x3_dev(h, in, in + n, in + n + p, out, out + n, out + n + p);
-    if (rc) return rc;
+    int rc;
+    if (h->factored && (rc = factor_resolve(h, true))) return rc;      // this entry point is synchronous anyway
+    if ((rc = cip_solve3x3_dev(h, in, in + n, in + n + p, out, out + n, out + n + p))) return rc;
     CIP_HIP_CHECK(hipMemcpyAsync(a, out, sizeof(double) * n, hipMemcpyDeviceToHost, s));
     if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(b, out + n, sizeof(double) * p, hipMemcpyDeviceToHost, s));
     if (m > 0) CIP_HIP_CHECK(hipMemcpyAsync(c, out + n + p, sizeof(double) * m, hipMemcpyDeviceToHost, s));
     CIP_HIP_CHECK(hipStreamSynchronize(s));
-    int info = 0;
-    CIP_HIP_CHECK(hipMemcpy(&info, h->ws.info, sizeof(int), hipMemcpyDeviceToHost));
-    if (info) { cip_set_error("LDL': zero, non-finite or wrong-sign pivot at column %d", info); return CIP_E_SINGULAR; }
+    return 0;
+}
+
+// The 2x2 form of the plugin (src/ConicIP.jl:450-466; what `pivot` wraps, src/kktsolvers.jl:297-302, :316-349):
+//   [Q + A'(F'F)^-1 A   G'] [dy]   [y]
+//   [G                  0 ] [dw] = [w]      on the factor of the Schur route.
+extern "C" int cip_solve2x2_dev(cip_handle *h, const double *y, const double *w, double *dy, double *dw) {
+    if (!h) return CIP_E_INVALID;
+    if (h->route != CIP_ROUTE_SCHUR) { cip_set_error("cip_solve2x2: needs the Schur route"); return CIP_E_UNSUPPORTED; }
+    if (!h->factored) { cip_set_error("cip_solve2x2: no factorisation (call cip_factor first)"); return CIP_E_NOTFACTORED; }
+    int rc;
+    if ((rc = factor_resolve(h, false))) return rc;
+    if (h->reg_rel > 0.0 && h->m > 0) {
+        // regularised factor: go through the refined 3x3 solve with z = 0 (its first two components are the 2x2 solution)
+        CIP_HIP_CHECK(hipMemsetAsync(h->mt1, 0, sizeof(double) * h->m, h->stream));
+        if (!h->c2x2) DMALLOC(h->c2x2, sizeof(double) * h->m);
+        return cip_solve3x3_dev(h, y, w, h->mt1, dy, dw, h->c2x2);
+    }
+    if (h->info_pending) h->spec_solves += 1;
+    h->n_solve += 1;
+    return solve3x3_once(h, y, w, nullptr, dy, dw, nullptr);
+}
+extern "C" int cip_solve2x2(cip_handle *h, const double *y, const double *w, double *dy, double *dw) {
+    if (!h) return CIP_E_INVALID;
+    hipStream_t s = h->stream;
+    const int n = h->n, p = h->p;
+    double *in = h->stage, *out = h->stage + (n + p + h->m);
+    CIP_HIP_CHECK(hipMemcpyAsync(in, y, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(in + n, w, sizeof(double) * p, hipMemcpyHostToDevice, s));
+    int rc;
+    if (h->factored && (rc = factor_resolve(h, true))) return rc;
+    if ((rc = cip_solve2x2_dev(h, in, in + n, out, out + n))) return rc;
+    CIP_HIP_CHECK(hipMemcpyAsync(dy, out, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(dw, out + n, sizeof(double) * p, hipMemcpyDeviceToHost, s));
+    CIP_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
 }
 

@@ -40,6 +40,12 @@ struct cip_handle {
     bool auto_reg = true;
     int n_regularized = 0;
     int x_zeroed = 0;               // block-inverse storage zero-initialised
+    // pivot flag of the last factorisation: read back asynchronously into pinned host memory, resolved lazily
+    // (api.hip: factor_resolve) so that cip_factor never waits for the GPU
+    int *info_host = nullptr;
+    hipEvent_t ev_info = nullptr;
+    bool info_pending = false;
+    int spec_solves = 0;            // solves enqueued while the flag was still in flight
 
     // ---- scratch
     double *rhs = nullptr;          // Npad
@@ -49,6 +55,7 @@ struct cip_handle {
     double *dot_scratch = nullptr; void *dot_ptrs = nullptr;
     double *stage = nullptr;        // device staging for the host-pointer entry points: 2*(n+p+m) doubles
     double *ref = nullptr;          // right-hand side / residual / correction of the refinement inside solve3x3 (regularised factor only)
+    double *c2x2 = nullptr;         // m-vector: discarded third component of a regularised 2x2 solve
     double *drv = nullptr;          // vectors of the native interior-point loop (cip_conicip), allocated on first use
 
     // ---- stats
@@ -58,3 +65,5 @@ struct cip_handle {
 };
 
 int cip_assemble(cip_handle *h);     // assemble.hip
+// api.hip: resolve the pivot flag of the last factorisation (wait = 0: only if its read-back has already landed)
+int cip_factor_resolve(cip_handle *h, int wait);

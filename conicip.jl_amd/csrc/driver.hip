@@ -82,7 +82,8 @@ struct Driver {
 extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_host, const double *d_host,
                            const cip_options *opt_in, double *y_out, double *w_out, double *v_out, cip_result *res,
                            double *trace, int trace_cap) {
-    if (!h || !res || !c_host || (h->m > 0 && !b_host) || (h->p > 0 && !d_host)) { cip_set_error("cip_conicip: null argument"); return CIP_E_INVALID; }
+    if (!h || !res || !c_host || (h->m > 0 && !b_host) || (h->p > 0 && !d_host) || !y_out || (h->p > 0 && !w_out) ||
+        (h->m > 0 && !v_out)) { cip_set_error("cip_conicip: null argument"); return CIP_E_INVALID; }
     const auto t_start = std::chrono::steady_clock::now();
     cip_options o;
     o.optTol = 1e-6; o.DTB = 0.01; o.infeasTol = -1.0; o.refinementThreshold = -1.0;
@@ -137,6 +138,7 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
     CK(cip_factor(h)); ++n_factor;
     CK(D.copy(n, c_d, r0.y)); CK(D.copy(p, d_d, r0.w)); CK(D.copy(m, b_d, r0.v));
     if (m > 0) CIP_HIP_CHECK(hipMemsetAsync(r0.s, 0, sizeof(double) * m, h->stream));
+    CK(cip_factor_resolve(h, 1));          // initial point: one wait (LPs meet their first bad pivot here)
     CK(cip_solve4x4_dev(h, e, r0.base, z.base)); ++n_solve;
     if (m > 0) {
         double a_v, a_s;
@@ -167,6 +169,7 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
         const int ln[16] = {m, n, n, m, m, n, p, m, p, m, n, n, m, m, p, n};
         double dt[16];
         CK(cip_dots_dev(h, 16, px, py, ln, dt));
+        CK(cip_factor_resolve(h, 1));      // the stream has just been drained: the pivot flag of this iteration's factorisation is in
         const double mubar = dt[0], cTy = dt[1], r0y2 = dt[2], r0v2 = dt[3], r0s2 = dt[4], yQy = dt[5], wr0w = dt[6],
                      vr0v = dt[7], dTw = dt[8], bTv = dt[9], pinf2 = dt[10], yy = dt[11], vv = dt[12], ays2 = dt[13],
                      gy2 = dt[14], qy2 = dt[15];

@@ -107,9 +107,13 @@ int cip_set_scaling_identity(cip_handle *h);                            /* F = I
  * writes lambda = F v (src/ConicIP.jl:735) when lambda_out != NULL. */
 int cip_set_scaling_from_iterate_dev(cip_handle *h, const double *v, const double *s, double *lambda_out);
 int cip_get_scaling_packed(cip_handle *h, double *packedF);             /* host pointer (tests) */
-/* assemble + factor the KKT system for the current scaling (asynchronous on the handle's stream) */
+/* assemble + factor the KKT system for the current scaling.  Asynchronous on the handle's stream: nothing waits for
+ * the GPU.  The pivot flag is read back into pinned host memory behind the factorisation and resolved lazily -- by
+ * cip_check_factor, by the host-pointer solves (which are synchronous anyway), or by the next *_dev solve / the
+ * interior-point loop once the read-back has landed.  A bad pivot then triggers the regularised re-factorisation
+ * described below; if that fails too the resolving call returns CIP_E_SINGULAR. */
 int cip_factor(cip_handle *h);
-/* synchronise and report the factorisation status: CIP_OK or CIP_E_SINGULAR */
+/* wait for the factorisation and report its status: CIP_OK or CIP_E_SINGULAR */
 int cip_check_factor(cip_handle *h);
 /* Static regularisation of the quasi-definite LDL' (K + delta diag(+1.. -1..), delta = rel * max|K_ii|).  Default:
  * rel = 0 and automatic = 1 -- the first factorisation that meets a zero / non-finite / wrong-sign pivot (singular S:
@@ -125,6 +129,12 @@ int cip_solve3x3(cip_handle *h, const double *x, const double *y, const double *
                  double *a, double *b, double *c);                       /* host pointers */
 int cip_solve3x3_dev(cip_handle *h, const double *x, const double *y, const double *z,
                      double *a, double *b, double *c);                   /* device pointers */
+
+/* ---- the 2x2 plugin form  solve2x2(y, w) -> (dy, dw)  (src/ConicIP.jl:450-466; src/kktsolvers.jl:297-302;
+ * what `pivot`, src/kktsolvers.jl:316-349, wraps):  [Q + A'(F'F)^-1 A, G'; G, 0][dy; dw] = [y; w].
+ * Served by the factor of the Schur route (CIP_E_UNSUPPORTED on the full-3x3 route). */
+int cip_solve2x2(cip_handle *h, const double *y, const double *w, double *dy, double *dw);      /* host pointers */
+int cip_solve2x2_dev(cip_handle *h, const double *y, const double *w, double *dy, double *dw);  /* device pointers */
 
 /* ---- the 4x4 -> 3x3 reduction of solve4x4 (src/ConicIP.jl:684-692), device pointers.
  * r and dz are 4-block vectors (y[n], w[p], v[m], s[m]) stored contiguously. */

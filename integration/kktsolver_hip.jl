@@ -18,7 +18,11 @@ mutable struct CipHandle
     end
 end
 
-# packed scaling, in cone order (layout documented in include/cipkkt.h)
+# packed scaling, in cone order (layout documented in include/cipkkt.h).  conicIP computes its initial point with
+# F = F⁻ᵀ = Block([Diagonal(ones(k)) for every cone]) (ConicIP.jl:704-706), so a (uniform) Diagonal element must be
+# accepted for "Q" and "S" cones as well as the NT elements built inside the loop.
+_uniform(D::Diagonal) = (d = D.diag[1]; (d > 0 && all(==(d), D.diag)) ? d :
+    error("kktsolver_hip: a Diagonal scaling element of a Q/S cone must be a positive multiple of the identity"))
 function _pack_scaling(F::Block, F⁻ᵀ::Block, cone_dims)
     out = Float64[]
     for (i, (ctype, k)) in enumerate(cone_dims)
@@ -26,11 +30,21 @@ function _pack_scaling(F::Block, F⁻ᵀ::Block, cone_dims)
         if ctype == "R"
             append!(out, Fi.diag)                       # Diagonal(sqrt.(s./v))       ConicIP.jl:598
         elseif ctype == "Q"
-            push!(out, -Fi.A.diag[1])                   # β   (J = Diagonal([-β; β…])) ConicIP.jl:189-192
-            append!(out, vec(Fi.B) .* sqrt(Fi.D[1]))    # w
+            if Fi isa Diagonal                          # d·I = diag(-β, β, …) + w wᵀ with β = d, w = √(2d)·e₁
+                d = _uniform(Fi)
+                push!(out, d); push!(out, sqrt(2d)); append!(out, zeros(k - 1))
+            else
+                push!(out, -Fi.A.diag[1])               # β   (J = Diagonal([-β; β…])) ConicIP.jl:189-192
+                append!(out, vec(Fi.B) .* sqrt(Fi.D[1]))  # w
+            end
         else
-            append!(out, vec(Fi.R))                     # VecCongurance(R)            ConicIP.jl:208
-            append!(out, vec(Matrix(F⁻ᵀ[i].R')))        # inv(R)  (F⁻ᵀ[i] = VecCongurance(inv(R)'))
+            if Fi isa Diagonal                          # vecm(RᵀXR) = d·vecm(X)  ⇔  R = √d·I
+                d = _uniform(Fi); r = ord(zeros(k))
+                append!(out, vec(Matrix(sqrt(d) * I, r, r))); append!(out, vec(Matrix(I / sqrt(d), r, r)))
+            else
+                append!(out, vec(Fi.R))                 # VecCongurance(R)            ConicIP.jl:208
+                append!(out, vec(Matrix(F⁻ᵀ[i].R')))    # inv(R)  (F⁻ᵀ[i] = VecCongurance(inv(R)'))
+            end
         end
     end
     out
@@ -39,23 +53,21 @@ end
 """
     kktsolver_hip(Q, A, G, cone_dims; route = CIP_ROUTE_SCHUR)
 
-Drop-in `kktsolver` for `conicIP` running the Newton step on an AMD MI355X.
+Drop-in `kktsolver` for `conicIP` running the Newton step on an AMD MI355X.  A `SparseMatrixCSC` A without "S"
+cones goes to the device as CSR (O(nnz) Schur assembly: the README box-QP, A = I); anything else is uploaded dense.
 """
 function kktsolver_hip(Q, A, G, cone_dims; route = CIP_ROUTE_SCHUR)
     n, m, p = size(Q, 1), size(A, 1), size(G, 1)
-    Qd, Ad, Gd = Matrix{Float64}(Q), Matrix{Float64}(A), Matrix{Float64}(G)   # column-major, as the C ABI expects
-    ctype = Cint[_CONE_CODE[c[1]] for c in cone_dims]
-    cdim  = Cint[c[2] for c in cone_dims]
-    href = Ref{Ptr{Cvoid}}(C_NULL)
-    _cipcheck(ccall((:cip_create, libcipkkt), Cint,
-        (Cint, Cint, Cint, Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Ref{Ptr{Cvoid}}),
-        n, m, p, length(cone_dims), ctype, cdim, Qd, Ad, Gd, route, href))
-    h = CipHandle(href[])
+    h = if A isa SparseMatrixCSC && !any(c -> c[1] == "S", cone_dims)
+        _cip_create_sparse(Q, A, G, cone_dims, route)
+    else
+        _cip_create_dense(Q, A, G, cone_dims, route)
+    end
 
     function solve3x3gen(F, F⁻ᵀ)                                              # level 2
         packed = _pack_scaling(F, F⁻ᵀ, cone_dims)
         _cipcheck(ccall((:cip_set_scaling_packed, libcipkkt), Cint, (Ptr{Cvoid}, Ptr{Float64}), h.ptr, packed))
-        _cipcheck(ccall((:cip_factor, libcipkkt), Cint, (Ptr{Cvoid},), h.ptr))
+        _cipcheck(ccall((:cip_factor, libcipkkt), Cint, (Ptr{Cvoid},), h.ptr))   # asynchronous; cip_solve3x3 resolves it
         function solve3x3(x, y, z)                                            # level 3
             a, b, c = zeros(n), zeros(p), zeros(m)    # fresh, Julia-owned (they become fields of z / Δz, ConicIP.jl:690)
             _cipcheck(ccall((:cip_solve3x3, libcipkkt), Cint,
@@ -66,6 +78,18 @@ function kktsolver_hip(Q, A, G, cone_dims; route = CIP_ROUTE_SCHUR)
         return solve3x3
     end
     return solve3x3gen
+end
+
+function _cip_create_dense(Q, A, G, cone_dims, route)
+    n, m, p = size(Q, 1), size(A, 1), size(G, 1)
+    Qd, Ad, Gd = Matrix{Float64}(Q), Matrix{Float64}(A), Matrix{Float64}(G)   # column-major, as the C ABI expects
+    ctype = Cint[_CONE_CODE[c[1]] for c in cone_dims]
+    cdim  = Cint[c[2] for c in cone_dims]
+    href = Ref{Ptr{Cvoid}}(C_NULL)
+    _cipcheck(ccall((:cip_create, libcipkkt), Cint,
+        (Cint, Cint, Cint, Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Ref{Ptr{Cvoid}}),
+        n, m, p, length(cone_dims), ctype, cdim, Qd, Ad, Gd, route, href))
+    CipHandle(href[])
 end
 
 # --- sparse A (e.g. the README box-QP, A = I): hand the CSR of A to cip_create_ex -------------------
@@ -101,9 +125,41 @@ function _cip_create_sparse(Q, A::SparseMatrixCSC, G, cone_dims, route)
     CipHandle(href[])
 end
 
-# --- the 2x2 form (src/ConicIP.jl:450-466; src/kktsolvers.jl:316-349): conicIP accepts either -------
-# `pivot(kktsolver_2x2)` wraps a 2x2 solver into the 3x3 interface; the HIP solver already IS a 3x3
-# solver (its Schur route performs the same block elimination on the device), so no wrapper is needed:
+# --- the 2x2 form (src/ConicIP.jl:450-466; src/kktsolvers.jl:281-349) -------------------------------------------
+# `kktsolver_2x2_hip` has the shape of ConicIP.kktsolver_2x2 and is meant to be wrapped by the reference's own
+# `pivot`:   conicIP(...; kktsolver = pivot(kktsolver_2x2_hip))
+# (cip_solve2x2 solves [Q + Aᵀ(FᵀF)⁻¹A  Gᵀ; G 0][Δy; Δw] = [y; w] on the factor of the Schur route).
+function kktsolver_2x2_hip(Q, A, G, cone_dims)
+    n, p = size(Q, 1), size(G, 1)
+    h = (A isa SparseMatrixCSC && !any(c -> c[1] == "S", cone_dims)) ?
+        _cip_create_sparse(Q, A, G, cone_dims, CIP_ROUTE_SCHUR) : _cip_create_dense(Q, A, G, cone_dims, CIP_ROUTE_SCHUR)
+    function solve2x2gen(F, F⁻ᵀ)
+        packed = _pack_scaling(F, F⁻ᵀ, cone_dims)
+        _cipcheck(ccall((:cip_set_scaling_packed, libcipkkt), Cint, (Ptr{Cvoid}, Ptr{Float64}), h.ptr, packed))
+        _cipcheck(ccall((:cip_factor, libcipkkt), Cint, (Ptr{Cvoid},), h.ptr))
+        function solve2x2(y, w)
+            Δy, Δw = zeros(n), zeros(p)
+            _cipcheck(ccall((:cip_solve2x2, libcipkkt), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                h.ptr, Vector{Float64}(y), Vector{Float64}(w), Δy, Δw))
+            return (Δy, Δw)
+        end
+        return solve2x2
+    end
+    return solve2x2gen
+end
+# The 3x3 solver needs no wrapper (its Schur route performs the block elimination on the device):
 #     conicIP(Q, c, A, b, cone_dims, G, d; kktsolver = kktsolver_hip)
 # and for the literal 3x3 assembly of kktsolver_sparse (src/kktsolvers.jl:254-256):
 #     conicIP(...; kktsolver = (Q, A, G, cd) -> kktsolver_hip(Q, A, G, cd; route = CIP_ROUTE_FULL3X3))
+
+# --- MathOptInterface: forwarding a kktsolver through `Optimizer` (src/MOI_wrapper.jl) --------------------------
+# `Optimizer` stores verbose/optTol/maxIters only (MOI_wrapper.jl:28-31) and calls preprocess_conicIP without a
+# kktsolver (:278-282).  The patch a maintainer applies (4 places):
+#   struct Optimizer ...                  # :28-31   add a field      kktsolver::Function
+#   Optimizer(; verbose=false, optTol=1e-6, maxIters=100, kktsolver=ConicIP.kktsolver_qr)   # :33, pass it through
+#   MOI.supports(::Optimizer, ::MOI.RawOptimizerAttribute) / MOI.set(model, MOI.RawOptimizerAttribute("kktsolver"), f)
+#                                         #          model.kktsolver = f   (so that JuMP's set_attribute works)
+#   dest.sol = preprocess_conicIP(Q, c_int, A, b, cone_dims, G, d; kktsolver = dest.kktsolver,
+#                                 verbose = dest.verbose, optTol = dest.optTol, maxIters = dest.maxIters)   # :278-282
+# after which   model = Model(() -> ConicIP.Optimizer(kktsolver = kktsolver_hip))   reaches this file from JuMP.

@@ -189,3 +189,35 @@ def pivotgen(kkt2x2, Q, A, G, cone_dims):
 def pivot(kkt2x2):
     """src/kktsolvers.jl:349."""
     return lambda Q, A, G, cone_dims: pivotgen(kkt2x2, Q, A, G, cone_dims)
+
+
+def kktsolver_schur_exact(Q, A, G, cone_dims):
+    """NOT a reference solver: the block elimination of `pivot` (src/kktsolvers.jl:316-338) with the mathematically
+    exact (F'F)^-1 = F^-1 F^-T and without ever forming F as a dense m x m matrix (columns of A are pushed through
+    the Block operator instead).  Same 3x3 system, same solution as `kktsolver_qr`; exists so that the oracle can run
+    problems whose single S cone makes `kktsolver_qr`'s dense F (k x k, k = r(r+1)/2) too large -- config 4 at
+    matrix order >= 128.  (`pivot` itself is exact only for symmetric scalings: SURVEY App. C.4.)"""
+    Qd = _dense(Q)
+    Ad = _dense(A)
+    n = Qd.shape[0]
+    Gd = _dense(G).reshape(-1, n)
+    p = Gd.shape[0]
+
+    def solve3x3gen(F, FinvT):
+        Fi = FinvT.adjoint()                                  # F^-1
+        W = FinvT.mul(Ad)                                     # F^-T A   (m x n, block operator on every column)
+        Z = np.zeros((n + p, n + p))
+        Z[:n, :n] = Qd + W.T @ W
+        Z[:n, n:] = Gd.T
+        Z[n:, :n] = Gd
+        lu = sla.lu_factor(Z)
+
+        def solve3x3(x, y, z):
+            t = Fi.mul(FinvT.mul(z))                          # (F'F)^-1 z
+            ab = sla.lu_solve(lu, np.concatenate([x + Ad.T @ t, y]))
+            a = ab[:n]
+            return a, ab[n:], t - Fi.mul(FinvT.mul(Ad @ a))
+
+        return solve3x3
+
+    return solve3x3gen

@@ -24,6 +24,8 @@ def imcols(A, b, eps=1e-8):
     if A.size == 0:                                          # :16
         return [], True
     nA = np.linalg.norm(A)                                   # :14 (Frobenius norm of a sparse matrix)
+    if nA == 0.0:                                            # sparse A/0 touches no stored entry -> zero R -> :25
+        return [], True
     A = A / nA
     b = b / nA
     _, R, piv = sla.qr(A.T, mode="economic", pivoting=True)  # :18-22

@@ -1,0 +1,123 @@
+"""Every BASELINE.json configuration at its stated size on the GPU ("configs untested"), inputs from the
+portable generator (cipkkt/workloads.py).  At full size the checks are size-independent properties -- status, the
+optimality conditions of the returned point (src/ConicIP.jl:763-788), a KKT backward error -- and, at the largest size
+the oracle finishes in seconds, identity of the trajectory with the oracle (iteration count, factorisations, iterates:
+the north-star's "identical iteration count to convergence")."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from cipkkt import workloads as W
+from oracle.conicip import conicIP as oracle_conicIP
+from oracle import kktsolvers as ok
+from test_gpu_configs import check_optimality
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c1_readme_boxqp_n1000_vs_oracle_qr():
+    """Config 1 as written in README.md:56-65 (Q = B'B, B 10 %-dense, c = 1, A = I): reference-faithful kktsolver_qr
+    restatement vs the HIP path, both routes."""
+    import cipkkt
+    Q, c, A, b, K = W.c1_readme_boxqp(1000, seed=42)
+    ref = oracle_conicIP(Q, c, A, b, K, optTol=1e-6)
+    assert ref.status == "Optimal"
+    for route in ("schur", "full3x3"):
+        got = cipkkt.conicIP(Q, c, A, b, K, optTol=1e-6, kktsolver=route)
+        assert got.status == "Optimal" and got.Iter == ref.Iter and got.n_factor == ref.n_factor
+        np.testing.assert_allclose(got.y, ref.y, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(got.v, ref.v, rtol=1e-6, atol=1e-7)
+
+
+def test_c2_family_n2048_identical_trajectory_to_oracle():
+    """Config 2's family at n = 2048 against the oracle's pivot(kktsolver_2x2) (src/kktsolvers.jl:281-349): same number
+    of iterations, factorisations and solves, same iterates, same per-iteration mu."""
+    import cipkkt
+    Q, c, A, b, K = W.c2_problem(2048, seed=1234)
+    ref = oracle_conicIP(Q, c, A, b, K, optTol=1e-6, kktsolver=ok.pivot(ok.kktsolver_2x2))
+    got = cipkkt.conicIP(Q, c, A, b, K, optTol=1e-6)
+    assert got.status == ref.status == "Optimal"
+    assert (got.Iter, got.n_factor, got.n_solve) == (ref.Iter, ref.n_factor, ref.n_solve)
+    np.testing.assert_allclose(got.y, ref.y, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(got.v, ref.v, rtol=1e-6, atol=1e-8)
+    for tg, tr in zip(got.trace, ref.trace):
+        assert abs(tg["mu"] - tr["mu"]) <= 1e-6 * abs(tr["mu"])
+        assert abs(tg.get("alpha", 0) - tr.get("alpha", 0)) <= 1e-6
+
+
+def test_c2_headline_n8192():
+    """Config 2 at full size, inputs generated in HBM: Optimal, optimality conditions, and the backward error of one
+    3x3 solve at a late-iteration scaling (||K x - rhs|| / (||K|| ||x|| + ||rhs||) < 1e-12, evaluated with the problem
+    operators on the host)."""
+    import torch
+    import cipkkt
+    n = 8192
+    Q, c, A, b, K = W.c2_problem(n, seed=1234, device="cuda")
+    ks = cipkkt.KKTSystem(Q, A, None, K)
+    its = []
+    sol = cipkkt.conicIP(Q, c, A, b, K, optTol=1e-6, system=ks, keep_iterates=its, driver="python")
+    assert sol.status == "Optimal" and 5 <= sol.Iter <= 20
+    nat = cipkkt.conicIP(Q, c, A, b, K, optTol=1e-6, system=ks)
+    assert nat.status == "Optimal" and nat.Iter == sol.Iter and np.array_equal(nat.y, sol.y)
+    Qh = Q.cpu().numpy()
+    check_optimality(Qh, c, A, b, K, np.zeros((0, n)), np.zeros(0), sol, 1e-5)
+    # a late-iteration NT scaling (two before the last), one solve3x3 through the host-pointer ABI
+    z = its[-2]
+    v, s = z[n:2 * n].clone(), z[2 * n:3 * n].clone()
+    ks.set_scaling_from_iterate(v, s)
+    ks.factor()
+    rng = np.random.default_rng(0)
+    x, zz = rng.standard_normal(n), rng.standard_normal(n)
+    a, _, cc = ks.solve3x3(x, np.zeros(0), zz)
+    d2 = (s / v).cpu().numpy()                                   # F'F for an R cone
+    r1 = Qh @ a - cc - x                                         # Q a - A'c = x   (A = I)
+    r2 = a + d2 * cc - zz                                        # A a + F'F c = z
+    normK = max(np.abs(Qh).sum(axis=1).max() + 1, d2.max() + 1)
+    berr = np.sqrt(r1 @ r1 + r2 @ r2) / (normK * np.sqrt(a @ a + cc @ cc) + np.sqrt(x @ x + zz @ zz))
+    assert berr < 1e-12, berr
+    ks.close()
+
+
+def test_c3_socp_full_size_portable_inputs():
+    import cipkkt
+    prob = W.c3_socp()
+    sol = cipkkt.conicIP(*prob, optTol=1e-6)
+    assert sol.status == "Optimal"
+    check_optimality(*prob, sol, 1e-5)
+
+
+@pytest.mark.parametrize("r,n,p", [(64, 96, 8), (140, 64, 4)])
+def test_c4_sdp_vs_oracle(r, n, p):
+    """Config 4's family against the oracle at r = 64 (LDS-resident S-cone kernels) and r = 140 (the path for matrix
+    orders 133-512).  The oracle runs the exact block elimination (oracle.kktsolvers.kktsolver_schur_exact): the dense
+    k x k F of kktsolver_qr would be 780 MB at r = 140."""
+    import cipkkt
+    prob = W.c4_sdp(r=r, n=n, p=p, seed=5)
+    ref = oracle_conicIP(*prob, optTol=1e-6, kktsolver=ok.kktsolver_schur_exact)
+    got = cipkkt.conicIP(*prob, optTol=1e-6)
+    assert got.status == ref.status == "Optimal" and got.Iter == ref.Iter
+    np.testing.assert_allclose(got.y, ref.y, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(got.v, ref.v, rtol=1e-5, atol=1e-6)
+
+
+def test_c4_sdp_r256_full_size():
+    """The literal reading of config 4: matrix order 256, ("S", 32896), n = 1024, p = 16."""
+    import cipkkt
+    prob = W.c4_sdp(r=256, n=1024, p=16, seed=5)
+    sol = cipkkt.conicIP(*prob, optTol=1e-6)
+    assert sol.status == "Optimal"
+    check_optimality(*prob, sol, 2e-5)
+
+
+def test_c5_all_64_problems():
+    """Config 5 in full: 64 independent dense QPs, n = 2048, seeds 4000 + i, generated in HBM, 4 in flight."""
+    from cipkkt.batch import solve_batch
+    probs = W.c5_batch(64, 2048, seed=4000, device="cuda")
+    sols, st = solve_batch(probs, concurrency=4)
+    assert st["n_problems"] == 64 and st["n_optimal"] == 64
+    iters = [sols[i].Iter for i in range(64)]
+    assert min(iters) >= 5 and max(iters) <= 20
+    for i in (0, 17, 63):                                       # spot-check optimality conditions
+        pr = probs[i]
+        check_optimality(pr["Q"].cpu().numpy(), pr["c"], pr["A"], pr["b"], pr["cone_dims"], np.zeros((0, 2048)),
+                         np.zeros(0), sols[i], 1e-5)

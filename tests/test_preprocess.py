@@ -31,6 +31,7 @@ def check_imcols(imcols):
     rows, ok = imcols(np.array([[1.0, 0, 0], [1.0, 0, 0]]), np.array([1.0, -1.0]))   # inconsistent duplicate
     assert (rows, ok) == ([], False)
     assert imcols(np.zeros((0, 5)), np.zeros(0)) == ([], True)
+    assert imcols(np.zeros((2, 5)), np.array([1.0, 0.0])) == ([], True)      # all-zero rows: the reference's empty-R branch
 
 
 def check_redundant(pre):
