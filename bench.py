@@ -12,9 +12,16 @@ with SOLVES_PER_FACTOR = the rounded mean the real solve used (predictor, correc
 refinement).  The scaling comes from a mid-trajectory iterate of the same problem; all
 inputs are resident in HBM before the timed region.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): every rank owns
-an independent problem of the same size (seed + rank): weak scaling, no data-path
-collective; one all-reduce (MAX) of the timing, as the contract asks.
+N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) measures the north-star's
+multi-GPU configuration, BASELINE.json configs[4]: 64 independent dense QPs with n = 2048
+(seeds 4000 + i), problem i -> rank i mod N, each rank running its shard through the library's
+batch entry point (cip_conicip_problems); no data-path collective, one all-reduce of the
+counts (SUM) and of the wall time (MAX).  A step is then one pass over the whole batch and
+`value` = KKT solves (factorisations) of all ranks per second; total work is fixed as N grows
+(`"scaling": "strong"`).  `--workload c5` runs that workload on one GPU; the default N = 1 line
+(the n = 8192 headline) carries the same figure as `c5_single_gpu` for cross-checking a SCALE run.
+
+Inputs come from the portable SplitMix64 generator (cipkkt/workloads.py), generated in HBM.
 
 Output: ONE JSON line on rank 0 with `roofline` (LDL' trailing-update kernel, fp64 MFMA,
 HIP-event timed per launch on the launch stream) and `cpu_baseline` (the oracle's
@@ -35,30 +42,43 @@ for _p in (ROOT, os.path.join(ROOT, "conicip.jl_amd")):
 import numpy as np
 import torch
 
+TRAILING_KERNELS = ("k_ldlt_trailing_64", "k_ldlt_workers")
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X vendor fp64 matrix peak (dense); see DESIGN.md §5
 HBM_PEAK_GBS = 8000.0
 
 
-def build_problem(n, seed, device):
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    M = torch.randn(n, n, generator=g, dtype=torch.float64, device=device)
-    Q = (M.t() @ M) / n                       # setup only (rocBLAS via torch); not part of the timed path
-    Q = 0.5 * (Q + Q.t())
-    c = torch.randn(n, generator=g, dtype=torch.float64, device=device)
-    del M
-    return Q, c
+def physical_cores():
+    try:
+        seen = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or (os.cpu_count() or 1)
+    except Exception:
+        return os.cpu_count() or 1
 
 
-def cpu_baseline(Q_host, n, solves_per_factor, budget_s=40.0):
-    """Reference-faithful CPU path: the oracle's restatement of kktsolver_qr
-    (src/kktsolvers.jl:18-58: dense F^-T, Atil = F^-T A, Q + Atil'Atil, QR, null-space solve),
-    all host cores via OpenBLAS.  Bounded sample: the full n when a small probe predicts it
-    fits the budget, otherwise the largest power-of-two n that does (scaled by the n^3 law)."""
+def cpu_baseline(Q_host, n, solves_per_factor, budget_s=80.0):
+    """CPU leg, timed on the host cores in this run (reported baseline, not the target).
+
+    (i) reference-faithful: the oracle's restatement of kktsolver_qr (src/kktsolvers.jl:18-58: dense F^-T,
+        Atil = F^-T A, Q + Atil'Atil, QR, null-space solve) -- measured at the full n when a probe at n = 1024
+        predicts it fits `budget_s`, otherwise at the largest power-of-two n that does, scaled by (n/n_s)^3
+        (`sample` says which);
+    (ii) strong CPU: the same Schur + Cholesky route the GPU takes (LAPACK potrf / potrs), ALWAYS measured at the
+        full n (about 7 s at n = 8192)."""
     from oracle.block import Block, Diagonal
     from oracle.kktsolvers import kktsolver_qr
     import scipy.linalg as sla
-    cores = os.cpu_count() or 1
+    logical = os.cpu_count() or 1
+    cores = logical
     # OpenBLAS does not scale to every hardware thread of a 2-socket box: probe a dgemm at a few
     # thread counts and run the baseline at the fastest one (reported as `cores`).
     limiter = None
@@ -79,47 +99,55 @@ def cpu_baseline(Q_host, n, solves_per_factor, budget_s=40.0):
         limiter = threadpool_limits(limits=cores)
     except Exception:
         pass
+    rng = np.random.default_rng(1)
 
-    def one(nn):
-        rng = np.random.default_rng(1)
+    def scaling(nn):
+        return Block([Diagonal(np.exp(np.random.default_rng(1).standard_normal(nn)))])
+
+    def faithful(nn):
         Qs = np.ascontiguousarray(Q_host[:nn, :nn])
-        A = np.eye(nn)
-        G = np.zeros((0, nn))
-        F = Block([Diagonal(np.exp(rng.standard_normal(nn)))])
+        F = scaling(nn)
         t0 = time.perf_counter()
-        gen = kktsolver_qr(Qs, A, G, [("R", nn)])
+        gen = kktsolver_qr(Qs, np.eye(nn), np.zeros((0, nn)), [("R", nn)])
         t1 = time.perf_counter()
         s3 = gen(F, None)
         t2 = time.perf_counter()
         for _ in range(solves_per_factor):
             s3(rng.standard_normal(nn), np.zeros(0), rng.standard_normal(nn))
         t3 = time.perf_counter()
-        # strong CPU variant: same Schur + Cholesky route as the GPU (LAPACK potrf/potrs)
+        return dict(level1=t1 - t0, factor=t2 - t1, solves=t3 - t2)
+
+    def strong(nn):
+        Qs = np.ascontiguousarray(Q_host[:nn, :nn])
+        F = scaling(nn)
         t4 = time.perf_counter()
         S = Qs + np.diag(1.0 / F.Blocks[0].diag ** 2)
         cf = sla.cho_factor(S, lower=True, overwrite_a=True, check_finite=False)
         for _ in range(solves_per_factor):
             sla.cho_solve(cf, rng.standard_normal(nn), check_finite=False)
-        t5 = time.perf_counter()
-        return dict(level1=t1 - t0, factor=t2 - t1, solves=t3 - t2, strong=t5 - t4)
+        return time.perf_counter() - t4
 
     probe_n = 1024
-    tp = one(probe_n)
+    tp = faithful(probe_n)
     per_step_probe = tp["factor"] + tp["solves"]
-    pred_full = per_step_probe * (n / probe_n) ** 3
     nn = n
     while nn > probe_n and per_step_probe * (nn / probe_n) ** 3 > budget_s:
         nn //= 2
-    t = one(nn)
+    t = faithful(nn) if nn > probe_n else tp
     step_s = (t["factor"] + t["solves"]) * (n / nn) ** 3
-    strong_s = t["strong"] * (n / nn) ** 3
-    sample = ("1 factorisation + %d solves of the kktsolver_qr restatement at n=%d%s (level-1 setup %.2fs excluded)"
-              % (solves_per_factor, nn, "" if nn == n else " scaled to n=%d by (n/n_s)^3" % n, t["level1"]))
+    strong_s = strong(n)
+    sample = ("1 factorisation + %d solves of the kktsolver_qr restatement at n=%d%s (level-1 setup %.2fs excluded); "
+              "strong variant measured at n=%d"
+              % (solves_per_factor, nn, " (measured at full size)" if nn == n else " scaled to n=%d by (n/n_s)^3" % n,
+                 t["level1"], n))
     if limiter is not None:
         limiter.restore_original_limits()
     return dict(value=1.0 / step_s, unit="KKT solves/s", cores=cores, kind="port", sample=sample,
-                strong_cpu_value=1.0 / strong_s,
-                strong_cpu_note="Schur + LAPACK Cholesky (same elimination route as the GPU), same sample"), pred_full
+                host_logical_cpus=logical, host_physical_cores=physical_cores(),
+                measured_at_full_size=bool(nn == n),
+                strong_cpu_value=1.0 / strong_s, strong_cpu_seconds_per_step=strong_s,
+                strong_cpu_note="Schur + LAPACK Cholesky (same elimination route as the GPU): 1 potrf + %d potrs "
+                                "measured at n=%d, same thread count" % (solves_per_factor, n))
 
 
 def pmc_traffic_per_launch():
@@ -127,11 +155,14 @@ def pmc_traffic_per_launch():
     the bytes of wide streaming reads -> doubled, MI355X_MICROARCH.md section HBM).  None when absent."""
     import csv
     try:
+        pdir = next(d for d in (os.path.join(ROOT, "profiles", r) for r in ("r2", "r1"))
+                    if os.path.exists(os.path.join(d, "final_pmc_fetch.csv")))
+
         def load(name, counter):
             out = {}
-            with open(os.path.join(ROOT, "profiles", "r1", name)) as f:
+            with open(os.path.join(pdir, name)) as f:
                 for r in csv.DictReader(f):
-                    if r["Counter_Name"] == counter and r["Kernel"].startswith("k_ldlt_trailing_64"):
+                    if r["Counter_Name"] == counter and r["Kernel"].startswith(TRAILING_KERNELS):
                         out[int(r["Dispatch_Id"])] = float(r["Counter_Value"])
             return out
         fe = load("final_pmc_fetch.csv", "FETCH_SIZE")
@@ -153,6 +184,10 @@ def main():
     ap.add_argument("--nbo", type=int, default=0, help="LDL' outer block (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true")
+    ap.add_argument("--workload", default=None, choices=["c2", "c5"],
+                    help="c2: dense QP n=8192 (default at --gpus 1); c5: 64 x n=2048 batch (default at --gpus > 1)")
+    ap.add_argument("--in-flight", type=int, default=4, help="c5: problems in flight per GPU")
+    ap.add_argument("--no-c5", action="store_true", help="c2: skip the single-GPU config-5 figure")
     ap.add_argument("--compare-lookahead", action="store_true",
                     help="also time the same steps under the opt-in look-ahead schedule (adds its kernels to a profile)")
     args = ap.parse_args()
@@ -170,17 +205,43 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)   # nccl == RCCL on ROCm
 
     import cipkkt
-    import scipy.sparse as sp
+    from cipkkt import workloads
+    from cipkkt.batch import run_config5
     n = args.n
     if args.nbo:
         cipkkt._lib.load().cip_set_ldlt_outer_block(args.nbo)
+    workload = args.workload or ("c5" if world > 1 else "c2")
 
-    Q, c = build_problem(n, 1234 + rank, device)
-    A = sp.identity(n, format="csr")
-    b = np.zeros(n)
-    cone_dims = [("R", n)]
+    def config5(steps, warmup):
+        stats, el = run_config5(rank, world, dist, device, steps, warmup, count=64, n=2048, seed=4000,
+                                in_flight=args.in_flight)
+        return dict(value=stats["n_factor"] * steps / el, unit="KKT solves/s", ms_per_pass=el / steps * 1e3,
+                    problems_per_s=64 * steps / el, n_optimal=stats["n_optimal"], n_problems=stats["n_problems"],
+                    iters=stats["iters"], n_factor=stats["n_factor"], n_solve=stats["n_solve"],
+                    in_flight_per_gpu=args.in_flight,
+                    note="64 dense QPs n=m=2048 (seeds 4000+i), problem i -> rank i mod N, level-1 upload included, "
+                         "cip_conicip_problems; KKT solves = factorisations")
+
+    if workload == "c5":
+        c5 = config5(args.steps, args.warmup)
+        if rank == 0:
+            out = {"metric": "KKT solves/sec, batch of 64 independent dense QPs n=2048 (BASELINE config 5), %d GPU(s)" % world,
+                   "value": c5["value"], "unit": "KKT solves/s", "n_gpus": world, "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": c5["ms_per_pass"], "higher_is_better": True,
+                   "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                   "config": {"workload": "config 5: 64 x dense QP n=m=2048 p=0 K=[(R,2048)] Q=M'M/n A=I(sparse) b=0 "
+                                          "optTol=1e-6, seeds 4000+i (SplitMix64), problem i -> rank i mod %d; "
+                                          "step = one pass over the batch" % world,
+                              "parallelism": "problem-per-GPU x%d, %d in flight per GPU" % (world, args.in_flight)},
+                   "batch": c5}
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    Q, c_host, A, b, cone_dims = workloads.c2_problem(n, 1234 + rank, device)
     ks = cipkkt.KKTSystem(Q, A, None, cone_dims, route=args.route, device=device)
-    c_host = c.cpu().numpy()
 
     # ---- wall-clock to converge (the second half of the metric) + the statistics that define a step
     iters = n_factor = n_solve = None
@@ -281,6 +342,10 @@ def main():
     torch.cuda.synchronize()
     solve_ms = (time.perf_counter() - t1) / 5 * 1e3
 
+    ks.close()
+    c5_single = None
+    if world == 1 and not args.no_c5 and n == 8192 and args.route == "schur":
+        c5_single = config5(2, 1)                     # single-GPU config-5 figure, for cross-checking a SCALE run
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
@@ -311,13 +376,16 @@ def main():
                          "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(1.0, prof["launches"]),
                          "algorithmic_flops_per_launch_avg": prof["flops"] / max(1.0, prof["launches"])},
         }
+        out["config"]["seed"] = 1234
+        out["config"]["rng"] = "SplitMix64 + Box-Muller (cipkkt/workloads.py), generated in HBM"
+        if c5_single is not None:
+            out["c5_single_gpu"] = c5_single
         if not args.no_cpu_baseline:
             Qh = Q.cpu().numpy()
             cb, _ = cpu_baseline(Qh, n, spf)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = (value / world) / cb["value"]
         print(json.dumps(out), flush=True)
-    ks.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

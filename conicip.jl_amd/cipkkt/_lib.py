@@ -50,6 +50,7 @@ SIGNATURES = {
     "cip_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "cip_create_ex": (C.c_int, [C.POINTER(CipProblem), C.POINTER(C.c_void_p)]),
+    "cip_update_problem": (C.c_int, [C.c_void_p, C.POINTER(CipProblem)]),
     "cip_destroy": (C.c_int, [C.c_void_p]),
     "cip_last_error": (C.c_char_p, []),
     "cip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -84,6 +85,8 @@ SIGNATURES = {
     "cip_batch_handle": (C.c_void_p, [C.c_void_p, C.c_int]),
     "cip_batch_conicip": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(CipOptions)] +
                           [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(CipResult), C.c_int]),
+    "cip_conicip_problems": (C.c_int, [C.c_int, C.POINTER(CipProblem)] + [C.POINTER(C.c_void_p)] * 3 +
+                             [C.POINTER(CipOptions)] + [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(CipResult), C.c_int]),
     "cip_conicip_many": (C.c_int, [C.POINTER(C.c_void_p), C.c_int] + [C.POINTER(C.c_void_p)] * 3 +
                          [C.POINTER(CipOptions)] + [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(CipResult), C.c_int]),
     "cip_ldlt_workspace_bytes": (C.c_int, [C.c_int, C.POINTER(C.c_size_t)]),

@@ -84,6 +84,52 @@ def _solve_many_native(prs, device, in_flight):
             ks.close()
 
 
+def _solve_problems_native(prs, device, in_flight):
+    """All problems of this rank through `cip_conicip_problems` (csrc/batch.hip): `in_flight` host threads inside the
+    library, each re-loading ONE handle on its own HIP stream with the next problem of the queue (no allocation per
+    problem), so the level-1 upload of one problem overlaps the interior-point loops of the others."""
+    import ctypes as C
+    from . import _lib as L
+    from .driver import solution_from_result
+    from .kkt import make_problem
+    lib = L.load()
+    kw = prs[0].get("kwargs", {})
+    opt = L.CipOptions(kw.get("optTol", 1e-6), kw.get("DTB", 0.01), kw.get("infeasTol", -1.0) or -1.0,
+                       kw.get("refinementThreshold", -1.0) or -1.0, kw.get("maxRefinementSteps", 3),
+                       kw.get("maxIters", 100), 0)
+    k = len(prs)
+    keep = []
+    structs = (L.CipProblem * k)()
+    dims = []
+    with torch.cuda.device(device):
+        for i, pr in enumerate(prs):
+            cd = [(str(t), int(kk)) for t, kk in pr["cone_dims"]]
+            st, kp, _ = make_problem(pr["Q"], pr["A"], pr.get("G"), cd, kw.get("kktsolver", "schur"), device)
+            structs[i] = st
+            keep.append(kp)
+            dims.append((st.n, st.m, st.p))
+        torch.cuda.current_stream(device).synchronize()     # the staging transposes ran on torch's stream
+        vp = C.c_void_p * k
+
+        def host(key, i, size):
+            x = prs[i].get(key)
+            a = np.zeros(max(size, 1)) if x is None else np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
+            keep.append(a)
+            return a
+
+        cs = [host("c", i, dims[i][0]) for i in range(k)]
+        bs = [host("b", i, dims[i][1]) for i in range(k)]
+        ds = [host("d", i, dims[i][2]) for i in range(k)]
+        ys = [np.zeros(max(dims[i][0], 1)) for i in range(k)]
+        ws = [np.zeros(max(dims[i][2], 1)) for i in range(k)]
+        vs = [np.zeros(max(dims[i][1], 1)) for i in range(k)]
+        arr = lambda xs: vp(*[x.ctypes.data for x in xs])
+        res = (L.CipResult * k)()
+        L.check(lib.cip_conicip_problems(k, structs, arr(cs), arr(bs), arr(ds), C.byref(opt), arr(ys), arr(ws), arr(vs),
+                                         res, int(in_flight)))
+    return [solution_from_result(res[i], ys[i][:dims[i][0]], ws[i][:dims[i][2]], vs[i][:dims[i][1]]) for i in range(k)]
+
+
 def solve_batch(problems, solve_fn=None, rank=0, world=1, dist=None, device=None, concurrency=1, native=False):
     """problems: list of dicts(Q, c, A, b, cone_dims, G, d, kwargs).  Each rank solves its
     shard with `solve_fn` (default: the HIP-backed cipkkt.conicIP) and the statistics are
@@ -91,9 +137,10 @@ def solve_batch(problems, solve_fn=None, rank=0, world=1, dist=None, device=None
     `concurrency` > 1 (default solver only) keeps that many problems in flight on separate
     HIP streams, one Python thread each: a thread builds its problem's handle, runs the native loop
     (`cip_conicip`, GIL released) and frees it, so level-1 setup of one problem overlaps the solve of another
-    (n = 2048, 8 problems: 583 KKT solves/s one at a time, 899 with 2 in flight).  `native=True` instead builds all
-    handles first and hands them to the library's batch entry point (`cip_conicip_many`: host threads inside the
-    library, what a C caller uses): 605-683 KKT solves/s on the same batch, the setup is not overlapped.
+    (n = 2048, 8 problems: 583 KKT solves/s one at a time, 899 with 2 in flight).  `native=True` hands the problems to
+    the library's batch entry point `cip_conicip_problems` (host threads inside the library, one re-loaded handle per
+    thread: what a C caller uses); `native="handles"` builds all handles first and calls `cip_conicip_many`
+    (605-683 KKT solves/s on the same batch: the setup is not overlapped).
     Returns (local_solutions, stats_dict)."""
     default_solver = solve_fn is None
     if solve_fn is None:
@@ -102,9 +149,10 @@ def solve_batch(problems, solve_fn=None, rank=0, world=1, dist=None, device=None
     sols = {}
     t0 = time.perf_counter()
     same_opts = all(problems[i].get("kwargs", {}) == problems[mine[0]].get("kwargs", {}) for i in mine) if mine else True
-    if default_solver and native and concurrency > 1 and len(mine) > 1 and same_opts:
+    if default_solver and native and len(mine) > 0 and same_opts:
         dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
-        for i, sol in zip(mine, _solve_many_native([problems[i] for i in mine], dev, concurrency)):
+        fn = _solve_many_native if native == "handles" else _solve_problems_native
+        for i, sol in zip(mine, fn([problems[i] for i in mine], dev, max(1, concurrency))):
             sols[i] = sol
     elif default_solver and concurrency > 1 and len(mine) > 1:
         from concurrent.futures import ThreadPoolExecutor
@@ -135,3 +183,41 @@ def solve_batch(problems, solve_fn=None, rank=0, world=1, dist=None, device=None
     stats = dict(iters=int(sums[0]), n_factor=int(sums[1]), n_solve=int(sums[2]), n_optimal=int(sums[3]),
                  n_problems=int(sums[4]), wall_s=float(mx[0]))
     return sols, stats
+
+
+def run_config5(rank, world, dist, device, steps, warmup, problems=None, count=64, n=2048, seed=4000, in_flight=4,
+                solve_fn=None, barrier=None):
+    """BASELINE config 5 as a timed job (bench.py --gpus N, N > 1; `--workload c5` on one GPU): `count` independent
+    problems, problem i -> rank i mod world, every rank's shard resident in HBM before the timed region; a step is one
+    pass over the whole batch (each rank its shard, `in_flight` problems at once through cip_conicip_problems).
+    Returns (stats of one pass reduced over ranks, elapsed seconds for `steps` passes = MAX over ranks).
+    `problems` / `solve_fn` are injectable (the gloo test runs the sharding and the reduction on CPU)."""
+    if problems is None:
+        from .workloads import c5_batch
+        mine = shard_indices(count, rank, world)
+        local = c5_batch(count, n, seed, device=device, indices=mine)
+        problems = [None] * count                      # only this rank's shard is materialised
+        for i, pr in zip(mine, local):
+            problems[i] = pr
+    sync = (lambda: torch.cuda.synchronize(device)) if device is not None and str(device) != "cpu" else (lambda: None)
+    if barrier is None:
+        barrier = (lambda: dist.barrier()) if (dist is not None and world > 1) else (lambda: None)
+
+    def one_pass(reduce):
+        return solve_batch(problems, solve_fn=solve_fn, rank=rank, world=world, dist=dist if reduce else None,
+                           device=device, concurrency=in_flight, native=solve_fn is None)
+
+    for _ in range(warmup):
+        one_pass(False)
+    sync(); barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_pass(False)
+    sync(); barrier(); sync()
+    elapsed = time.perf_counter() - t0
+    _, stats = one_pass(True)                          # untimed: the reduced statistics of one pass
+    if dist is not None and world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return stats, elapsed

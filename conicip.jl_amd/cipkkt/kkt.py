@@ -85,6 +85,49 @@ def pack_scaling(cone_dims, F, FinvT=None):
 
 
 
+def make_problem(Q, A, G, cone_dims, route, device):
+    """(cip_problem, keep-alive list, A_is_sparse): every matrix handed over as a DEVICE pointer.  Host arrays are
+    uploaded in whatever (row-major) layout they have and re-laid out column-major by a device transpose --
+    numpy.asfortranarray of a 2048 x 2048 Q alone cost 33 ms of the 42 ms level 1 took, cip_create_ex itself 3 ms.
+    The staging copies run on torch's current stream: synchronise it before handing the struct to the library."""
+    n = Q.shape[0]
+    m = A.shape[0] if A is not None else 0
+    p = G.shape[0] if G is not None else 0
+    keep = []
+    pr = L.CipProblem()
+    pr.n, pr.m, pr.p, pr.ncones = n, m, p, len(cone_dims)
+    ct = (C.c_int * max(1, len(cone_dims)))(*[_CONE_CODE[t] for t, _ in cone_dims])
+    cdm = (C.c_int * max(1, len(cone_dims)))(*[k for _, k in cone_dims])
+    keep += [ct, cdm]
+    pr.cone_type, pr.cone_dim = ct, cdm
+
+    def dense(M, rows, cols):
+        """column-major fp64 device buffer"""
+        if not isinstance(M, torch.Tensor):
+            M = torch.from_numpy(np.ascontiguousarray(M.toarray() if _is_sparse(M) else M, dtype=np.float64))
+        Mt = M.to(dtype=torch.float64, device=device).reshape(rows, cols).t().contiguous()
+        keep.append(Mt)            # row-major of M' == column-major of M
+        return C.c_void_p(Mt.data_ptr())
+
+    pr.Q, pr.ldq = dense(Q, n, n), n
+    a_sparse = False
+    if m > 0 and _is_sparse(A) and not any(t == "S" for t, _ in cone_dims):
+        csr = A.tocsr()
+        csr.sort_indices()
+        rp_t, ci_t, av_t = (torch.as_tensor(np.ascontiguousarray(x, dtype=dt), device=device)
+                            for x, dt in ((csr.indptr, np.int32), (csr.indices, np.int32), (csr.data, np.float64)))
+        keep += [rp_t, ci_t, av_t]
+        pr.A_rowptr, pr.A_colind, pr.A_val = _ptr(rp_t), _ptr(ci_t), _ptr(av_t)
+        pr.A = None
+        a_sparse = True
+    else:
+        pr.A, pr.lda = (dense(A, m, n) if m > 0 else None), max(m, 1)
+    pr.G, pr.ldg = (dense(G, p, n) if p > 0 else None), max(p, 1)
+    pr.route = L.ROUTE_SCHUR if route in ("schur", L.ROUTE_SCHUR) else L.ROUTE_FULL3X3
+    pr.flags = L.FLAG_DEVICE_PTRS
+    return pr, keep, a_sparse
+
+
 class KKTSystem:
     """Level-1 object: problem matrices resident in HBM, cone layout, workspaces.
     ≙ what `kktsolver(Q,A,G,cone_dims)` captures (src/kktsolvers.jl:18-28, :180-190, :281-285)."""
@@ -109,48 +152,7 @@ class KKTSystem:
         self.n, self.m, self.p = n, m, p
         self.route = L.ROUTE_SCHUR if route in ("schur", L.ROUTE_SCHUR) else L.ROUTE_FULL3X3
 
-        keep = []                      # keep staging buffers alive across the create call
-        flags = 0
-        pr = L.CipProblem()
-        pr.n, pr.m, pr.p, pr.ncones = n, m, p, len(self.cone_dims)
-        ct = (C.c_int * max(1, len(self.cone_dims)))(*[_CONE_CODE[t] for t, _ in self.cone_dims])
-        cdm = (C.c_int * max(1, len(self.cone_dims)))(*[k for _, k in self.cone_dims])
-        pr.cone_type, pr.cone_dim = ct, cdm
-        # Every matrix is handed over as a device pointer: host arrays are uploaded in whatever (row-major) layout
-        # they have and re-laid out column-major by a device transpose -- numpy.asfortranarray of a 2048 x 2048 Q
-        # alone cost 33 ms of the 42 ms this constructor took, cip_create_ex itself 3 ms.
-        on_dev = True
-        flags |= L.FLAG_DEVICE_PTRS
-
-        def dense(M, rows, cols):
-            """column-major fp64 device buffer"""
-            if not isinstance(M, torch.Tensor):
-                M = torch.from_numpy(np.ascontiguousarray(M.toarray() if _is_sparse(M) else M, dtype=np.float64))
-            Mt = M.to(dtype=torch.float64, device=self.device).reshape(rows, cols).t().contiguous()
-            keep.append(Mt)            # row-major of M' == column-major of M
-            return C.c_void_p(Mt.data_ptr())
-
-        pr.Q, pr.ldq = dense(Q, n, n), n
-        if m > 0 and _is_sparse(A) and not any(t == "S" for t, _ in self.cone_dims):
-            csr = A.tocsr()
-            csr.sort_indices()
-            rp = np.ascontiguousarray(csr.indptr, dtype=np.int32)
-            ci = np.ascontiguousarray(csr.indices, dtype=np.int32)
-            av = np.ascontiguousarray(csr.data, dtype=np.float64)
-            if on_dev:
-                rp_t, ci_t, av_t = (torch.as_tensor(x, device=self.device) for x in (rp, ci, av))
-                keep += [rp_t, ci_t, av_t]
-                pr.A_rowptr, pr.A_colind, pr.A_val = _ptr(rp_t), _ptr(ci_t), _ptr(av_t)
-            else:
-                keep += [rp, ci, av]
-                pr.A_rowptr, pr.A_colind, pr.A_val = _ptr(rp), _ptr(ci), _ptr(av)
-            pr.A = None
-            self.A_sparse = True
-        else:
-            pr.A, pr.lda = (dense(A, m, n) if m > 0 else None), max(m, 1)
-            self.A_sparse = False
-        pr.G, pr.ldg = (dense(G, p, n) if p > 0 else None), max(p, 1)
-        pr.route, pr.flags = self.route, flags
+        pr, keep, self.A_sparse = make_problem(Q, A, G, self.cone_dims, self.route, self.device)
         h = C.c_void_p()
         torch.cuda.current_stream(self.device).synchronize()    # staging transposes ran on torch's current stream
         L.check(self.lib.cip_create_ex(C.byref(pr), C.byref(h)))

@@ -72,6 +72,64 @@ static int transpose_dev(hipStream_t s, const double *src, long ld_src, int rows
     return 0;
 }
 
+// Contents of Q, G (+G'), A (+A', or the CSR of A and of A') into the handle's buffers, on its stream.
+static int upload_problem(cip_handle *h, const cip_problem *pr) {
+    const int n = h->n, m = h->m, p = h->p;
+    const bool dev = (pr->flags & CIP_FLAG_DEVICE_PTRS) != 0;
+    hipStream_t s = h->stream;
+    int rc;
+    if ((rc = upload_matrix(h->Q, n, pr->Q, pr->ldq > 0 ? pr->ldq : n, n, n, dev, s))) return rc;
+    if (p > 0) {
+        if ((rc = upload_matrix(h->G, p, pr->G, pr->ldg > 0 ? pr->ldg : p, p, n, dev, s))) return rc;
+        if ((rc = transpose_dev(s, h->G, p, p, n, h->Gt, n))) return rc;
+    }
+    if (!h->A_sparse) {
+        if (m > 0) {
+            if ((rc = upload_matrix(h->A, m, pr->A, pr->lda > 0 ? pr->lda : m, m, n, dev, s))) return rc;
+            if ((rc = transpose_dev(s, h->A, m, m, n, h->At, h->npad))) return rc;
+        }
+        return 0;
+    }
+    // CSR of A (given) and of A' (built here on the host)
+    std::vector<int> rp(m + 1);
+    if (dev) CIP_HIP_CHECK(hipMemcpy(rp.data(), pr->A_rowptr, sizeof(int) * (m + 1), hipMemcpyDeviceToHost));
+    else memcpy(rp.data(), pr->A_rowptr, sizeof(int) * (m + 1));
+    const int nnz = rp[m];
+    if (rp[0] != 0 || nnz != h->A_nnz) { cip_set_error("bad CSR row pointer (nnz %d, handle holds %d)", nnz, h->A_nnz); return CIP_E_INVALID; }
+    std::vector<int> ci(nnz > 0 ? nnz : 1);
+    std::vector<double> av(nnz > 0 ? nnz : 1);
+    if (nnz > 0) {
+        if (dev) {
+            CIP_HIP_CHECK(hipMemcpy(ci.data(), pr->A_colind, sizeof(int) * nnz, hipMemcpyDeviceToHost));
+            CIP_HIP_CHECK(hipMemcpy(av.data(), pr->A_val, sizeof(double) * nnz, hipMemcpyDeviceToHost));
+        } else {
+            memcpy(ci.data(), pr->A_colind, sizeof(int) * nnz);
+            memcpy(av.data(), pr->A_val, sizeof(double) * nnz);
+        }
+    }
+    for (int q = 0; q < nnz; ++q)
+        if (ci[q] < 0 || ci[q] >= n) { cip_set_error("CSR column index out of range"); return CIP_E_INVALID; }
+    std::vector<int> trp(n + 1, 0), tci(nnz > 0 ? nnz : 1);
+    std::vector<double> tv(nnz > 0 ? nnz : 1);
+    for (int q = 0; q < nnz; ++q) trp[ci[q] + 1]++;
+    for (int i = 0; i < n; ++i) trp[i + 1] += trp[i];
+    {
+        std::vector<int> fill(trp.begin(), trp.end() - 1);
+        for (int r = 0; r < m; ++r)
+            for (int q = rp[r]; q < rp[r + 1]; ++q) { const int d = fill[ci[q]]++; tci[d] = r; tv[d] = av[q]; }
+    }
+    CIP_HIP_CHECK(hipMemcpyAsync(h->A_rp, rp.data(), sizeof(int) * (m + 1), hipMemcpyHostToDevice, s));
+    CIP_HIP_CHECK(hipMemcpyAsync(h->T_rp, trp.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, s));
+    if (nnz > 0) {
+        CIP_HIP_CHECK(hipMemcpyAsync(h->A_ci, ci.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, s));
+        CIP_HIP_CHECK(hipMemcpyAsync(h->A_v, av.data(), sizeof(double) * nnz, hipMemcpyHostToDevice, s));
+        CIP_HIP_CHECK(hipMemcpyAsync(h->T_ci, tci.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, s));
+        CIP_HIP_CHECK(hipMemcpyAsync(h->T_v, tv.data(), sizeof(double) * nnz, hipMemcpyHostToDevice, s));
+    }
+    CIP_HIP_CHECK(hipStreamSynchronize(s));          // the host vectors above die with this frame
+    return 0;
+}
+
 static int create_impl(const cip_problem *pr, cip_handle *h) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -152,71 +210,28 @@ static int create_impl(const cip_problem *pr, cip_handle *h) {
     h->Npad = rup(h->N, CIP_NB);
     h->ldk = h->Npad;
 
-    // ---- Q, G
+    // ---- Q, G, A: buffers here, contents by upload_problem (also used by cip_update_problem)
     DMALLOC(h->Q, sizeof(double) * (size_t)n * n);
-    int rc;
-    if ((rc = upload_matrix(h->Q, n, pr->Q, pr->ldq > 0 ? pr->ldq : n, n, n, dev, s))) return rc;
     DMALLOC(h->G, sizeof(double) * (size_t)p * n);
     DMALLOC(h->Gt, sizeof(double) * (size_t)p * n);
-    if (p > 0) {
-        if ((rc = upload_matrix(h->G, p, pr->G, pr->ldg > 0 ? pr->ldg : p, p, n, dev, s))) return rc;
-        if ((rc = transpose_dev(s, h->G, p, p, n, h->Gt, n))) return rc;
-    }
-
-    // ---- A
     h->A_sparse = (pr->A == NULL && m > 0);
+    int rc;
     if (!h->A_sparse) {
         DMALLOC(h->A, sizeof(double) * (size_t)m * n);
         DMALLOC(h->At, sizeof(double) * (size_t)h->npad * h->mpad);
         CIP_HIP_CHECK(hipMemsetAsync(h->At, 0, sizeof(double) * (size_t)h->npad * h->mpad, s));
-        if (m > 0) {
-            if ((rc = upload_matrix(h->A, m, pr->A, pr->lda > 0 ? pr->lda : m, m, n, dev, s))) return rc;
-            if ((rc = transpose_dev(s, h->A, m, m, n, h->At, h->npad))) return rc;
-        }
         if (h->route == CIP_ROUTE_SCHUR) {
             DMALLOC(h->Wt, sizeof(double) * (size_t)h->npad * h->mpad);
             CIP_HIP_CHECK(hipMemsetAsync(h->Wt, 0, sizeof(double) * (size_t)h->npad * h->mpad, s));
         }
     } else {
-        // CSR of A (given) and of A' (built here on the host)
-        std::vector<int> rp(m + 1);
-        if (dev) CIP_HIP_CHECK(hipMemcpy(rp.data(), pr->A_rowptr, sizeof(int) * (m + 1), hipMemcpyDeviceToHost));
-        else memcpy(rp.data(), pr->A_rowptr, sizeof(int) * (m + 1));
-        const int nnz = rp[m];
-        if (rp[0] != 0 || nnz < 0) { cip_set_error("bad CSR row pointer"); return CIP_E_INVALID; }
-        std::vector<int> ci(nnz > 0 ? nnz : 1);
-        std::vector<double> av(nnz > 0 ? nnz : 1);
-        if (nnz > 0) {
-            if (dev) {
-                CIP_HIP_CHECK(hipMemcpy(ci.data(), pr->A_colind, sizeof(int) * nnz, hipMemcpyDeviceToHost));
-                CIP_HIP_CHECK(hipMemcpy(av.data(), pr->A_val, sizeof(double) * nnz, hipMemcpyDeviceToHost));
-            } else {
-                memcpy(ci.data(), pr->A_colind, sizeof(int) * nnz);
-                memcpy(av.data(), pr->A_val, sizeof(double) * nnz);
-            }
-        }
-        for (int q = 0; q < nnz; ++q)
-            if (ci[q] < 0 || ci[q] >= n) { cip_set_error("CSR column index out of range"); return CIP_E_INVALID; }
-        std::vector<int> trp(n + 1, 0), tci(nnz > 0 ? nnz : 1);
-        std::vector<double> tv(nnz > 0 ? nnz : 1);
-        for (int q = 0; q < nnz; ++q) trp[ci[q] + 1]++;
-        for (int i = 0; i < n; ++i) trp[i + 1] += trp[i];
-        {
-            std::vector<int> fill(trp.begin(), trp.end() - 1);
-            for (int r = 0; r < m; ++r)
-                for (int q = rp[r]; q < rp[r + 1]; ++q) { const int d = fill[ci[q]]++; tci[d] = r; tv[d] = av[q]; }
-        }
+        int nnz = 0;
+        if (dev) CIP_HIP_CHECK(hipMemcpy(&nnz, pr->A_rowptr + m, sizeof(int), hipMemcpyDeviceToHost));
+        else nnz = pr->A_rowptr[m];
+        if (nnz < 0) { cip_set_error("bad CSR row pointer"); return CIP_E_INVALID; }
         h->A_nnz = nnz;
         DMALLOC(h->A_rp, sizeof(int) * (m + 1)); DMALLOC(h->A_ci, sizeof(int) * nnz); DMALLOC(h->A_v, sizeof(double) * nnz);
         DMALLOC(h->T_rp, sizeof(int) * (n + 1)); DMALLOC(h->T_ci, sizeof(int) * nnz); DMALLOC(h->T_v, sizeof(double) * nnz);
-        CIP_HIP_CHECK(hipMemcpy(h->A_rp, rp.data(), sizeof(int) * (m + 1), hipMemcpyHostToDevice));
-        CIP_HIP_CHECK(hipMemcpy(h->T_rp, trp.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice));
-        if (nnz > 0) {
-            CIP_HIP_CHECK(hipMemcpy(h->A_ci, ci.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
-            CIP_HIP_CHECK(hipMemcpy(h->A_v, av.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
-            CIP_HIP_CHECK(hipMemcpy(h->T_ci, tci.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
-            CIP_HIP_CHECK(hipMemcpy(h->T_v, tv.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
-        }
         std::vector<int> rc_(m > 0 ? m : 1);
         for (size_t c = 0; c < h->h_cones.size(); ++c)
             for (int e = 0; e < h->h_cones[c].dim; ++e) rc_[h->h_cones[c].off + e] = (int)c;
@@ -224,6 +239,7 @@ static int create_impl(const cip_problem *pr, cip_handle *h) {
         if (m > 0) CIP_HIP_CHECK(hipMemcpy(h->row_cone, rc_.data(), sizeof(int) * m, hipMemcpyHostToDevice));
         if (h->route == CIP_ROUTE_SCHUR) DMALLOC(h->Gm, sizeof(double) * (size_t)h->npad * h->nqpad);
     }
+    if ((rc = upload_problem(h, pr))) return rc;
 
     // ---- KKT matrix, workspace, scratch
     DMALLOC(h->K, sizeof(double) * (size_t)h->ldk * h->Npad);
@@ -267,6 +283,24 @@ extern "C" int cip_create(int n, int m, int p, int ncones, const int *cone_type,
     pr.Q = Q; pr.ldq = n; pr.A = A; pr.lda = m; pr.G = G; pr.ldg = p; pr.route = route; pr.flags = 0;
     if (m > 0 && !A) { cip_set_error("A is NULL"); return CIP_E_INVALID; }
     return cip_create_ex(&pr, out);
+}
+
+// Level 1 again on an existing handle: new Q / A / G of the SAME shape (n, m, p, cones, route, dense-or-CSR A with the same
+// number of non-zeros).  Keeps every allocation -- hipMalloc / hipFree synchronise the whole device, which is what a
+// batch of small problems on several streams must avoid (csrc/batch.hip reuses one handle per worker this way).
+extern "C" int cip_update_problem(cip_handle *h, const cip_problem *pr) {
+    if (!h || !pr) { cip_set_error("NULL argument"); return CIP_E_INVALID; }
+    if (pr->n != h->n || pr->m != h->m || pr->p != h->p || pr->ncones != h->ncones || pr->route != h->route ||
+        (pr->A == NULL && pr->m > 0) != h->A_sparse) { cip_set_error("cip_update_problem: shape differs from the handle's"); return CIP_E_INVALID; }
+    for (int c = 0; c < pr->ncones; ++c)
+        if (pr->cone_type[c] != h->h_cones[c].type || pr->cone_dim[c] != h->h_cones[c].dim) { cip_set_error("cip_update_problem: cone %d differs", c); return CIP_E_INVALID; }
+    if (!pr->Q || (h->p > 0 && !pr->G)) { cip_set_error("NULL matrix"); return CIP_E_INVALID; }
+    int rc;
+    if ((rc = upload_problem(h, pr))) return rc;
+    h->assembled = h->factored = false;
+    h->info_pending = false;
+    h->reg_rel = 0.0; h->n_regularized = 0;          // a fresh problem starts unregularised, as a fresh handle does
+    return cip_cones_identity_scaling(h->stream, h->cs);
 }
 
 extern "C" int cip_destroy(cip_handle *h) {

@@ -89,6 +89,9 @@ typedef struct cip_problem {
 int cip_create(int n, int m, int p, int ncones, const int *cone_type, const int *cone_dim,
                const double *Q, const double *A, const double *G, int route, cip_handle **out);
 int cip_create_ex(const cip_problem *prob, cip_handle **out);
+/* level 1 again on an existing handle: new Q / A / G of the same shape (n, m, p, cones, route, dense-or-CSR A with the
+ * same nnz); keeps every device allocation (hipMalloc / hipFree synchronise the whole device) */
+int cip_update_problem(cip_handle *h, const cip_problem *prob);
 int cip_destroy(cip_handle *h);
 const char *cip_last_error(void);
 int cip_set_stream(cip_handle *h, void *hip_stream);
@@ -191,6 +194,11 @@ cip_handle *cip_batch_handle(cip_batch *b, int i);
 int cip_batch_conicip(cip_batch *b, const double *const *c, const double *const *bvec, const double *const *d,
                       const cip_options *opt, double *const *y, double *const *w, double *const *v, cip_result *res,
                       int in_flight);
+/* problems in, solutions out: `in_flight` host threads, each re-loading ONE handle (cip_update_problem) on its own
+ * stream with the next problem of the queue -- level-1 upload of one problem overlaps the loops of the others */
+int cip_conicip_problems(int count, const cip_problem *probs, const double *const *c, const double *const *bvec,
+                         const double *const *d, const cip_options *opt, double *const *y, double *const *w,
+                         double *const *v, cip_result *res, int in_flight);
 int cip_conicip_many(cip_handle *const *handles, int count, const double *const *c, const double *const *bvec,
                      const double *const *d, const cip_options *opt, double *const *y, double *const *w,
                      double *const *v, cip_result *res, int in_flight);

@@ -61,6 +61,53 @@ def test_two_rank_sharding_and_reduction():
     assert st["wall_s"] > 0
 
 
+def _worker_c5(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "conicip.jl_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cipkkt import workloads as W
+    from cipkkt.batch import run_config5, shard_indices
+    from oracle.conicip import conicIP as oracle_conicIP
+    # config 5's shard map at its full count (64 problems, seeds 4000 + i) with tiny systems and the oracle injected
+    # as the per-problem solver: what runs here is bench.py's multi-GPU code path minus the GPU.
+    probs = W.c5_batch(64, 12, seed=4000)
+    seen = []
+
+    def solver(Q, c, A, b, K, G=None, d=None, **kw):
+        seen.append(float(c[0]))
+        return oracle_conicIP(Q, c, A, b, K, G, d, **kw)
+
+    stats, elapsed = run_config5(rank, world, dist, None, steps=1, warmup=0, problems=probs, solve_fn=solver, in_flight=1)
+    mine = shard_indices(64, rank, world)
+    per_pass = seen[:len(mine)]
+    q.put((rank, stats, elapsed, per_pass == [float(probs[i]["c"][0]) for i in mine], len(seen)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config5_shard_map_and_reduction_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c5, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, st0, el0, ok0, n0), (r1, st1, el1, ok1, n1) = res
+    assert ok0 and ok1                          # rank r solved exactly problems r, r+2, ... in order
+    assert n0 == n1 == 64                       # one timed pass + the untimed pass that collects the statistics, 32 each
+    assert st0 == st1 and st0["n_problems"] == 64 and st0["n_optimal"] == 64
+    assert st0["n_factor"] == st0["iters"] + 64           # one factorisation per iteration + the initial point
+    assert el0 == el1 > 0                       # MAX over ranks, seen by both
+
+
 def test_shard_indices():
     sys.path.insert(0, os.path.join(ROOT, "conicip.jl_amd"))
     from cipkkt.batch import shard_indices

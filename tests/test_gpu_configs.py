@@ -107,7 +107,7 @@ def test_config5_batch_of_qps():
         check_optimality(pr["Q"], pr["c"], pr["A"], pr["b"], pr["cone_dims"], np.zeros((0, n)), np.zeros(0), sols[i], 1e-5)
 
 
-@pytest.mark.parametrize("native", [True, False], ids=["cip_conicip_many", "python-threads"])
+@pytest.mark.parametrize("native", [True, "handles", False], ids=["cip_conicip_problems", "cip_conicip_many", "python-threads"])
 def test_config5_batch_in_flight(native):
     """The same batch with several problems in flight on separate HIP streams: through the library's batch entry
     point (csrc/batch.hip) and through Python threads; both must reproduce the one-at-a-time solutions exactly

@@ -113,7 +113,7 @@ def test_c5_all_64_problems():
     """Config 5 in full: 64 independent dense QPs, n = 2048, seeds 4000 + i, generated in HBM, 4 in flight."""
     from cipkkt.batch import solve_batch
     probs = W.c5_batch(64, 2048, seed=4000, device="cuda")
-    sols, st = solve_batch(probs, concurrency=4)
+    sols, st = solve_batch(probs, concurrency=4, native=True)
     assert st["n_problems"] == 64 and st["n_optimal"] == 64
     iters = [sols[i].Iter for i in range(64)]
     assert min(iters) >= 5 and max(iters) <= 20
