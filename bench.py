@@ -65,12 +65,12 @@ def physical_cores():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(Q_host, n, solves_per_factor, budget_s=80.0):
+def cpu_baseline(Q_host, n, solves_per_factor, budget_s=100.0):
     """CPU leg, timed on the host cores in this run (reported baseline, not the target).
 
     (i) reference-faithful: the oracle's restatement of kktsolver_qr (src/kktsolvers.jl:18-58: dense F^-T,
-        Atil = F^-T A, Q + Atil'Atil, QR, null-space solve) -- measured at the full n when a probe at n = 1024
-        predicts it fits `budget_s`, otherwise at the largest power-of-two n that does, scaled by (n/n_s)^3
+        Atil = F^-T A, Q + Atil'Atil, QR, null-space solve) -- measured at the full n when the n/2 run
+        predicts it fits `budget_s`, otherwise at n/2, scaled by (n/n_s)^3
         (`sample` says which);
     (ii) strong CPU: the same Schur + Cholesky route the GPU takes (LAPACK potrf / potrs), ALWAYS measured at the
         full n (about 7 s at n = 8192)."""
@@ -127,13 +127,15 @@ def cpu_baseline(Q_host, n, solves_per_factor, budget_s=80.0):
             sla.cho_solve(cf, rng.standard_normal(nn), check_finite=False)
         return time.perf_counter() - t4
 
-    probe_n = 1024
-    tp = faithful(probe_n)
-    per_step_probe = tp["factor"] + tp["solves"]
+    # ladder: n/2 first (an eighth of the work); the full size only if eight times that fits the budget
     nn = n
-    while nn > probe_n and per_step_probe * (nn / probe_n) ** 3 > budget_s:
-        nn //= 2
-    t = faithful(nn) if nn > probe_n else tp
+    t = None
+    if n > 2048:
+        half = faithful(n // 2)
+        if (half["factor"] + half["solves"]) * 8.0 > budget_s:
+            nn, t = n // 2, half
+    if t is None:
+        t = faithful(nn)
     step_s = (t["factor"] + t["solves"]) * (n / nn) ** 3
     strong_s = strong(n)
     sample = ("1 factorisation + %d solves of the kktsolver_qr restatement at n=%d%s (level-1 setup %.2fs excluded); "
@@ -382,7 +384,7 @@ def main():
             out["c5_single_gpu"] = c5_single
         if not args.no_cpu_baseline:
             Qh = Q.cpu().numpy()
-            cb, _ = cpu_baseline(Qh, n, spf)
+            cb = cpu_baseline(Qh, n, spf)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = (value / world) / cb["value"]
         print(json.dumps(out), flush=True)

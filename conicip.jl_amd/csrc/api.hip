@@ -257,8 +257,8 @@ static int create_impl(const cip_problem *pr, cip_handle *h) {
     DMALLOC(h->stage, sizeof(double) * 2 * (size_t)(n + p + m));
     CIP_HIP_CHECK(hipEventCreate(&h->ev0)); CIP_HIP_CHECK(hipEventCreate(&h->ev1)); CIP_HIP_CHECK(hipEventCreate(&h->ev2));
     CIP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_info, hipEventDisableTiming));
-    CIP_HIP_CHECK(hipHostMalloc((void **)&h->info_host, sizeof(int), hipHostMallocDefault));
-    *h->info_host = 0;
+    CIP_HIP_CHECK(hipHostMalloc((void **)&h->info_host, 4 * sizeof(int), hipHostMallocDefault));
+    memset(h->info_host, 0, 4 * sizeof(int));
     if ((rc = cip_cones_identity_scaling(s, h->cs))) return rc;
     CIP_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
@@ -363,10 +363,11 @@ static int factor_enqueue(cip_handle *h) {
     if (h->timing) CIP_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
     if ((rc = cip_ldlt_factor(h->stream, h->K, h->Npad, h->ldk, h->ws))) return rc;
     h->n_factor += 1;
-    CIP_HIP_CHECK(hipMemcpyAsync(h->info_host, h->ws.info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    CIP_HIP_CHECK(hipMemcpyAsync(h->info_host, h->ws.info, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     CIP_HIP_CHECK(hipEventRecord(h->ev_info, h->stream));
     h->info_pending = true;
     h->spec_solves = 0;
+    h->factored = true;
     return 0;
 }
 
@@ -387,18 +388,24 @@ static int factor_resolve(cip_handle *h, bool wait) {
         CIP_HIP_CHECK(hipEventSynchronize(h->ev_info));
     }
     h->info_pending = false;
-    int info = *h->info_host;
+    // info_host: [0] first bad pivot of any kind (1-based column), [1] bail-out flag of the sweep kernels,
+    //            [2] first zero / non-finite pivot
+    int info = h->info_host[0];
     if (info == 0) return 0;
     const int spec = h->spec_solves;
-    if (h->auto_reg && h->reg_rel <= 0.0) {
+    if (h->reg_rel > 0.0) {
+        // regularised factor: a wrong-sign pivot (|d| ~ delta, rounding decides its sign) is harmless -- the refinement in
+        // solve3x3 works against the true operator -- but a zero / non-finite one is not
+        if (h->info_host[2] == 0) return 0;
+        info = h->info_host[2];
+    } else if (h->auto_reg) {
         h->reg_rel = getenv("CIP_AUTO_REG") ? atof(getenv("CIP_AUTO_REG")) : CIP_AUTO_REG;
         h->n_regularized += 1;
         int rc;
         if ((rc = factor_enqueue(h))) return rc;
         CIP_HIP_CHECK(hipEventSynchronize(h->ev_info));
         h->info_pending = false;
-        info = *h->info_host;
-        if (info == 0) {
+        if (h->info_host[2] == 0) {
             if (spec > 0) {
                 cip_set_error("LDL': %d solve(s) were enqueued on a factorisation that met a bad pivot; the handle has switched "
                               "to the regularised factorisation -- repeat them", spec);
@@ -406,6 +413,7 @@ static int factor_resolve(cip_handle *h, bool wait) {
             }
             return 0;
         }
+        info = h->info_host[2];
     }
     h->factored = false;
     cip_set_error("LDL': zero, non-finite or wrong-sign pivot at column %d%s", info,

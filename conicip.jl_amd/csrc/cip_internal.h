@@ -68,6 +68,8 @@ struct LdltWorkspace {        // carved out of one device allocation
     double *dinv;             // Npad   1/d
     double *dvec;             // Npad   d
     double *tmp;              // Npad   scratch vector for the solves
+    double *ybuf;             // Npad   forward-sweep result (solve.hip)
+    unsigned *sweep_ctr;      // tickets / arrival counters / flags of the two sweep kernels
     int *info;                // device int: 0 ok, >0 = 1-based column of a bad pivot (zero, non-finite, or of the wrong sign)
     PivotSigns signs;
     unsigned *qcounter;       // device tile counter of the work-queue trailing update

@@ -101,7 +101,11 @@ __device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int l
         // a bad pivot: zero, non-finite, or -- the matrix is quasi-definite in this static order -- of the wrong sign
         const int col = col0 + c + l15;
         const bool want_pos = (col >= sg.p0 && col < sg.p1) || col >= sg.N;
-        if (!(fabs(dsel) > 0.0 && fabs(dsel) < 1.7e308) || (sg.p0 >= 0 && (dsel > 0.0) != want_pos)) atomicCAS(info, 0, col + 1);
+        // info[0]: first bad pivot of any kind; info[2]: first zero / non-finite one (fatal even for a regularised factor,
+        // whose wrong-sign pivots the refinement of solve3x3 absorbs)
+        const bool dead = !(fabs(dsel) > 0.0 && fabs(dsel) < 1.7e308);
+        if (dead || (sg.p0 >= 0 && (dsel > 0.0) != want_pos)) atomicCAS(info, 0, col + 1);
+        if (dead) atomicCAS(info + 2, 0, col + 1);
         a[128 + (c + l15) * DP] = dsel;
         a[129 + (c + l15) * DP] = fast_rcp(dsel);
     }

@@ -138,7 +138,8 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
     CK(cip_factor(h)); ++n_factor;
     CK(D.copy(n, c_d, r0.y)); CK(D.copy(p, d_d, r0.w)); CK(D.copy(m, b_d, r0.v));
     if (m > 0) CIP_HIP_CHECK(hipMemsetAsync(r0.s, 0, sizeof(double) * m, h->stream));
-    CK(cip_factor_resolve(h, 1));          // initial point: one wait (LPs meet their first bad pivot here)
+    // initial point: one wait (LPs meet their first bad pivot here)
+    if ((rc = cip_factor_resolve(h, 1)) != 0) { if (rc == CIP_E_SINGULAR) return finish(CIP_STATUS_ERROR); return rc; }
     CK(cip_solve4x4_dev(h, e, r0.base, z.base)); ++n_solve;
     if (m > 0) {
         double a_v, a_s;
@@ -169,7 +170,10 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
         const int ln[16] = {m, n, n, m, m, n, p, m, p, m, n, n, m, m, p, n};
         double dt[16];
         CK(cip_dots_dev(h, 16, px, py, ln, dt));
-        CK(cip_factor_resolve(h, 1));      // the stream has just been drained: the pivot flag of this iteration's factorisation is in
+        // the stream has just been drained: the pivot flag of this iteration's factorisation is in.  A dead (zero /
+        // non-finite) pivot even after regularisation is where the reference's LU hands back NaNs and the loop ends
+        // with :Error at its next residual check (src/ConicIP.jl:870-873)
+        if ((rc = cip_factor_resolve(h, 1)) != 0) { if (rc == CIP_E_SINGULAR) return finish(CIP_STATUS_ERROR); return rc; }
         const double mubar = dt[0], cTy = dt[1], r0y2 = dt[2], r0v2 = dt[3], r0s2 = dt[4], yQy = dt[5], wr0w = dt[6],
                      vr0v = dt[7], dTw = dt[8], bTv = dt[9], pinf2 = dt[10], yy = dt[11], vv = dt[12], ays2 = dt[13],
                      gy2 = dt[14], qy2 = dt[15];

@@ -87,7 +87,8 @@ size_t cip_ldlt_ws_bytes(int Npad) {
         b += al256(nbk * (size_t)(Bs / 2) * (Bs / 2) * 8 + 256);   // Tt
         b += al256((size_t)Npad * 8);                    // zbuf
     }
-    b += al256((size_t)Npad * 8) * 3;                    // dinv, dvec, tmp
+    b += al256((size_t)Npad * 8) * 4;                    // dinv, dvec, tmp, ybuf
+    b += al256(4 * 2 * (2 + 2 * nblk + (size_t)Npad / 8));  // sweep counters / flags (solve.hip)
     b += al256(64 + 4 * (2 * nblk + 8));                 // info, work-queue counters
     return b;
 }
@@ -110,6 +111,8 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     ws->dinv = (double *)p;  p += al256((size_t)Npad * 8);
     ws->dvec = (double *)p;  p += al256((size_t)Npad * 8);
     ws->tmp = (double *)p;   p += al256((size_t)Npad * 8);
+    ws->ybuf = (double *)p;  p += al256((size_t)Npad * 8);
+    ws->sweep_ctr = (unsigned *)p; p += al256(4 * 2 * (2 + 2 * nblk + (size_t)Npad / 8));
     ws->info = (int *)p;
     ws->qcounter = (unsigned *)(p + 64);
     ws->prof = nullptr;
@@ -125,6 +128,7 @@ int cip_launch_diag_inverse(hipStream_t s, const double *K, long ld, int nblk, c
 int cip_launch_trsm_subst(hipStream_t s, double *Ap, long ld, int rows, const double *L11, const double *xm,
                           const double *dinv, double *W, long ldw);
 #include <stdlib.h>
+#include <string.h>
 
 // right-looking update inside the outer block: after inner panel t, the remaining panel columns of the block
 //   K[c0+128:, c0+128 : C0+wblk] -= W_t[c0+128:, :] * L_t[c0+128 : C0+wblk, :]'        (K = 128, wide and short:
@@ -285,7 +289,7 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
     const int NBO = g_nbo;
     int rc;
     if ((rc = lookahead_init())) return rc;
-    CIP_HIP_CHECK(hipMemsetAsync(ws.info, 0, g_lookahead ? 64 + 4 * (2 * (size_t)(Npad / CIP_NB) + 8) : sizeof(int), s));
+    CIP_HIP_CHECK(hipMemsetAsync(ws.info, 0, g_lookahead ? 64 + 4 * (2 * (size_t)(Npad / CIP_NB) + 8) : 64, s));   // info[1]: sweep bail-out flag
     const size_t wstride = (size_t)Npad * CIP_NBO_MAX;
     const bool la = g_lookahead && Npad - NBO >= g_la_min;
     if (!la) {
@@ -390,7 +394,15 @@ __global__ __launch_bounds__(256) void k_scale_vec(int n, const double *x, const
     if (i < n) y[i] = x[i] * d[i];
 }
 
+int cip_ldlt_solve_sweeps(hipStream_t s, const double *K, int Npad, long ld, const LdltWorkspace &ws, double *rhs);   // solve.hip
+// CIP_SOLVE=sweeps: one persistent kernel per sweep with flag hand-offs between workgroups (solve.hip).  Measured at
+// N = 8192: solve4x4 0.56 ms against 0.31 ms for the block-step form below -- a fan-in + broadcast hop under a
+// streaming load costs 13-14 us (MI355X_MICROARCH.md price list) and a sweep has 16 of them; kept for experiments.
+static int g_solve_steps = -1;
+
 int cip_ldlt_solve(hipStream_t s, const double *K, int Npad, long ld, const LdltWorkspace &ws, double *rhs) {
+    if (g_solve_steps < 0) { const char *e = getenv("CIP_SOLVE"); g_solve_steps = (e && !strcmp(e, "sweeps")) ? 0 : 1; }
+    if (!g_solve_steps) return cip_ldlt_solve_sweeps(s, K, Npad, ld, ws, rhs);
     const int Bs = ws.Bs;
     const int nbk = Npad / Bs;
     const double *X = (Bs == CIP_NB) ? ws.Linv : ws.X;

