@@ -287,6 +287,11 @@ class KKTSystem:
         L.check(self.lib.cip_profile_get(self.h, out))
         return dict(launches=out[0], ms=out[1], flops=out[2])
 
+    def profile_lookahead(self):
+        out = (C.c_double * 4)()
+        L.check(self.lib.cip_profile_lookahead(self.h, out))
+        return dict(busy_ticks=out[0], tiles=out[1], workers=out[2], err=out[3])
+
     def set_timing(self, on):
         L.check(self.lib.cip_set_timing(self.h, int(bool(on))))
 

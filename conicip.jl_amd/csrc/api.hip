@@ -390,6 +390,11 @@ static int factor_resolve(cip_handle *h, bool wait) {
     h->info_pending = false;
     // info_host: [0] first bad pivot of any kind (1-based column), [1] bail-out flag of the sweep kernels,
     //            [2] first zero / non-finite pivot
+    if (h->info_host[3] != 0 || h->info_host[1] != 0) {
+        cip_set_error("LDL': in-launch scheduler gave up waiting (look-ahead %d, sweeps %d)", h->info_host[3], h->info_host[1]);
+        h->factored = false;
+        return CIP_E_HIP;
+    }
     int info = h->info_host[0];
     if (info == 0) return 0;
     const int spec = h->spec_solves;
@@ -780,6 +785,16 @@ extern "C" int cip_profile_trailing(cip_handle *h, int enabled) {
 extern "C" int cip_profile_get(cip_handle *h, double *out3) {
     if (!h || !out3 || !h->ws.prof) { cip_set_error("profiling not enabled"); return CIP_E_INVALID; }
     return cip_ldlt_profile_collect(h->ws.prof, &out3[0], &out3[1], &out3[2]);
+}
+// out4 = [ticks (100 MHz) the persistent workers of the LAST factorisation spent inside tile computations (summed over
+// workers), tiles computed, workers, scheduler error flag]
+int cip_la_read_stats(void *ctrl_dev, hipStream_t s, double *busy_ticks, double *tiles, double *workers, int *err);
+extern "C" int cip_profile_lookahead(cip_handle *h, double *out4) {
+    if (!h || !out4) return CIP_E_INVALID;
+    int err = 0;
+    const int rc = cip_la_read_stats(h->ws.la_ctrl, h->stream, &out4[0], &out4[1], &out4[2], &err);
+    out4[3] = err;
+    return rc;
 }
 extern "C" int cip_set_ldlt_lookahead(int on) { return cip_ldlt_set_lookahead(on); }
 extern "C" int cip_set_ldlt_outer_block(int nbo) { cip_ldlt_set_outer_block(nbo); return cip_ldlt_outer_block(); }

@@ -38,9 +38,8 @@ struct GemmArgs {
     int by, bz;
     long sAy, sAz, sBy, sBz, sCy, sCz;
     int overwrite;               // EPI_ACCUM: C = alpha*acc instead of C += alpha*acc
+    const double *dk;            // lower-triangular trailing update only, optional: A is scaled by dk[k] column-wise (A = L, dk = d)
     double *Ct; long ldct, sCty, sCtz;   // 128-tile EPI_ACCUM only, optional: the result is also stored transposed, Ct[j + i*ldct]
-    unsigned *queue_counter;     // non-NULL: persistent work-queue form (look-ahead trailing update)
-    int reserve;                 // work-queue form: CUs left free per (XCD, SE) pair for the panel chain (0, 1 or 2)
 };
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g);
 
@@ -72,7 +71,7 @@ struct LdltWorkspace {        // carved out of one device allocation
     unsigned *sweep_ctr;      // tickets / arrival counters / flags of the two sweep kernels
     int *info;                // device int: 0 ok, >0 = 1-based column of a bad pivot (zero, non-finite, or of the wrong sign)
     PivotSigns signs;
-    unsigned *qcounter;       // device tile counter of the work-queue trailing update
+    void *la_ctrl;            // device control block of the look-ahead schedule (gemm_f64.hip: LaCtrl + done[])
     LdltProfile *prof;        // host object or NULL
 };
 int cip_ldlt_set_lookahead(int on);

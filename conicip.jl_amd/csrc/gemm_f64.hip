@@ -23,6 +23,7 @@
 //     tiles (bijective variant of the xcd swizzle).
 #include "cip_internal.h"
 #include <stdlib.h>
+#include <mutex>
 
 #define LDS_TILE (CIP_KT * CIP_NB)        // doubles per operand per buffer (2048)
 
@@ -166,8 +167,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_128(GemmArgs g) {
 // 4x the workgroups and a quarter of the per-tile latency of the 128x128 kernel, at twice the LDS
 // traffic per flop -- these launches carry < 10 % of the flops.  Accumulate epilogue only.
 #define SB 64
-template <int EPI = EPI_ACCUM>
-__device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, long i0, long j0) {
+__device__ __forceinline__ v2d ld16_sc1(const double *p) {
+    v2d v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void st16_sc1(double *p, v2d v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+// SC1C: the C tile is read with L1-bypassing loads and written through (`sc1`): tiles handed from workgroup to
+// workgroup inside one launch (k_ldlt_workers).  SCALEA: the A operand is column-scaled on its way into LDS,
+// A[i,k] * dk[k] -- the trailing update then reads W = L D as L (from K itself) times d, no separate W panel.
+template <int EPI = EPI_ACCUM, bool SC1C = false, bool SCALEA = false>
+__device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, long i0, long j0, const double *dk = nullptr) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -179,18 +191,21 @@ __device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, lon
     const double *Ap = g.A + i0 + 2 * rp;
     const double *Bp = g.B + j0 + 2 * rp;
     v2d ra[2], rb[2];
+    double rd[2] = {1.0, 1.0};
     auto gload = [&](int kt) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const long k = (long)kt * CIP_KT + q * 8 + k_ld;
             ra[q] = *(const v2d *)(Ap + k * g.lda);
             rb[q] = *(const v2d *)(Bp + k * g.ldb);
+            if (SCALEA) rd[q] = dk[k];
         }
     };
     auto lstore = [&](int buf) {
         double *la = lds + buf * (2 * CIP_KT * SB);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
+            if (SCALEA) ra[q] *= rd[q];
             *(v2d *)(la + (q * 8 + k_ld) * SB + 2 * rp) = ra[q];
             *(v2d *)(la + CIP_KT * SB + (q * 8 + k_ld) * SB + 2 * rp) = rb[q];
         }
@@ -223,6 +238,23 @@ __device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, lon
         __syncthreads();
     }
     // lane holds, for tile (ti,tj), reg q: row = i0 + wm*32 + 2*l15 + ti, col = j0 + wn*32 + 2*(l4 + 4q) + tj
+    if (SC1C) {
+        v2d cv[2][4];
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                cv[tj][q] = ld16_sc1(g.C + (i0 + wm * 32 + 2 * l15) + (j0 + wn * 32 + 2 * (l4 + 4 * q) + tj) * g.ldc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v2d c = cv[tj][q] + g.alpha * (v2d){acc[0][tj][q], acc[1][tj][q]};
+                st16_sc1(g.C + (i0 + wm * 32 + 2 * l15) + (j0 + wn * 32 + 2 * (l4 + 4 * q) + tj) * g.ldc, c);
+            }
+        return;
+    }
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
@@ -262,6 +294,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_64(GemmArgs g) {
 // profiles separate it from the skinny in-block updates): block b -> 128-tile b/4, quadrant b%4.
 // 5 workgroups (20 waves) per CU; measured against the 128x128-tile kernel at 2 workgroups per CU:
 // 55.0 vs 52.4 TFLOP/s at r = 8192, K = 512 and 53.1 vs 44.0 at K = 256 (tools/gemm_bench.hip, same session).
+template <bool SCALEA>
 __global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
     __builtin_amdgcn_s_setprio(3);       // measured: 58.0 vs 56.6 TFLOP/s without
@@ -269,7 +302,9 @@ __global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64(GemmArgs g) {
     tile_coords((int)(blockIdx.x >> 2), 1, g.M / CIP_NB, bi, bj);
     const int sub = blockIdx.x & 3;
     if (bi == bj && sub == 2) return;            // strictly-upper quadrant of a diagonal tile: never referenced
-    gemm_tile_64(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB);
+    // SCALEA: A = L (from K) scaled by d on its way into LDS -- the operand form of the look-ahead schedule's workers,
+    // on the serial schedule (bit-identical results: the cross-check of the in-launch hand-offs, tests/test_gpu_lookahead.py)
+    gemm_tile_64<EPI_ACCUM, false, SCALEA>(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB, g.dk);
 }
 
 // Batched small products (block-inverse doubling): grid.y x grid.z independent problems, C = alpha A B' (overwrite)
@@ -311,15 +346,13 @@ __global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64p(GemmArgs g, int ps
     gemm_tile_64(g, lds, (long)qi * SB, (long)qj * SB);
 }
 
-// Persistent form of the lower-triangular trailing update for the look-ahead schedule: 5 workgroups per CU pull
-// quarter tiles from an atomic counter, and workgroups that find themselves on a RESERVED CU exit at once, so the
-// reserved CUs stay empty for the whole launch.  The serial panel chain of the next outer block -- whose diagonal
-// kernel needs a CU's entire LDS and otherwise waits until the last workgroup of this grid has been placed --
-// then starts at once on the side stream.  Workgroups are dealt round-robin to the XCDs and, inside an XCD, to the
-// shader engines whatever their occupancy (measured: with the reservation in one SE only, the single-workgroup
-// diagonal kernel started at once in one launch out of four), so EVERY (XCD, SE) pair keeps `reserve` (1 or 2) CUs
-// free.  CU ids differ per SE (harvesting); the ids are found once by a probe launch.  Placement is used for speed
-// only: any workgroup can take any tile.
+// CU reservation for the look-ahead schedule.  The panel chain of the next outer blocks runs beside the persistent
+// trailing-update launch; its diagonal kernel needs a CU's entire LDS and would otherwise wait until a CU has drained.
+// Workgroups are dealt round-robin to the XCDs and, inside an XCD, to the shader engines whatever their occupancy
+// (measured: with the reservation in one SE only, the single-workgroup diagonal kernel started at once in one launch
+// out of four), so EVERY (XCD, SE) pair keeps `reserve` (1 or 2) CUs free: persistent workgroups that find themselves
+// on a reserved CU exit at once.  CU ids differ per SE (harvesting); the ids are found once by a probe launch.
+// Placement is used for speed only: any workgroup can take any tile.
 struct ReserveMap { unsigned char cu[32][2]; };       // [xcc*4 + se][k] = k-th lowest CU id present (0xff: none)
 __global__ void k_probe_cus(unsigned *out) {
     if (threadIdx.x == 0) {
@@ -332,7 +365,9 @@ __global__ void k_probe_cus(unsigned *out) {
 }
 static ReserveMap g_rmap;
 static int g_rmap_ready = 0;
+static std::mutex g_rmap_mutex;
 static int reserve_map_init(void) {
+    std::lock_guard<std::mutex> lock(g_rmap_mutex);
     if (g_rmap_ready) return 0;
     const int nb = 1024;
     unsigned *d = nullptr;
@@ -353,34 +388,235 @@ static int reserve_map_init(void) {
     g_rmap_ready = 1;
     return 0;
 }
-__global__ __launch_bounds__(256, 4) void k_gemm_nt_64_queue(GemmArgs g, int nq, unsigned *counter, int reserve,
-                                                              ReserveMap rm) {
+// ---------------------------------------------------------------------------------------------
+// Deep look-ahead: ONE persistent launch carries every trailing update of a factorisation (ldlt.hip: factor_lookahead).
+//
+// Round J = the update with outer block J:  C[i, j] -= (L[i, J] D_J) L[j, J]'  for all 64x64 tiles (i >= j) of the
+// trailing matrix.  The panel chain of block J+1 (diag / TRSM / in-block kernels, a serial chain of small launches on a
+// high-priority stream, on CUs this kernel leaves free) needs only the column strip of block J+1 updated, so each round
+// is split into a CRITICAL strip (the next outer block's columns) and the BULK (everything to its right), in two
+// queues: a free worker always serves the critical queue first.  The chain therefore never waits for the bulk of any
+// round (the first-generation look-ahead put strip and bulk on one in-order stream: one round of overlap at most),
+// and the bulk of round J runs beside the chain of blocks J+1, J+2, ...
+//
+// Dependencies, all through device memory inside the launch:
+//   flag[J]        set by a tiny kernel at the end of chain J on the chain's stream: L[:, J] and d_J are final.  A worker
+//                  entering round J polls it (`sc1`), then ONE wave does an agent-scope acquire (invalidates the CU's L1)
+//                  before the panel loads (MI355X_MICROARCH.md: consumer = poll -> acquire -> barrier -> plain loads).
+//   done[tile]     rounds completed on that 64x64 tile of K: round J of a tile follows round J-1 of the same tile,
+//                  possibly on another CU / XCD -> the C tile is read with `sc1` loads and written through with `sc1`
+//                  stores, every storing wave drains (`vmcnt(0)`), barrier, one lane publishes done = J+1.
+//   stripdone[S]   completed tile-rounds in the columns of outer block S; the chain of block S starts behind a gate
+//                  kernel that waits for S * tiles(S).
+// A critical tile of round J is handed out only when every round-(J-1) tile of the same strip has been HANDED OUT
+// (bulk queue head beyond that strip), and bulk tiles are handed out in round order: every wait is for a tile some
+// running workgroup already owns, whatever the number of workers.
+#define LA_MAX_ROUNDS 64
+struct LaPlan {
+    int nrounds, nbo, Npad, nt;                 // nt = Npad / 64
+    int crit_start[LA_MAX_ROUNDS + 1];          // prefix sums of the critical-tile counts
+    int bulk_start[LA_MAX_ROUNDS + 1];          // prefix sums of the bulk-tile counts
+    int bulk_first_strip_end[LA_MAX_ROUNDS];    // bulk-queue index where round J's first bulk strip ends
+};
+struct LaCtrl {                                 // device, zeroed before every factorisation
+    unsigned crit_next, bulk_next;
+    int err;
+    unsigned workers_done;
+    unsigned long long busy_ticks, tiles;       // s_memtime ticks (100 MHz) inside tile computations, summed over workers
+    unsigned pad[8];
+    unsigned flag[LA_MAX_ROUNDS + 1];
+    unsigned stripdone[LA_MAX_ROUNDS + 1];
+    // followed by done[nt * nt]
+};
+
+__device__ __forceinline__ unsigned la_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// bounded spin (thread 0 only): returns false after ~1 s and raises ctrl->err, so a logic error cannot hang the GPU
+template <int SLEEP>
+__device__ __forceinline__ bool la_wait_ge(const unsigned *p, unsigned target, LaCtrl *ctrl) {
+    const long t0 = __builtin_amdgcn_s_memtime();
+    while (la_load(p) < target) {
+        __builtin_amdgcn_s_sleep(SLEEP);
+        if (__builtin_amdgcn_s_memtime() - t0 > 100000000L || la_load((const unsigned *)&ctrl->err) != 0) { atomicExch(&ctrl->err, -7); return false; }
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256, 4) void k_ldlt_workers(double *K, long ld, const double *dvec, LaPlan pl, LaCtrl *ctrl,
+                                                          unsigned *done, int reserve, ReserveMap rm) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
-    __shared__ int s_t;
+    __shared__ int s_round, s_ci, s_cj;
     if (reserve) {
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
         const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0x7;
         const unsigned cu = (hw >> 8) & 0xf, gse = xcc * 4 + ((hw >> 13) & 0x3);
         if (cu == rm.cu[gse][0] || (reserve > 1 && cu == rm.cu[gse][1])) return;
     }
-    const int tm = g.M / CIP_NB;
-    while (true) {
-        if (threadIdx.x == 0) s_t = (int)atomicAdd(counter, 1u);
-        __syncthreads();
-        const int t = s_t;
-        if (t >= nq) return;
-        if (g.lower) {
-            int bi, bj;
-            tile_coords(t >> 2, 1, tm, bi, bj);
-            const int sub = t & 3;
-            if (!(bi == bj && sub == 2))
-                gemm_tile_64(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB);
-        } else {
-            const int tm64 = g.M / SB;
-            gemm_tile_64(g, lds, (long)(t % tm64) * SB, (long)(t / tm64) * SB);
+    __builtin_amdgcn_s_setprio(3);
+    const int total_crit = pl.crit_start[pl.nrounds], total_bulk = pl.bulk_start[pl.nrounds];
+    int cur_round = -1;
+    long busy = 0, ntiles = 0;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int round = -1, ci = 0, cj = 0;
+            for (int spins = 0;; ++spins) {
+                // ---- critical queue first
+                const unsigned c = la_load(&ctrl->crit_next);
+                if ((int)c < total_crit) {
+                    int Jc = 0;
+                    while (pl.crit_start[Jc + 1] <= (int)c) ++Jc;
+                    if (la_load(&ctrl->flag[Jc]) && (Jc == 0 || (int)la_load(&ctrl->bulk_next) >= pl.bulk_first_strip_end[Jc - 1])) {
+                        const int t = (int)atomicAdd(&ctrl->crit_next, 1u);
+                        if (t < total_crit) {
+                            int J = Jc;
+                            while (pl.crit_start[J + 1] <= t) ++J;
+                            const int r0q = (J + 1) * (pl.nbo / SB), nq = pl.nt - r0q;     // trailing matrix in 64-tiles
+                            int idx = t - pl.crit_start[J];
+                            cj = 0;
+                            while (idx >= nq - cj) { idx -= nq - cj; ++cj; }              // column-major, rows cj .. nq-1
+                            ci = cj + idx;
+                            ci += r0q; cj += r0q; round = J;
+                            break;
+                        }
+                    }
+                }
+                // ---- bulk queue
+                if ((int)la_load(&ctrl->bulk_next) < total_bulk) {
+                    const int t = (int)atomicAdd(&ctrl->bulk_next, 1u);
+                    if (t < total_bulk) {
+                        int J = 0;
+                        while (pl.bulk_start[J + 1] <= t) ++J;
+                        const int r0q = (J + 1) * (pl.nbo / SB), nq = pl.nt - r0q;
+                        const int sw = (nq < pl.nbo / SB) ? nq : pl.nbo / SB, n2 = nq - sw;  // bulk = columns sw .. nq-1
+                        const int idx = t - pl.bulk_start[J];
+                        // column c of the n2 x n2 lower triangle starts at c*n2 - c(c-1)/2
+                        int cc = (int)(((2.0 * n2 + 1.0) - sqrt((2.0 * n2 + 1.0) * (2.0 * n2 + 1.0) - 8.0 * (double)idx)) * 0.5);
+                        if (cc < 0) cc = 0;
+                        if (cc > n2 - 1) cc = n2 - 1;
+                        while (cc > 0 && cc * n2 - cc * (cc - 1) / 2 > idx) --cc;
+                        while (cc + 1 < n2 && (cc + 1) * n2 - (cc + 1) * cc / 2 <= idx) ++cc;
+                        const int rr = idx - (cc * n2 - cc * (cc - 1) / 2);
+                        cj = r0q + sw + cc; ci = cj + rr; round = J;
+                        break;
+                    }
+                }
+                if ((int)c >= total_crit) { round = -2; break; }          // both queues exhausted
+                if (la_load((const unsigned *)&ctrl->err) != 0) { round = -2; break; }
+                if (spins < 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(100);   // nothing to hand out yet: the chain is the bottleneck
+                if (spins > 4000000) { atomicExch(&ctrl->err, -8); round = -2; break; }
+            }
+            if (round >= 0) {
+                bool ok = la_wait_ge<4>(&ctrl->flag[round], 1u, ctrl);                          // L[:, J], d_J final
+                ok = ok && la_wait_ge<2>(done + (long)ci * pl.nt + cj, (unsigned)round, ctrl);  // round J-1 of this tile
+                if (!ok) round = -2;
+                else if (round != cur_round) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            s_round = round; s_ci = ci; s_cj = cj;
         }
-        __syncthreads();      // LDS buffers and s_t are reused by the next tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int J = s_round;
+        if (J < 0) break;
+        cur_round = J;
+        const long t0 = __builtin_amdgcn_s_memtime();
+        {
+            const long C0 = (long)J * pl.nbo;
+            GemmArgs g = {};
+            g.A = K + C0 * ld; g.lda = ld;
+            g.B = K + C0 * ld; g.ldb = ld;
+            g.C = K; g.ldc = ld;
+            g.K = pl.nbo; g.alpha = -1.0;
+            gemm_tile_64<EPI_ACCUM, true, true>(g, lds, (long)s_ci * SB, (long)s_cj * SB, dvec + C0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(done + (long)s_ci * pl.nt + s_cj, (unsigned)(J + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(&ctrl->stripdone[s_cj / (pl.nbo / SB)], 1u);
+            busy += __builtin_amdgcn_s_memtime() - t0; ++ntiles;
+        }
     }
+    if (threadIdx.x == 0) {
+        atomicAdd(&ctrl->busy_ticks, (unsigned long long)busy);
+        atomicAdd(&ctrl->tiles, (unsigned long long)ntiles);
+        atomicAdd(&ctrl->workers_done, 1u);
+    }
+}
+
+// chain side: publish "block J is final" / wait for the strip of block S
+__global__ void k_la_signal(unsigned *flag) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_la_gate(const unsigned *counter, unsigned target, LaCtrl *ctrl) {
+    if (threadIdx.x == 0) (void)la_wait_ge<2>(counter, target, ctrl);
+}
+
+size_t cip_la_ctrl_bytes(int Npad) { return sizeof(LaCtrl) + sizeof(unsigned) * (size_t)(Npad / SB) * (Npad / SB); }
+
+static int g_ncu = 0;
+int cip_la_launch_workers(hipStream_t s, double *K, int Npad, long ld, const double *dvec, int nbo, void *ctrl_dev, int reserve) {
+    LaPlan pl = {};
+    pl.nbo = nbo; pl.Npad = Npad; pl.nt = Npad / SB;
+    const int nblocks = (Npad + nbo - 1) / nbo;
+    pl.nrounds = nblocks - 1;
+    if (pl.nrounds > LA_MAX_ROUNDS) { cip_set_error("look-ahead: too many outer blocks (%d)", nblocks); return -1; }
+    const int swq = nbo / SB;
+    for (int J = 0; J < pl.nrounds; ++J) {
+        const int nq = pl.nt - (J + 1) * swq;
+        const int sw = nq < swq ? nq : swq, n2 = nq - sw;
+        pl.crit_start[J + 1] = pl.crit_start[J] + sw * nq - sw * (sw - 1) / 2;
+        pl.bulk_start[J + 1] = pl.bulk_start[J] + n2 * (n2 + 1) / 2;
+        const int s2 = n2 < swq ? n2 : swq;                  // the first bulk strip = the next round's critical strip
+        pl.bulk_first_strip_end[J] = pl.bulk_start[J] + s2 * n2 - s2 * (s2 - 1) / 2;
+    }
+    if (!g_ncu) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        CIP_HIP_CHECK(hipGetDevice(&dev));
+        CIP_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        g_ncu = prop.multiProcessorCount;
+    }
+    if (reserve && reserve_map_init()) return -1;
+    LaCtrl *ctrl = (LaCtrl *)ctrl_dev;
+    long total = (long)pl.crit_start[pl.nrounds] + pl.bulk_start[pl.nrounds];
+    long grid = (long)g_ncu * 5;                             // 32 KB of LDS each: 5 per CU
+    if (grid > total) grid = total;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_ldlt_workers, dim3((unsigned)grid), dim3(256), 0, s, K, ld, dvec, pl, ctrl,
+                       (unsigned *)((char *)ctrl_dev + sizeof(LaCtrl)), reserve, g_rmap);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int cip_la_signal(hipStream_t s, void *ctrl_dev, int J) {
+    hipLaunchKernelGGL(k_la_signal, dim3(1), dim3(64), 0, s, &((LaCtrl *)ctrl_dev)->flag[J]);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+// wait until every tile of the column strip of outer block S has received the updates of rounds 0 .. S-1
+int cip_la_gate(hipStream_t s, void *ctrl_dev, int Npad, int nbo, int S) {
+    const int swq = nbo / SB, nq = Npad / SB - S * swq;
+    const int sw = nq < swq ? nq : swq;
+    const unsigned target = (unsigned)S * (unsigned)(sw * nq - sw * (sw - 1) / 2);
+    hipLaunchKernelGGL(k_la_gate, dim3(1), dim3(64), 0, s, &((LaCtrl *)ctrl_dev)->stripdone[S], target, (LaCtrl *)ctrl_dev);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+__global__ void k_la_finish(const LaCtrl *ctrl, int *info) {
+    if (threadIdx.x == 0 && ctrl->err != 0) info[3] = ctrl->err;
+}
+int cip_la_finish(hipStream_t s, void *ctrl_dev, int *info) {
+    hipLaunchKernelGGL(k_la_finish, dim3(1), dim3(64), 0, s, (const LaCtrl *)ctrl_dev, info);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int cip_la_read_stats(void *ctrl_dev, hipStream_t s, double *busy_ticks, double *tiles, double *workers, int *err) {
+    LaCtrl h;
+    CIP_HIP_CHECK(hipMemcpyAsync(&h, ctrl_dev, sizeof(LaCtrl), hipMemcpyDeviceToHost, s));
+    CIP_HIP_CHECK(hipStreamSynchronize(s));
+    if (busy_ticks) *busy_ticks = (double)h.busy_ticks;
+    if (tiles) *tiles = (double)h.tiles;
+    if (workers) *workers = (double)h.workers_done;
+    if (err) *err = h.err;
+    return 0;
 }
 
 static int g_tile = -1;
@@ -412,25 +648,6 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     }
     // CIP_GEMM_TILE=128: the lower-triangular update on the 128x128 kernel (kept for A/B runs of tools/gemm_bench.hip)
     if (g_tile < 0) g_tile = (getenv("CIP_GEMM_TILE") && atoi(getenv("CIP_GEMM_TILE")) == 128) ? 128 : 64;
-    if (epi == EPI_ACCUM && g.queue_counter && !g.overwrite) {
-        // persistent work-queue form (look-ahead schedule); the caller hands over a zeroed counter
-        static int ncu = 0;
-        if (!ncu) {
-            hipDeviceProp_t prop;
-            int dev = 0;
-            CIP_HIP_CHECK(hipGetDevice(&dev));
-            CIP_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-            ncu = prop.multiProcessorCount;
-        }
-        const long nq = 4 * tiles;
-        long grid = (long)ncu * 5;                    // 32 KB of LDS each: 5 per CU, the whole grid is co-resident
-        if (grid > nq) grid = nq;
-        if (g.reserve && reserve_map_init()) return -1;
-        hipLaunchKernelGGL(k_gemm_nt_64_queue, dim3((unsigned)grid), dim3(256), 0, s, g, (int)nq, g.queue_counter, g.reserve,
-                           g_rmap);
-        CIP_HIP_CHECK(hipGetLastError());
-        return 0;
-    }
     if (epi == EPI_ACCUM && g.lower && g_tile == 64) {
         // the LDL' trailing update: every 128-tile of the lower triangle as four 64x64 quarter tiles
         // Optional XCD-aware patch order (CIP_TRAIL_PATCH=4 or 8).  PMC at r = 8192, K = 512: 1.52 GB of L2-miss
@@ -447,7 +664,8 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
             CIP_HIP_CHECK(hipGetLastError());
             return 0;
         }
-        hipLaunchKernelGGL(k_ldlt_trailing_64, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
+        if (g.dk) hipLaunchKernelGGL(k_ldlt_trailing_64<true>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
+        else hipLaunchKernelGGL(k_ldlt_trailing_64<false>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }

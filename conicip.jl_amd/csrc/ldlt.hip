@@ -74,6 +74,7 @@ int cip_solve_block(int Npad) {
     return CIP_NB;
 }
 
+size_t cip_la_ctrl_bytes(int Npad);
 size_t cip_ldlt_ws_bytes(int Npad) {
     const size_t nblk = Npad / CIP_NB;
     size_t b = 0;
@@ -89,7 +90,8 @@ size_t cip_ldlt_ws_bytes(int Npad) {
     }
     b += al256((size_t)Npad * 8) * 4;                    // dinv, dvec, tmp, ybuf
     b += al256(4 * 2 * (2 + 2 * nblk + (size_t)Npad / 8));  // sweep counters / flags (solve.hip)
-    b += al256(64 + 4 * (2 * nblk + 8));                 // info, work-queue counters
+    b += al256(64);                                      // info
+    b += al256(cip_la_ctrl_bytes(Npad));                 // look-ahead control block (gemm_f64.hip: LaCtrl + done[])
     return b;
 }
 
@@ -113,8 +115,8 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     ws->tmp = (double *)p;   p += al256((size_t)Npad * 8);
     ws->ybuf = (double *)p;  p += al256((size_t)Npad * 8);
     ws->sweep_ctr = (unsigned *)p; p += al256(4 * 2 * (2 + 2 * nblk + (size_t)Npad / 8));
-    ws->info = (int *)p;
-    ws->qcounter = (unsigned *)(p + 64);
+    ws->info = (int *)p;     p += al256(64);
+    ws->la_ctrl = (void *)p;
     ws->prof = nullptr;
     ws->signs = PivotSigns{-1, 0, 0};
     ws->x_zeroed = nullptr;
@@ -168,49 +170,53 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
     return 0;
 }
 
-// Look-ahead plumbing: the panel chain (diag -> TRSM -> strip, serial, tiny grids) runs on a high-priority
-// side stream while the big trailing update of the previous outer block runs on the caller's stream.
-// One process-wide side stream and event ring (factorisations of one process are issued from one thread).
-static thread_local hipStream_t g_side = nullptr;      // panel chain: high priority (one per host thread: handles of a batch factor concurrently)
-static thread_local hipEvent_t g_evP[2] = {nullptr, nullptr}, g_evU[2] = {nullptr, nullptr};
-static thread_local hipEvent_t g_evStart = nullptr;
-static int g_lookahead = -1;
-static int g_queue = 0;                   // CIP_GEMM_QUEUE=1: persistent work-queue trailing update
-static int g_reserve_fixed = 0;           // CIP_RESERVE given: use it for every block
-static int g_la_min = 3072;               // look-ahead only while the trailing matrix has at least this many rows
-static int g_reserve = 0;                 // CUs per XCD kept free by the work-queue trailing update (0 = plain launch)
-// run-time switch of the schedule (bench.py measures both in one process); -1 = not decided yet (environment)
-int cip_ldlt_set_lookahead(int on) {
-    const int prev = g_lookahead;
-    g_lookahead = on ? 1 : 0;
-    g_reserve = on ? 2 : 0;
-    if (const char *e = getenv("CIP_RESERVE")) { if (on) { g_reserve = atoi(e); g_reserve_fixed = 1; } }
+// Look-ahead plumbing.  The panel chain (diag -> TRSM -> in-block update, serial, small grids) runs on a high-priority
+// side stream; every trailing update of the factorisation is carried by ONE persistent launch on the caller's stream
+// (gemm_f64.hip: k_ldlt_workers) that leaves `reserve` CUs per (XCD, SE) pair to the chain.
+// The side stream and its events belong to the calling host thread (handles of a batch factor concurrently from
+// several threads; a thread's objects are destroyed when it exits); the process-wide switches are set once.
+#include <mutex>
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_chain = nullptr;
+    ~SideStream() {
+        if (ev_start) (void)hipEventDestroy(ev_start);
+        if (ev_chain) (void)hipEventDestroy(ev_chain);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+static thread_local SideStream g_side;
+static std::once_flag g_la_once;
+static int g_lookahead = 1;               // default schedule for Npad >= g_la_min (CIP_LOOKAHEAD=0: serial everywhere)
+static int g_la_min = 4096;               // below this order a factorisation is chain-bound whatever the schedule
+static int g_reserve = 2;                 // CUs per (XCD, SE) pair left to the chain: 1 -> 32 CUs, 2 -> 64
+static void lookahead_env(void) {
+    if (const char *e = getenv("CIP_LOOKAHEAD")) g_lookahead = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("CIP_RESERVE")) { const int r = atoi(e); if (r >= 0 && r <= 2) g_reserve = r; }
     if (const char *e = getenv("CIP_LA_MIN")) g_la_min = atoi(e);
-    g_queue = g_reserve ? 1 : 0;
+}
+// run-time switch of the schedule (bench.py measures both in one process); returns the previous setting
+int cip_ldlt_set_lookahead(int on) {
+    std::call_once(g_la_once, lookahead_env);
+    const int prev = g_lookahead;
+    g_lookahead = (on == 2) ? 2 : (on ? 1 : 0);      // 2: serial schedule with the workers' operand form (tests)
     return prev;
 }
 static int lookahead_init(void) {
-    // Opt-in (CIP_LOOKAHEAD=1); the serial single-stream schedule is the default.  Same-session A/B at n = 8192:
-    // 133.2 vs 125.3 KKT solves/s (factorisation 6.56 vs 7.0 ms) with CIP_RESERVE=2, but the trailing-update kernel
-    // then runs at 38 instead of 51 TFLOP/s because it gives 64 CUs to the panel chain -- see DESIGN.md.
-    if (g_lookahead < 0) {
-        g_lookahead = getenv("CIP_LOOKAHEAD") ? 1 : 0;
-        g_reserve = g_lookahead ? 2 : 0;      // CUs per (XCD, SE) the persistent trailing update keeps free: 32 or 64 in all
-        if (const char *e = getenv("CIP_RESERVE")) { g_reserve = atoi(e); g_reserve_fixed = 1; }
-        if (const char *e = getenv("CIP_LA_MIN")) g_la_min = atoi(e);
-        g_queue = getenv("CIP_GEMM_QUEUE") ? atoi(getenv("CIP_GEMM_QUEUE")) : (g_reserve ? 1 : 0);
-    }
-    if (!g_lookahead || g_side) return 0;     // the stream and the events are per host thread
+    if (g_side.stream) return 0;
     int lo = 0, hi = 0;
     CIP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    CIP_HIP_CHECK(hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, hi));
-    for (int i = 0; i < 2; ++i) {
-        CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evP[i], hipEventDisableTiming));
-        CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evU[i], hipEventDisableTiming));
-    }
-    CIP_HIP_CHECK(hipEventCreateWithFlags(&g_evStart, hipEventDisableTiming));
+    CIP_HIP_CHECK(hipStreamCreateWithPriority(&g_side.stream, hipStreamNonBlocking, hi));
+    CIP_HIP_CHECK(hipEventCreateWithFlags(&g_side.ev_start, hipEventDisableTiming));
+    CIP_HIP_CHECK(hipEventCreateWithFlags(&g_side.ev_chain, hipEventDisableTiming));
     return 0;
 }
+// gemm_f64.hip
+size_t cip_la_ctrl_bytes(int Npad);
+int cip_la_launch_workers(hipStream_t s, double *K, int Npad, long ld, const double *dvec, int nbo, void *ctrl_dev, int reserve);
+int cip_la_signal(hipStream_t s, void *ctrl_dev, int J);
+int cip_la_gate(hipStream_t s, void *ctrl_dev, int Npad, int nbo, int S);
+int cip_la_finish(hipStream_t s, void *ctrl_dev, int *info);
 
 // upper triangle <- (strictly lower triangle)': gives the forward sweep the same coalesced
 // "column-dot" access as the backward sweep (U[k, i] = L[i, k])
@@ -288,10 +294,9 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
     if (Npad % CIP_NB) { cip_set_error("ldlt: N must be a multiple of 128"); return -1; }
     const int NBO = g_nbo;
     int rc;
-    if ((rc = lookahead_init())) return rc;
-    CIP_HIP_CHECK(hipMemsetAsync(ws.info, 0, g_lookahead ? 64 + 4 * (2 * (size_t)(Npad / CIP_NB) + 8) : 64, s));   // info[1]: sweep bail-out flag
-    const size_t wstride = (size_t)Npad * CIP_NBO_MAX;
-    const bool la = g_lookahead && Npad - NBO >= g_la_min;
+    std::call_once(g_la_once, lookahead_env);
+    CIP_HIP_CHECK(hipMemsetAsync(ws.info, 0, 64, s));      // [0] bad pivot, [1] sweep bail-out, [2] dead pivot, [3] look-ahead scheduler
+    const bool la = g_lookahead == 1 && Npad >= g_la_min && Npad > 2 * NBO && NBO % 64 == 0;
     if (!la) {
         // serial right-looking schedule: panels of the outer block, then ONE trailing update
         for (int C0 = 0; C0 < Npad; C0 += NBO) {
@@ -304,6 +309,7 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
                 g.B = K + r0 + (long)C0 * ld; g.ldb = ld;
                 g.C = K + r0 + (long)r0 * ld; g.ldc = ld;
                 g.M = Npad - r0; g.N = Npad - r0; g.K = wblk; g.alpha = -1.0; g.lower = 1;
+                if (g_lookahead == 2) { g.A = K + r0 + (long)C0 * ld; g.lda = ld; g.dk = ws.dvec + C0; }   // the workers' operand form
                 if (ws.prof) {
                     if ((rc = prof_event(ws.prof, s))) return rc;
                     const double r = (double)(Npad - r0);
@@ -317,71 +323,32 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
             return rc;
         return build_solve_blocks(s, K, Npad, ld, ws);
     }
-    // Look-ahead schedule: the panel chain of outer block J+1 runs on the high-priority side stream beside the
-    // trailing update of block J (persistent form, reserved CUs), for as long as the trailing matrix is large enough
-    // for that update to cover the chain; below g_la_min rows the blocks are chain-bound either way and the plain
-    // serial order is faster (measured per-block periods).
-    hipStream_t sp = g_side;
-    CIP_HIP_CHECK(hipEventRecord(g_evStart, s));
-    CIP_HIP_CHECK(hipStreamWaitEvent(sp, g_evStart, 0));
-    {
-        const int wblk = (Npad < NBO) ? Npad : NBO;
-        if ((rc = factor_outer_panels(sp, K, Npad, ld, ws, ws.Wbuf, 0, wblk))) return rc;
-        CIP_HIP_CHECK(hipEventRecord(g_evP[0], sp));
+    // Deep look-ahead (default for Npad >= 4096): the persistent worker launch on the caller's stream carries all
+    // trailing updates, the panel chain of every outer block runs on the side stream behind a gate that waits for its
+    // column strip only (see gemm_f64.hip: k_ldlt_workers for the dependency protocol).
+    if ((rc = lookahead_init())) return rc;
+    hipStream_t sp = g_side.stream;
+    CIP_HIP_CHECK(hipMemsetAsync(ws.la_ctrl, 0, cip_la_ctrl_bytes(Npad), s));
+    CIP_HIP_CHECK(hipEventRecord(g_side.ev_start, s));
+    CIP_HIP_CHECK(hipStreamWaitEvent(sp, g_side.ev_start, 0));
+    if (ws.prof) {
+        if ((rc = prof_event(ws.prof, s))) return rc;
+        double fl = 0;
+        for (int C0 = 0; C0 + NBO < Npad; C0 += NBO) { const double r = (double)(Npad - C0 - NBO); fl += r * (r + 1.0) * (double)NBO; }
+        ws.prof->flops.push_back(fl);
     }
+    if ((rc = cip_la_launch_workers(s, K, Npad, ld, ws.dvec, NBO, ws.la_ctrl, g_reserve))) return rc;
+    if (ws.prof && (rc = prof_event(ws.prof, s))) return rc;
     int J = 0;
     for (int C0 = 0; C0 < Npad; C0 += NBO, ++J) {
-        const int wblk = (Npad - C0 < NBO) ? (Npad - C0) : NBO;     // width of this outer block
-        const int r0 = C0 + wblk;
-        if (r0 >= Npad) break;
-        const int w1 = (Npad - r0 < NBO) ? (Npad - r0) : NBO;       // width of the next outer block
-        double *Wcur = ws.Wbuf + (size_t)(J & 1) * wstride;
-        double *Wnext = ws.Wbuf + (size_t)((J + 1) & 1) * wstride;
-        CIP_HIP_CHECK(hipStreamWaitEvent(s, g_evP[J & 1], 0));      // panel J (wherever it was factored)
-        const bool ahead = Npad - r0 >= g_la_min;
-        auto trailing = [&](int from, unsigned *qc) -> int {        // K[from:, from:] -= W[from:, :] L[from:, C0:C0+wblk]'
-            GemmArgs g = {};
-            g.A = Wcur + from; g.lda = Npad;
-            g.B = K + from + (long)C0 * ld; g.ldb = ld;
-            g.C = K + from + (long)from * ld; g.ldc = ld;
-            g.M = Npad - from; g.N = Npad - from; g.K = wblk; g.alpha = -1.0; g.lower = 1;
-            // reserved CUs per (XCD, SE): one while the update is long enough to cover a chain squeezed onto 32 CUs
-            // (top blocks), two below (CIP_RESERVE fixes the number)
-            if (qc) { g.queue_counter = qc; g.reserve = g_reserve_fixed ? g_reserve : (Npad - from >= 6144 ? 1 : 2); }
-            int e;
-            if (ws.prof) {
-                if ((e = prof_event(ws.prof, s))) return e;
-                const double r = (double)(Npad - from);
-                ws.prof->flops.push_back(r * (r + 1.0) * (double)wblk);   // 2 flop/MAC on the lower triangle
-            }
-            if ((e = cip_launch_gemm(s, EPI_ACCUM, g))) return e;
-            return ws.prof ? prof_event(ws.prof, s) : 0;
-        };
-        if (!ahead) {
-            // serial order from here on: whole trailing update, then the next panel, both on the caller's stream
-            if ((rc = trailing(r0, nullptr))) return rc;
-            if ((rc = factor_outer_panels(s, K, Npad, ld, ws, Wnext, r0, w1))) return rc;
-            CIP_HIP_CHECK(hipEventRecord(g_evP[(J + 1) & 1], s));
-            continue;
-        }
-        {
-            // U1: the column strip of the NEXT outer block first (all its rows), so that its panel factorisation can
-            // start while the rest of the trailing matrix is still being updated
-            GemmArgs g = {};
-            g.A = Wcur + r0; g.lda = Npad;
-            g.B = K + r0 + (long)C0 * ld; g.ldb = ld;
-            g.C = K + r0 + (long)r0 * ld; g.ldc = ld;
-            g.M = Npad - r0; g.N = w1; g.K = wblk; g.alpha = -1.0; g.lower = 0;
-            if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
-        }
-        CIP_HIP_CHECK(hipEventRecord(g_evU[J & 1], s));
-        CIP_HIP_CHECK(hipStreamWaitEvent(sp, g_evU[J & 1], 0));
-        if ((rc = factor_outer_panels(sp, K, Npad, ld, ws, Wnext, r0, w1))) return rc;
-        CIP_HIP_CHECK(hipEventRecord(g_evP[(J + 1) & 1], sp));
-        // U2: the rest of the trailing matrix beside the chain (persistent form: leaves the reserved CUs to it)
-        if (r0 + w1 < Npad && (rc = trailing(r0 + w1, g_queue ? ws.qcounter + J : nullptr))) return rc;
+        const int wblk = (Npad - C0 < NBO) ? (Npad - C0) : NBO;
+        if (J > 0 && (rc = cip_la_gate(sp, ws.la_ctrl, Npad, NBO, J))) return rc;
+        if ((rc = factor_outer_panels(sp, K, Npad, ld, ws, ws.Wbuf, C0, wblk))) return rc;
+        if (C0 + wblk < Npad && (rc = cip_la_signal(sp, ws.la_ctrl, J))) return rc;
     }
-    CIP_HIP_CHECK(hipStreamWaitEvent(s, g_evP[J & 1], 0));
+    CIP_HIP_CHECK(hipEventRecord(g_side.ev_chain, sp));
+    CIP_HIP_CHECK(hipStreamWaitEvent(s, g_side.ev_chain, 0));
+    if ((rc = cip_la_finish(s, ws.la_ctrl, ws.info))) return rc;
     if ((rc = cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.Linv, ws.LinvT)))
         return rc;
     return build_solve_blocks(s, K, Npad, ld, ws);

@@ -1,0 +1,120 @@
+"""The deep look-ahead schedule of the blocked LDL' (ldlt.hip: one persistent worker launch for every trailing update,
+the panel chain on a side stream; gemm_f64.hip: k_ldlt_workers).  Inside that launch 64x64 tiles of K are handed from
+workgroup to workgroup, round after round, through device-memory flags -- so the test that matters is a BIT-FOR-BIT
+comparison with the serial schedule running the same arithmetic (mode 2: one plain launch per trailing update, same
+operand form): a single stale read anywhere changes bits.  Repeated, and under a concurrent memory-streaming load."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import cipkkt
+    return cipkkt._lib.load()
+
+
+def _factor(lib, dK0, N, mode, ws):
+    from cipkkt import _lib as L
+    prev = lib.cip_set_ldlt_lookahead(mode)
+    dK = dK0.clone()
+    info = C.c_int(-1)
+    L.check(lib.cip_ldlt_factor_dev(None, dK.data_ptr(), N, N, ws.data_ptr(), C.byref(info)))
+    torch.cuda.synchronize()
+    lib.cip_set_ldlt_lookahead(prev)
+    assert info.value == 0
+    return dK
+
+
+def _spd(N, seed, quasi=0):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    M = torch.randn(N, N, generator=g, dtype=torch.float64, device="cuda")
+    K = M @ M.t() / N + torch.eye(N, dtype=torch.float64, device="cuda")
+    if quasi:                                   # [S G'; G 0]: the last `quasi` pivots are negative
+        K[N - quasi:, N - quasi:] = 0.0
+    return K.contiguous()                       # symmetric: row-major == column-major
+
+
+@pytest.mark.parametrize("N,quasi", [(4096, 0), (4608, 512), (8192, 0), (5120, 0)])
+def test_lookahead_bitwise_equals_serial(lib, N, quasi):
+    from cipkkt import _lib as L
+    nbytes = C.c_size_t()
+    L.check(lib.cip_ldlt_workspace_bytes(N, C.byref(nbytes)))
+    ws = torch.zeros(nbytes.value // 8 + 8, dtype=torch.float64, device="cuda")
+    K0 = _spd(N, N + quasi, quasi)
+    ref = _factor(lib, K0, N, 2, ws)
+    low = torch.tril(ref)
+    for rep in range(4):
+        got = _factor(lib, K0, N, 1, ws)
+        assert torch.equal(torch.tril(got.t()), torch.tril(ref.t())), "repetition %d differs from the serial schedule" % rep
+    # and it is a factorisation: L D L' = K  (sampled rows: the full product at N = 8192 is setup-sized work)
+    F = ref.t()                                  # column-major buffer viewed row-major = transpose
+    Lf = torch.tril(F, -1) + torch.eye(N, dtype=torch.float64, device="cuda")
+    D = torch.diagonal(F).clone()
+    rows = torch.arange(0, N, 97, device="cuda")
+    rec = (Lf[rows] * D[None, :]) @ Lf.t()
+    want = K0[rows]
+    mask = torch.arange(N, device="cuda")[None, :] <= rows[:, None]
+    err = ((rec - want) * mask).abs().max() / K0.abs().max()
+    assert err < 1e-12, float(err)
+    del low
+
+
+def test_lookahead_under_memory_streaming_load(lib):
+    """The hand-offs must survive an uneven, L1-warm, bandwidth-loaded chip: a second stream copies 1 GiB buffers
+    back and forth while the factorisation runs."""
+    from cipkkt import _lib as L
+    N = 6144
+    nbytes = C.c_size_t()
+    L.check(lib.cip_ldlt_workspace_bytes(N, C.byref(nbytes)))
+    ws = torch.zeros(nbytes.value // 8 + 8, dtype=torch.float64, device="cuda")
+    K0 = _spd(N, 77)
+    ref = _factor(lib, K0, N, 2, ws)
+    a = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+    b = torch.empty_like(a)
+    side = torch.cuda.Stream()
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                b.copy_(a)
+                a.copy_(b)
+        got = _factor(lib, K0, N, 1, ws)
+        side.synchronize()
+        assert torch.equal(torch.tril(got.t()), torch.tril(ref.t()))
+
+
+def test_lookahead_through_the_kkt_path_n8192():
+    """Level 2 + 3 of the plugin at the headline size under both schedules: same solution to rounding, worker stats sane."""
+    import cipkkt
+    from cipkkt import workloads as W
+    n = 8192
+    Q, c, A, b, K = W.c2_problem(n, seed=99, device="cuda")
+    ks = cipkkt.KKTSystem(Q, A, None, K)
+    lib = ks.lib
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    v = torch.rand(n, generator=g, dtype=torch.float64, device="cuda") + 0.05
+    s = torch.rand(n, generator=g, dtype=torch.float64, device="cuda") + 0.05
+    rhs = torch.randn(3 * n, generator=g, dtype=torch.float64, device="cuda")
+    lam = torch.zeros(n, dtype=torch.float64, device="cuda")
+    outs = []
+    for mode in (0, 1):
+        prev = lib.cip_set_ldlt_lookahead(mode)
+        dz = torch.zeros(3 * n, dtype=torch.float64, device="cuda")
+        ks.set_scaling_from_iterate(v, s, lam)
+        ks.factor()
+        ks.solve4x4_dev(lam, rhs, dz)
+        ks.check_factor()
+        outs.append(dz.cpu().numpy())
+        if mode == 1:
+            st = ks.profile_lookahead()
+            assert st["err"] == 0 and st["workers"] >= 5 * 128 and st["tiles"] == sum(
+                (128 - 8 * (J + 1)) * (128 - 8 * (J + 1) + 1) // 2 for J in range(15))
+        lib.cip_set_ldlt_lookahead(prev)
+    np.testing.assert_allclose(outs[1], outs[0], rtol=1e-9, atol=1e-11)
+    ks.close()
