@@ -167,14 +167,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_128(GemmArgs g) {
 // 4x the workgroups and a quarter of the per-tile latency of the 128x128 kernel, at twice the LDS
 // traffic per flop -- these launches carry < 10 % of the flops.  Accumulate epilogue only.
 #define SB 64
-__device__ __forceinline__ v2d ld16_sc1(const double *p) {
-    v2d v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ void st16_sc1(double *p, v2d v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
 // SC1C: the C tile is read with L1-bypassing loads and written through (`sc1`): tiles handed from workgroup to
 // workgroup inside one launch (k_ldlt_workers).  SCALEA: the A operand is column-scaled on its way into LDS,
 // A[i,k] * dk[k] -- the trailing update then reads W = L D as L (from K itself) times d, no separate W panel.
@@ -239,19 +231,29 @@ __device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, lon
     }
     // lane holds, for tile (ti,tj), reg q: row = i0 + wm*32 + 2*l15 + ti, col = j0 + wn*32 + 2*(l4 + 4q) + tj
     if (SC1C) {
-        v2d cv[2][4];
+        // agent-scope relaxed atomics = `global_load/store_dwordx2 ... sc1` the compiler schedules and waits for itself
+        // (a hand-written asm load is invisible to its s_waitcnt / spill logic: the first version of this epilogue
+        // produced garbage whenever the register allocator moved an asm result before the manual wait)
+        // four passes of 4 loads in flight: the register budget of five workgroups per CU (102) leaves no room for more
+        const long rowo = i0 + wm * 32 + 2 * l15;
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                cv[tj][q] = ld16_sc1(g.C + (i0 + wm * 32 + 2 * l15) + (j0 + wn * 32 + 2 * (l4 + 4 * q) + tj) * g.ldc);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int qh = 0; qh < 2; ++qh) {
+                double cv[2][2];
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
+                for (int qq = 0; qq < 2; ++qq) {
+                    const double *cp = g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * (2 * qh + qq)) + tj) * g.ldc;
+                    cv[qq][0] = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cv[qq][1] = __hip_atomic_load(cp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const v2d c = cv[tj][q] + g.alpha * (v2d){acc[0][tj][q], acc[1][tj][q]};
-                st16_sc1(g.C + (i0 + wm * 32 + 2 * l15) + (j0 + wn * 32 + 2 * (l4 + 4 * q) + tj) * g.ldc, c);
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int q = 2 * qh + qq;
+                    double *cp = g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * q) + tj) * g.ldc;
+                    __hip_atomic_store(cp, cv[qq][0] + g.alpha * acc[0][tj][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cp + 1, cv[qq][1] + g.alpha * acc[1][tj][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         return;
     }
@@ -412,12 +414,21 @@ static int reserve_map_init(void) {
 // (bulk queue head beyond that strip), and bulk tiles are handed out in round order: every wait is for a tile some
 // running workgroup already owns, whatever the number of workers.
 #define LA_MAX_ROUNDS 64
-struct LaPlan {
-    int nrounds, nbo, Npad, nt;                 // nt = Npad / 64
-    int crit_start[LA_MAX_ROUNDS + 1];          // prefix sums of the critical-tile counts
-    int bulk_start[LA_MAX_ROUNDS + 1];          // prefix sums of the bulk-tile counts
-    int bulk_first_strip_end[LA_MAX_ROUNDS];    // bulk-queue index where round J's first bulk strip ends
-};
+// Queue geometry, recomputed on the fly by the scheduling lane (at most nrounds iterations of integer arithmetic per
+// tile: no table in LDS -- the GEMM's 32 KB are all a workgroup may use if five are to share a CU).
+struct LaGeom { int nrounds, nbo, nt, swq; };          // nt = Npad / 64, swq = nbo / 64
+__host__ __device__ inline int la_crit_count(const LaGeom &g, int J) {            // tiles of round J's critical strip
+    const int nq = g.nt - (J + 1) * g.swq, sw = nq < g.swq ? nq : g.swq;
+    return sw * nq - sw * (sw - 1) / 2;
+}
+__host__ __device__ inline int la_bulk_count(const LaGeom &g, int J) {            // tiles right of it
+    const int nq = g.nt - (J + 1) * g.swq, sw = nq < g.swq ? nq : g.swq, n2 = nq - sw;
+    return n2 * (n2 + 1) / 2;
+}
+__host__ __device__ inline int la_bulk_first_strip(const LaGeom &g, int J) {      // ... of which in round J+1's critical strip
+    const int nq = g.nt - (J + 1) * g.swq, sw = nq < g.swq ? nq : g.swq, n2 = nq - sw, s2 = n2 < g.swq ? n2 : g.swq;
+    return s2 * n2 - s2 * (s2 - 1) / 2;
+}
 struct LaCtrl {                                 // device, zeroed before every factorisation
     unsigned crit_next, bulk_next;
     int err;
@@ -441,97 +452,116 @@ __device__ __forceinline__ bool la_wait_ge(const unsigned *p, unsigned target, L
     return true;
 }
 
-__global__ __launch_bounds__(256, 4) void k_ldlt_workers(double *K, long ld, const double *dvec, LaPlan pl, LaCtrl *ctrl,
-                                                          unsigned *done, int reserve, ReserveMap rm) {
+// Scheduler (one lane per workgroup): next tile for this worker as (round, ci, cj) in global 64-tile coordinates;
+// round = -2: nothing left (or the launch is being abandoned).  Critical queue first; see the protocol above.
+__device__ __forceinline__ int3 la_next_tile(const LaGeom &g, int total_crit, int total_bulk, LaCtrl *ctrl, const unsigned *done) {
+    int round = -1, ci = 0, cj = 0;
+    for (int spins = 0;; ++spins) {
+        // ---- critical queue first
+        const int c = (int)la_load(&ctrl->crit_next);
+        if (c < total_crit) {
+            int Jc = 0, start = 0;
+            for (int n; c >= start + (n = la_crit_count(g, Jc)); ++Jc) start += n;
+            bool ready = la_load(&ctrl->flag[Jc]) != 0;
+            if (ready && Jc > 0) {
+                // every round-(Jc-1) tile of this strip must have been handed out (it sits at the head of that round's bulk list)
+                int bs = 0;
+                for (int J = 0; J < Jc - 1; ++J) bs += la_bulk_count(g, J);
+                ready = (int)la_load(&ctrl->bulk_next) >= bs + la_bulk_first_strip(g, Jc - 1);
+            }
+            if (ready) {
+                const int t = (int)atomicAdd(&ctrl->crit_next, 1u);
+                if (t < total_crit) {
+                    int J = Jc;
+                    for (int n; t >= start + (n = la_crit_count(g, J)); ++J) start += n;
+                    const int r0q = (J + 1) * g.swq, nq = g.nt - r0q;                 // trailing matrix in 64-tiles
+                    int idx = t - start;
+                    cj = 0;
+                    while (idx >= nq - cj) { idx -= nq - cj; ++cj; }                  // column-major, rows cj .. nq-1
+                    ci = cj + idx + r0q; cj += r0q; round = J;
+                    cj |= 1 << 30;                                                    // marks a critical tile
+                    break;
+                }
+            }
+        }
+        // ---- bulk queue
+        if ((int)la_load(&ctrl->bulk_next) < total_bulk) {
+            const int t = (int)atomicAdd(&ctrl->bulk_next, 1u);
+            if (t < total_bulk) {
+                int J = 0, start = 0;
+                for (int n; t >= start + (n = la_bulk_count(g, J)); ++J) start += n;
+                const int r0q = (J + 1) * g.swq, nq = g.nt - r0q;
+                const int sw = (nq < g.swq) ? nq : g.swq, n2 = nq - sw;               // bulk = columns sw .. nq-1
+                const int idx = t - start;
+                // column c of the n2 x n2 lower triangle starts at c*n2 - c(c-1)/2
+                const float bq = 2.0f * n2 + 1.0f;
+                int cc = (int)((bq - sqrtf(fmaxf(bq * bq - 8.0f * (float)idx, 0.0f))) * 0.5f);   // estimate, corrected below
+                if (cc < 0) cc = 0;
+                if (cc > n2 - 1) cc = n2 - 1;
+                while (cc > 0 && cc * n2 - cc * (cc - 1) / 2 > idx) --cc;
+                while (cc + 1 < n2 && (cc + 1) * n2 - (cc + 1) * cc / 2 <= idx) ++cc;
+                const int rr = idx - (cc * n2 - cc * (cc - 1) / 2);
+                cj = r0q + sw + cc; ci = cj + rr; round = J;
+                break;
+            }
+        }
+        if (c >= total_crit) return make_int3(-2, 0, 0);                              // both queues exhausted
+        if (la_load((const unsigned *)&ctrl->err) != 0) return make_int3(-2, 0, 0);
+        if (spins < 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(100);   // nothing to hand out yet: the chain is the bottleneck
+        if (spins > 4000000) { atomicExch(&ctrl->err, -8); return make_int3(-2, 0, 0); }
+    }
+    bool ok = la_wait_ge<4>(&ctrl->flag[round], 1u, ctrl);                            // L[:, J], d_J final
+    ok = ok && la_wait_ge<2>(done + (long)ci * g.nt + (cj & 0xffff), (unsigned)round, ctrl);     // round J-1 of this tile
+    return ok ? make_int3(round, ci, cj) : make_int3(-2, 0, 0);
+}
+
+__device__ __noinline__ void la_tile(double *K, long ld, const double *dvec, int nbo, int J, int ci, int cj, double *lds) {
+    const long C0 = (long)J * nbo;
+    GemmArgs g = {};
+    g.A = K + C0 * ld; g.lda = ld;
+    g.B = K + C0 * ld; g.ldb = ld;
+    g.C = K; g.ldc = ld;
+    g.K = nbo; g.alpha = -1.0;
+    gemm_tile_64<EPI_ACCUM, true, true>(g, lds, (long)ci * SB, (long)cj * SB, dvec + C0);
+}
+__global__ __launch_bounds__(256, 5) void k_ldlt_workers(double *K, long ld, const double *dvec, int Npad, int nbo, LaCtrl *ctrl,
+                                                          unsigned *done, int reserve, ReserveMap rm, int dbg) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
-    __shared__ int s_round, s_ci, s_cj;
+    int *sh = (int *)lds;            // (round, ci, cj) of the next tile: handed over in the first bytes of the GEMM buffer
     if (reserve) {
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
         const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0x7;
         const unsigned cu = (hw >> 8) & 0xf, gse = xcc * 4 + ((hw >> 13) & 0x3);
         if (cu == rm.cu[gse][0] || (reserve > 1 && cu == rm.cu[gse][1])) return;
     }
-    __builtin_amdgcn_s_setprio(3);
-    const int total_crit = pl.crit_start[pl.nrounds], total_bulk = pl.bulk_start[pl.nrounds];
+    LaGeom geo;
+    geo.nbo = nbo; geo.nt = Npad / SB; geo.swq = nbo / SB; geo.nrounds = (Npad + nbo - 1) / nbo - 1;
+    int total_crit = 0, total_bulk = 0;
+    for (int J = 0; J < geo.nrounds; ++J) { total_crit += la_crit_count(geo, J); total_bulk += la_bulk_count(geo, J); }
     int cur_round = -1;
     long busy = 0, ntiles = 0;
     for (;;) {
         if (threadIdx.x == 0) {
-            int round = -1, ci = 0, cj = 0;
-            for (int spins = 0;; ++spins) {
-                // ---- critical queue first
-                const unsigned c = la_load(&ctrl->crit_next);
-                if ((int)c < total_crit) {
-                    int Jc = 0;
-                    while (pl.crit_start[Jc + 1] <= (int)c) ++Jc;
-                    if (la_load(&ctrl->flag[Jc]) && (Jc == 0 || (int)la_load(&ctrl->bulk_next) >= pl.bulk_first_strip_end[Jc - 1])) {
-                        const int t = (int)atomicAdd(&ctrl->crit_next, 1u);
-                        if (t < total_crit) {
-                            int J = Jc;
-                            while (pl.crit_start[J + 1] <= t) ++J;
-                            const int r0q = (J + 1) * (pl.nbo / SB), nq = pl.nt - r0q;     // trailing matrix in 64-tiles
-                            int idx = t - pl.crit_start[J];
-                            cj = 0;
-                            while (idx >= nq - cj) { idx -= nq - cj; ++cj; }              // column-major, rows cj .. nq-1
-                            ci = cj + idx;
-                            ci += r0q; cj += r0q; round = J;
-                            break;
-                        }
-                    }
-                }
-                // ---- bulk queue
-                if ((int)la_load(&ctrl->bulk_next) < total_bulk) {
-                    const int t = (int)atomicAdd(&ctrl->bulk_next, 1u);
-                    if (t < total_bulk) {
-                        int J = 0;
-                        while (pl.bulk_start[J + 1] <= t) ++J;
-                        const int r0q = (J + 1) * (pl.nbo / SB), nq = pl.nt - r0q;
-                        const int sw = (nq < pl.nbo / SB) ? nq : pl.nbo / SB, n2 = nq - sw;  // bulk = columns sw .. nq-1
-                        const int idx = t - pl.bulk_start[J];
-                        // column c of the n2 x n2 lower triangle starts at c*n2 - c(c-1)/2
-                        int cc = (int)(((2.0 * n2 + 1.0) - sqrt((2.0 * n2 + 1.0) * (2.0 * n2 + 1.0) - 8.0 * (double)idx)) * 0.5);
-                        if (cc < 0) cc = 0;
-                        if (cc > n2 - 1) cc = n2 - 1;
-                        while (cc > 0 && cc * n2 - cc * (cc - 1) / 2 > idx) --cc;
-                        while (cc + 1 < n2 && (cc + 1) * n2 - (cc + 1) * cc / 2 <= idx) ++cc;
-                        const int rr = idx - (cc * n2 - cc * (cc - 1) / 2);
-                        cj = r0q + sw + cc; ci = cj + rr; round = J;
-                        break;
-                    }
-                }
-                if ((int)c >= total_crit) { round = -2; break; }          // both queues exhausted
-                if (la_load((const unsigned *)&ctrl->err) != 0) { round = -2; break; }
-                if (spins < 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(100);   // nothing to hand out yet: the chain is the bottleneck
-                if (spins > 4000000) { atomicExch(&ctrl->err, -8); round = -2; break; }
-            }
-            if (round >= 0) {
-                bool ok = la_wait_ge<4>(&ctrl->flag[round], 1u, ctrl);                          // L[:, J], d_J final
-                ok = ok && la_wait_ge<2>(done + (long)ci * pl.nt + cj, (unsigned)round, ctrl);  // round J-1 of this tile
-                if (!ok) round = -2;
-                else if (round != cur_round) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            s_round = round; s_ci = ci; s_cj = cj;
+            const int3 nx = la_next_tile(geo, total_crit, total_bulk, ctrl, done);
+            if (nx.x >= 0 && nx.x != cur_round) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            sh[0] = nx.x; sh[1] = nx.y; sh[2] = nx.z;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int J = s_round;
+        const int J = sh[0], ci = sh[1], cj = sh[2] & 0xffff;
+        const bool critical = (sh[2] >> 30) != 0;
+        __syncthreads();                 // everyone has read them: the tile's staging may overwrite the buffer
         if (J < 0) break;
         cur_round = J;
         const long t0 = __builtin_amdgcn_s_memtime();
-        {
-            const long C0 = (long)J * pl.nbo;
-            GemmArgs g = {};
-            g.A = K + C0 * ld; g.lda = ld;
-            g.B = K + C0 * ld; g.ldb = ld;
-            g.C = K; g.ldc = ld;
-            g.K = pl.nbo; g.alpha = -1.0;
-            gemm_tile_64<EPI_ACCUM, true, true>(g, lds, (long)s_ci * SB, (long)s_cj * SB, dvec + C0);
-        }
+        // a critical tile out-prioritises the bulk tiles it shares the CU with (MFMA issue is arbitrated by priority)
+        if (critical) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
+        if (!(dbg & 64)) la_tile(K, ld, dvec, nbo, J, ci, cj, lds);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            __hip_atomic_store(done + (long)s_ci * pl.nt + s_cj, (unsigned)(J + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            atomicAdd(&ctrl->stripdone[s_cj / (pl.nbo / SB)], 1u);
+            __hip_atomic_store(done + (long)ci * geo.nt + cj, (unsigned)(J + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(&ctrl->stripdone[cj / geo.swq], 1u);
             busy += __builtin_amdgcn_s_memtime() - t0; ++ntiles;
         }
     }
@@ -554,20 +584,11 @@ size_t cip_la_ctrl_bytes(int Npad) { return sizeof(LaCtrl) + sizeof(unsigned) * 
 
 static int g_ncu = 0;
 int cip_la_launch_workers(hipStream_t s, double *K, int Npad, long ld, const double *dvec, int nbo, void *ctrl_dev, int reserve) {
-    LaPlan pl = {};
-    pl.nbo = nbo; pl.Npad = Npad; pl.nt = Npad / SB;
-    const int nblocks = (Npad + nbo - 1) / nbo;
-    pl.nrounds = nblocks - 1;
-    if (pl.nrounds > LA_MAX_ROUNDS) { cip_set_error("look-ahead: too many outer blocks (%d)", nblocks); return -1; }
-    const int swq = nbo / SB;
-    for (int J = 0; J < pl.nrounds; ++J) {
-        const int nq = pl.nt - (J + 1) * swq;
-        const int sw = nq < swq ? nq : swq, n2 = nq - sw;
-        pl.crit_start[J + 1] = pl.crit_start[J] + sw * nq - sw * (sw - 1) / 2;
-        pl.bulk_start[J + 1] = pl.bulk_start[J] + n2 * (n2 + 1) / 2;
-        const int s2 = n2 < swq ? n2 : swq;                  // the first bulk strip = the next round's critical strip
-        pl.bulk_first_strip_end[J] = pl.bulk_start[J] + s2 * n2 - s2 * (s2 - 1) / 2;
-    }
+    LaGeom geo;
+    geo.nbo = nbo; geo.nt = Npad / SB; geo.swq = nbo / SB; geo.nrounds = (Npad + nbo - 1) / nbo - 1;
+    if (geo.nrounds > LA_MAX_ROUNDS) { cip_set_error("look-ahead: too many outer blocks"); return -1; }
+    long total = 0;
+    for (int J = 0; J < geo.nrounds; ++J) total += la_crit_count(geo, J) + la_bulk_count(geo, J);
     if (!g_ncu) {
         hipDeviceProp_t prop;
         int dev = 0;
@@ -577,12 +598,12 @@ int cip_la_launch_workers(hipStream_t s, double *K, int Npad, long ld, const dou
     }
     if (reserve && reserve_map_init()) return -1;
     LaCtrl *ctrl = (LaCtrl *)ctrl_dev;
-    long total = (long)pl.crit_start[pl.nrounds] + pl.bulk_start[pl.nrounds];
     long grid = (long)g_ncu * 5;                             // 32 KB of LDS each: 5 per CU
     if (grid > total) grid = total;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_ldlt_workers, dim3((unsigned)grid), dim3(256), 0, s, K, ld, dvec, pl, ctrl,
-                       (unsigned *)((char *)ctrl_dev + sizeof(LaCtrl)), reserve, g_rmap);
+    hipLaunchKernelGGL(k_ldlt_workers, dim3((unsigned)grid), dim3(256), 0, s, K, ld, dvec, Npad, nbo, ctrl,
+                       (unsigned *)((char *)ctrl_dev + sizeof(LaCtrl)), reserve, g_rmap,
+                       getenv("CIP_LA_DBG") ? atoi(getenv("CIP_LA_DBG")) : 0);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -187,7 +187,13 @@ struct SideStream {
 };
 static thread_local SideStream g_side;
 static std::once_flag g_la_once;
-static int g_lookahead = 1;               // default schedule for Npad >= g_la_min (CIP_LOOKAHEAD=0: serial everywhere)
+// Opt-in (CIP_LOOKAHEAD=1 / cip_set_ldlt_lookahead(1)).  Measured at N = 8192 (profiles/r2/lookahead_*): 9.7 ms against
+// 7.05 ms for the serial schedule.  The hand-offs work (bit-identical factors, tests/test_gpu_lookahead.py) and the bulk
+// of every round does run beside the chain, but the chain is not the narrow latency-bound thing the schedule assumes:
+// at the top of the matrix its TRSM + in-block updates are 17 % of the factorisation's flops and want the whole chip --
+// on 64 reserved CUs the chain ALONE takes 6.0 ms (tile compute switched off: CIP_LA_DBG=64) against 3.5 ms on an idle
+// chip, 9.4 ms with the workers' memory traffic beside it -- and at the bottom there is no bulk left to overlap.
+static int g_lookahead = 0;
 static int g_la_min = 4096;               // below this order a factorisation is chain-bound whatever the schedule
 static int g_reserve = 2;                 // CUs per (XCD, SE) pair left to the chain: 1 -> 32 CUs, 2 -> 64
 static void lookahead_env(void) {
@@ -323,7 +329,7 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
             return rc;
         return build_solve_blocks(s, K, Npad, ld, ws);
     }
-    // Deep look-ahead (default for Npad >= 4096): the persistent worker launch on the caller's stream carries all
+    // Deep look-ahead (opt-in, Npad >= 4096): the persistent worker launch on the caller's stream carries all
     // trailing updates, the panel chain of every outer block runs on the side stream behind a gate that waits for its
     // column strip only (see gemm_f64.hip: k_ldlt_workers for the dependency protocol).
     if ((rc = lookahead_init())) return rc;

@@ -221,9 +221,9 @@ int cip_assemble_only(cip_handle *h);                                   /* level
 int cip_stats(cip_handle *h, double *out8);
 int cip_set_timing(cip_handle *h, int enabled);
 int cip_set_ldlt_outer_block(int nbo);
-/* schedule of the blocked LDL' for orders >= 4096: 1 = deep look-ahead (default: every trailing update in one persistent
- * launch, the panel chain of each outer block on a side stream behind a gate on its own column strip), 0 = serial
- * single-stream (also CIP_LOOKAHEAD=0), 2 = serial with the look-ahead's operand form (bit-identical to 1; tests).
+/* schedule of the blocked LDL': 0 = serial single-stream (default), 1 = deep look-ahead for orders >= 4096 (also
+ * CIP_LOOKAHEAD=1: every trailing update in one persistent launch, the panel chain of each outer block on a side
+ * stream behind a gate on its own column strip), 2 = serial with the look-ahead's operand form (bit-identical to 1; tests).
  * Process-wide; returns the previous setting. */
 int cip_set_ldlt_lookahead(int on);
 /* out4 = [100 MHz ticks the persistent workers of the last look-ahead factorisation spent inside tile computations
