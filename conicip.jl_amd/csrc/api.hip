@@ -28,7 +28,8 @@ static int rup(int x, int q) { return ((x + q - 1) / q) * q; }
     } while (0)
 
 static void free_all(cip_handle *h) {
-    void *ptrs[] = {h->cs.d_sidx, h->cs.d_sdpws, h->cs.d_sdpvec, h->cs.d_sdpflag, h->Q, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->row_cone, h->G, h->Gt,
+    if (h->cs.lg) { cip_sdp_large_destroy(h->cs.lg); h->cs.lg = nullptr; }
+    void *ptrs[] = {h->cs.d_sidx_small, h->cs.d_sidx, h->cs.d_sdpws, h->cs.d_sdpvec, h->cs.d_sdpflag, h->Q, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->row_cone, h->G, h->Gt,
                     h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->cs.d_partial, h->cs.d_scalar, h->K, h->Wt, h->Gm,
                     h->ws_base, h->rhs, h->mt1, h->mt2, h->mt3, h->nt1, h->pt1, h->dot_scratch, h->dot_ptrs, h->stage, h->drv, h->ref, h->c2x2};
     for (void *p : ptrs)
@@ -188,6 +189,23 @@ static int create_impl(const cip_problem *pr, cip_handle *h) {
     DMALLOC(h->cs.d_partial, sizeof(double) * (h->h_items.size() + 1));
     DMALLOC(h->cs.d_scalar, sizeof(double) * 8);
     h->cs.ns = (int)sidx.size(); h->cs.rmax = rmax; h->cs.kmax = kmax;
+    h->cs.ns_small = 0; h->cs.nlarge = 0; h->cs.lg = nullptr; h->cs.d_sidx_small = nullptr;
+    h->cs.h_cones = h->h_cones.data();
+    if (has_S) {
+        std::vector<int> small;
+        int rmax_large = 0;
+        for (int c : sidx) {
+            if (h->h_cones[c].r >= CIP_LARGE_S_MIN) {
+                if (h->cs.nlarge == CIP_MAX_LARGE_S) { cip_set_error("more than %d S cones of order >= %d", CIP_MAX_LARGE_S, CIP_LARGE_S_MIN); return CIP_E_UNSUPPORTED; }
+                h->cs.large_cone[h->cs.nlarge++] = c;
+                if (h->h_cones[c].r > rmax_large) rmax_large = h->h_cones[c].r;
+            } else small.push_back(c);
+        }
+        h->cs.ns_small = (int)small.size();
+        DMALLOC(h->cs.d_sidx_small, sizeof(int) * (small.size() + 1));
+        if (!small.empty()) CIP_HIP_CHECK(hipMemcpy(h->cs.d_sidx_small, small.data(), sizeof(int) * small.size(), hipMemcpyHostToDevice));
+        if (h->cs.nlarge > 0) { int rcl = cip_sdp_large_create(rmax_large, h->cs.nlarge, &h->cs.lg); if (rcl) return rcl; }
+    }
     if (has_S) {
         const int per = n < 64 ? n : 64;
         h->cs.sdp_slots = h->cs.ns * (per > 0 ? per : 1);
@@ -260,6 +278,7 @@ static int create_impl(const cip_problem *pr, cip_handle *h) {
     CIP_HIP_CHECK(hipHostMalloc((void **)&h->info_host, 4 * sizeof(int), hipHostMallocDefault));
     memset(h->info_host, 0, 4 * sizeof(int));
     if ((rc = cip_cones_identity_scaling(s, h->cs))) return rc;
+    if ((rc = cip_sdp_scaling_changed(s, h->cs))) return rc;
     CIP_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
 }
@@ -300,7 +319,8 @@ extern "C" int cip_update_problem(cip_handle *h, const cip_problem *pr) {
     h->assembled = h->factored = false;
     h->info_pending = false;
     h->reg_rel = 0.0; h->n_regularized = 0;          // a fresh problem starts unregularised, as a fresh handle does
-    return cip_cones_identity_scaling(h->stream, h->cs);
+    if ((rc = cip_cones_identity_scaling(h->stream, h->cs))) return rc;
+    return cip_sdp_scaling_changed(h->stream, h->cs);
 }
 
 extern "C" int cip_destroy(cip_handle *h) {
@@ -326,7 +346,7 @@ extern "C" int cip_set_scaling_packed(cip_handle *h, const double *packedF) {
     CIP_HIP_CHECK(hipMemcpyAsync(h->cs.d_scal, packedF, sizeof(double) * h->cs.scal_len, hipMemcpyHostToDevice, h->stream));
     CIP_HIP_CHECK(hipStreamSynchronize(h->stream));
     h->assembled = h->factored = false;
-    return 0;
+    return cip_sdp_scaling_changed(h->stream, h->cs);
 }
 extern "C" int cip_get_scaling_packed(cip_handle *h, double *packedF) {
     if (!h || !packedF) { cip_set_error("NULL argument"); return CIP_E_INVALID; }
@@ -337,7 +357,8 @@ extern "C" int cip_get_scaling_packed(cip_handle *h, double *packedF) {
 extern "C" int cip_set_scaling_identity(cip_handle *h) {
     if (!h) return CIP_E_INVALID;
     h->assembled = h->factored = false;
-    return cip_cones_identity_scaling(h->stream, h->cs);
+    int rc = cip_cones_identity_scaling(h->stream, h->cs);
+    return rc ? rc : cip_sdp_scaling_changed(h->stream, h->cs);
 }
 extern "C" int cip_set_scaling_from_iterate_dev(cip_handle *h, const double *v, const double *s, double *lambda_out) {
     if (!h || (h->m > 0 && (!v || !s))) { cip_set_error("NULL argument"); return CIP_E_INVALID; }

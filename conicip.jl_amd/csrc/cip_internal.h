@@ -114,9 +114,30 @@ struct ConeSet {
     double *d_sdpws;          // sdp_slots x 6 x rmax^2
     double *d_sdpvec;         // sdp_slots x 2 x kmax
     int *d_sdpflag;           // device int: Cholesky failure (iterate left the cone)
+    // S cones of order >= 133 (sdp_large.hip): NT scaling, max-step and the Schur scaling take a multi-workgroup path
+    int ns_small;             // number of S cones below that order, listed in d_sidx_small
+    int *d_sidx_small;
+    int nlarge;               // the others (at most CIP_MAX_LARGE_S)
+    int large_cone[8];        // their cone indices
+    const ConeDesc *h_cones;  // host copy of the cone table (owned by the handle)
+    struct LargeWs *lg;       // workspace of the large path (NULL when nlarge == 0)
 };
+#define CIP_MAX_LARGE_S 8
+#define CIP_LARGE_S_MIN 133
+struct LargeWs;
+int cip_sdp_large_create(int rmax_large, int nlarge, LargeWs **out);
+void cip_sdp_large_destroy(LargeWs *w);
+int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, const double *v, const double *sv, double *scal,
+                     double *lambda, int *flag);
+int cip_sdp_large_refresh(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, const double *scal);
+int cip_sdp_large_apply(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, int mode, const double *x, double *out);
+int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *d, double scale,
+                          double *partial);
+int cip_sdp_large_scale_At(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, int n, const double *At, long ldat, double *Wt,
+                           long ldwt);
 int cip_cones_nt_scaling(hipStream_t s, const ConeSet &cs, const double *v, const double *sv, double *lambda);
 int cip_cones_identity_scaling(hipStream_t s, const ConeSet &cs);
+int cip_sdp_scaling_changed(hipStream_t s, const ConeSet &cs);     // sdp.hip: the packed scaling was replaced from outside
 int cip_cones_apply(hipStream_t s, const ConeSet &cs, int mode, const double *x, double *out);
 int cip_cones_prod(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out);
 int cip_cones_div(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out);

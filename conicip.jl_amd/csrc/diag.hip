@@ -57,6 +57,9 @@ __device__ __forceinline__ double bperm_d(double x, int byte_addr) {
 // g+12 -- so each of the 16 pivot steps costs a quarter of the column updates per lane; the pivot is broadcast
 // with v_readlane, the pivot column / pivot row entries move between lane groups with ds_bpermute.  X is updated
 // right-looking by the same multipliers (lane (cc = l15, g) owns rows g+4q of column cc).
+// (A row-per-lane variant -- lane i holds row i and column i of X, pivot column broadcast with v_readlane only, no LDS
+// round trip -- was built and measured in round 2: 40.5 us per kernel against 30.9: with 16 useful lanes a pivot
+// issues (15-j) x 5 fp64 instructions instead of 4 x 3, and the issue time exceeds the bpermute latency it removes.)
 __device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int lane, int *info, int col0, PivotSigns sg) {
     const int l15 = lane & 15, g = lane >> 4;
     const int c = kb * 16;

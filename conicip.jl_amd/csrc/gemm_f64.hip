@@ -656,7 +656,7 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
         tiles = (long)tm * tn;
     }
     const int by = g.by > 0 ? g.by : 1, bz = g.bz > 0 ? g.bz : 1;
-    if (by * bz > 1) {
+    if (by * bz > 1 || (g.overwrite && epi == EPI_ACCUM && !g.lower)) {
         if (epi != EPI_ACCUM || g.lower) { cip_set_error("gemm: batching needs the plain accumulate form"); return -1; }
         if (g.overwrite) {
             hipLaunchKernelGGL(k_gemm_nt_64_batched, dim3((unsigned)(4 * tiles), by, bz), dim3(256), 0, s, g);

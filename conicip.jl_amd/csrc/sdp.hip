@@ -751,6 +751,25 @@ __global__ __launch_bounds__(SD_TMAX) void k_sdp_div(const ConeDesc *cones, cons
            *T = sd_ws(wsb, blockIdx.x, r, 3), *W = sd_ws(wsb, blockIdx.x, r, 4);
     sd_mat(x + cd.off, 1, X, r);
     sd_mat(y + cd.off, 1, Y, r);
+    {
+        // Y diagonal (every division of the interior-point loop is by lambda = vecm(diag(Lambda)), src/ConicIP.jl:686):
+        // the Lyapunov solve is an element-wise quotient -- same numbers as the general path with V = I, none of its
+        // four r^3 products
+        __shared__ double dred[32];
+        double off = 0.0, tot = 0.0;
+        for (int e = threadIdx.x; e < r * r; e += SD_T) { const double a = Y[e]; tot += a * a; if (e % r != e / r) off += a * a; }
+        for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o); tot += __shfl_xor(tot, o); }
+        if ((threadIdx.x & 63) == 0) { dred[threadIdx.x >> 6] = off; dred[16 + (threadIdx.x >> 6)] = tot; }
+        __syncthreads();
+        off = 0.0; tot = 0.0;
+        for (int q = 0; q < SD_T / 64; ++q) { off += dred[q]; tot += dred[16 + q]; }
+        if (off == 0.0 && tot > 0.0) {
+            for (int e = threadIdx.x; e < r * r; e += SD_T) { const int i = e % r, j = e / r; X[e] /= (Y[i + i * r] + Y[j + j * r]); }
+            __syncthreads();
+            sd_vecm(X, out + cd.off, 1, r, 1.0);
+            return;
+        }
+    }
     sd_jacobi(Y, V, r, sh, cap);                             // Y = V diag V'
     sd_gemm(T, X, false, V, false, r);
     sd_gemm(W, V, true, T, false, r);                        // V' X V
@@ -831,15 +850,36 @@ static int sd_set_lds_attr(const void *fn, int rmax, int nmat) {
 }
 
 int cip_sdp_nt_scaling(hipStream_t s, const ConeSet &cs, const double *v, const double *sv, double *lambda) {
-    if (sd_set_lds_attr((const void *)k_sdp_nt_scaling, cs.rmax, 1)) return -3;
-    hipLaunchKernelGGL(k_sdp_nt_scaling, dim3(cs.ns), dim3(sd_threads(cs.rmax)), sd_shmem(cs.rmax, 1), s, cs.d_cones, cs.d_sidx, v, sv,
-                       cs.d_scal, lambda, cs.d_sdpws, cs.d_sdpflag, sd_cap(cs.rmax, 1) + SD_SCRATCH(cs.rmax));
-    CIP_HIP_CHECK(hipGetLastError());
+    if (cs.ns_small > 0) {
+        if (sd_set_lds_attr((const void *)k_sdp_nt_scaling, cs.rmax, 1)) return -3;
+        hipLaunchKernelGGL(k_sdp_nt_scaling, dim3(cs.ns_small), dim3(sd_threads(cs.rmax)), sd_shmem(cs.rmax, 1), s, cs.d_cones,
+                           cs.d_sidx_small, v, sv, cs.d_scal, lambda, cs.d_sdpws, cs.d_sdpflag, sd_cap(cs.rmax, 1) + SD_SCRATCH(cs.rmax));
+        CIP_HIP_CHECK(hipGetLastError());
+    }
+    for (int li = 0; li < cs.nlarge; ++li) {                 // orders 133 .. 512: chip-wide pieces (sdp_large.hip)
+        const int rc = cip_sdp_large_nt(s, cs.lg, cs.h_cones[cs.large_cone[li]], li, v, sv, cs.d_scal, lambda, cs.d_sdpflag);
+        if (rc) return rc;
+    }
+    return 0;
+}
+// the packed scaling was replaced from outside (cip_set_scaling_packed / identity): refresh what the large path derives from it
+int cip_sdp_scaling_changed(hipStream_t s, const ConeSet &cs) {
+    for (int li = 0; li < cs.nlarge; ++li) {
+        const int rc = cip_sdp_large_refresh(s, cs.lg, cs.h_cones[cs.large_cone[li]], li, cs.d_scal);
+        if (rc) return rc;
+    }
     return 0;
 }
 int cip_sdp_apply(hipStream_t s, const ConeSet &cs, int mode, const double *x, double *out) {
-    hipLaunchKernelGGL(k_sdp_apply, dim3(cs.ns), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx, cs.d_scal, mode, x, out, cs.d_sdpws);
-    CIP_HIP_CHECK(hipGetLastError());
+    if (cs.ns_small > 0) {
+        hipLaunchKernelGGL(k_sdp_apply, dim3(cs.ns_small), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx_small, cs.d_scal, mode, x,
+                           out, cs.d_sdpws);
+        CIP_HIP_CHECK(hipGetLastError());
+    }
+    for (int li = 0; li < cs.nlarge; ++li) {
+        const int rc = cip_sdp_large_apply(s, cs.lg, cs.h_cones[cs.large_cone[li]], li, mode, x, out);
+        if (rc) return rc;
+    }
     return 0;
 }
 int cip_sdp_prod(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out) {
@@ -859,17 +899,29 @@ int cip_sdp_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const dou
     const long want = (long)cs.rmax * (cs.rmax + 1), room = SD_LDS_CAPMAX - SD_SCRATCH_TRI(cs.rmax);
     const int cap = (int)(want < room ? want : (room > 0 ? room : 0));
     const size_t shm = ((size_t)SD_SCRATCH_TRI(cs.rmax) + cap) * sizeof(double);
-    CIP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sdp_maxstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(k_sdp_maxstep, dim3(cs.ns), dim3(sd_threads(cs.rmax)), shm, s, cs.d_cones, cs.d_sidx, x, d, scale, partial,
-                       cs.d_sdpws, cap);
-    CIP_HIP_CHECK(hipGetLastError());
+    if (cs.ns_small > 0) {
+        CIP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sdp_maxstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL(k_sdp_maxstep, dim3(cs.ns_small), dim3(sd_threads(cs.rmax)), shm, s, cs.d_cones, cs.d_sidx_small, x, d, scale,
+                           partial, cs.d_sdpws, cap);
+        CIP_HIP_CHECK(hipGetLastError());
+    }
+    for (int li = 0; li < cs.nlarge; ++li) {
+        const int rc = cip_sdp_large_maxstep(s, cs.lg, cs.h_cones[cs.large_cone[li]], x, d, scale, partial);
+        if (rc) return rc;
+    }
     return 0;
 }
 int cip_sdp_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, long ldat, double *Wt, long ldwt) {
-    const int gx = n < cs.sdp_slots / cs.ns ? n : cs.sdp_slots / cs.ns;
-    hipLaunchKernelGGL(k_sdp_scale_At, dim3(gx, cs.ns), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx, cs.d_scal, n, At, ldat, Wt, ldwt,
-                       cs.d_sdpws);
-    CIP_HIP_CHECK(hipGetLastError());
+    if (cs.ns_small > 0) {
+        const int gx = n < cs.sdp_slots / cs.ns ? n : cs.sdp_slots / cs.ns;
+        hipLaunchKernelGGL(k_sdp_scale_At, dim3(gx, cs.ns_small), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx_small, cs.d_scal, n,
+                           At, ldat, Wt, ldwt, cs.d_sdpws);
+        CIP_HIP_CHECK(hipGetLastError());
+    }
+    for (int li = 0; li < cs.nlarge; ++li) {
+        const int rc = cip_sdp_large_scale_At(s, cs.lg, cs.h_cones[cs.large_cone[li]], li, n, At, ldat, Wt, ldwt);
+        if (rc) return rc;
+    }
     return 0;
 }
 int cip_sdp_fill_ftf(hipStream_t s, const ConeSet &cs, double *K, long ldk) {

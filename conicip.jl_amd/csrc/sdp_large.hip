@@ -1,0 +1,613 @@
+// S cones of matrix order 133 .. 512: the stages that do not fit one workgroup's LDS.
+//
+// The workgroup-per-cone kernels of sdp.hip keep ONE r x r matrix LDS-resident up to r = 132; above that they ran the
+// same serial chains from global memory (BASELINE config 4 at its literal size, r = 256: 67 ms per NT scaling, 10.9 ms
+// per max-step, 10 ms per Schur scaling).  Here the three expensive entry points are rebuilt from chip-wide pieces:
+//
+//   nestod_sdc  (src/ConicIP.jl:196-210)
+//       chol(mat(z)), chol(mat(s))        the library's own blocked LDL' (ldlt.hip: MFMA trailing updates) on the matrix
+//                                         padded to 256 / 512 with an identity block; L_chol = L D^1/2
+//       G = Lz' Ls                        one fp64-MFMA GEMM (64x64 tiles over the chip)
+//       svd(G): U, Lambda                 BLOCK one-sided Jacobi: column blocks of 32 (16 above r = 256), disjoint block
+//                                         pairs on different workgroups (a pair = 128 KB of LDS), a full inner sweep per
+//                                         pair, rounds separated by a grid barrier inside ONE persistent launch
+//       R = Lz^-T U Lambda^1/2, R^-1      GEMMs with the explicit inverse of the unit-lower factor (the block inverses the
+//                                         LDL' builds for its solves: one block = the whole matrix here)
+//   maxstep_sdc (src/ConicIP.jl:272-303)
+//       lambda_max(L^-1 D L^-T)           LDL' + two GEMMs with inv(L), then a COOPERATIVE Householder tridiagonalisation:
+//                                         each of r/32 workgroups keeps a 32-column slab of the matrix in LDS for the whole
+//                                         reduction; per column two grid barriers and two r-vectors through global memory
+//                                         (coherent 8-byte accesses); Sturm multisection as before
+//   A' F^-1 for the Schur complement (Block * matrix, src/blockmatrices.jl:176-177; src/kktsolvers.jl:289-290)
+//       vecm(Rinv mat(a_i) Rinv') for all columns i: two BATCHED MFMA GEMMs per chunk of 64 columns
+//
+// apply / product / division stay on the workgroup-per-cone kernels (one or two r^3 GEMMs each, 0.1-0.3 ms at r = 256).
+#include "cip_handle.h"
+#include "../../include/cipkkt.h"
+#include <math.h>
+#include <vector>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define LG_T 1024
+#define LG_SQRT2 1.4142135623730951
+#define LG_SQRT1_2 0.7071067811865476
+
+struct LargeWs {
+    int rp = 0;                    // padded order (256 or 512)
+    int chunk = 64;                // columns of A per batched congruence
+    double *base = nullptr;        // one allocation
+    double *Kz, *Ks, *Tz, *Ts, *G, *M1, *M2, *M3;      // rp x rp
+    double *Rip;                   // nlarge x 4 x rp x rp: Rinv, Rinv', R, R' of every large cone, zero padded
+    double *vec;                   // 12 x rp: lam, dg, of, xbuf[2], pbuf, ...
+    double *batchX, *batchT;       // chunk x rp x rp each
+    unsigned *ctr;                 // barrier counters / sweep flags (256 words)
+    void *ldl_z = nullptr, *ldl_s = nullptr;
+    LdltWorkspace wz, ws;
+};
+
+__device__ __forceinline__ int lg_vidx(int i, int j, int r) { return i * r - i * (i - 1) / 2 + (j - i); }   // i <= j
+__device__ __forceinline__ double lg_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lg_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// grid barrier for the few workgroups of a cooperative launch (all resident: <= 16 workgroups): monotonic counter,
+// every thread drains its stores, one lane arrives and polls (`sc1` loads).  Bounded spin -> *err.
+__device__ __forceinline__ void lg_grid_barrier(unsigned *ctr, unsigned nwg, unsigned &phase, int *err) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ++phase;
+    if (threadIdx.x == 0) {
+        atomicAdd(ctr, 1u);
+        const long t0 = __builtin_amdgcn_s_memtime();
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg * phase) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memtime() - t0 > 2000000000L) { atomicExch(err, -9); break; }
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ double lg_block_sum(double x, double *red) {
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    double s = 0.0;
+    for (int q = 0; q < LG_T / 64; ++q) s += red[q];
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------ element-wise pieces
+// X[b] (rp x rp) = mat(x_b) in the leading r x r block, pad: `padval` on the diagonal, 0 elsewhere.
+// x_b = x + b * xb, element e at stride xs (a column block of A' is strided by its leading dimension).
+__global__ __launch_bounds__(256) void k_lg_mat(const double *x, long xs, long xb, double *X, int r, int rp, double padval) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)rp * rp) return;
+    const int i = (int)(e % rp), j = (int)(e / rp);
+    double v;
+    if (i < r && j < r) {
+        const int a = i < j ? i : j, b = i < j ? j : i;
+        v = x[(long)blockIdx.y * xb + (long)lg_vidx(a, b, r) * xs];
+        if (a != b) v *= LG_SQRT1_2;
+    } else {
+        v = (i == j) ? padval : 0.0;
+    }
+    X[(size_t)blockIdx.y * rp * rp + e] = v;
+}
+// out_b = vecm(Y_b leading r x r), strided like the input of k_lg_mat
+__global__ __launch_bounds__(256) void k_lg_vecm(const double *Y, double *out, long os, long ob, int r, int rp) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)r * r) return;
+    const int i = (int)(e % r), j = (int)(e / r);
+    if (i > j) return;
+    const double y = Y[(size_t)blockIdx.y * rp * rp + i + (long)j * rp];
+    out[(long)blockIdx.y * ob + (long)lg_vidx(i, j, r) * os] = (i == j) ? y : y * LG_SQRT2;
+}
+// T = (L D^1/2)' as a dense matrix, from the factored K (unit L strictly below, L' mirrored above, d separately):
+//   T[i, k] = L[k, i] sqrt(d_i)  (k > i),  sqrt(d_i) on the diagonal, 0 below
+__global__ __launch_bounds__(256) void k_lg_tfac(const double *K, const double *d, double *T, int rp) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)rp * rp) return;
+    const int i = (int)(e % rp), k = (int)(e / rp);
+    const double sd = sqrt(d[i]);
+    T[e] = (i < k) ? K[e] * sd : (i == k ? sd : 0.0);
+}
+// lam[j] = || G[:, j] ||   (one wave per column)
+__global__ __launch_bounds__(256) void k_lg_colnorm(const double *G, double *lam, int rp) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= rp) return;
+    double s = 0.0;
+    for (int i = lane; i < rp; i += 64) { const double g = G[i + (long)j * rp]; s += g * g; }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) lam[j] = sqrt(s);
+}
+// operands of the two closing GEMMs of nestod_sdc, from G = U diag(lam) (columns), d_z and the factored K_z:
+//   U2t[j, k] = U[k, j] sqrt(lam_j) / sqrt(dz_k)        R    = inv(Lz_unit)' (U2t)'
+//   U3t[i, k] = U[k, i] sqrt(dz_k) / sqrt(lam_i)        Rinv = U3t Lz_unit'
+//   Lu        = Lz_unit as a dense lower-triangular matrix
+__global__ __launch_bounds__(256) void k_lg_build(const double *G, const double *lam, const double *dz, const double *Kz,
+                                                   double *U2t, double *U3t, double *Lu, int rp) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)rp * rp) return;
+    const int k = (int)(e % rp), j = (int)(e / rp);          // element (k, j) of G
+    const double u = G[e] / lam[j];
+    const double sl = sqrt(lam[j]), sd = sqrt(dz[k]);
+    U2t[j + (long)k * rp] = u * sl / sd;
+    U3t[j + (long)k * rp] = u * sd / sl;
+    Lu[e] = (k > j) ? Kz[e] : (k == j ? 1.0 : 0.0);
+}
+// compact copies into the packed scaling (R, Rinv: r x r, pitch r) + zero-padded Rinv, Rinv', R, R' (pad[0..3]) for the
+// chip-wide congruences; lambda = vecm(diag(lam)) (src/ConicIP.jl:735: lambda = F v = vecm(R' Z R))
+__global__ __launch_bounds__(256) void k_lg_store(const double *Rp, const double *Rip_full, double *R, double *Ri, double *pad,
+                                                   const double *lam, double *lambda, int r, int rp, int kdim) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < (long)rp * rp) {
+        const int i = (int)(e % rp), j = (int)(e / rp);
+        const bool in = i < r && j < r;
+        const double rv = in ? Rp[e] : 0.0, iv = in ? Rip_full[e] : 0.0;
+        if (in) { R[i + (long)j * r] = rv; Ri[i + (long)j * r] = iv; }
+        const long n2 = (long)rp * rp, et = j + (long)i * rp;
+        pad[e] = iv; pad[n2 + et] = iv; pad[2 * n2 + e] = rv; pad[3 * n2 + et] = rv;
+    }
+    if (lambda && e < kdim) {
+        // diagonal positions of the row-major upper triangle: i r - i (i - 1) / 2
+        lambda[e] = 0.0;
+    }
+}
+__global__ __launch_bounds__(256) void k_lg_lambda_diag(const double *lam, double *lambda, int r) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < r) lambda[lg_vidx(i, i, r)] = lam[i];
+}
+// the four padded matrices from a packed scaling handed over by the host (cip_set_scaling_packed / identity)
+__global__ __launch_bounds__(256) void k_lg_pad(const double *R, const double *Ri, double *pad, int r, int rp) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)rp * rp) return;
+    const int i = (int)(e % rp), j = (int)(e / rp);
+    const bool in = i < r && j < r;
+    const double rv = in ? R[i + (long)j * r] : 0.0, iv = in ? Ri[i + (long)j * r] : 0.0;
+    const long n2 = (long)rp * rp, et = j + (long)i * rp;
+    pad[e] = iv; pad[n2 + et] = iv; pad[2 * n2 + e] = rv; pad[3 * n2 + et] = rv;
+}
+// a non-positive pivot of either Cholesky = the iterate has left the cone: same flag the small-cone kernels raise
+__global__ void k_lg_flag(const int *info_a, const int *info_b, int *flag) {
+    if (threadIdx.x == 0) {
+        if (info_a[0]) *flag = info_a[0];
+        else if (info_b && info_b[0]) *flag = info_b[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ block one-sided Jacobi
+__host__ __device__ inline int lg_pitch(int rows) { return rows + ((4 - rows % 32) + 32) % 32; }   // == 4 (mod 32) doubles
+__device__ __forceinline__ double lg_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(r, fma(-d, r, 1.0), r);
+    r = fma(r, fma(-d, r, 1.0), r);
+    return r;
+}
+__device__ __forceinline__ double lg_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
+    r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
+    return r;
+}
+// One persistent launch, nbk / 2 workgroups, every column pair rotated exactly once per sweep (cyclic Jacobi):
+//   intra-block phase   workgroup k holds blocks 2k, 2k+1 in LDS: b - 1 rounds of the round-robin tournament inside
+//                       each block (b / 2 + b / 2 disjoint pairs per round)
+//   nbk - 1 outer rounds of the tournament over blocks: the workgroup holds its block pair (I, J) and rotates the
+//                       b x b cross pairs in b rounds of b disjoint pairs (p in I with p + it in J)
+// with a grid barrier after every phase (the blocks travel through global memory with coherent accesses): 255 rotation
+// rounds per sweep at r = 256 -- the depth of the plain parallel ordering -- where a full inner sweep per block pair
+// cost 441 (first version: 12.7 ms; this one: see DESIGN.md).  rp / 8 lanes per pair, both columns in registers between
+// the dot products and the rotation.  Ends after the first sweep whose largest rotation had cos^2 < 1e-16 (the next
+// sweep would find nothing above the 1e-30 threshold: quadratic convergence), or after a sweep without any rotation.
+// G_in V = U diag(sigma): column i ends as sigma_i u_i, all of svd(Lz' Ls) that nestod_sdc uses (src/ConicIP.jl:204-208).
+__global__ __launch_bounds__(LG_T) void k_lg_jacobi(double *G, int rp, int b, unsigned *ctr, int *err) {
+    extern __shared__ double sh[];
+    __shared__ int s_rot;
+    const int tid = threadIdx.x;
+    const int nbk = rp / b, m = nbk, nwg = nbk / 2;
+    const int ld = lg_pitch(rp);
+    const int nc = 2 * b;                                  // columns in LDS
+    const int tpp = LG_T / b;                              // lanes per column pair (32 or 64); rp == 8 * tpp
+    const int part = tid % tpp, pair = tid / tpp;
+    unsigned phase = 0;
+    unsigned *bar = ctr, *sweepflag = ctr + 8;
+    // rotation of LDS columns p, q; returns 0 / 1 (rotated, small) / 2 (rotated, cos^2 >= 1e-16)
+    auto rotate = [&](int p, int q) -> int {
+        double *gp = sh + p * ld, *gq = sh + q * ld;
+        double xv[8], yv[8], a = 0.0, bb = 0.0, c = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { xv[u] = gp[part + u * tpp]; yv[u] = gq[part + u * tpp]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a += xv[u] * xv[u]; bb += yv[u] * yv[u]; c += xv[u] * yv[u]; }
+        for (int o = tpp >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o); bb += __shfl_xor(bb, o); c += __shfl_xor(c, o); }
+        if (!(c * c > 1e-30 * (a * bb) && c != 0.0)) return 0;
+        const double zeta = (bb - a) * 0.5 * lg_rcp(c);
+        const double h2 = 1.0 + zeta * zeta;
+        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * lg_rcp(fabs(zeta) + h2 * lg_rsqrt(h2));
+        const double cs = lg_rsqrt(1.0 + tt * tt), sn = cs * tt;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            gp[part + u * tpp] = cs * xv[u] - sn * yv[u];
+            gq[part + u * tpp] = sn * xv[u] + cs * yv[u];
+        }
+        return (c * c > 1e-16 * (a * bb)) ? 2 : 1;
+    };
+    auto load = [&](int bp, int bq) {                      // coherent loads: other workgroups wrote these blocks
+        for (int e = tid; e < nc * rp; e += LG_T) {
+            const int i = e % rp, c = e / rp;
+            sh[i + c * ld] = lg_ld(G + i + (long)(c < b ? bp * b + c : bq * b + (c - b)) * rp);
+        }
+        if (tid == 0) s_rot = 0;
+        __syncthreads();
+    };
+    auto store = [&](int bp, int bq) {
+        for (int e = tid; e < nc * rp; e += LG_T) {
+            const int i = e % rp, c = e / rp;
+            lg_st(G + i + (long)(c < b ? bp * b + c : bq * b + (c - b)) * rp, sh[i + c * ld]);
+        }
+    };
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        int rotated = 0;
+        // ---- pairs inside the blocks
+        {
+            const int bp = 2 * (int)blockIdx.x, bq = bp + 1;
+            load(bp, bq);
+            const int hb = b / 2, blk = pair / hb, kk = pair % hb;
+            for (int it = 0; it < b - 1; ++it) {
+                int p, q;
+                if (kk == 0) { p = b - 1; q = it; }
+                else { p = (it + kk) % (b - 1); q = (it - kk + (b - 1)) % (b - 1); }
+                const int rr = rotate(blk * b + p, blk * b + q);
+                if (rr && part == 0) atomicMax(&s_rot, rr);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            rotated = s_rot > rotated ? s_rot : rotated;
+            store(bp, bq);
+            lg_grid_barrier(bar, nwg, phase, err);
+        }
+        // ---- pairs across blocks
+        for (int t = 0; t < m - 1; ++t) {
+            int bp, bq;
+            const int k = blockIdx.x;
+            if (k == 0) { bp = m - 1; bq = t; }
+            else { bp = (t + k) % (m - 1); bq = (t - k + (m - 1)) % (m - 1); }
+            load(bp, bq);
+            for (int it = 0; it < b; ++it) {
+                const int rr = rotate(pair, b + (pair + it) % b);
+                if (rr && part == 0) atomicMax(&s_rot, rr);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            rotated = s_rot > rotated ? s_rot : rotated;
+            store(bp, bq);
+            lg_grid_barrier(bar, nwg, phase, err);
+        }
+        if (tid == 0 && rotated == 2) atomicAdd(sweepflag + sweep, 1u);
+        lg_grid_barrier(bar, nwg, phase, err);
+        const unsigned any = __hip_atomic_load(sweepflag + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!any || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ cooperative tridiagonalisation
+// A = the symmetric r x r matrix  0.5 (M + M') .* (rs rs')  (rs == NULL: no scaling), column slab [32 w, 32 w + 32) in the
+// LDS of workgroup w for the whole reduction.  Output: dg[0..r), of[0..r-1) (sub-diagonal).  Householder by columns
+// exactly as sd_extreme_eig (sdp.hip) does it in one workgroup.
+#define LG_SLAB 32
+// ONE grid barrier per column: beside its entries of p = beta A v every step also publishes the NOT YET UPDATED next
+// column (by its owner), so that after the barrier every workgroup can form the updated next column -- the Householder
+// vector of the following step -- by itself:  a[:, k+1] - v w_0 - w v_0.
+__global__ __launch_bounds__(LG_T) void k_lg_tridiag(const double *M, int ldm, const double *dscale, int r, double *dg, double *of,
+                                                      double *xbuf /* 2 x ldm */, double *pbuf /* 2 x ldm */, unsigned *ctr, int *err) {
+    extern __shared__ double sh[];
+    const int tid = threadIdx.x;
+    const int nwg = gridDim.x, w = blockIdx.x;
+    const int c0 = w * LG_SLAB, ncol = (r - c0 < LG_SLAB) ? (r - c0) : LG_SLAB;
+    const int ld = r | 1;
+    double *a = sh;                                  // slab: a[i + c * ld]
+    double *v = sh + (size_t)LG_SLAB * ld, *wv = v + r, *vn = wv + r, *red = vn + r;
+    unsigned phase = 0;
+    for (int e = tid; e < ncol * r; e += LG_T) {
+        const int i = e % r, c = e / r, j = c0 + c;
+        double x = 0.5 * (M[i + (long)j * ldm] + M[j + (long)i * ldm]);
+        if (dscale) x *= rsqrt(dscale[i]) * rsqrt(dscale[j]);
+        a[i + c * ld] = x;
+    }
+    __syncthreads();
+    // column `col` below its diagonal, as it stands in the owner's slab -> xb
+    auto publish = [&](int col, double *xb) {
+        if (col / LG_SLAB == w) {
+            const int cc = col - c0, mm = r - col - 1;
+            for (int i = tid; i < mm; i += LG_T) lg_st(xb + i, a[(col + 1 + i) + cc * ld]);
+        }
+    };
+    publish(0, xbuf);
+    lg_grid_barrier(ctr, nwg, phase, err);
+    for (int i = tid; i < r - 1; i += LG_T) v[i] = lg_ld(xbuf + i);
+    __syncthreads();
+    for (int k = 0; k + 1 < r; ++k) {
+        const int m = r - k - 1;
+        const int owner = k / LG_SLAB, kc = k - owner * LG_SLAB;
+        double *xb = xbuf + (size_t)((k + 1) & 1) * ldm, *pb = pbuf + (size_t)(k & 1) * ldm;
+        if (w == owner && tid == 0) dg[k] = a[k + kc * ld];
+        double part = 0.0;
+        for (int i = tid; i < m; i += LG_T) part += v[i] * v[i];
+        const double sigma = lg_block_sum(part, red);
+        const double x0 = v[0];
+        if (m == 1) { if (w == owner && tid == 0) of[k] = x0; break; }
+        const bool flat = !(sigma - x0 * x0 > 0.0);          // already tridiagonal in this column (uniform over the grid)
+        double alpha = x0, beta = 0.0;
+        if (!flat) {
+            alpha = -copysign(sqrt(sigma), x0);
+            beta = 1.0 / (sigma - x0 * alpha);               // 2 / ||v||^2 with v = x - alpha e1
+        }
+        __syncthreads();
+        if (tid == 0) { if (!flat) v[0] = x0 - alpha; if (w == owner) of[k] = alpha; }
+        __syncthreads();
+        if (!flat) {
+            // p_j = beta sum_i A[i, j] v_i for the slab's columns j > k: 32 lanes per column
+            const int c = tid >> 5, l32 = tid & 31, j = c0 + c;
+            if (c < ncol && j > k) {
+                double acc = 0.0;
+                const double *col = a + (k + 1) + c * ld;
+                for (int i = l32; i < m; i += 32) acc += col[i] * v[i];
+                for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+                if (l32 == 0) lg_st(pb + (j - k - 1), beta * acc);
+            }
+        }
+        publish(k + 1, xb);                                  // the next column BEFORE this step's update
+        lg_grid_barrier(ctr, nwg, phase, err);
+        if (flat) {
+            for (int i = tid; i < m - 1; i += LG_T) v[i] = lg_ld(xb + i);
+            __syncthreads();
+            continue;
+        }
+        part = 0.0;
+        for (int i = tid; i < m; i += LG_T) { const double p = lg_ld(pb + i); wv[i] = p; part += p * v[i]; }
+        const double kk = 0.5 * beta * lg_block_sum(part, red);
+        for (int i = tid; i < m; i += LG_T) wv[i] -= kk * v[i];
+        __syncthreads();
+        // A22 -= v w' + w v' on the slab's columns j > k
+        for (int e = tid; e < ncol * m; e += LG_T) {
+            const int i = e % m, c = e / m, j = c0 + c;
+            if (j > k) a[(k + 1 + i) + c * ld] -= v[i] * wv[j - k - 1] + wv[i] * v[j - k - 1];
+        }
+        // the updated column k+1 below its diagonal = next step's x, formed by everybody
+        for (int i = tid; i < m - 1; i += LG_T) vn[i] = lg_ld(xb + i) - (v[i + 1] * wv[0] + wv[i + 1] * v[0]);
+        __syncthreads();
+        double *t = v; v = vn; vn = t;
+    }
+    if ((r - 1) / LG_SLAB == w && tid == 0) { dg[r - 1] = a[(r - 1) + ((r - 1) - c0) * ld]; of[r - 1] = 0.0; }
+}
+
+// extreme eigenvalue of the tridiagonal (dg, of) by multisection on the Sturm count (one workgroup), then the max-step
+// verdict of maxstep_sdc (src/ConicIP.jl:272-303): partial[item] <- Inf / 1/(scale lambda_max) / the `nothing` variant
+__global__ __launch_bounds__(LG_T) void k_lg_sturm(const double *dgg, const double *ofg, int r, int want_max, double scale,
+                                                    const int *info, double *partial, int item) {
+    __shared__ double dg[512], of[512], red[64];
+    __shared__ int first;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double INF = __builtin_inf();
+    if (info && info[0]) {                                   // X not positive definite -> Inf (:277-280)
+        if (tid == 0) partial[item] = INF;
+        return;
+    }
+    for (int i = tid; i < r; i += LG_T) { dg[i] = dgg[i]; of[i] = ofg[i]; }
+    __syncthreads();
+    double lo = INF, hi = -INF;
+    for (int i = tid; i < r; i += LG_T) {
+        const double rad = (i > 0 ? fabs(of[i - 1]) : 0.0) + (i + 1 < r ? fabs(of[i]) : 0.0);
+        lo = fmin(lo, dg[i] - rad);
+        hi = fmax(hi, dg[i] + rad);
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
+    if (lane == 0) { red[wave] = lo; red[16 + wave] = hi; }
+    __syncthreads();
+    lo = red[0]; hi = red[16];
+    for (int q = 1; q < LG_T / 64; ++q) { lo = fmin(lo, red[q]); hi = fmax(hi, red[16 + q]); }
+    const double span = fmax(fabs(lo), fabs(hi));
+    hi += 1e-15 * span + 1e-300;
+    lo -= 1e-15 * span + 1e-300;
+    for (int round = 0; round < 12; ++round) {
+        if (!(hi - lo > 4.4e-16 * fmax(fabs(lo), fabs(hi)))) break;
+        const double step = (hi - lo) / (LG_T + 1);
+        const double xs = lo + step * (tid + 1);
+        int cnt = 0;
+        double q = dg[0] - xs;
+        if (q < 0.0) ++cnt;
+        for (int i = 1; i < r; ++i) {
+            if (q == 0.0) q = 1e-300;
+            q = (dg[i] - xs) - of[i - 1] * of[i - 1] / q;
+            if (q < 0.0) ++cnt;
+        }
+        const bool hit = want_max ? (cnt >= r) : (cnt >= 1);
+        if (tid == 0) first = LG_T;
+        __syncthreads();
+        if (hit) atomicMin(&first, tid);
+        __syncthreads();
+        const int f = first;
+        __syncthreads();
+        const double nlo = (f == 0) ? lo : lo + step * f;
+        const double nhi = (f == LG_T) ? hi : lo + step * (f + 1);
+        lo = nlo; hi = nhi;
+    }
+    const double ev = 0.5 * (lo + hi);
+    if (tid == 0) {
+        if (want_max) { const double mx = ev * scale; partial[item] = (mx < 0.0) ? INF : 1.0 / mx; }
+        else partial[item] = (ev > 0.0) ? 0.0 : -1.0 + ev;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+int cip_sdp_large_padded(int r) { return r <= 256 ? 256 : 512; }
+
+int cip_sdp_large_create(int rmax_large, int nlarge, LargeWs **out) {
+    LargeWs *w = new LargeWs();
+    const int rp = cip_sdp_large_padded(rmax_large);
+    w->rp = rp;
+    const size_t m2 = al256((size_t)rp * rp * 8);
+    size_t bytes = 8 * m2 + 4 * (size_t)nlarge * m2 + al256(12 * (size_t)rp * 8) + 2 * (size_t)w->chunk * m2 + al256(1024) +
+                   2 * al256(cip_ldlt_ws_bytes(rp));
+    CIP_HIP_CHECK(hipMalloc((void **)&w->base, bytes));
+    char *p = (char *)w->base;
+    double **mats[8] = {&w->Kz, &w->Ks, &w->Tz, &w->Ts, &w->G, &w->M1, &w->M2, &w->M3};
+    for (auto m : mats) { *m = (double *)p; p += m2; }
+    w->Rip = (double *)p; p += 4 * (size_t)nlarge * m2;
+    w->vec = (double *)p; p += al256(12 * (size_t)rp * 8);
+    w->batchX = (double *)p; p += (size_t)w->chunk * m2;
+    w->batchT = (double *)p; p += (size_t)w->chunk * m2;
+    w->ctr = (unsigned *)p; p += al256(1024);
+    w->ldl_z = p; p += al256(cip_ldlt_ws_bytes(rp));
+    w->ldl_s = p;
+    cip_ldlt_ws_carve(w->ldl_z, rp, &w->wz);
+    cip_ldlt_ws_carve(w->ldl_s, rp, &w->ws);
+    w->wz.signs = w->ws.signs = PivotSigns{0, rp, rp};       // a Cholesky in disguise: every pivot must be positive
+    *out = w;
+    return 0;
+}
+void cip_sdp_large_destroy(LargeWs *w) {
+    if (!w) return;
+    if (w->base) (void)hipFree(w->base);
+    delete w;
+}
+
+static dim3 lg_grid(long n) { return dim3((unsigned)((n + 255) / 256)); }
+// C_b = A_b B_b'  (rp x rp each, 64x64 fp64-MFMA tiles); stride 0 = operand shared by the batch
+static int lg_gemm(hipStream_t s, double *C, long sC, const double *A, long sA, const double *B, long sB, int rp, int batch) {
+    GemmArgs g = {};
+    g.A = A; g.lda = rp; g.B = B; g.ldb = rp; g.C = C; g.ldc = rp;
+    g.M = g.N = g.K = rp; g.alpha = 1.0; g.overwrite = 1; g.by = batch; g.bz = 1;
+    g.sAy = sA; g.sBy = sB; g.sCy = sC;
+    return cip_launch_gemm(s, EPI_ACCUM, g);
+}
+static int lg_set_attr(const void *fn, size_t bytes) {
+    CIP_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+static int lg_tridiag(hipStream_t s, LargeWs *w, const double *M, const double *dscale, int r) {
+    const int nwg = (r + LG_SLAB - 1) / LG_SLAB;
+    const size_t shm = ((size_t)LG_SLAB * (r | 1) + 3 * (size_t)r + 64) * sizeof(double);
+    int rc;
+    if ((rc = lg_set_attr((const void *)k_lg_tridiag, shm))) return rc;
+    CIP_HIP_CHECK(hipMemsetAsync(w->ctr, 0, 1024, s));
+    double *dg = w->vec + 1 * w->rp, *of = w->vec + 2 * w->rp, *xbuf = w->vec + 3 * w->rp, *pbuf = w->vec + 5 * w->rp;   // 2 x rp each
+    hipLaunchKernelGGL(k_lg_tridiag, dim3(nwg), dim3(LG_T), shm, s, M, w->rp, dscale, r, dg, of, xbuf, pbuf, w->ctr,
+                       (int *)(w->ctr + 128));
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// nestod_sdc for one large cone (index li among the large cones)
+int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, const double *v, const double *sv, double *scal,
+                     double *lambda, int *flag) {
+    const int r = cd.r, rp = w->rp;
+    const long n2 = (long)rp * rp;
+    int rc;
+    hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, v + cd.off, 1L, 0L, w->Kz, r, rp, 1.0);
+    hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, sv + cd.off, 1L, 0L, w->Ks, r, rp, 1.0);
+    if ((rc = cip_ldlt_factor(s, w->Kz, rp, rp, w->wz))) return rc;                 // Lz (unit) and d_z  (:202-203)
+    if ((rc = cip_ldlt_factor(s, w->Ks, rp, rp, w->ws))) return rc;
+    hipLaunchKernelGGL(k_lg_flag, dim3(1), dim3(64), 0, s, w->wz.info, w->ws.info, flag);
+    hipLaunchKernelGGL(k_lg_tfac, lg_grid(n2), dim3(256), 0, s, w->Kz, w->wz.dvec, w->Tz, rp);
+    hipLaunchKernelGGL(k_lg_tfac, lg_grid(n2), dim3(256), 0, s, w->Ks, w->ws.dvec, w->Ts, rp);
+    if ((rc = lg_gemm(s, w->G, 0, w->Tz, 0, w->Ts, 0, rp, 1))) return rc;           // G = Lz' Ls          (:204)
+    {
+        const int b = rp <= 256 ? 32 : 16;
+        const size_t shm = (size_t)2 * b * lg_pitch(rp) * sizeof(double);
+        if ((rc = lg_set_attr((const void *)k_lg_jacobi, shm))) return rc;
+        CIP_HIP_CHECK(hipMemsetAsync(w->ctr, 0, 1024, s));
+        hipLaunchKernelGGL(k_lg_jacobi, dim3(rp / b / 2), dim3(LG_T), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
+    }
+    if (getenv("CIP_LG_DEBUG")) {
+        unsigned hc[64];
+        CIP_HIP_CHECK(hipMemcpyAsync(hc, w->ctr, sizeof(hc), hipMemcpyDeviceToHost, s));
+        CIP_HIP_CHECK(hipStreamSynchronize(s));
+        int sweeps = 0;
+        for (int q = 8; q < 48; ++q) if (hc[q]) ++sweeps;
+        fprintf(stderr, "[lg] jacobi: %d sweeps with a rotation above cos^2 = 1e-16, %u barriers\n", sweeps, hc[0] / (unsigned)(rp / (rp <= 256 ? 32 : 16) / 2));
+    }
+    double *lam = w->vec;
+    hipLaunchKernelGGL(k_lg_colnorm, dim3((rp + 3) / 4), dim3(256), 0, s, w->G, lam, rp);
+    hipLaunchKernelGGL(k_lg_build, lg_grid(n2), dim3(256), 0, s, w->G, lam, w->wz.dvec, w->Kz, w->M1, w->M2, w->M3, rp);
+    const double *XTz = (w->wz.Bs == CIP_NB) ? w->wz.LinvT : w->wz.XT;             // inv(Lz_unit)' (one block = the matrix)
+    if ((rc = lg_gemm(s, w->Tz, 0, XTz, 0, w->M1, 0, rp, 1))) return rc;            // R    = Lz^-T U Lambda^1/2   (:206-208)
+    if ((rc = lg_gemm(s, w->Ts, 0, w->M2, 0, w->M3, 0, rp, 1))) return rc;          // Rinv = Lambda^-1/2 U' Lz'
+    double *R = scal + cd.soff, *Ri = R + (size_t)r * r;
+    hipLaunchKernelGGL(k_lg_store, lg_grid(n2 > cd.dim ? n2 : cd.dim), dim3(256), 0, s, w->Tz, w->Ts, R, Ri, w->Rip + 4 * (size_t)li * n2,
+                       lam, lambda ? lambda + cd.off : nullptr, r, rp, cd.dim);
+    if (lambda) hipLaunchKernelGGL(k_lg_lambda_diag, lg_grid(r), dim3(256), 0, s, lam, lambda + cd.off, r);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// padded Rinv after the host replaced the packed scaling
+int cip_sdp_large_refresh(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, const double *scal) {
+    const int r = cd.r, rp = w->rp;
+    hipLaunchKernelGGL(k_lg_pad, lg_grid((long)rp * rp), dim3(256), 0, s, scal + cd.soff, scal + cd.soff + (size_t)r * r,
+                       w->Rip + 4 * (size_t)li * rp * rp, r, rp);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// maxstep_sdc for one large cone: partial[cd.item]
+int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *d, double scale,
+                          double *partial) {
+    const int r = cd.r, rp = w->rp;
+    const long n2 = (long)rp * rp;
+    int rc;
+    double *dg = w->vec + 1 * rp, *of = w->vec + 2 * rp;
+    if (!d) {                                                                       // maxstep_sdc(x, nothing) :295-303
+        hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, x + cd.off, 1L, 0L, w->M3, r, rp, 0.0);
+        if ((rc = lg_tridiag(s, w, w->M3, nullptr, r))) return rc;
+        hipLaunchKernelGGL(k_lg_sturm, dim3(1), dim3(LG_T), 0, s, dg, of, r, 0, 1.0, (const int *)nullptr, partial, cd.item);
+        CIP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, x + cd.off, 1L, 0L, w->Kz, r, rp, 1.0);
+    if ((rc = cip_ldlt_factor(s, w->Kz, rp, rp, w->wz))) return rc;                 // X = L D L'
+    hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, d + cd.off, 1L, 0L, w->M1, r, rp, 0.0);
+    const double *Xi = (w->wz.Bs == CIP_NB) ? w->wz.Linv : w->wz.X;                // inv(L_unit)
+    if ((rc = lg_gemm(s, w->M2, 0, Xi, 0, w->M1, 0, rp, 1))) return rc;             // inv(L) D        (D symmetric)
+    if ((rc = lg_gemm(s, w->M3, 0, w->M2, 0, Xi, 0, rp, 1))) return rc;             // inv(L) D inv(L)'
+    if ((rc = lg_tridiag(s, w, w->M3, w->wz.dvec, r))) return rc;                   // ... scaled by d^-1/2 on both sides
+    hipLaunchKernelGGL(k_lg_sturm, dim3(1), dim3(LG_T), 0, s, dg, of, r, 1, scale, (const int *)w->wz.info, partial, cd.item);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Wt[i, off + e] = (F^-T a_i)_e = vecm(Rinv mat(a_i) Rinv')_e for every row i of At (= column of A), in chunks
+int cip_sdp_large_scale_At(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, int n, const double *At, long ldat, double *Wt,
+                           long ldwt) {
+    const int r = cd.r, rp = w->rp;
+    const long n2 = (long)rp * rp;
+    const double *Rip = w->Rip + 4 * (size_t)li * n2;
+    int rc;
+    for (int i0 = 0; i0 < n; i0 += w->chunk) {
+        const int nb = (n - i0 < w->chunk) ? (n - i0) : w->chunk;
+        dim3 gm((unsigned)((n2 + 255) / 256), nb);
+        hipLaunchKernelGGL(k_lg_mat, gm, dim3(256), 0, s, At + i0 + (long)cd.off * ldat, ldat, 1L, w->batchX, r, rp, 0.0);
+        if ((rc = lg_gemm(s, w->batchT, n2, Rip, 0, w->batchX, n2, rp, nb))) return rc;     // Rinv X      (X symmetric)
+        if ((rc = lg_gemm(s, w->batchX, n2, w->batchT, n2, Rip, 0, rp, nb))) return rc;     // (Rinv X) Rinv'
+        dim3 gv((unsigned)(((long)r * r + 255) / 256), nb);
+        hipLaunchKernelGGL(k_lg_vecm, gv, dim3(256), 0, s, w->batchX, Wt + i0 + (long)cd.off * ldwt, ldwt, 1L, r, rp);
+    }
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// out = vecm(P' mat(x) P), P = R (F), R' (F'), Rinv (F^-1), Rinv' (F^-T)  (VecCongurance, src/ConicIP.jl:35-40, :69):
+// two chip-wide GEMMs  Y = Q X Q'  with Q = P' taken from the padded copies
+int cip_sdp_large_apply(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, int mode, const double *x, double *out) {
+    const int r = cd.r, rp = w->rp;
+    const long n2 = (long)rp * rp;
+    // pad[]: 0 Rinv, 1 Rinv', 2 R, 3 R'
+    const int which = (mode == CIP_OP_F) ? 3 : (mode == CIP_OP_FT) ? 2 : (mode == CIP_OP_FINV) ? 1 : 0;
+    const double *Q = w->Rip + (4 * (size_t)li + which) * n2;
+    int rc;
+    hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, x + cd.off, 1L, 0L, w->M1, r, rp, 0.0);
+    if ((rc = lg_gemm(s, w->M2, 0, Q, 0, w->M1, 0, rp, 1))) return rc;              // Q X      (X symmetric)
+    if ((rc = lg_gemm(s, w->M3, 0, w->M2, 0, Q, 0, rp, 1))) return rc;              // (Q X) Q'
+    hipLaunchKernelGGL(k_lg_vecm, lg_grid((long)r * r), dim3(256), 0, s, w->M3, out + cd.off, 1L, 0L, r, rp);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -39,8 +39,8 @@ def interior(cone_dims, rng):
 
 @pytest.mark.parametrize("cone_dims", [[("S", 6)], [("S", 21)], [("S", 15), ("S", 3)],
                                        [("R", 5), ("Q", 4), ("S", 10)], [("S", 465)], [("S", 2080)], [("S", 5050), ("S", 6)],
-                                       [("S", 8256)], [("S", 11325)]],
-                         ids=["r3", "r6", "r5+r2", "mixed", "r30", "r64", "r100+r3", "r128", "r150"])
+                                       [("S", 8256)], [("S", 11325)], [("S", 20100), ("S", 10)], [("S", 32896)], [("S", 45150)]],
+                         ids=["r3", "r6", "r5+r2", "mixed", "r30", "r64", "r100+r3", "r128", "r150", "r200+r4", "r256", "r300"])
 def test_sdp_cone_ops(cone_dims):
     import cipkkt
     from cipkkt import OP_F, OP_FT, OP_FINV, OP_FINVT
