@@ -368,6 +368,14 @@ def main():
             "breakdown_ms": {"assemble": st["ms_assemble"], "ldlt_factor": st["ms_ldlt"], "solve4x4": solve_ms,
                              "ldlt_tflops_whole_factor": (N ** 3 / 3.0) / (st["ms_ldlt"] * 1e-3) / 1e12
                              if st["ms_ldlt"] > 0 else None},
+            "roofline_solve": {"bound": "hbm", "kernel": "LDL' triangular sweeps inside cip_solve4x4 (k_gemv_t block steps)",
+                               "achieved": (8.0 * N * (N + 1) + 16.0 * N * min(1024, ks.Npad)) / (solve_ms * 1e-3) / 1e9,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": (8.0 * N * (N + 1) + 16.0 * N * min(1024, ks.Npad)) / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "traffic": None,
+                               "note": "algorithmic bytes of one solve = L read once per sweep (8 N (N+1)) + the 1024-wide block "
+                                       "inverses (16 N Bs); time = whole cip_solve4x4 call (cone division, A'/A products, "
+                                       "two sweeps), host-timed average of 5"},
             "roofline": {"bound": "mfma",
                          "kernel": "LDL' trailing update: k_ldlt_trailing_64 (64x64 fp64-MFMA tiles, K = outer block)",
                          "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

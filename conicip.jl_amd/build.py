@@ -51,7 +51,7 @@ def build(force=False, verbose=False):
                 if verbose and warn.strip():
                     print(warn)
     if force or jobs or not os.path.exists(OUT):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"])
     return OUT
 
 

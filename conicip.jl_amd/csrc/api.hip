@@ -18,6 +18,34 @@ void cip_set_error(const char *fmt, ...) {
 }
 extern "C" const char *cip_last_error(void) { return g_err; }
 
+// ------------------------------------------------------------------ profiler ranges (roctx)
+// "cip:scaling", "cip:assemble", "cip:ldlt", "cip:solve3x3", "cip:iteration" ranges for rocprofv3 --marker-trace.  The
+// marker library is looked up at run time (no link-time dependency: the library links libamdhip64 only); absent or
+// CIP_ROCTX=0 -> no-ops.
+#include <dlfcn.h>
+#include <mutex>
+static int (*g_roctx_push)(const char *) = nullptr;
+static int (*g_roctx_pop)(void) = nullptr;
+static std::once_flag g_roctx_once;
+static void roctx_init(void) {
+    const char *e = getenv("CIP_ROCTX");
+    if (e && atoi(e) == 0) return;
+    for (const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+        if (void *lib = dlopen(name, RTLD_LAZY | RTLD_LOCAL)) {
+            g_roctx_push = (int (*)(const char *))dlsym(lib, "roctxRangePushA");
+            g_roctx_pop = (int (*)(void))dlsym(lib, "roctxRangePop");
+            if (g_roctx_push && g_roctx_pop) return;
+            g_roctx_push = nullptr; g_roctx_pop = nullptr;
+        }
+    }
+}
+void cip_range_push(const char *name) {
+    std::call_once(g_roctx_once, roctx_init);
+    if (g_roctx_push) (void)g_roctx_push(name);
+}
+void cip_range_pop(void) { if (g_roctx_pop) (void)g_roctx_pop(); }
+struct CipRange { explicit CipRange(const char *n) { cip_range_push(n); } ~CipRange() { cip_range_pop(); } };
+
 static int rup(int x, int q) { return ((x + q - 1) / q) * q; }
 
 #define DMALLOC(ptr, bytes)                                                        \
@@ -363,6 +391,7 @@ extern "C" int cip_set_scaling_identity(cip_handle *h) {
 extern "C" int cip_set_scaling_from_iterate_dev(cip_handle *h, const double *v, const double *s, double *lambda_out) {
     if (!h || (h->m > 0 && (!v || !s))) { cip_set_error("NULL argument"); return CIP_E_INVALID; }
     h->assembled = h->factored = false;
+    CipRange rg("cip:scaling");
     return cip_cones_nt_scaling(h->stream, h->cs, v, s, lambda_out);
 }
 
@@ -380,9 +409,9 @@ extern "C" int cip_assemble_only(cip_handle *h) {
 // assembly + LDL' + an asynchronous read-back of the pivot flag into pinned host memory; nothing here waits for the GPU
 static int factor_enqueue(cip_handle *h) {
     int rc;
-    if ((rc = cip_assemble(h))) return rc;
+    { CipRange rg("cip:assemble"); if ((rc = cip_assemble(h))) return rc; }
     if (h->timing) CIP_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
-    if ((rc = cip_ldlt_factor(h->stream, h->K, h->Npad, h->ldk, h->ws))) return rc;
+    { CipRange rg("cip:ldlt"); if ((rc = cip_ldlt_factor(h->stream, h->K, h->Npad, h->ldk, h->ws))) return rc; }
     h->n_factor += 1;
     CIP_HIP_CHECK(hipMemcpyAsync(h->info_host, h->ws.info, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     CIP_HIP_CHECK(hipEventRecord(h->ev_info, h->stream));
@@ -576,6 +605,7 @@ extern "C" int cip_solve3x3_dev(cip_handle *h, const double *x, const double *y,
     if (!h->factored) { cip_set_error("cip_solve3x3: no factorisation (call cip_factor first)"); return CIP_E_NOTFACTORED; }
     const int n = h->n, m = h->m, p = h->p;
     int rc;
+    CipRange rg("cip:solve3x3");
     if ((rc = factor_resolve(h, false))) return rc;      // no host wait: resolved only if the flag has already landed
     if (h->info_pending) h->spec_solves += 1;
     h->n_solve += 1;

@@ -67,3 +67,7 @@ struct cip_handle {
 int cip_assemble(cip_handle *h);     // assemble.hip
 // api.hip: resolve the pivot flag of the last factorisation (wait = 0: only if its read-back has already landed)
 int cip_factor_resolve(cip_handle *h, int wait);
+
+// api.hip: roctx ranges (no-ops when the marker library is not present)
+void cip_range_push(const char *name);
+void cip_range_pop(void);

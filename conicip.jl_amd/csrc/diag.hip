@@ -316,42 +316,74 @@ __global__ __launch_bounds__(256) void k_diag_inverse_batched(const double *K, l
 // Half the flops of the inverse-GEMM form, 4x more workgroups, no 128x128 inverse on the critical path.
 // (A 96-register cap -- launch bound 5 waves/SIMD -- lets these workgroups co-reside with the look-ahead's GEMM
 // workgroups, but serialises the operand loads: same-session A/B 117.0 vs 118.8 KKT solves/s without the cap.)
+// (First version: L11 tiles, micro inverses and the A21 row tile were loaded from L2 INSIDE the chain, 8 + 28 dependent
+// round trips per wave: 12 us on an idle chip.  Now everything the chain touches is fetched before it starts -- the 28
+// strictly-lower 16x16 tiles of L11, the 8 micro inverses and 1/d staged once per workgroup in LDS (73 KB, two
+// workgroups per CU), the wave's own 16 x 128 row tile in registers -- so the kernel is one memory round trip plus
+// 144 dependent MFMAs per wave.  Same operations in the same order: bit-identical results.)
+#define TRSM_LDS_DOUBLES (28 * 256 + 8 * 256 + 128)
+__device__ __forceinline__ int trsm_tile_index(int kb, int qq) { return kb * (kb - 1) / 2 + qq; }        // qq < kb
 __global__ __launch_bounds__(256) void k_trsm_subst(double *__restrict__ Ap, long ld, const double *__restrict__ L11,
                                                         const double *__restrict__ xm, const double *__restrict__ dinv,
                                                         double *__restrict__ W, long ldw) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *lt = sm, *xs = sm + 28 * 256, *ds = xs + 8 * 256;
     __builtin_amdgcn_s_setprio(3);       // panel chain is latency-critical: win issue arbitration against co-resident GEMM waves
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const long row = (long)blockIdx.x * 64 + wave * 16 + l15;
     double *ap = Ap + row + (long)g * ld;
     double *wp = W + row + (long)g * ldw;
-    const double *lp = L11 + l15 + (long)g * ld;       // + kb*16 rows, + (q*16 + 4s) columns
+    // ---- everything in flight at once: the wave's A21 rows ...
+    double areg[8][4];
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) areg[kb][q] = ap[(long)(kb * 16 + 4 * q) * ld];
+    // ... and the shared operands: tile (kb, qq) stored [column][row] so that a lane's operand (row l15, column 4s + g)
+    // sits at ((4s + g) * 16 + l15): 64 consecutive doubles per MFMA step, conflict-free
+    {
+        const int r = tid & 15, c = tid >> 4;
+        double tl[28];
+#pragma unroll
+        for (int kb = 1; kb < 8; ++kb)
+#pragma unroll
+            for (int qq = 0; qq < kb; ++qq) tl[trsm_tile_index(kb, qq)] = L11[kb * 16 + r + (long)(qq * 16 + c) * ld];
+        double xv[8];
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) xv[kb] = xm[kb * 256 + tid];
+        const double dv = tid < CIP_NB ? dinv[tid] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 28; ++t) lt[t * 256 + c * 16 + r] = tl[t];
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) xs[kb * 256 + tid] = xv[kb];
+        if (tid < CIP_NB) ds[tid] = dv;
+    }
+    __syncthreads();
     double wneg[8][4];
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
-        v4d acc;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = ap[(long)(kb * 16 + 4 * q) * ld];
+        v4d acc = (v4d){areg[kb][0], areg[kb][1], areg[kb][2], areg[kb][3]};
 #pragma unroll
         for (int qq = 0; qq < kb; ++qq) {
+            const double *t = lt + trsm_tile_index(kb, qq) * 256 + g * 16 + l15;
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                acc = MFMA(lp[kb * 16 + (long)(qq * 16 + 4 * s) * ld], wneg[qq][s], acc);
+            for (int s = 0; s < 4; ++s) acc = MFMA(t[64 * s], wneg[qq][s], acc);
         }
         v4d w = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) w = MFMA(xm[kb * 256 + (g + 4 * s) * 16 + l15], acc[s], w);
+        for (int s = 0; s < 4; ++s) w = MFMA(xs[kb * 256 + (g + 4 * s) * 16 + l15], acc[s], w);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long col = kb * 16 + 4 * q;
             wneg[kb][q] = -w[q];
             wp[col * ldw] = w[q];
-            ap[col * ld] = w[q] * dinv[col + g];
+            ap[col * ld] = w[q] * ds[col + g];
         }
     }
 }
 
-static bool g_attr_diag = false, g_attr_inv = false;
+static bool g_attr_diag = false, g_attr_inv = false, g_attr_trsm = false;
 int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
                        PivotSigns sg) {
     if (!g_attr_diag) {
@@ -377,7 +409,12 @@ int cip_launch_diag_inverse(hipStream_t s, const double *K, long ld, int nblk, c
 int cip_launch_trsm_subst(hipStream_t s, double *Ap, long ld, int rows, const double *L11, const double *xm,
                           const double *dinv, double *W, long ldw) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(k_trsm_subst, dim3(rows / 64), dim3(256), 0, s, Ap, ld, L11, xm, dinv, W, ldw);
+    if (!g_attr_trsm) {
+        CIP_HIP_CHECK(hipFuncSetAttribute((const void *)k_trsm_subst, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(TRSM_LDS_DOUBLES * sizeof(double))));
+        g_attr_trsm = true;
+    }
+    hipLaunchKernelGGL(k_trsm_subst, dim3(rows / 64), dim3(256), TRSM_LDS_DOUBLES * sizeof(double), s, Ap, ld, L11, xm, dinv, W, ldw);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -149,7 +149,9 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
         CK(D.axpby(m, -a_s, e, 1.0, z.s));
     }
 
+    struct IterRange { IterRange() { cip_range_push("cip:iteration"); } ~IterRange() { cip_range_pop(); } };
     for (int Iter = 1; Iter <= o.maxIters; ++Iter) {                                   // :730
+        IterRange iter_range;
         if (m > 0) CK(cip_set_scaling_from_iterate_dev(h, z.v, z.s, lam));             // :732-735 (F, lambda = F v)
         CK(cip_factor(h)); ++n_factor;                                                 // :737 -> :682
         if (m > 0) CK(cip_cone_prod_dev(h, lam, lam, rleft.s));                        // :746
