@@ -198,23 +198,45 @@ static int create_impl(const cip_problem *pr, cip_handle *h) {
             if (cd.dim > kmax) kmax = cd.dim;
         } else { cip_set_error("cone %d: unknown type %d", c, cd.type); return CIP_E_INVALID; }
         if (soff > 0x7fffffffULL) { cip_set_error("scaling storage too large"); return CIP_E_INVALID; }
-        cd.item = (int)h->h_items.size();
         h->h_cones.push_back(cd);
-        if (cd.type == CIP_CONE_R) {
-            for (int st = 0; st < cd.dim; st += 2048) h->h_items.push_back(WorkItem{c, st, (cd.dim - st < 2048) ? cd.dim - st : 2048});
-        } else {
-            h->h_items.push_back(WorkItem{c, 0, cd.dim});       // Q and S cones: one item per cone
-        }
         off += cd.dim;
+    }
+    // work items (one workgroup each) and partial-result slots.  Consecutive Q cones of dimension <= 64 are packed:
+    // lane segments of width W = next power of two of the run's largest cone, 256 / W cones per workgroup.
+    int nslots = 0;
+    for (int c = 0; c < pr->ncones;) {
+        ConeDesc &cd = h->h_cones[c];
+        if (cd.type == CIP_CONE_R) {
+            cd.item = nslots;
+            for (int st = 0; st < cd.dim; st += 2048) h->h_items.push_back(WorkItem{c, st, (cd.dim - st < 2048) ? cd.dim - st : 2048, nslots++, 0});
+            ++c;
+        } else if (cd.type == CIP_CONE_Q && cd.dim <= 64) {
+            int e = c, dmax = 0;
+            while (e < pr->ncones && h->h_cones[e].type == CIP_CONE_Q && h->h_cones[e].dim <= 64) { if (h->h_cones[e].dim > dmax) dmax = h->h_cones[e].dim; ++e; }
+            int W = 1;
+            while (W < dmax) W *= 2;
+            const int per = 256 / W;
+            for (int q = c; q < e; q += per) {
+                const int cnt = (e - q < per) ? (e - q) : per;
+                for (int u = 0; u < cnt; ++u) h->h_cones[q + u].item = nslots + u;
+                h->h_items.push_back(WorkItem{q, 0, cnt, nslots, W});
+                nslots += cnt;
+            }
+            c = e;
+        } else {
+            cd.item = nslots;
+            h->h_items.push_back(WorkItem{c, 0, cd.dim, nslots++, 0});      // a large Q cone or an S cone: one workgroup
+            ++c;
+        }
     }
     if (off != m) { cip_set_error("cone_dims cover %d rows but A has %d", off, m); return CIP_E_INVALID; }
     if (has_S && pr->A == NULL && m > 0) { cip_set_error("S cones need a dense A"); return CIP_E_UNSUPPORTED; }
     h->nq = nq; h->nqpad = rup(nq > 0 ? nq : 1, CIP_KT);
-    h->cs.ncones = pr->ncones; h->cs.nitems = (int)h->h_items.size(); h->cs.m = m; h->cs.scal_len = soff; h->cs.has_S = has_S;
+    h->cs.ncones = pr->ncones; h->cs.nitems = (int)h->h_items.size(); h->cs.nslots = nslots; h->cs.m = m; h->cs.scal_len = soff; h->cs.has_S = has_S;
     DMALLOC(h->cs.d_cones, sizeof(ConeDesc) * h->h_cones.size());
     DMALLOC(h->cs.d_items, sizeof(WorkItem) * h->h_items.size());
     DMALLOC(h->cs.d_scal, sizeof(double) * soff);
-    DMALLOC(h->cs.d_partial, sizeof(double) * (h->h_items.size() + 1));
+    DMALLOC(h->cs.d_partial, sizeof(double) * (nslots + 1));
     DMALLOC(h->cs.d_scalar, sizeof(double) * 8);
     h->cs.ns = (int)sidx.size(); h->cs.rmax = rmax; h->cs.kmax = kmax;
     h->cs.ns_small = 0; h->cs.nlarge = 0; h->cs.lg = nullptr; h->cs.d_sidx_small = nullptr;

@@ -102,19 +102,23 @@ __global__ __launch_bounds__(256) void k_fill_ftf(const ConeDesc *cones, const W
             K[g + g * ldk] = -d * d;
         }
     } else if (cd.type == CIP_CONE_Q) {
-        // F'F = F^2 = beta^2 (2 wbar wbar' - J)
-        const int k = cd.dim;
-        const double beta = scal[cd.soff];
-        const double *w = scal + cd.soff + 1;
-        const double b2 = beta * beta, w0 = w[0];
-        for (long e = tid; e < (long)k * k; e += 256) {
-            const int i = (int)(e % k), j = (int)(e / k);
-            if (i < j) continue;
-            const double wi = (i == 0) ? (w0 * w0 / beta - 1.0) : (w0 * w[i] / beta);
-            const double wj = (j == 0) ? (w0 * w0 / beta - 1.0) : (w0 * w[j] / beta);
-            double v = 2.0 * wi * wj;
-            if (i == j) v -= (i == 0) ? 1.0 : -1.0;
-            K[(cd.off + i) + (long)(cd.off + j) * ldk] = -b2 * v;
+        // F'F = F^2 = beta^2 (2 wbar wbar' - J); a pack of small cones: the workgroup walks through its cones
+        const int ncone = it.width ? it.len : 1;
+        for (int q = 0; q < ncone; ++q) {
+            const ConeDesc qc = cones[it.cone + q];
+            const int k = qc.dim;
+            const double beta = scal[qc.soff];
+            const double *w = scal + qc.soff + 1;
+            const double b2 = beta * beta, w0 = w[0];
+            for (long e = tid; e < (long)k * k; e += 256) {
+                const int i = (int)(e % k), j = (int)(e / k);
+                if (i < j) continue;
+                const double wi = (i == 0) ? (w0 * w0 / beta - 1.0) : (w0 * w[i] / beta);
+                const double wj = (j == 0) ? (w0 * w0 / beta - 1.0) : (w0 * w[j] / beta);
+                double v = 2.0 * wi * wj;
+                if (i == j) v -= (i == 0) ? 1.0 : -1.0;
+                K[(qc.off + i) + (long)(qc.off + j) * ldk] = -b2 * v;
+            }
         }
     }
 }

@@ -91,20 +91,22 @@ struct ConeDesc {             // one per cone
     int soff;                 // offset into the packed scaling storage
     int r;                    // S cone: matrix order
     int qidx;                 // Q cone: running index among Q cones (else -1)
-    int item;                 // index of this cone's (first) work item
+    int item;                 // this cone's (first) slot in the partial-result array
 };
-struct WorkItem {             // unit of work for the per-cone kernels
-    int cone;                 // index into ConeDesc[]
+struct WorkItem {             // unit of work (one 256-thread workgroup) of the per-cone kernels
+    int cone;                 // index into ConeDesc[] (first cone of a pack)
     int start;                // first element (relative to the cone) -- R cones are chunked
-    int len;
+    int len;                  // elements of the chunk; for a pack: number of cones
+    int slot;                 // first slot of the per-cone partial results (max-step); a pack owns `len` consecutive slots
+    int width;                // 0, or the lane-segment width of a pack of consecutive Q cones of dimension <= width <= 64
 };
 struct ConeSet {
-    int ncones, nitems, m;
+    int ncones, nitems, nslots, m;
     ConeDesc *d_cones;        // device
     WorkItem *d_items;        // device
     double *d_scal;           // device packed scaling
     size_t scal_len;
-    double *d_partial;        // nitems doubles (reductions)
+    double *d_partial;        // nslots doubles (reductions)
     double *d_scalar;         // 8 doubles
     int has_S;
     // S cones (sdp.hip)

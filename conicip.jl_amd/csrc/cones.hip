@@ -6,8 +6,12 @@
 //   maxstep                         src/ConicIP.jl:212-270, :571-587
 //   cone identity e                 src/ConicIP.jl:559-565
 //
-// One workgroup (256 threads = 4 wave64) per work item; a work item is a whole Q cone
-// or a <=2048-element chunk of an R cone.  All reductions are wave shuffles + one LDS hop.
+// One workgroup (256 threads = 4 wave64) per work item.  A work item is a <= 2048-element chunk of an R cone, one Q cone
+// of dimension > 64 (all 256 threads: wave shuffles + one LDS hop per reduction), or a PACK of consecutive Q cones of
+// dimension <= 64: each cone gets a lane segment of width W = the next power of two (256 / W cones per workgroup, e.g.
+// 32 cones of BASELINE config 3's ("Q", 8) per workgroup, 8 per wavefront), its reductions are xor-shuffles inside the
+// segment and no barrier is needed at all.  (The first version spent a 256-thread workgroup on every Q(8): 8 of 256
+// lanes busy, 512 workgroups per call for config 3; now 16.)
 //
 // Packed scaling storage per cone (== what the Julia shim reads off the Block elements):
 //   R: diag(F) (k)      Q: beta, w (1+k) with F = diag(-beta,beta,..) + w w'      S: R, inv(R)
@@ -45,6 +49,24 @@ __device__ __forceinline__ double block_min(double a, double *sh) {
     return fmin(fmin(sh[0], sh[1]), fmin(sh[2], sh[3]));
 }
 
+// the lanes that work on one Q cone: the whole workgroup (T = 256) or a segment of a wavefront (T = pack width)
+struct QTeam { ConeDesc cd; int T, tl, slot; bool active; };
+__device__ __forceinline__ QTeam q_team(const ConeDesc *cones, const WorkItem &it, const ConeDesc &first) {
+    QTeam t;
+    t.cd = first; t.T = 256; t.tl = threadIdx.x; t.slot = it.slot; t.active = true;
+    if (it.width) {
+        const int seg = threadIdx.x / it.width;
+        t.T = it.width; t.tl = threadIdx.x - seg * it.width; t.active = seg < it.len; t.slot = it.slot + seg;
+        t.cd = cones[it.cone + (t.active ? seg : 0)];
+    }
+    return t;
+}
+__device__ __forceinline__ void team_sum3(double &a, double &b, double &c, int T, double *sh) {
+    if (T == 256) { block_sum3(a, b, c, sh); return; }
+    for (int o = T >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+}
+__device__ __forceinline__ void team_sync(int T) { if (T == 256) __syncthreads(); }   // a segment lives inside one wavefront
+
 // ------------------------------------------------------------------ NT scaling
 __global__ __launch_bounds__(256) void k_nt_scaling(const ConeDesc *cones, const WorkItem *items, const double *v,
                                                      const double *s, double *scal, double *lambda) {
@@ -61,11 +83,14 @@ __global__ __launch_bounds__(256) void k_nt_scaling(const ConeDesc *cones, const
         }
     } else if (cd.type == CIP_CONE_Q) {
         // nestod_soc(z = v block, s = s block)  src/ConicIP.jl:165-194
-        const double *z = v + cd.off, *sv = s + cd.off;
-        const int k = cd.dim;
+        const QTeam tm = q_team(cones, it, cd);
+        const ConeDesc qc = tm.cd;
+        const int T = tm.T, tl = tm.tl;
+        const double *z = v + qc.off, *sv = s + qc.off;
+        const int k = qc.dim;
         double zz = 0, ss = 0, zs = 0;
-        for (int e = 1 + tid; e < k; e += 256) { zz += z[e] * z[e]; ss += sv[e] * sv[e]; zs += z[e] * sv[e]; }
-        block_sum3(zz, ss, zs, sh);
+        for (int e = 1 + tl; e < k; e += T) { zz += z[e] * z[e]; ss += sv[e] * sv[e]; zs += z[e] * sv[e]; }
+        team_sum3(zz, ss, zs, T, sh);
         const double z0 = z[0], s0 = sv[0];
         const double qfz = z0 * z0 - zz, qfs = s0 * s0 - ss;       // QF(.)
         const double beta = sqrt(sqrt(qfs / qfz));                 // (QF(s)/QF(z))^(1/4)
@@ -78,16 +103,18 @@ __global__ __launch_bounds__(256) void k_nt_scaling(const ConeDesc *cones, const
         // w = c * (wbar + e1), wbar_t = h (sbar_t - zbar_t)
         // w . v (v == z):  c * (wbar.z + z0),  wbar.z = h * (s.z * rs + QF(z) * rz)
         const double wdotz = c * (h * ((z0 * s0 + zs) * rs + qfz * rz) + z0);
-        if (tid == 0) {
-            scal[cd.soff] = beta;
-            const double w0 = c * (wb0 + 1.0);
-            scal[cd.soff + 1] = w0;
-            if (lambda) lambda[cd.off] = -beta * z0 + w0 * wdotz;
-        }
-        for (int e = 1 + tid; e < k; e += 256) {
-            const double we = c * h * (sv[e] * rs - z[e] * rz);
-            scal[cd.soff + 1 + e] = we;
-            if (lambda) lambda[cd.off + e] = beta * z[e] + we * wdotz;
+        if (tm.active) {
+            if (tl == 0) {
+                scal[qc.soff] = beta;
+                const double w0 = c * (wb0 + 1.0);
+                scal[qc.soff + 1] = w0;
+                if (lambda) lambda[qc.off] = -beta * z0 + w0 * wdotz;
+            }
+            for (int e = 1 + tl; e < k; e += T) {
+                const double we = c * h * (sv[e] * rs - z[e] * rz);
+                scal[qc.soff + 1 + e] = we;
+                if (lambda) lambda[qc.off + e] = beta * z[e] + we * wdotz;
+            }
         }
     }
 }
@@ -100,8 +127,11 @@ __global__ __launch_bounds__(256) void k_identity_scaling(const ConeDesc *cones,
         for (int e = it.start + tid; e < it.start + it.len; e += 256) scal[cd.soff + e] = 1.0;
     } else if (cd.type == CIP_CONE_Q) {
         // I = diag(-beta, beta, ...) + w w' with beta = 1, w = sqrt(2) e1
-        if (tid == 0) { scal[cd.soff] = 1.0; scal[cd.soff + 1] = sqrt(2.0); }
-        for (int e = 1 + tid; e < cd.dim; e += 256) scal[cd.soff + 1 + e] = 0.0;
+        const QTeam tm = q_team(cones, it, cd);
+        if (tm.active) {
+            if (tm.tl == 0) { scal[tm.cd.soff] = 1.0; scal[tm.cd.soff + 1] = sqrt(2.0); }
+            for (int e = 1 + tm.tl; e < tm.cd.dim; e += tm.T) scal[tm.cd.soff + 1 + e] = 0.0;
+        }
     } else {
         const int r = cd.r;
         for (int e = tid; e < r * r; e += 256) {
@@ -126,26 +156,30 @@ __global__ __launch_bounds__(256) void k_apply(const ConeDesc *cones, const Work
             out[cd.off + e] = inv ? x[cd.off + e] / d : x[cd.off + e] * d;
         }
     } else if (cd.type == CIP_CONE_Q) {
-        const int k = cd.dim;
-        const double beta = scal[cd.soff];
-        const double *w = scal + cd.soff + 1;
-        const double *xb = x + cd.off;
-        double *ob = out + cd.off;
+        const QTeam tm = q_team(cones, it, cd);
+        const ConeDesc qc = tm.cd;
+        const int T = tm.T, tl = tm.tl;
+        const int k = qc.dim;
+        const double beta = scal[qc.soff];
+        const double *w = scal + qc.soff + 1;
+        const double *xb = x + qc.off;
+        double *ob = out + qc.off;
         double wx = 0, d1 = 0, d2 = 0;
-        for (int e = 1 + tid; e < k; e += 256) wx += w[e] * xb[e];
+        for (int e = 1 + tl; e < k; e += T) wx += w[e] * xb[e];
         const double w0 = w[0], x0 = xb[0];      // read before the barriers: out may alias x
-        block_sum3(wx, d1, d2, sh);
+        team_sum3(wx, d1, d2, T, sh);
+        if (!tm.active) return;
         if (!inv) {
             // F x = -beta J x + w (w.x)
             const double t = w0 * x0 + wx;
-            if (tid == 0) ob[0] = -beta * x0 + w0 * t;
-            for (int e = 1 + tid; e < k; e += 256) ob[e] = beta * xb[e] + w[e] * t;
+            if (tl == 0) ob[0] = -beta * x0 + w0 * t;
+            for (int e = 1 + tl; e < k; e += T) ob[e] = beta * xb[e] + w[e] * t;
         } else {
             // F^-1 x = ( (Jw) (Jw.x)/beta - J x ) / beta
             const double t = (w0 * x0 - wx) / beta;
             const double ib = 1.0 / beta;
-            if (tid == 0) ob[0] = (w0 * t - x0) * ib;
-            for (int e = 1 + tid; e < k; e += 256) ob[e] = (xb[e] - w[e] * t) * ib;
+            if (tl == 0) ob[0] = (w0 * t - x0) * ib;
+            for (int e = 1 + tl; e < k; e += T) ob[e] = (xb[e] - w[e] * t) * ib;
         }
     }
 }
@@ -163,17 +197,21 @@ __global__ __launch_bounds__(256) void k_scale_At(const ConeDesc *cones, const W
             Wt[i + c * ldwt] = At[i + c * ldat] / scal[cd.soff + e];
         }
     } else if (cd.type == CIP_CONE_Q) {
-        const int k = cd.dim;
-        const double beta = scal[cd.soff];
-        const double *w = scal + cd.soff + 1;
-        const double *ap = At + i + (long)cd.off * ldat;
-        double *wp = Wt + i + (long)cd.off * ldwt;
-        double t = w[0] * ap[0];
-        for (int e = 1; e < k; ++e) t -= w[e] * ap[(long)e * ldat];
-        t /= beta;
-        const double ib = 1.0 / beta;
-        wp[0] = (w[0] * t - ap[0]) * ib;
-        for (int e = 1; e < k; ++e) wp[(long)e * ldwt] = (ap[(long)e * ldat] - w[e] * t) * ib;
+        const int ncone = it.width ? it.len : 1;          // a pack of small cones: this thread's row through each of them
+        for (int q = 0; q < ncone; ++q) {
+            const ConeDesc qc = cones[it.cone + q];
+            const int k = qc.dim;
+            const double beta = scal[qc.soff];
+            const double *w = scal + qc.soff + 1;
+            const double *ap = At + i + (long)qc.off * ldat;
+            double *wp = Wt + i + (long)qc.off * ldwt;
+            double t = w[0] * ap[0];
+            for (int e = 1; e < k; ++e) t -= w[e] * ap[(long)e * ldat];
+            t /= beta;
+            const double ib = 1.0 / beta;
+            wp[0] = (w[0] * t - ap[0]) * ib;
+            for (int e = 1; e < k; ++e) wp[(long)e * ldwt] = (ap[(long)e * ldat] - w[e] * t) * ib;
+        }
     }
 }
 
@@ -188,16 +226,19 @@ __global__ __launch_bounds__(256) void k_cone_prod(const ConeDesc *cones, const 
         for (int e = it.start + tid; e < it.start + it.len; e += 256)
             out[cd.off + e] = x[cd.off + e] * y[cd.off + e];
     } else if (cd.type == CIP_CONE_Q) {                            // xsoc! :340-345
-        const int k = cd.dim;
-        const double *xb = x + cd.off, *yb = y + cd.off;
-        double *ob = out + cd.off;
+        const QTeam tm = q_team(cones, it, cd);
+        const int T = tm.T, tl = tm.tl;
+        const int k = tm.cd.dim;
+        const double *xb = x + tm.cd.off, *yb = y + tm.cd.off;
+        double *ob = out + tm.cd.off;
         double xy = 0, d1 = 0, d2 = 0;
-        for (int e = 1 + tid; e < k; e += 256) xy += xb[e] * yb[e];
-        block_sum3(xy, d1, d2, sh);
-        const double x0 = xb[0], y0 = yb[0];
-        __syncthreads();
-        if (tid == 0) ob[0] = x0 * y0 + xy;
-        for (int e = 1 + tid; e < k; e += 256) ob[e] = x0 * yb[e] + y0 * xb[e];
+        for (int e = 1 + tl; e < k; e += T) xy += xb[e] * yb[e];
+        team_sum3(xy, d1, d2, T, sh);
+        const double x0 = xb[0], y0 = yb[0];                       // out may alias an input: heads read before any write
+        team_sync(T);                                              // (a pack segment lives in one wavefront: program order)
+        if (!tm.active) return;
+        if (tl == 0) ob[0] = x0 * y0 + xy;
+        for (int e = 1 + tl; e < k; e += T) ob[e] = x0 * yb[e] + y0 * xb[e];
     }
 }
 
@@ -212,19 +253,22 @@ __global__ __launch_bounds__(256) void k_cone_div(const ConeDesc *cones, const W
         for (int e = it.start + tid; e < it.start + it.len; e += 256)
             out[cd.off + e] = x[cd.off + e] / y[cd.off + e];
     } else if (cd.type == CIP_CONE_Q) {                            // dsoc! :317-338 (arrow inverse)
-        const int k = cd.dim;
-        const double *xb = x + cd.off, *yb = y + cd.off;
-        double *ob = out + cd.off;
+        const QTeam tm = q_team(cones, it, cd);
+        const int T = tm.T, tl = tm.tl;
+        const int k = tm.cd.dim;
+        const double *xb = x + tm.cd.off, *yb = y + tm.cd.off;
+        double *ob = out + tm.cd.off;
         double yy = 0, yx = 0, d2 = 0;
-        for (int e = 1 + tid; e < k; e += 256) { yy += yb[e] * yb[e]; yx += yb[e] * xb[e]; }
-        block_sum3(yy, yx, d2, sh);
+        for (int e = 1 + tl; e < k; e += T) { yy += yb[e] * yb[e]; yx += yb[e] * xb[e]; }
+        team_sum3(yy, yx, d2, T, sh);
         const double y1 = yb[0], x1 = xb[0];
         const double alpha = y1 * y1 - yy;
         const double b1 = (-x1 / alpha) + yx / (y1 * alpha);
         const double b2 = 1.0 / y1;
-        __syncthreads();
-        if (tid == 0) ob[0] = (y1 * x1 - yx) / alpha;
-        for (int e = 1 + tid; e < k; e += 256) ob[e] = yb[e] * b1 + xb[e] * b2;
+        team_sync(T);
+        if (!tm.active) return;
+        if (tl == 0) ob[0] = (y1 * x1 - yx) / alpha;
+        for (int e = 1 + tl; e < k; e += T) ob[e] = yb[e] * b1 + xb[e] * b2;
     }
 }
 
@@ -251,21 +295,23 @@ __global__ __launch_bounds__(256) void k_maxstep(const ConeDesc *cones, const Wo
             mn = block_min(mn, sh);
             mn = (mn > 0) ? 0.0 : -1.0 + mn;
         }
-        if (tid == 0) partial[blockIdx.x] = mn;
+        if (tid == 0) partial[it.slot] = mn;
     } else if (cd.type == CIP_CONE_Q) {
-        const int k = cd.dim;
-        const double *xb = x + cd.off;
+        const QTeam tm = q_team(cones, it, cd);
+        const int T = tm.T, tl = tm.tl;
+        const int k = tm.cd.dim;
+        const double *xb = x + tm.cd.off;
         if (!d) {                                                  // maxstep_soc(x, nothing) :264-270
             double xx = 0, a1 = 0, a2 = 0;
-            for (int e = 1 + tid; e < k; e += 256) xx += xb[e] * xb[e];
-            block_sum3(xx, a1, a2, sh);
+            for (int e = 1 + tl; e < k; e += T) xx += xb[e] * xb[e];
+            team_sum3(xx, a1, a2, T, sh);
             const double a = sqrt(xx) - xb[0];
-            if (tid == 0) partial[blockIdx.x] = (a < 0) ? 0.0 : -1.0 - a;
+            if (tl == 0 && tm.active) partial[tm.slot] = (a < 0) ? 0.0 : -1.0 - a;
         } else {                                                   // maxstep_soc(x, d) :242-262
-            const double *db = d + cd.off;
+            const double *db = d + tm.cd.off;
             double xx = 0, xd = 0, a2 = 0;
-            for (int e = 1 + tid; e < k; e += 256) { xx += xb[e] * xb[e]; xd += xb[e] * (-scale * db[e]); }
-            block_sum3(xx, xd, a2, sh);
+            for (int e = 1 + tl; e < k; e += T) { xx += xb[e] * xb[e]; xd += xb[e] * (-scale * db[e]); }
+            team_sum3(xx, xd, a2, T, sh);
             const double x0 = xb[0], d0 = -scale * db[0];
             const double gam = x0 * x0 - xx;                       // Q(x,x)
             const double rg = 1.0 / sqrt(gam);
@@ -273,16 +319,16 @@ __global__ __launch_bounds__(256) void k_maxstep(const ConeDesc *cones, const Wo
             const double rho1 = bet * rg;
             const double mu = (bet + d0) / (x0 * rg + 1.0);
             double r2 = 0, b1 = 0, b2 = 0;
-            for (int e = 1 + tid; e < k; e += 256) {
+            for (int e = 1 + tl; e < k; e += T) {
                 const double t = (-scale * db[e]) - mu * xb[e] * rg;
                 r2 += t * t;
             }
-            block_sum3(r2, b1, b2, sh);
+            team_sum3(r2, b1, b2, T, sh);
             const double alpha = sqrt(r2) * rg - rho1;
-            if (tid == 0) partial[blockIdx.x] = (alpha < 0) ? INF : 1.0 / alpha;
+            if (tl == 0 && tm.active) partial[tm.slot] = (alpha < 0) ? INF : 1.0 / alpha;
         }
     } else {
-        if (tid == 0) partial[blockIdx.x] = INF;      // S cone: written by k_sdp_maxstep afterwards
+        if (tid == 0) partial[it.slot] = INF;         // S cone: written by k_sdp_maxstep afterwards
     }
 }
 
@@ -307,7 +353,8 @@ __global__ __launch_bounds__(256) void k_cone_identity(const ConeDesc *cones, co
     if (cd.type == CIP_CONE_R) {
         for (int q = it.start + tid; q < it.start + it.len; q += 256) e[cd.off + q] = 1.0;
     } else if (cd.type == CIP_CONE_Q) {
-        for (int q = tid; q < cd.dim; q += 256) e[cd.off + q] = (q == 0) ? 1.0 : 0.0;
+        const QTeam tm = q_team(cones, it, cd);
+        if (tm.active) for (int q = tm.tl; q < tm.cd.dim; q += tm.T) e[tm.cd.off + q] = (q == 0) ? 1.0 : 0.0;
     } else {
         // vecm(I): row-major upper triangle, diagonal entries at positions i*r - i(i-1)/2
         const int r = cd.r;
@@ -364,7 +411,7 @@ int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const d
     hipLaunchKernelGGL(k_maxstep, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x, d, scale, cs.d_partial);
     CIP_HIP_CHECK(hipGetLastError());
     if (cs.has_S) { int rc = cip_sdp_maxstep(s, cs, x, d, scale, cs.d_partial); if (rc) return rc; }
-    hipLaunchKernelGGL(k_min_reduce, dim3(1), dim3(256), 0, s, cs.d_partial, cs.nitems, cs.d_scalar);
+    hipLaunchKernelGGL(k_min_reduce, dim3(1), dim3(256), 0, s, cs.d_partial, cs.nslots, cs.d_scalar);
     CIP_HIP_CHECK(hipGetLastError());
     CIP_HIP_CHECK(hipMemcpyAsync(alpha_host, cs.d_scalar, sizeof(double), hipMemcpyDeviceToHost, s));
     CIP_HIP_CHECK(hipStreamSynchronize(s));

@@ -159,6 +159,10 @@ CONESETS = [
     [("Q", 8)] * 5,
     [("R", 7), ("Q", 4), ("R", 3), ("Q", 9)],
     [("R", 5000), ("Q", 700)],
+    # sub-wavefront packing of small Q cones (cones.hip): runs of mixed sizes (pack width = next power of two of the
+    # run's largest cone), a run split by an R cone, the boundary 64 / 65, more cones than one workgroup holds
+    [("Q", 3), ("Q", 8), ("Q", 5), ("R", 7), ("Q", 64), ("Q", 65), ("Q", 2), ("Q", 33)],
+    [("Q", 8)] * 70 + [("Q", 2)] * 3,
 ]
 
 
@@ -251,6 +255,10 @@ ASM_CASES = [
     dict(cone_dims=[("R", 30), ("Q", 6), ("Q", 4)], n=17, p=3),
     dict(cone_dims=[("Q", 8)] * 20, n=150, p=10),
     dict(cone_dims=[("R", 100), ("Q", 40)], n=130, p=7),
+    dict(cone_dims=[("Q", 5), ("Q", 16), ("R", 4), ("Q", 65), ("Q", 3)] + [("Q", 8)] * 40, n=90, p=4),
+    # large-k second-order cone with a CSR A: the rank-1 column of the Schur complement (SURVEY 8f rank 3;
+    # the reference's benchmark/profile.jl single SOC n = 500)
+    dict(cone_dims=[("Q", 501)], n=500, p=0),
 ]
 
 
