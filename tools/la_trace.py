@@ -1,5 +1,5 @@
 import csv,collections,sys,glob
-f=glob.glob(sys.argv[1]+'/*/*kernel_trace.csv')[0]
+f=(glob.glob(sys.argv[1]+'/*/*kernel_trace.csv')+glob.glob(sys.argv[1]+'/*kernel_trace.csv'))[0]
 rows=list(csv.DictReader(open(f)))
 ws=[r for r in rows if r['Kernel_Name'].startswith('k_ldlt_workers')]
 w=ws[-1]; t0=int(w['Start_Timestamp']); t1=int(w['End_Timestamp'])
