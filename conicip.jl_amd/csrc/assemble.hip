@@ -45,48 +45,54 @@ __global__ __launch_bounds__(256) void k_copy_block_lower(double *K, long ldk, i
 }
 
 // ---------------------------------------------------------------- sparse-A Schur terms (R and Q cones)
-// per row r of A:  K[i,j] += w_r a_ri a_rj  (i >= j), w_r = 1/d_r^2 (R),  -J_rr/beta^2 (Q)
-__global__ __launch_bounds__(256) void k_schur_rows(int m, const int *rp, const int *ci, const double *av,
-                                                     const int *row_cone, const ConeDesc *cones, const double *scal,
-                                                     double *K, long ldk, int base) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= m) return;
-    const ConeDesc cd = cones[row_cone[r]];
-    double w;
-    if (cd.type == CIP_CONE_R) {
-        const double d = scal[cd.soff + (r - cd.off)];
-        w = 1.0 / (d * d);
-    } else {
-        const double beta = scal[cd.soff];
-        w = ((r == cd.off) ? -1.0 : 1.0) / (beta * beta);
-    }
-    const int q0 = rp[r], q1 = rp[r + 1];
-    for (int a = q0; a < q1; ++a) {
-        const double wa = w * av[a];
-        const int ca = ci[a];
-        for (int b = q0; b <= a; ++b) {
-            const int cb = ci[b];
-            const int i = ca > cb ? ca : cb, j = ca > cb ? cb : ca;
-            unsafeAtomicAdd(&K[(base + i) + (long)(base + j) * ldk], wa * av[b]);
+// K[i, j] += sum_r w_r a_ri a_rj  (i >= j), w_r = 1/d_r^2 (R), -J_rr/beta^2 (Q).  One thread per variable i OWNS row i
+// of the lower triangle: it walks column i of A (= row i of the CSR of A', rows r ascending) and, for every r, row r
+// of A.  No atomics, fixed summation order: bit-reproducible (the first version scattered with unsafeAtomicAdd per
+// row of A).
+__device__ __forceinline__ double schur_row_weight(const ConeDesc &cd, const double *scal, int r) {
+    if (cd.type == CIP_CONE_R) { const double d = scal[cd.soff + (r - cd.off)]; return 1.0 / (d * d); }
+    const double beta = scal[cd.soff];
+    return ((r == cd.off) ? -1.0 : 1.0) / (beta * beta);
+}
+__global__ __launch_bounds__(256) void k_schur_rows(int n, const int *trp, const int *tci, const double *tv, const int *rp,
+                                                     const int *ci, const double *av, const int *row_cone,
+                                                     const ConeDesc *cones, const double *scal, double *K, long ldk, int base) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int q = trp[i]; q < trp[i + 1]; ++q) {
+        const int r = tci[q];
+        const double wa = schur_row_weight(cones[row_cone[r]], scal, r) * tv[q];
+        for (int b = rp[r]; b < rp[r + 1]; ++b) {
+            const int j = ci[b];
+            if (j <= i) K[(base + i) + (long)(base + j) * ldk] += wa * av[b];
         }
     }
 }
-// Gm[:, qidx] += (sqrt2/beta) (J wbar)_r * A[r, :]'   for rows r of Q cones
-__global__ __launch_bounds__(256) void k_schur_qcols(int m, const int *rp, const int *ci, const double *av,
+// Gm[i, qidx] = sum over the rows r of Q cone qidx of (sqrt2/beta) (J wbar)_r A[r, i]: same ownership (thread i, column i of
+// A in ascending r; the rows of one cone are consecutive)
+__global__ __launch_bounds__(256) void k_schur_qcols(int n, const int *trp, const int *tci, const double *tv,
                                                       const int *row_cone, const ConeDesc *cones, const double *scal,
                                                       double *Gm, long ldgm) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= m) return;
-    const ConeDesc cd = cones[row_cone[r]];
-    if (cd.type != CIP_CONE_Q) return;
-    const double beta = scal[cd.soff];
-    const double *w = scal + cd.soff + 1;
-    const int e = r - cd.off;
-    // wbar_1 = w1^2/beta - 1 ; wbar_t = w1 w_t / beta ; (J wbar)_t = -wbar_t
-    const double jw = (e == 0) ? (w[0] * w[0] / beta - 1.0) : -(w[0] * w[e] / beta);
-    const double coef = jw * 1.4142135623730951 / beta;
-    for (int q = rp[r]; q < rp[r + 1]; ++q)
-        unsafeAtomicAdd(&Gm[ci[q] + (long)cd.qidx * ldgm], coef * av[q]);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int cur = -1;
+    double acc = 0.0;
+    for (int q = trp[i]; q < trp[i + 1]; ++q) {
+        const int r = tci[q];
+        const ConeDesc cd = cones[row_cone[r]];
+        if (cd.type != CIP_CONE_Q) continue;
+        if (cd.qidx != cur) {
+            if (cur >= 0) Gm[i + (long)cur * ldgm] = acc;
+            cur = cd.qidx; acc = 0.0;
+        }
+        const double beta = scal[cd.soff];
+        const double *w = scal + cd.soff + 1;
+        const int e = r - cd.off;
+        // wbar_1 = w1^2/beta - 1 ; wbar_t = w1 w_t / beta ; (J wbar)_t = -wbar_t
+        const double jw = (e == 0) ? (w[0] * w[0] / beta - 1.0) : -(w[0] * w[e] / beta);
+        acc += (jw * 1.4142135623730951 / beta) * tv[q];
+    }
+    if (cur >= 0) Gm[i + (long)cur * ldgm] = acc;
 }
 
 // ---------------------------------------------------------------- full 3x3 route: -F'F block
@@ -151,12 +157,12 @@ static int assemble_schur(cip_handle *h) {
                                (long)n, n, 1.0);
         }
         if (h->m > 0) {
-            hipLaunchKernelGGL(k_schur_rows, dim3((h->m + 255) / 256), dim3(256), 0, s, h->m, h->A_rp, h->A_ci, h->A_v,
-                               h->row_cone, h->cs.d_cones, h->cs.d_scal, h->K, h->ldk, 0);
+            hipLaunchKernelGGL(k_schur_rows, dim3((n + 255) / 256), dim3(256), 0, s, n, h->T_rp, h->T_ci, h->T_v, h->A_rp, h->A_ci,
+                               h->A_v, h->row_cone, h->cs.d_cones, h->cs.d_scal, h->K, h->ldk, 0);
             if (h->nq > 0) {
                 CIP_HIP_CHECK(hipMemsetAsync(h->Gm, 0, sizeof(double) * (size_t)h->npad * h->nqpad, s));
-                hipLaunchKernelGGL(k_schur_qcols, dim3((h->m + 255) / 256), dim3(256), 0, s, h->m, h->A_rp, h->A_ci,
-                                   h->A_v, h->row_cone, h->cs.d_cones, h->cs.d_scal, h->Gm, (long)h->npad);
+                hipLaunchKernelGGL(k_schur_qcols, dim3((n + 255) / 256), dim3(256), 0, s, n, h->T_rp, h->T_ci, h->T_v,
+                                   h->row_cone, h->cs.d_cones, h->cs.d_scal, h->Gm, (long)h->npad);
             }
         }
     }

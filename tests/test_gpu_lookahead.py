@@ -118,3 +118,35 @@ def test_lookahead_through_the_kkt_path_n8192():
         lib.cip_set_ldlt_lookahead(prev)
     np.testing.assert_allclose(outs[1], outs[0], rtol=1e-9, atol=1e-11)
     ks.close()
+
+
+def test_factor_is_asynchronous():
+    """cip_factor must not wait for the GPU (include/cipkkt.h): at n = 8192 the call returns in a
+    fraction of the factorisation's device time, the pivot flag is resolved later (cip_check_factor / the solves)."""
+    import time
+    import cipkkt
+    from cipkkt import workloads as W
+    n = 8192
+    Q, c, A, b, K = W.c2_problem(n, seed=7, device="cuda")
+    ks = cipkkt.KKTSystem(Q, A, None, K)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    v = torch.rand(n, generator=g, dtype=torch.float64, device="cuda") + 0.05
+    s = torch.rand(n, generator=g, dtype=torch.float64, device="cuda") + 0.05
+    lam = torch.zeros(n, dtype=torch.float64, device="cuda")
+    rhs = torch.randn(3 * n, generator=g, dtype=torch.float64, device="cuda")
+    dz = torch.zeros(3 * n, dtype=torch.float64, device="cuda")
+    for _ in range(2):
+        ks.set_scaling_from_iterate(v, s, lam); ks.factor(); ks.solve4x4_dev(lam, rhs, dz)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ks.set_scaling_from_iterate(v, s, lam)
+    ks.factor()
+    ks.solve4x4_dev(lam, rhs, dz)                 # speculative: enqueued behind the factorisation, no host wait
+    t_enqueue = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_total = time.perf_counter() - t0
+    ks.check_factor()
+    assert t_total > 4e-3, t_total                 # the factorisation alone is ~7 ms of device time
+    assert t_enqueue < 0.5 * t_total, (t_enqueue, t_total)
+    ks.close()
