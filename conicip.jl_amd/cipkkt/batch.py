@@ -173,7 +173,7 @@ def solve_batch(problems, solve_fn=None, rank=0, world=1, dist=None, device=None
                      sum(1 for s in sols.values() if s.status == "Optimal"),
                      len(sols)], dtype=np.float64)
     mx = np.array([wall], dtype=np.float64)
-    if dist is not None and world > 1:
+    if dist is not None:                 # also with one rank (bench.py's CIP_BENCH_FORCE_DIST exercises RCCL on one GPU)
         tdev = device if device is not None else "cpu"
         ts = torch.as_tensor(sums, device=tdev)
         tm = torch.as_tensor(mx, device=tdev)
@@ -201,7 +201,7 @@ def run_config5(rank, world, dist, device, steps, warmup, problems=None, count=6
             problems[i] = pr
     sync = (lambda: torch.cuda.synchronize(device)) if device is not None and str(device) != "cpu" else (lambda: None)
     if barrier is None:
-        barrier = (lambda: dist.barrier()) if (dist is not None and world > 1) else (lambda: None)
+        barrier = (lambda: dist.barrier()) if dist is not None else (lambda: None)
 
     def one_pass(reduce):
         return solve_batch(problems, solve_fn=solve_fn, rank=rank, world=world, dist=dist if reduce else None,
@@ -216,7 +216,7 @@ def run_config5(rank, world, dist, device, steps, warmup, problems=None, count=6
     sync(); barrier(); sync()
     elapsed = time.perf_counter() - t0
     _, stats = one_pass(True)                          # untimed: the reduced statistics of one pass
-    if dist is not None and world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
