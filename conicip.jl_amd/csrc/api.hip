@@ -56,6 +56,8 @@ static int rup(int x, int q) { return ((x + q - 1) / q) * q; }
     } while (0)
 
 static void free_all(cip_handle *h) {
+    if (h->gx_factor) { (void)hipGraphExecDestroy(h->gx_factor); h->gx_factor = nullptr; }
+    if (h->gx_solve) { (void)hipGraphExecDestroy(h->gx_solve); h->gx_solve = nullptr; }
     if (h->cs.lg) { cip_sdp_large_destroy(h->cs.lg); h->cs.lg = nullptr; }
     void *ptrs[] = {h->cs.d_sidx_small, h->cs.d_sidx, h->cs.d_sdpws, h->cs.d_sdpvec, h->cs.d_sdpflag, h->Q, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->row_cone, h->G, h->Gt,
                     h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->cs.d_partial, h->cs.d_scalar, h->K, h->Wt, h->Gm,
@@ -166,6 +168,7 @@ static int create_impl(const cip_problem *pr, cip_handle *h) {
         return CIP_E_NODEVICE;
     }
     CIP_HIP_CHECK(hipGetDevice(&h->device));
+    if (cip_kernels_init()) return CIP_E_HIP;
     const int n = pr->n, m = pr->m, p = pr->p;
     if (n <= 0 || m < 0 || p < 0 || pr->ncones < 0) { cip_set_error("bad dimensions n=%d m=%d p=%d", n, m, p); return CIP_E_INVALID; }
     if (!pr->Q) { cip_set_error("Q is NULL"); return CIP_E_INVALID; }
@@ -385,6 +388,7 @@ extern "C" int cip_set_stream(cip_handle *h, void *stream) {
     if (!h) return CIP_E_INVALID;
     CIP_HIP_CHECK(hipStreamSynchronize(h->stream));
     h->stream = (hipStream_t)stream;
+    h->graph_state = 0;              // graphs are decided per stream (no capture on the null stream); existing ones stay valid
     return 0;
 }
 
@@ -428,12 +432,51 @@ extern "C" int cip_assemble_only(cip_handle *h) {
 // small value work.  CIP_AUTO_REG overrides.
 #define CIP_AUTO_REG 1e-13
 
+// ---- hipGraph replay of the LDL' factorisation / the triangular solves of SMALL systems (opt-in: CIP_GRAPH=1).  The
+// launch sequence of a handle never changes (same pointers, same sizes), so it is recorded once as an explicit graph
+// (cip_launch, cip_internal.h) and replayed: ~60 launches per factorisation and ~10-33 per solve become one graph launch.
+// Built for config 5 (64 x n = 2048, 8 problems in flight) on the hypothesis that the batch is bound by the host's launch
+// rate (95 k launches per pass).  It is not: 1936 KKT solves/s with graphs, 1995 without.  A kernel trace of a pass
+// (profiles/r2/c5_*) shows 16.8 ms of serial kernel time per problem and an average of 3.4 kernels executing at once with
+// 8 problems in flight (more hardware queues make it worse): the ceiling is the number of concurrently progressing
+// launch-latency-bound streams, which only a lock-step batch (one launch for many problems) would lift.  Off by default
+// (rocprofv3 also crashed on the graph path with several host threads).
+static bool graph_wanted(cip_handle *h) {
+    if (h->graph_state == 0) {
+        const char *e = getenv("CIP_GRAPH");
+        const int npmax = getenv("CIP_GRAPH_NMAX") ? atoi(getenv("CIP_GRAPH_NMAX")) : 4096;
+        h->graph_state = (h->Npad <= npmax && e && atoi(e) == 1 && !h->timing && !h->ws.prof) ? 1 : -1;
+    }
+    return h->graph_state == 1;
+}
+thread_local CipGraphBuilder *cip_tl_builder = nullptr;
+template <class F>
+static int graph_run(cip_handle *h, hipGraphExec_t *exec, F &&enqueue) {
+    if (!graph_wanted(h) || h->timing || h->ws.prof) return enqueue();
+    if (!*exec) {
+        CipGraphBuilder b = {nullptr, nullptr, false, true};
+        if (hipGraphCreate(&b.graph, 0) != hipSuccess) { (void)hipGetLastError(); h->graph_state = -1; return enqueue(); }
+        cip_tl_builder = &b;
+        const int rc = enqueue();                // records kernel nodes, launches nothing
+        cip_tl_builder = nullptr;
+        hipError_t ei = hipErrorUnknown;
+        if (rc == 0 && b.ok && b.have_last) ei = hipGraphInstantiate(exec, b.graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(b.graph);
+        if (ei != hipSuccess) { (void)hipGetLastError(); *exec = nullptr; h->graph_state = -1; return enqueue(); }
+    }
+    CIP_HIP_CHECK(hipGraphLaunch(*exec, h->stream));
+    return 0;
+}
+
 // assembly + LDL' + an asynchronous read-back of the pivot flag into pinned host memory; nothing here waits for the GPU
 static int factor_enqueue(cip_handle *h) {
     int rc;
     { CipRange rg("cip:assemble"); if ((rc = cip_assemble(h))) return rc; }
     if (h->timing) CIP_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
-    { CipRange rg("cip:ldlt"); if ((rc = cip_ldlt_factor(h->stream, h->K, h->Npad, h->ldk, h->ws))) return rc; }
+    {
+        CipRange rg("cip:ldlt");
+        if ((rc = graph_run(h, &h->gx_factor, [&]() { return cip_ldlt_factor(h->stream, h->K, h->Npad, h->ldk, h->ws); }))) return rc;
+    }
     h->n_factor += 1;
     CIP_HIP_CHECK(hipMemcpyAsync(h->info_host, h->ws.info, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     CIP_HIP_CHECK(hipEventRecord(h->ev_info, h->stream));
@@ -573,7 +616,7 @@ static int solve3x3_once(cip_handle *h, const double *x, const double *y, const 
         if (m > 0 && (rc = mul_At(h, 1.0, t, 1.0, h->rhs))) return rc;
         if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(h->rhs + n, y, sizeof(double) * p, hipMemcpyDeviceToDevice, s));
         if (h->Npad > h->N) CIP_HIP_CHECK(hipMemsetAsync(h->rhs + h->N, 0, sizeof(double) * (h->Npad - h->N), s));
-        if ((rc = cip_ldlt_solve(s, h->K, h->Npad, h->ldk, h->ws, h->rhs))) return rc;
+        if ((rc = graph_run(h, &h->gx_solve, [&]() { return cip_ldlt_solve(s, h->K, h->Npad, h->ldk, h->ws, h->rhs); }))) return rc;
         CIP_HIP_CHECK(hipMemcpyAsync(a, h->rhs, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
         if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(b, h->rhs + n, sizeof(double) * p, hipMemcpyDeviceToDevice, s));
         if (m > 0) {
@@ -588,7 +631,7 @@ static int solve3x3_once(cip_handle *h, const double *x, const double *y, const 
         CIP_HIP_CHECK(hipMemcpyAsync(h->rhs + m, x, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
         if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(h->rhs + m + n, y, sizeof(double) * p, hipMemcpyDeviceToDevice, s));
         if (h->Npad > h->N) CIP_HIP_CHECK(hipMemsetAsync(h->rhs + h->N, 0, sizeof(double) * (h->Npad - h->N), s));
-        if ((rc = cip_ldlt_solve(s, h->K, h->Npad, h->ldk, h->ws, h->rhs))) return rc;
+        if ((rc = graph_run(h, &h->gx_solve, [&]() { return cip_ldlt_solve(s, h->K, h->Npad, h->ldk, h->ws, h->rhs); }))) return rc;
         if (m > 0) CIP_HIP_CHECK(hipMemcpyAsync(c, h->rhs, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
         CIP_HIP_CHECK(hipMemcpyAsync(a, h->rhs + m, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
         if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(b, h->rhs + m + n, sizeof(double) * p, hipMemcpyDeviceToDevice, s));

@@ -58,6 +58,10 @@ struct cip_handle {
     double *c2x2 = nullptr;         // m-vector: discarded third component of a regularised 2x2 solve
     double *drv = nullptr;          // vectors of the native interior-point loop (cip_conicip), allocated on first use
 
+    // ---- hipGraphs of the two launch-bound inner loops of small systems (opt-in, CIP_GRAPH=1; api.hip: graph_run)
+    hipGraphExec_t gx_factor = nullptr, gx_solve = nullptr;
+    int graph_state = 0;            // 0 undecided, 1 in use, -1 off (null stream, large system, capture failed, CIP_GRAPH=0)
+
     // ---- stats
     double n_factor = 0, n_solve = 0, ms_assemble = 0, ms_ldlt = 0, flops_ldlt = 0;
     bool timing = false;

@@ -22,6 +22,31 @@ void cip_set_error(const char *fmt, ...);
         }                                                                         \
     } while (0)
 
+// ---------------------------------------------------------------- launches that can be recorded into a hipGraph
+// The LDL' factorisation and the triangular solves of a handle are fixed launch sequences (same pointers, same sizes
+// every time).  For small systems they are recorded ONCE as an explicit graph -- kernel nodes added one after the other
+// through cip_launch while a thread-local builder is active, no stream capture involved (capture in thread-local mode
+// was invalidated at random by the other host threads of a batch on ROCm 7.0) -- and replayed with one hipGraphLaunch.
+#include <tuple>
+struct CipGraphBuilder { hipGraph_t graph; hipGraphNode_t last; bool have_last; bool ok; };
+extern thread_local CipGraphBuilder *cip_tl_builder;
+template <typename Tuple, size_t... I>
+inline void cip_tuple_ptrs(Tuple &t, void **out, std::index_sequence<I...>) { ((out[I] = (void *)&std::get<I>(t)), ...); }
+template <typename... KArgs, typename... Args>
+inline void cip_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t s, Args... args) {
+    if (!cip_tl_builder) { hipLaunchKernelGGL(kernel, grid, block, shmem, s, args...); return; }
+    CipGraphBuilder *b = cip_tl_builder;
+    std::tuple<KArgs...> targs{static_cast<KArgs>(args)...};
+    void *ptrs[sizeof...(KArgs) > 0 ? sizeof...(KArgs) : 1];
+    cip_tuple_ptrs(targs, ptrs, std::index_sequence_for<KArgs...>{});
+    hipKernelNodeParams kp = {};
+    kp.func = (void *)kernel; kp.gridDim = grid; kp.blockDim = block; kp.sharedMemBytes = (unsigned)shmem;
+    kp.kernelParams = ptrs; kp.extra = nullptr;
+    hipGraphNode_t node;
+    if (hipGraphAddKernelNode(&node, b->graph, b->have_last ? &b->last : nullptr, b->have_last ? 1 : 0, &kp) != hipSuccess) { b->ok = false; return; }
+    b->last = node; b->have_last = true;
+}
+
 // ---------------------------------------------------------------- GEMM (gemm_f64.hip)
 enum { EPI_ACCUM = 0, EPI_SYRKQ = 2, EPI_STORE = 3 };
 
@@ -74,6 +99,7 @@ struct LdltWorkspace {        // carved out of one device allocation
     void *la_ctrl;            // device control block of the look-ahead schedule (gemm_f64.hip: LaCtrl + done[])
     LdltProfile *prof;        // host object or NULL
 };
+int cip_kernels_init(void);                // diag.hip: one-time kernel attributes (before any hipGraph capture)
 int cip_ldlt_set_lookahead(int on);
 int cip_solve_block(int Npad);
 size_t cip_ldlt_ws_bytes(int Npad);

@@ -383,38 +383,42 @@ __global__ __launch_bounds__(256) void k_trsm_subst(double *__restrict__ Ap, lon
     }
 }
 
-static bool g_attr_diag = false, g_attr_inv = false, g_attr_trsm = false;
+// dynamic-LDS attributes of the three kernels, set once per process (std::call_once) and -- through cip_kernels_init(),
+// called by cip_create -- before any stream of the process can be under hipGraph capture: hipFuncSetAttribute is not a
+// capturable call
+#include <mutex>
+static std::once_flag g_attr_once;
+static hipError_t g_attr_err = hipSuccess;
+static void diag_attr_init(void) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_ldlt_diag128_v2, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_diag_inverse_batched, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_trsm_subst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TRSM_LDS_DOUBLES * sizeof(double)));
+    g_attr_err = e;
+}
+int cip_kernels_init(void) {
+    std::call_once(g_attr_once, diag_attr_init);
+    if (g_attr_err != hipSuccess) { cip_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(g_attr_err)); return -3; }
+    return 0;
+}
 int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
                        PivotSigns sg) {
-    if (!g_attr_diag) {
-        CIP_HIP_CHECK(hipFuncSetAttribute((const void *)k_ldlt_diag128_v2, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          DIAG2_LDS_BYTES));
-        g_attr_diag = true;
-    }
-    hipLaunchKernelGGL(k_ldlt_diag128_v2, dim3(1), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg);
+    if (cip_kernels_init()) return -3;
+    cip_launch(k_ldlt_diag128_v2, dim3(1), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 int cip_launch_diag_inverse(hipStream_t s, const double *K, long ld, int nblk, const double *xm_all, double *Linv,
                             double *LinvT) {
-    if (!g_attr_inv) {
-        CIP_HIP_CHECK(hipFuncSetAttribute((const void *)k_diag_inverse_batched, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          DIAG2_LDS_BYTES));
-        g_attr_inv = true;
-    }
-    hipLaunchKernelGGL(k_diag_inverse_batched, dim3(nblk), dim3(256), DIAG2_LDS_BYTES, s, K, ld, xm_all, Linv, LinvT);
+    if (cip_kernels_init()) return -3;
+    cip_launch(k_diag_inverse_batched, dim3(nblk), dim3(256), DIAG2_LDS_BYTES, s, K, ld, xm_all, Linv, LinvT);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 int cip_launch_trsm_subst(hipStream_t s, double *Ap, long ld, int rows, const double *L11, const double *xm,
                           const double *dinv, double *W, long ldw) {
     if (rows <= 0) return 0;
-    if (!g_attr_trsm) {
-        CIP_HIP_CHECK(hipFuncSetAttribute((const void *)k_trsm_subst, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)(TRSM_LDS_DOUBLES * sizeof(double))));
-        g_attr_trsm = true;
-    }
-    hipLaunchKernelGGL(k_trsm_subst, dim3(rows / 64), dim3(256), TRSM_LDS_DOUBLES * sizeof(double), s, Ap, ld, L11, xm, dinv, W, ldw);
+    if (cip_kernels_init()) return -3;
+    cip_launch(k_trsm_subst, dim3(rows / 64), dim3(256), TRSM_LDS_DOUBLES * sizeof(double), s, Ap, ld, L11, xm, dinv, W, ldw);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -659,11 +659,11 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     if (by * bz > 1 || (g.overwrite && epi == EPI_ACCUM && !g.lower)) {
         if (epi != EPI_ACCUM || g.lower) { cip_set_error("gemm: batching needs the plain accumulate form"); return -1; }
         if (g.overwrite) {
-            hipLaunchKernelGGL(k_gemm_nt_64_batched, dim3((unsigned)(4 * tiles), by, bz), dim3(256), 0, s, g);
+            cip_launch(k_gemm_nt_64_batched, dim3((unsigned)(4 * tiles), by, bz), dim3(256), 0, s, g);
             CIP_HIP_CHECK(hipGetLastError());
             return 0;
         }
-        hipLaunchKernelGGL(k_gemm_nt_128<EPI_ACCUM>, dim3((unsigned)tiles, by, bz), dim3(256), 0, s, g);
+        cip_launch(k_gemm_nt_128<EPI_ACCUM>, dim3((unsigned)tiles, by, bz), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -681,31 +681,31 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
         if (psz > 0) {
             const int nq = g.M / SB, P = (nq + psz - 1) / psz, npatch = P * (P + 1) / 2;
             const long grid = (long)((npatch + 7) / 8) * 8 * psz * psz;
-            hipLaunchKernelGGL(k_ldlt_trailing_64p, dim3((unsigned)grid), dim3(256), 0, s, g, psz, npatch, P);
+            cip_launch(k_ldlt_trailing_64p, dim3((unsigned)grid), dim3(256), 0, s, g, psz, npatch, P);
             CIP_HIP_CHECK(hipGetLastError());
             return 0;
         }
-        if (g.dk) hipLaunchKernelGGL(k_ldlt_trailing_64<true>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
-        else hipLaunchKernelGGL(k_ldlt_trailing_64<false>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
+        if (g.dk) cip_launch(k_ldlt_trailing_64<true>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
+        else cip_launch(k_ldlt_trailing_64<false>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
     if (epi == EPI_SYRKQ && g.lower && g_tile == 64) {
-        hipLaunchKernelGGL(k_syrkq_64, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
+        cip_launch(k_syrkq_64, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
     if (epi == EPI_ACCUM && !g.lower && !g.overwrite && tiles < 256 && g.M % SB == 0 && g.N % SB == 0) {
         // skinny, latency-critical: quarter-size tiles
         const long t64 = (long)(g.M / SB) * (g.N / SB);
-        hipLaunchKernelGGL(k_gemm_nt_64, dim3((unsigned)t64), dim3(256), 0, s, g);
+        cip_launch(k_gemm_nt_64, dim3((unsigned)t64), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
     dim3 grid((unsigned)tiles), block(256);
     switch (epi) {
-        case EPI_ACCUM: hipLaunchKernelGGL(k_gemm_nt_128<EPI_ACCUM>, grid, block, 0, s, g); break;
-        case EPI_SYRKQ: hipLaunchKernelGGL(k_gemm_nt_128<EPI_SYRKQ>, grid, block, 0, s, g); break;
+        case EPI_ACCUM: cip_launch(k_gemm_nt_128<EPI_ACCUM>, grid, block, 0, s, g); break;
+        case EPI_SYRKQ: cip_launch(k_gemm_nt_128<EPI_SYRKQ>, grid, block, 0, s, g); break;
         default: cip_set_error("gemm: bad epilogue"); return -1;
     }
     CIP_HIP_CHECK(hipGetLastError());

@@ -224,6 +224,22 @@ int cip_la_signal(hipStream_t s, void *ctrl_dev, int J);
 int cip_la_gate(hipStream_t s, void *ctrl_dev, int Npad, int nbo, int S);
 int cip_la_finish(hipStream_t s, void *ctrl_dev, int *info);
 
+// zero fill as a kernel: these fills sit inside the launch sequences that small systems replay as hipGraphs, and a
+// captured hipMemsetAsync node left the flag words of ws.info unset on ROCm 7.0 (the factorisation then reported a
+// scheduler error out of uninitialised memory)
+__global__ __launch_bounds__(256) void k_zero_words(unsigned *p, size_t nwords) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+static int zero_fill(hipStream_t s, void *p, size_t bytes) {
+    const size_t nw = bytes / 4;
+    size_t nb = (nw + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (nb == 0) return 0;
+    cip_launch(k_zero_words, dim3((unsigned)nb), dim3(256), 0, s, (unsigned *)p, nw);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // upper triangle <- (strictly lower triangle)': gives the forward sweep the same coalesced
 // "column-dot" access as the backward sweep (U[k, i] = L[i, k])
 __global__ __launch_bounds__(256) void k_mirror_lower(double *K, long ld) {
@@ -261,15 +277,15 @@ static int build_solve_blocks(hipStream_t s, double *K, int Npad, long ld, const
     const int Bs = ws.Bs;
     const int nbk = Npad / Bs;
     int rc;
-    hipLaunchKernelGGL(k_mirror_lower, dim3(Npad / 32, Npad / 32), dim3(256), 0, s, K, ld);
+    cip_launch(k_mirror_lower, dim3(Npad / 32, Npad / 32), dim3(256), 0, s, K, ld);
     if (Bs == CIP_NB) { CIP_HIP_CHECK(hipGetLastError()); return 0; }   // X == Linv, XT == LinvT
     if (!ws.x_zeroed || !*ws.x_zeroed) {
         // the strictly upper blocks of X (lower of XT) are never written afterwards: zero them once per workspace
-        CIP_HIP_CHECK(hipMemsetAsync(ws.X, 0, sizeof(double) * (size_t)nbk * Bs * Bs, s));
-        CIP_HIP_CHECK(hipMemsetAsync(ws.XT, 0, sizeof(double) * (size_t)nbk * Bs * Bs, s));
+        if ((rc = zero_fill(s, ws.X, sizeof(double) * (size_t)nbk * Bs * Bs))) return rc;
+        if ((rc = zero_fill(s, ws.XT, sizeof(double) * (size_t)nbk * Bs * Bs))) return rc;
         if (ws.x_zeroed) *ws.x_zeroed = 1;
     }
-    hipLaunchKernelGGL(k_seed_block_inverse, dim3(Npad / CIP_NB), dim3(256), 0, s, ws.Linv, ws.LinvT, ws.X, ws.XT, Bs);
+    cip_launch(k_seed_block_inverse, dim3(Npad / CIP_NB), dim3(256), 0, s, ws.Linv, ws.LinvT, ws.X, ws.XT, Bs);
     CIP_HIP_CHECK(hipGetLastError());
     const long bs2 = (long)Bs * Bs, tt2 = (long)(Bs / 2) * (Bs / 2);
     for (int h = CIP_NB; h < Bs; h *= 2) {
@@ -301,8 +317,9 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
     const int NBO = g_nbo;
     int rc;
     std::call_once(g_la_once, lookahead_env);
-    CIP_HIP_CHECK(hipMemsetAsync(ws.info, 0, 64, s));      // [0] bad pivot, [1] sweep bail-out, [2] dead pivot, [3] look-ahead scheduler
-    const bool la = g_lookahead == 1 && Npad >= g_la_min && Npad > 2 * NBO && NBO % 64 == 0;
+    if ((rc = zero_fill(s, ws.info, 64))) return rc;       // [0] bad pivot, [1] sweep bail-out, [2] dead pivot, [3] look-ahead scheduler
+    bool la = g_lookahead == 1 && Npad >= g_la_min && Npad > 2 * NBO && NBO % 64 == 0;
+    if (cip_tl_builder) la = false;                           // recording a hipGraph: the single-stream schedule
     if (!la) {
         // serial right-looking schedule: panels of the outer block, then ONE trailing update
         for (int C0 = 0; C0 < Npad; C0 += NBO) {
@@ -375,7 +392,7 @@ static int g_solve_steps = -1;
 
 int cip_ldlt_solve(hipStream_t s, const double *K, int Npad, long ld, const LdltWorkspace &ws, double *rhs) {
     if (g_solve_steps < 0) { const char *e = getenv("CIP_SOLVE"); g_solve_steps = (e && !strcmp(e, "sweeps")) ? 0 : 1; }
-    if (!g_solve_steps) return cip_ldlt_solve_sweeps(s, K, Npad, ld, ws, rhs);
+    if (!g_solve_steps && !cip_tl_builder) return cip_ldlt_solve_sweeps(s, K, Npad, ld, ws, rhs);
     const int Bs = ws.Bs;
     const int nbk = Npad / Bs;
     const double *X = (Bs == CIP_NB) ? ws.Linv : ws.X;
@@ -391,7 +408,7 @@ int cip_ldlt_solve(hipStream_t s, const double *K, int Npad, long ld, const Ldlt
             (rc = cip_gemv_t(s, Bs, below, -1.0, K + C0 + (C0 + Bs) * ld, ld, y + C0, 1.0, rhs + C0 + Bs)))
             return rc;
     }
-    hipLaunchKernelGGL(k_scale_vec, dim3((Npad + 255) / 256), dim3(256), 0, s, Npad, y, ws.dinv, z);
+    cip_launch(k_scale_vec, dim3((Npad + 255) / 256), dim3(256), 0, s, Npad, y, ws.dinv, z);
     for (int J = nbk - 1; J >= 0; --J) {
         const long C0 = (long)J * Bs;
         if ((rc = cip_gemv_t(s, Bs, Bs, 1.0, X + J * bs2, Bs, z + C0, 0.0, rhs + C0))) return rc;

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_gemv_t(int rows, int cols, double alpha
 int cip_gemv_t(hipStream_t s, int rows, int cols, double alpha, const double *A, long lda, const double *x,
                double beta, double *y) {
     if (cols <= 0) return 0;
-    hipLaunchKernelGGL(k_gemv_t, dim3((cols + 3) / 4), dim3(256), 0, s, rows, cols, alpha, A, lda, x, beta, y);
+    cip_launch(k_gemv_t, dim3((cols + 3) / 4), dim3(256), 0, s, rows, cols, alpha, A, lda, x, beta, y);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
