@@ -386,8 +386,10 @@ __global__ __launch_bounds__(256) void k_scale_vec(int n, const double *x, const
 
 int cip_ldlt_solve_sweeps(hipStream_t s, const double *K, int Npad, long ld, const LdltWorkspace &ws, double *rhs);   // solve.hip
 // CIP_SOLVE=sweeps: one persistent kernel per sweep with flag hand-offs between workgroups (solve.hip).  Measured at
-// N = 8192: solve4x4 0.56 ms against 0.31 ms for the block-step form below -- a fan-in + broadcast hop under a
-// streaming load costs 13-14 us (MI355X_MICROARCH.md price list) and a sweep has 16 of them; kept for experiments.
+// N = 8192: solve4x4 0.51 ms (0.56 with every wave polling) against 0.27 ms for the block-step form below; at N = 2048
+// 0.128 against 0.077 ms.  A block step costs two hand-offs on the critical path (partial sums in, block result out: poll,
+// coherent load of the vector, reduction, coherent store, flag) -- ~12 us per block, no cheaper than the two ~7.5 us
+// launches they replace, and the HBM stream beside them runs less efficiently than in the plain gemv.  Kept for experiments.
 static int g_solve_steps = -1;
 
 int cip_ldlt_solve(hipStream_t s, const double *K, int Npad, long ld, const LdltWorkspace &ws, double *rhs) {

@@ -22,15 +22,17 @@
 // Sums are taken in a fixed order: results are bit-reproducible run to run.
 #include "cip_internal.h"
 
-#define SOLVE_WG_COLS 8            // columns per workgroup (4 waves x 2)
+#define SOLVE_WG_COLS 32           // columns per workgroup (16 waves x 2): one workgroup per CU at N = 8192, ONE polling lane each
 
+// agent-scope relaxed atomics = `global_load/store_dwordx2 ... sc1` that the compiler schedules and waits for itself (a
+// hand-written asm load is invisible to its s_waitcnt / spill logic -- see the GEMM epilogue of the look-ahead workers)
 __device__ __forceinline__ v2d ld_sc1(const double *p) {
-    v2d v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
+    return (v2d){__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                 __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
 }
 __device__ __forceinline__ void st_sc1(double *p, v2d v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    __hip_atomic_store(p, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -40,31 +42,35 @@ __device__ __forceinline__ double wsum64(double v) {
     return v;
 }
 
-// one lane polls (relaxed agent-scope load = `sc1`), the wave reconverges behind it; a bounded spin so that a logic
-// error can never hang the GPU: after ~0.2 s the wave gives up and raises `*err`
+// ONE lane of the workgroup polls (relaxed agent-scope load = `sc1`), the others wait at the barrier -- the first
+// version let every wave poll: 4096 pollers on one line, and a sweep took 0.25 ms.  Bounded spin so that a logic error
+// can never hang the GPU: after ~0.1 s the lane gives up and raises `*err`.
 __device__ __forceinline__ void wait_count(const unsigned *ctr, unsigned target, int *err) {
-    if ((threadIdx.x & 63) == 0) {
+    if (threadIdx.x == 0) {
         const long t0 = __builtin_amdgcn_s_memtime();
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (__builtin_amdgcn_s_memtime() - t0 > (1L << 25)) { atomicExch(err, -7); break; }
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memtime() - t0 > (1L << 28)) { atomicExch(err, -7); break; }
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
 }
 
-// all of flags[0 .. q] set?  (64 lanes poll two flags each; q < 128)
+// all of flags[0 .. q] set?  (wave 0 polls, 64 lanes x two flags each, q < 128; the other waves wait at the barrier)
 __device__ __forceinline__ void wait_prefix(const unsigned *flags, int q, int *err) {
-    const int lane = threadIdx.x & 63;
-    const long t0 = __builtin_amdgcn_s_memtime();
-    for (;;) {
-        bool ok = true;
-        if (lane <= q) ok = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        if (lane + 64 <= q) ok = ok && __hip_atomic_load(flags + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(1);
-        if (__builtin_amdgcn_s_memtime() - t0 > (1L << 25)) { if (lane == 0) atomicExch(err, -7); break; }
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const long t0 = __builtin_amdgcn_s_memtime();
+        for (;;) {
+            bool ok = true;
+            if (lane <= q) ok = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (lane + 64 <= q) ok = ok && __hip_atomic_load(flags + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memtime() - t0 > (1L << 28)) { if (lane == 0) atomicExch(err, -7); break; }
+        }
     }
+    __syncthreads();
 }
 
 // ctr: [0] ticket, [1 .. nbk] result arrivals per block (in ticket order of the blocks), [1 + nbk ...] one "r published"
@@ -72,7 +78,7 @@ __device__ __forceinline__ void wait_prefix(const unsigned *flags, int q, int *e
 // (their result counter) and, inside its own block, the predecessors whose r entries its triangular diagonal operand
 // touches (inv(L_JJ) is lower triangular: y_j needs r_i for i <= j only).
 template <int BS, bool FWD>
-__global__ __launch_bounds__(256, 4) void k_ldlt_sweep(const double *__restrict__ K, long ld, const double *__restrict__ Xinv,
+__global__ __launch_bounds__(1024) void k_ldlt_sweep(const double *__restrict__ K, long ld, const double *__restrict__ Xinv,
                                                         const double *__restrict__ dinv, const double *__restrict__ in,
                                                         double *__restrict__ rbuf, double *__restrict__ out,
                                                         double *__restrict__ out_scaled, unsigned *ctr, int *err, int Npad) {
@@ -171,7 +177,7 @@ static int launch_sweeps(hipStream_t s, const double *K, int Npad, long ld, cons
     const size_t per = 1 + (size_t)nbk + Npad / SOLVE_WG_COLS;           // ticket, block counters, per-workgroup flags
     unsigned *cf = ws.sweep_ctr, *cb = ws.sweep_ctr + per;
     CIP_HIP_CHECK(hipMemsetAsync(ws.sweep_ctr, 0, sizeof(unsigned) * 2 * per, s));
-    const dim3 grid(Npad / SOLVE_WG_COLS), block(256);
+    const dim3 grid(Npad / SOLVE_WG_COLS), block(1024);
     // forward: b = rhs -> y (ws.ybuf), z = D^-1 y (ws.zbuf); backward: z -> x (rhs)
     hipLaunchKernelGGL((k_ldlt_sweep<BS, true>), grid, block, 0, s, K, ld, XT, ws.dinv, rhs, ws.tmp, ws.ybuf, ws.zbuf, cf, ws.info + 1, Npad);
     hipLaunchKernelGGL((k_ldlt_sweep<BS, false>), grid, block, 0, s, K, ld, X, ws.dinv, ws.zbuf, ws.tmp, rhs, (double *)nullptr, cb, ws.info + 1, Npad);
