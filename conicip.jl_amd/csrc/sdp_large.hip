@@ -203,6 +203,7 @@ __device__ __forceinline__ double lg_rsqrt(double x) {
 __global__ __launch_bounds__(LG_T) void k_lg_jacobi(double *G, int rp, int b, unsigned *ctr, int *err) {
     extern __shared__ double sh[];
     __shared__ int s_rot;
+    __shared__ double s_nrm[32];
     const int tid = threadIdx.x;
     const int nbk = rp / b, m = nbk, nwg = nbk / 2;
     const int ld = lg_pitch(rp);
@@ -272,10 +273,50 @@ __global__ __launch_bounds__(LG_T) void k_lg_jacobi(double *G, int rp, int b, un
             if (k == 0) { bp = m - 1; bq = t; }
             else { bp = (t + k) % (m - 1); bq = (t - k + (m - 1)) % (m - 1); }
             load(bp, bq);
-            for (int it = 0; it < b; ++it) {
-                const int rr = rotate(pair, b + (pair + it) % b);
-                if (rr && part == 0) atomicMax(&s_rot, rr);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            {
+                // column p = `pair` of block I stays with this lane group for all b rounds: it lives in registers, its
+                // squared norm `a` and the partners' (s_nrm, in LDS) follow the rotations (a' = a - t c, b' = b + t c)
+                // instead of being re-summed -- a round is then one dot product, 8 LDS loads and 8 stores per lane
+                double *gp = sh + pair * ld;
+                double xv[8], a = 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { xv[u] = gp[part + u * tpp]; a += xv[u] * xv[u]; }
+                {
+                    double *gq0 = sh + (b + pair) * ld;
+                    double bq2 = 0.0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const double y = gq0[part + u * tpp]; bq2 += y * y; }
+                    for (int o = tpp >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o); bq2 += __shfl_xor(bq2, o); }
+                    if (part == 0) s_nrm[pair] = bq2;
+                }
+                __syncthreads();
+                for (int it = 0; it < b; ++it) {
+                    const int qi = (pair + it) % b;
+                    double *gq = sh + (b + qi) * ld;
+                    double yv[8], c = 0.0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { yv[u] = gq[part + u * tpp]; c += xv[u] * yv[u]; }
+                    for (int o = tpp >> 1; o > 0; o >>= 1) c += __shfl_xor(c, o);
+                    const double bb = s_nrm[qi];
+                    if (c * c > 1e-30 * (a * bb) && c != 0.0) {
+                        const double zeta = (bb - a) * 0.5 * lg_rcp(c);
+                        const double h2 = 1.0 + zeta * zeta;
+                        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * lg_rcp(fabs(zeta) + h2 * lg_rsqrt(h2));
+                        const double cs = lg_rsqrt(1.0 + tt * tt), sn = cs * tt;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const double x = xv[u];
+                            xv[u] = cs * x - sn * yv[u];
+                            gq[part + u * tpp] = sn * x + cs * yv[u];
+                        }
+                        if (part == 0) { s_nrm[qi] = bb + tt * c; atomicMax(&s_rot, (c * c > 1e-16 * (a * bb)) ? 2 : 1); }
+                        a -= tt * c;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) gp[part + u * tpp] = xv[u];
+                __syncthreads();
             }
             rotated = s_rot > rotated ? s_rot : rotated;
             store(bp, bq);

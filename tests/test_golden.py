@@ -17,6 +17,7 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 PRIM = json.load(open(os.path.join(G, "primitives.json")))
 PINS = json.load(open(os.path.join(G, "reference_pins.json")))
 TRAJ = json.load(open(os.path.join(G, "oracle_trajectories.json")))
+SDC = json.load(open(os.path.join(G, "primitives_sdc.json")))      # S-cone invariants, mpmath at 50 digits
 
 
 def test_oracle_primitives_match_golden():
@@ -36,6 +37,20 @@ def test_oracle_primitives_match_golden():
         R = cones.nestod_sdc(np.array(r["z"]), np.array(r["s"]))
         lam = np.sort(np.diag(R.T @ cones.mat(np.array(r["z"])) @ R))
         np.testing.assert_allclose(lam, r["lam"], rtol=1e-10)
+
+
+def test_oracle_sdc_primitives_match_mpmath():
+    for r in SDC["nestod_sdc"]:
+        Z = cones.mat(np.array(r["z"]))
+        R = cones.nestod_sdc(np.array(r["z"]), np.array(r["s"]))
+        np.testing.assert_allclose(np.sort(np.diag(R.T @ Z @ R)), r["lam"], rtol=1e-11)
+        Ri = np.linalg.inv(R)
+        np.testing.assert_allclose(np.sort(np.diag(Ri @ cones.mat(np.array(r["s"])) @ Ri.T)), r["lam"], rtol=1e-9)
+    for r in SDC["maxstep_sdc"]:
+        a = cones.maxstep_sdc(np.array(r["x"]), np.array(r["d"]))
+        assert (r["alpha"] is None and np.isinf(a)) or a == pytest.approx(r["alpha"], rel=1e-10)
+    for r in SDC["dsdc"]:
+        np.testing.assert_allclose(cones.dsdc(np.array(r["x"]), np.array(r["y"])), r["out"], rtol=1e-9, atol=1e-11)
 
 
 @pytest.mark.parametrize("name", ["sphere", "combined", "simplex", "psd_projection"])
@@ -87,6 +102,30 @@ def test_hip_cone_kernels_match_golden():
         np.testing.assert_allclose(out.cpu().numpy(), r["out"], rtol=1e-11, atol=1e-13)
         ks.cone_prod(dv(rx["x"]), dv(rx["y"]), out)
         np.testing.assert_allclose(out.cpu().numpy(), rx["out"], rtol=1e-13, atol=1e-14)
+        ks.close()
+
+
+@pytest.mark.gpu
+def test_hip_sdc_kernels_match_mpmath():
+    """S-cone kernels against the 50-digit invariants (the reference holds no numeric pin at this granularity)."""
+    import torch
+    import cipkkt
+    dv = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float64, device="cuda")
+    for r, rm, rd in zip(SDC["nestod_sdc"], SDC["maxstep_sdc"], SDC["dsdc"]):
+        k = len(r["z"])
+        ks = cipkkt.KKTSystem(np.eye(2), np.zeros((k, 2)), None, [("S", k)])
+        lam = torch.zeros(k, dtype=torch.float64, device="cuda")
+        ks.set_scaling_from_iterate(dv(r["z"]), dv(r["s"]), lam)
+        got = np.sort(np.linalg.eigvalsh(cones.mat(lam.cpu().numpy())))      # lambda = vecm(diag(Lambda)) up to ordering
+        np.testing.assert_allclose(got, r["lam"], rtol=1e-11)
+        # F^-T s = lambda as well (R^-1 S R^-T = Lambda)
+        t = torch.zeros(k, dtype=torch.float64, device="cuda")
+        ks.apply_F(cipkkt.OP_FINVT, dv(r["s"]), t)
+        np.testing.assert_allclose(np.sort(np.linalg.eigvalsh(cones.mat(t.cpu().numpy()))), r["lam"], rtol=1e-9)
+        a = ks.maxstep(dv(rm["x"]), dv(rm["d"]))
+        assert (rm["alpha"] is None and np.isinf(a)) or a == pytest.approx(rm["alpha"], rel=1e-10)
+        ks.cone_div(dv(rd["x"]), dv(rd["y"]), t)
+        np.testing.assert_allclose(t.cpu().numpy(), rd["out"], rtol=1e-8, atol=1e-10)
         ks.close()
 
 
