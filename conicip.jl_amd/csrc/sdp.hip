@@ -883,8 +883,14 @@ int cip_sdp_apply(hipStream_t s, const ConeSet &cs, int mode, const double *x, d
     return 0;
 }
 int cip_sdp_prod(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out) {
-    hipLaunchKernelGGL(k_sdp_prod, dim3(cs.ns), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx, x, y, out, cs.d_sdpws);
-    CIP_HIP_CHECK(hipGetLastError());
+    if (cs.ns_small > 0) {
+        hipLaunchKernelGGL(k_sdp_prod, dim3(cs.ns_small), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx_small, x, y, out, cs.d_sdpws);
+        CIP_HIP_CHECK(hipGetLastError());
+    }
+    for (int li = 0; li < cs.nlarge; ++li) {
+        const int rc = cip_sdp_large_prod(s, cs.lg, cs.h_cones[cs.large_cone[li]], x, y, out);
+        if (rc) return rc;
+    }
     return 0;
 }
 int cip_sdp_div(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out) {

@@ -102,6 +102,15 @@ __global__ __launch_bounds__(256) void k_lg_vecm(const double *Y, double *out, l
     const double y = Y[(size_t)blockIdx.y * rp * rp + i + (long)j * rp];
     out[(long)blockIdx.y * ob + (long)lg_vidx(i, j, r) * os] = (i == j) ? y : y * LG_SQRT2;
 }
+// out = vecm(Y + Y') of the leading r x r block (Jordan product X o Y = XY + YX from the one product XY)
+__global__ __launch_bounds__(256) void k_lg_vecm_sym(const double *Y, double *out, int r, int rp) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)r * r) return;
+    const int i = (int)(e % r), j = (int)(e / r);
+    if (i > j) return;
+    const double y = Y[i + (long)j * rp] + Y[j + (long)i * rp];
+    out[lg_vidx(i, j, r)] = (i == j) ? y : y * LG_SQRT2;
+}
 // T = (L D^1/2)' as a dense matrix, from the factored K (unit L strictly below, L' mirrored above, d separately):
 //   T[i, k] = L[k, i] sqrt(d_i)  (k > i),  sqrt(d_i) on the diagonal, 0 below
 __global__ __launch_bounds__(256) void k_lg_tfac(const double *K, const double *d, double *T, int rp) {
@@ -649,6 +658,19 @@ int cip_sdp_large_apply(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, i
     if ((rc = lg_gemm(s, w->M2, 0, Q, 0, w->M1, 0, rp, 1))) return rc;              // Q X      (X symmetric)
     if ((rc = lg_gemm(s, w->M3, 0, w->M2, 0, Q, 0, rp, 1))) return rc;              // (Q X) Q'
     hipLaunchKernelGGL(k_lg_vecm, lg_grid((long)r * r), dim3(256), 0, s, w->M3, out + cd.off, 1L, 0L, r, rp);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// out = x o y = vecm(XY + YX)  (xsdc!, src/ConicIP.jl:355-360): one chip-wide GEMM
+int cip_sdp_large_prod(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *y, double *out) {
+    const int r = cd.r, rp = w->rp;
+    const long n2 = (long)rp * rp;
+    int rc;
+    hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, x + cd.off, 1L, 0L, w->M1, r, rp, 0.0);
+    hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, y + cd.off, 1L, 0L, w->M2, r, rp, 0.0);
+    if ((rc = lg_gemm(s, w->M3, 0, w->M1, 0, w->M2, 0, rp, 1))) return rc;          // X Y'  = X Y  (Y symmetric)
+    hipLaunchKernelGGL(k_lg_vecm_sym, lg_grid((long)r * r), dim3(256), 0, s, w->M3, out + cd.off, r, rp);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
