@@ -191,7 +191,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=8, help="c5: problems in flight per GPU (measured on one GPU: 4 -> 1703, 8 -> 2024 KKT solves/s)")
     ap.add_argument("--no-c5", action="store_true", help="c2: skip the single-GPU config-5 figure")
     ap.add_argument("--compare-lookahead", action="store_true",
-                    help="also time the same steps under the opt-in look-ahead schedule (adds its kernels to a profile)")
+                    help="also time the same steps under the opt-in deep look-ahead schedule (slower than the serial one: "
+                         "DESIGN.md section 5; adds its kernels to a profile)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -329,8 +330,8 @@ def main():
         torch.cuda.synchronize()
         la = {"value": args.steps / e_la, "ms_per_step": e_la / args.steps * 1e3,
               "trailing_update_tflops": p_la["flops"] / (p_la["ms"] * 1e-3) / 1e12 if p_la["ms"] > 0 else None,
-              "note": "cip_set_ldlt_lookahead(1): panel chain of the next outer block on a side stream beside a persistent "
-                      "trailing update that leaves 64 CUs free; same steps, same process"}
+              "note": "cip_set_ldlt_lookahead(1): every trailing update in one persistent worker launch (critical strip / "
+                      "bulk queues), panel chain on a side stream behind strip gates, 64 CUs left to it; same steps, same process"}
 
     # separate factor / solve split (untimed region, for the report)
     ks.set_timing(True)

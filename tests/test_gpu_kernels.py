@@ -459,3 +459,62 @@ def test_singular_schur_block_is_regularised_and_refined():
         assert times.value == 1 and rel.value > 0, "the factorisation should have switched to the regularised form"
         np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-9)
         gen.system.close()
+
+
+def test_update_problem_reuses_the_handle():
+    """cip_update_problem (level 1 again on an existing handle: what the batch workers do between problems) must give
+    exactly what a fresh handle gives, and refuse another shape."""
+    import cipkkt
+    from cipkkt import _lib as L
+    from cipkkt.kkt import make_problem
+    rng = np.random.default_rng(31)
+    n, m = 96, 96
+    K = [("R", 60), ("Q", 36)]
+
+    def problem(seed):
+        r = np.random.default_rng(seed)
+        M = r.standard_normal((n, n))
+        return M @ M.T / n + np.eye(n), sp.identity(m, format="csr") * (1.0 + 0.1 * seed), r.standard_normal((3, n))
+
+    Q1, A1, G1 = problem(1)
+    Q2, A2, G2 = problem(2)
+    ks = cipkkt.KKTSystem(Q1, A1, G1, K)
+    pr, keep, _ = make_problem(Q2, A2, G2, K, "schur", ks.device)
+    torch.cuda.synchronize()
+    L.check(ks.lib.cip_update_problem(ks.h, C.byref(pr)))
+    fresh = cipkkt.KKTSystem(Q2, A2, G2, K)
+    v, s = interior_point(K, rng), interior_point(K, rng)
+    x, y, z = rng.standard_normal(n), rng.standard_normal(3), rng.standard_normal(m)
+    outs = []
+    for sysm in (ks, fresh):
+        sysm.set_scaling_from_iterate(dev(v), dev(s))
+        sysm.factor()
+        outs.append(np.concatenate(sysm.solve3x3(x, y, z)))
+    np.testing.assert_array_equal(outs[0], outs[1])
+    pr_bad, keep2, _ = make_problem(Q2[:50, :50], sp.identity(50, format="csr"), None, [("R", 50)], "schur", ks.device)
+    assert ks.lib.cip_update_problem(ks.h, C.byref(pr_bad)) == -1
+    ks.close(); fresh.close()
+
+
+def test_single_entry_and_tiny_cones():
+    """Q cones of dimension 1 and 2, an R cone of one element, beside larger ones (pack width 1, 2, ...)."""
+    import cipkkt
+    K = [("Q", 1), ("Q", 1), ("R", 1), ("Q", 2), ("Q", 1), ("Q", 7)]
+    rng = np.random.default_rng(5)
+    m = sum(k for _, k in K)
+    ks, Q, A, G = make_system(K, n=5)
+    maxstep, nt_scaling, cone_div, cone_prod = make_cone_ops(K)
+    v, s = interior_point(K, rng), interior_point(K, rng)
+    lam = torch.zeros(m, dtype=torch.float64, device="cuda")
+    ks.set_scaling_from_iterate(dev(v), dev(s), lam)
+    F = nt_scaling(v, s)
+    np.testing.assert_allclose(lam.cpu().numpy(), F.mul(v), rtol=1e-12, atol=1e-14)
+    x = rng.standard_normal(m)
+    out = torch.zeros(m, dtype=torch.float64, device="cuda")
+    ks.apply_F(cipkkt.OP_FINVT, dev(x), out)
+    np.testing.assert_allclose(out.cpu().numpy(), F.inv_adjoint().mul(x), rtol=1e-11, atol=1e-13)
+    ks.cone_div(dev(x), dev(s), out)
+    np.testing.assert_allclose(out.cpu().numpy(), cone_div(x, s), rtol=1e-11, atol=1e-13)
+    d = rng.standard_normal(m)
+    assert ks.maxstep(dev(v), dev(d)) == pytest.approx(maxstep(v, d), rel=1e-11)
+    ks.close()

@@ -44,7 +44,8 @@ def main():
     if only == "c5":
         pass
     # C4: single S cone.  ("S",256) is not a legal cone spec (256 is not triangular, src/ConicIP.jl:85);
-    # measured here at matrix order r=64 (k=2080) and r=128 (k=8256), n=256, p=16
+    # measured here at matrix order r=64 (k=2080) and r=128 (k=8256), n=256, p=16; the literal size (r=256, n=1024):
+    # tools/c4_time.py
     for r in (64, 128):
         rng = np.random.default_rng(5)
         n, p = 256, 16
