@@ -5,12 +5,18 @@
 //   xsdc! / dsdc! (lyap)            src/ConicIP.jl:347-360
 //   maxstep_sdc                     src/ConicIP.jl:272-303
 //
-// One 256-thread workgroup per cone (or per column of A for the Schur scaling); the r x r matrices live in
-// a global workspace (r is small in every reference test, <= 30; the layout scales to a few hundred).  The
-// dense symmetric eigenproblems behind nestod_sdc (the reference uses chol + SVD; here chol + symmetric
-// eigendecomposition of Lz' S Lz, which has the same invariant subspaces), maxstep_sdc (eigvals, X^-1/2) and
-// dsdc! (Lyapunov solve) all go through one two-sided Jacobi routine with the round-robin parallel ordering:
-// r/2 disjoint rotations per round, applied as row pass + column pass across the whole workgroup.
+// One workgroup per cone (256 threads up to order 48, 1024 above; or per column of A for the Schur scaling), the ONE
+// matrix a serial chain works on resident in LDS (pitch padded against bank conflicts) up to order 132, r x r GEMMs on
+// v_mfma_f64_16x16x4_f64 with operands straight from L2:
+//   nestod_sdc    two Choleskys, G = Lz' Ls, LEFT singular vectors of G by one-sided (Hestenes) Jacobi with the parallel
+//                 round-robin ordering (r/2 disjoint rotations per round, columns in registers between the dot products
+//                 and the rotation), R = Lz^-T U Lambda^1/2, Rinv = Lambda^-1/2 U' Lz'
+//   maxstep_sdc   lambda_max(L^-1 D L^-T) (X = L L'): Cholesky, two triangular solves, Householder tridiagonalisation,
+//                 multisection on the Sturm count (one shift per thread)
+//   dsdc!         element-wise when the divisor is diagonal (every division of the interior-point loop), two-sided
+//                 Jacobi with vectors otherwise (sd_jacobi_core below -- the only user left of the two-sided routine)
+// Orders 133 .. 512 take the chip-wide path of sdp_large.hip for NT scaling, max-step, congruences, Jordan products and
+// the Schur scaling; the launchers at the end of this file split the S cones of a problem between the two.
 // R is determined only up to a signed permutation of its columns; F'F, F'(F x) and every norm the driver forms
 // are invariant under it.
 #include "cip_internal.h"
