@@ -382,7 +382,7 @@ def main():
                          "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic_per_launch(),
                          "traffic_note": "HBM-side bytes per trailing-update launch = (2*FETCH_SIZE + WRITE_SIZE) KiB of "
-                                         "k_ldlt_trailing_64, averaged over the launches of profiles/r1/final_pmc_*.csv "
+                                         "k_ldlt_trailing_64, averaged over the launches of profiles/r2/final_pmc_*.csv (r1 when absent) "
                                          "(separate rocprofv3 --pmc passes of this command; null if not present)",
                          "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(1.0, prof["launches"]),
                          "algorithmic_flops_per_launch_avg": prof["flops"] / max(1.0, prof["launches"])},

@@ -3,7 +3,9 @@
  * (cip_conicip).  Built and run by tests/test_c_abi_program.py:
  *     gcc -std=c99 -I include tests/c_abi/solve_qp.c -L conicip.jl_amd/cipkkt -lcipkkt -lm
  * Problem:  min 1/2 y'Qy - c'y  s.t.  y >= 0   (A = I, b = 0, K = R^n), Q = tridiag(-1, 4, -1).
- * Checks:   the KKT residuals of the level-3 solve, the optimality conditions of the final iterate. */
+ * Checks:   the KKT residuals of the level-3 solve, the optimality conditions of the final iterate.
+ * With -DCIP_PLUGIN_LEVELS_ONLY the program stops after level 3: that build is linked against the CPU reference of
+ * the ABI (oracle/cpu_ref, tests/test_cpu_ref.py), which implements the plugin levels only. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -41,7 +43,12 @@ int main(void) {
     }
     printf("solve3x3 residuals %.3e %.3e\n", r1, r2);
     if (!(r1 < 1e-10 && r2 < 1e-10)) return 1;
-
+#ifdef CIP_PLUGIN_LEVELS_ONLY
+    (void)c; (void)b; (void)y; (void)v;
+    CHECK(cip_destroy(h));
+    free(Q); free(A);
+    return 0;
+#else
     cip_options opt = {1e-8, 0.01, -1.0, -1.0, 3, 100, 0};
     cip_result res;
     CHECK(cip_conicip(h, c, b, NULL, &opt, y, NULL, v, &res, NULL, 0));
@@ -58,4 +65,5 @@ int main(void) {
     CHECK(cip_destroy(h));
     free(Q); free(A);
     return (res.status == CIP_STATUS_OPTIMAL && feas < 1e-6 && stat < 1e-6 && comp < 1e-5) ? 0 : 1;
+#endif
 }
