@@ -15,6 +15,7 @@ OP_F, OP_FT, OP_FINV, OP_FINVT = 0, 1, 2, 3
 MAT_Q, MAT_A, MAT_G = 0, 1, 2
 FLAG_DEVICE_PTRS = 1
 E_SINGULAR = -5
+E_UNSUPPORTED = -6
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -87,6 +88,10 @@ SIGNATURES = {
                           [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(CipResult), C.c_int]),
     "cip_conicip_problems": (C.c_int, [C.c_int, C.POINTER(CipProblem)] + [C.POINTER(C.c_void_p)] * 3 +
                              [C.POINTER(CipOptions)] + [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(CipResult), C.c_int]),
+    "cip_conicip_lockstep": (C.c_int, [C.c_int, C.POINTER(CipProblem)] + [C.POINTER(C.c_void_p)] * 3 +
+                             [C.POINTER(CipOptions)] + [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(CipResult)]),
+    "cip_release_cached_memory": (C.c_int, []),
+    "cip_lockstep_stats": (C.c_int, [c_int_p]),
     "cip_conicip_many": (C.c_int, [C.POINTER(C.c_void_p), C.c_int] + [C.POINTER(C.c_void_p)] * 3 +
                          [C.POINTER(CipOptions)] + [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(CipResult), C.c_int]),
     "cip_ldlt_workspace_bytes": (C.c_int, [C.c_int, C.POINTER(C.c_size_t)]),
@@ -100,6 +105,7 @@ SIGNATURES = {
     "cip_stats": (C.c_int, [C.c_void_p, c_double_p]),
     "cip_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "cip_set_ldlt_outer_block": (C.c_int, [C.c_int]),
+    "cip_set_solve_block_max": (C.c_int, [C.c_int]),
     "cip_set_ldlt_lookahead": (C.c_int, [C.c_int]),
     "cip_profile_lookahead": (C.c_int, [C.c_void_p, c_double_p]),
     "cip_profile_trailing": (C.c_int, [C.c_void_p, C.c_int]),

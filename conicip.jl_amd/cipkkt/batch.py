@@ -5,6 +5,7 @@ is data parallelism over independent problems: problem i -> rank (i mod world). 
 is no data-path collective; one tiny all-reduce (RCCL over xGMI on the GPU box, gloo in
 the CPU tests) combines convergence / timing statistics.
 """
+import os
 import time
 
 import numpy as np
@@ -84,10 +85,13 @@ def _solve_many_native(prs, device, in_flight):
             ks.close()
 
 
-def _solve_problems_native(prs, device, in_flight):
-    """All problems of this rank through `cip_conicip_problems` (csrc/batch.hip): `in_flight` host threads inside the
-    library, each re-loading ONE handle on its own HIP stream with the next problem of the queue (no allocation per
-    problem), so the level-1 upload of one problem overlaps the interior-point loops of the others."""
+def _solve_problems_native(prs, device, in_flight, mode="auto"):
+    """All problems of this rank through the library's batch entry points.
+    mode "lockstep": `cip_conicip_lockstep` (csrc/lockstep.hip) -- problems of identical shape advance through the loop
+    together, every step one launch with the problem index in the grid; "threads": `cip_conicip_problems`
+    (csrc/batch.hip) -- `in_flight` host threads inside the library, each re-loading ONE handle on its own HIP stream
+    with the next problem of the queue; "auto": lock-step when the batch qualifies (same shape, no S cones; the
+    library answers CIP_E_UNSUPPORTED otherwise), else threads.  CIP_BATCH=threads|lockstep overrides "auto"."""
     import ctypes as C
     from . import _lib as L
     from .driver import solution_from_result
@@ -125,8 +129,18 @@ def _solve_problems_native(prs, device, in_flight):
         vs = [np.zeros(max(dims[i][1], 1)) for i in range(k)]
         arr = lambda xs: vp(*[x.ctypes.data for x in xs])
         res = (L.CipResult * k)()
-        L.check(lib.cip_conicip_problems(k, structs, arr(cs), arr(bs), arr(ds), C.byref(opt), arr(ys), arr(ws), arr(vs),
-                                         res, int(in_flight)))
+        if mode == "auto":
+            mode = os.environ.get("CIP_BATCH", "auto")
+        done = False
+        if mode in ("auto", "lockstep") and k > 1:
+            rc = lib.cip_conicip_lockstep(k, structs, arr(cs), arr(bs), arr(ds), C.byref(opt), arr(ys), arr(ws), arr(vs), res)
+            if rc == 0:
+                done = True
+            elif rc != L.E_UNSUPPORTED or mode == "lockstep":
+                L.check(rc)
+        if not done:
+            L.check(lib.cip_conicip_problems(k, structs, arr(cs), arr(bs), arr(ds), C.byref(opt), arr(ys), arr(ws), arr(vs),
+                                             res, int(in_flight)))
     return [solution_from_result(res[i], ys[i][:dims[i][0]], ws[i][:dims[i][2]], vs[i][:dims[i][1]]) for i in range(k)]
 
 
@@ -151,8 +165,12 @@ def solve_batch(problems, solve_fn=None, rank=0, world=1, dist=None, device=None
     same_opts = all(problems[i].get("kwargs", {}) == problems[mine[0]].get("kwargs", {}) for i in mine) if mine else True
     if default_solver and native and len(mine) > 0 and same_opts:
         dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
-        fn = _solve_many_native if native == "handles" else _solve_problems_native
-        for i, sol in zip(mine, fn([problems[i] for i in mine], dev, max(1, concurrency))):
+        shard = [problems[i] for i in mine]
+        if native == "handles":
+            out = _solve_many_native(shard, dev, max(1, concurrency))
+        else:
+            out = _solve_problems_native(shard, dev, max(1, concurrency), native if native in ("lockstep", "threads") else "auto")
+        for i, sol in zip(mine, out):
             sols[i] = sol
     elif default_solver and concurrency > 1 and len(mine) > 1:
         from concurrent.futures import ThreadPoolExecutor

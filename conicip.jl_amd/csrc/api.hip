@@ -48,12 +48,25 @@ struct CipRange { explicit CipRange(const char *n) { cip_range_push(n); } ~CipRa
 
 static int rup(int x, int q) { return ((x + q - 1) / q) * q; }
 
+int cip_handle_alloc(cip_handle *h, void **out, size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    const size_t b = (bytes + 255) & ~(size_t)255;
+    h->alloc_bytes += b;
+    if (h->arena) {
+        if (h->arena_used + b <= h->arena_cap) { *out = h->arena + h->arena_used; h->arena_used += b; return 0; }
+        h->arena_overflow = true;                  // falls back to its own allocation: the slab layout is broken
+    }
+    CIP_HIP_CHECK(hipMalloc(out, bytes));
+    return 0;
+}
 #define DMALLOC(ptr, bytes)                                                        \
     do {                                                                           \
-        size_t b__ = (size_t)(bytes);                                              \
-        if (b__ == 0) b__ = 256;                                                   \
-        CIP_HIP_CHECK(hipMalloc((void **)&(ptr), b__));                            \
+        int rc__ = cip_handle_alloc(h, (void **)&(ptr), (size_t)(bytes));          \
+        if (rc__) return rc__;                                                     \
     } while (0)
+static bool in_arena(const cip_handle *h, const void *p) {
+    return h->arena && (const char *)p >= h->arena && (const char *)p < h->arena + h->arena_cap;
+}
 
 static void free_all(cip_handle *h) {
     if (h->gx_factor) { (void)hipGraphExecDestroy(h->gx_factor); h->gx_factor = nullptr; }
@@ -63,7 +76,7 @@ static void free_all(cip_handle *h) {
                     h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->cs.d_partial, h->cs.d_scalar, h->K, h->Wt, h->Gm,
                     h->ws_base, h->rhs, h->mt1, h->mt2, h->mt3, h->nt1, h->pt1, h->dot_scratch, h->dot_ptrs, h->stage, h->drv, h->ref, h->c2x2};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p && !in_arena(h, p)) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -347,6 +360,20 @@ extern "C" int cip_create_ex(const cip_problem *prob, cip_handle **out) {
     return 0;
 }
 
+// A handle whose creation-time buffers are carved out of `slab` (lock-step batches, driver.hip); the slab belongs to the
+// caller and outlives the handle.
+int cip_create_in_arena(const cip_problem *pr, char *slab, size_t cap, hipStream_t stream, cip_handle **out) {
+    *out = nullptr;
+    cip_handle *h = new (std::nothrow) cip_handle();
+    if (!h) { cip_set_error("out of host memory"); return CIP_E_INVALID; }
+    h->arena = slab; h->arena_cap = cap; h->arena_used = 0;
+    h->stream = stream;
+    const int rc = create_impl(pr, h);
+    if (rc) { free_all(h); delete h; return rc; }
+    *out = h;
+    return 0;
+}
+
 extern "C" int cip_create(int n, int m, int p, int ncones, const int *cone_type, const int *cone_dim, const double *Q,
                           const double *A, const double *G, int route, cip_handle **out) {
     cip_problem pr;
@@ -452,7 +479,7 @@ static bool graph_wanted(cip_handle *h) {
 thread_local CipGraphBuilder *cip_tl_builder = nullptr;
 template <class F>
 static int graph_run(cip_handle *h, hipGraphExec_t *exec, F &&enqueue) {
-    if (!graph_wanted(h) || h->timing || h->ws.prof) return enqueue();
+    if (cip_in_batch() || !graph_wanted(h) || h->timing || h->ws.prof) return enqueue();
     if (!*exec) {
         CipGraphBuilder b = {nullptr, nullptr, false, true};
         if (hipGraphCreate(&b.graph, 0) != hipSuccess) { (void)hipGetLastError(); h->graph_state = -1; return enqueue(); }
@@ -588,7 +615,7 @@ static int mul_A(cip_handle *h, double alpha, const double *x, double beta, doub
     return cip_gemv_t(h->stream, h->n, h->m, alpha, h->At, h->npad, x, beta, y);
 }
 static int mul_At(cip_handle *h, double alpha, const double *x, double beta, double *y) {     // y = alpha A' x + beta y (n)
-    if (h->m == 0) { if (beta == 0.0) CIP_HIP_CHECK(hipMemsetAsync(y, 0, sizeof(double) * h->n, h->stream)); return 0; }
+    if (h->m == 0) { if (beta == 0.0) { int rcc = cip_zero(h->stream, h->n, y); if (rcc) return rcc; } return 0; }
     if (h->A_sparse) return cip_spmv_csr(h->stream, h->n, h->T_rp, h->T_ci, h->T_v, alpha, x, beta, y);
     return cip_gemv_t(h->stream, h->m, h->n, alpha, h->A, h->m, x, beta, y);
 }
@@ -612,13 +639,13 @@ static int solve3x3_once(cip_handle *h, const double *x, const double *y, const 
         //   t = (F'F)^-1 z ; [S G'; G 0][a; b] = [x + A't; y] ; c = t - (F'F)^-1 A a
         double *t = h->mt1, *tmp = h->mt2, *u = h->mt3;
         if (m > 0 && (rc = apply_FtF_inv(h, z, tmp, t))) return rc;
-        CIP_HIP_CHECK(hipMemcpyAsync(h->rhs, x, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+        { int rcc = cip_copy(s, n, x, h->rhs); if (rcc) return rcc; }
         if (m > 0 && (rc = mul_At(h, 1.0, t, 1.0, h->rhs))) return rc;
-        if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(h->rhs + n, y, sizeof(double) * p, hipMemcpyDeviceToDevice, s));
-        if (h->Npad > h->N) CIP_HIP_CHECK(hipMemsetAsync(h->rhs + h->N, 0, sizeof(double) * (h->Npad - h->N), s));
+        if (p > 0) { int rcc = cip_copy(s, p, y, h->rhs + n); if (rcc) return rcc; }
+        if (h->Npad > h->N) { int rcc = cip_zero(s, (h->Npad - h->N), h->rhs + h->N); if (rcc) return rcc; }
         if ((rc = graph_run(h, &h->gx_solve, [&]() { return cip_ldlt_solve(s, h->K, h->Npad, h->ldk, h->ws, h->rhs); }))) return rc;
-        CIP_HIP_CHECK(hipMemcpyAsync(a, h->rhs, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-        if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(b, h->rhs + n, sizeof(double) * p, hipMemcpyDeviceToDevice, s));
+        { int rcc = cip_copy(s, n, h->rhs, a); if (rcc) return rcc; }
+        if (p > 0) { int rcc = cip_copy(s, p, h->rhs + n, b); if (rcc) return rcc; }
         if (m > 0) {
             if ((rc = mul_A(h, 1.0, h->rhs, 0.0, u))) return rc;
             if ((rc = apply_FtF_inv(h, u, tmp, u))) return rc;
@@ -628,13 +655,13 @@ static int solve3x3_once(cip_handle *h, const double *x, const double *y, const 
     } else {
         // [-F'F -A 0; -A' Q G'; 0 G 0] [c; a; b] = [-z; x; y]
         if (m > 0 && (rc = cip_axpby(s, m, -1.0, z, 0.0, h->rhs))) return rc;
-        CIP_HIP_CHECK(hipMemcpyAsync(h->rhs + m, x, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-        if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(h->rhs + m + n, y, sizeof(double) * p, hipMemcpyDeviceToDevice, s));
-        if (h->Npad > h->N) CIP_HIP_CHECK(hipMemsetAsync(h->rhs + h->N, 0, sizeof(double) * (h->Npad - h->N), s));
+        { int rcc = cip_copy(s, n, x, h->rhs + m); if (rcc) return rcc; }
+        if (p > 0) { int rcc = cip_copy(s, p, y, h->rhs + m + n); if (rcc) return rcc; }
+        if (h->Npad > h->N) { int rcc = cip_zero(s, (h->Npad - h->N), h->rhs + h->N); if (rcc) return rcc; }
         if ((rc = graph_run(h, &h->gx_solve, [&]() { return cip_ldlt_solve(s, h->K, h->Npad, h->ldk, h->ws, h->rhs); }))) return rc;
-        if (m > 0) CIP_HIP_CHECK(hipMemcpyAsync(c, h->rhs, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
-        CIP_HIP_CHECK(hipMemcpyAsync(a, h->rhs + m, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-        if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(b, h->rhs + m + n, sizeof(double) * p, hipMemcpyDeviceToDevice, s));
+        if (m > 0) { int rcc = cip_copy(s, m, h->rhs, c); if (rcc) return rcc; }
+        { int rcc = cip_copy(s, n, h->rhs + m, a); if (rcc) return rcc; }
+        if (p > 0) { int rcc = cip_copy(s, p, h->rhs + m + n, b); if (rcc) return rcc; }
     }
     return 0;
 }
@@ -683,9 +710,9 @@ extern "C" int cip_solve3x3_dev(cip_handle *h, const double *x, const double *y,
     double *xs = h->ref, *ys = xs + n, *zs = ys + p;              // private copy of the right-hand side (z may alias c)
     double *rx = h->ref + tot + 8, *ry = rx + n, *rz = ry + p;
     double *da = h->ref + 2 * (tot + 8), *db = da + n, *dc = db + p;
-    CIP_HIP_CHECK(hipMemcpyAsync(xs, x, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-    if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(ys, y, sizeof(double) * p, hipMemcpyDeviceToDevice, s));
-    if (m > 0) CIP_HIP_CHECK(hipMemcpyAsync(zs, z, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
+    { int rcc = cip_copy(s, n, x, xs); if (rcc) return rcc; }
+    if (p > 0) { int rcc = cip_copy(s, p, y, ys); if (rcc) return rcc; }
+    if (m > 0) { int rcc = cip_copy(s, m, z, zs); if (rcc) return rcc; }
     if ((rc = solve3x3_once(h, xs, ys, zs, a, b, c))) return rc;
     double prev = __builtin_inf();
     for (int it = 0; it < 6; ++it) {
@@ -735,7 +762,7 @@ extern "C" int cip_solve2x2_dev(cip_handle *h, const double *y, const double *w,
     if ((rc = factor_resolve(h, false))) return rc;
     if (h->reg_rel > 0.0 && h->m > 0) {
         // regularised factor: go through the refined 3x3 solve with z = 0 (its first two components are the 2x2 solution)
-        CIP_HIP_CHECK(hipMemsetAsync(h->mt1, 0, sizeof(double) * h->m, h->stream));
+        { int rcc = cip_zero(h->stream, h->m, h->mt1); if (rcc) return rcc; }
         if (!h->c2x2) DMALLOC(h->c2x2, sizeof(double) * h->m);
         return cip_solve3x3_dev(h, y, w, h->mt1, dy, dw, h->c2x2);
     }
@@ -815,7 +842,7 @@ extern "C" int cip_gemv_dev(cip_handle *h, int which, int trans, double alpha, c
         case CIP_MAT_A: return trans ? mul_At(h, alpha, x, beta, y) : mul_A(h, alpha, x, beta, y);
         case CIP_MAT_G:
             if (h->p == 0) {
-                if (trans && beta == 0.0) CIP_HIP_CHECK(hipMemsetAsync(y, 0, sizeof(double) * h->n, s));
+                if (trans && beta == 0.0) { int rcc = cip_zero(s, h->n, y); if (rcc) return rcc; }
                 else if (trans && beta != 1.0) return cip_axpby(s, h->n, 0.0, y, beta, y);
                 return 0;
             }
@@ -913,4 +940,5 @@ extern "C" int cip_profile_lookahead(cip_handle *h, double *out4) {
     return rc;
 }
 extern "C" int cip_set_ldlt_lookahead(int on) { return cip_ldlt_set_lookahead(on); }
+extern "C" int cip_set_solve_block_max(int b) { return cip_solve_block_max_set(b); }
 extern "C" int cip_set_ldlt_outer_block(int nbo) { cip_ldlt_set_outer_block(nbo); return cip_ldlt_outer_block(); }

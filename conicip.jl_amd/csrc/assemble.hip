@@ -12,7 +12,9 @@
 #include "../../include/cipkkt.h"
 
 // rows >= n of the Schur-route matrix: G block, zero block, identity padding (lower part)
-__global__ __launch_bounds__(256) void k_fill_rest(double *K, long ldk, int n, int p, int Npad, const double *G, long ldg) {
+__global__ __launch_bounds__(256) void k_fill_rest(double *K, long ldk, int n, int p, int Npad, const double *G, long ldg, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO2(cb, K, G);
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= Npad) return;
     for (int i = n + blockIdx.y; i < Npad; i += gridDim.y) {
@@ -26,7 +28,9 @@ __global__ __launch_bounds__(256) void k_fill_rest(double *K, long ldk, int n, i
 
 // K[r0 + i, c0 + j] = sign * M[i + j*ldm]   (i < rows, j < cols); coalesced along i
 __global__ __launch_bounds__(256) void k_copy_block(double *K, long ldk, int r0, int c0, const double *M, long ldm,
-                                                     int rows, int cols, double sign) {
+                                                     int rows, int cols, double sign, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO2(cb, K, M);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= rows) return;
     for (int j = blockIdx.y; j < cols; j += gridDim.y)
@@ -36,7 +40,9 @@ __global__ __launch_bounds__(256) void k_copy_block(double *K, long ldk, int r0,
 // The same for a square block on the diagonal (r0 == c0), restricted to the 128x128 tiles of K on or below the
 // diagonal: the factorisation never references a tile above it, and Q is half of the assembly's HBM traffic
 // (n = 8192: 1.07 GB -> 0.56 GB per factorisation).
-__global__ __launch_bounds__(256) void k_copy_block_lower(double *K, long ldk, int r0, const double *M, long ldm, int n, double sign) {
+__global__ __launch_bounds__(256) void k_copy_block_lower(double *K, long ldk, int r0, const double *M, long ldm, int n, double sign, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO2(cb, K, M);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int jend = min(n, (((r0 + i) >> 7) + 1) * 128 - r0);      // columns up to the end of this row's diagonal tile
@@ -56,7 +62,9 @@ __device__ __forceinline__ double schur_row_weight(const ConeDesc &cd, const dou
 }
 __global__ __launch_bounds__(256) void k_schur_rows(int n, const int *trp, const int *tci, const double *tv, const int *rp,
                                                      const int *ci, const double *av, const int *row_cone,
-                                                     const ConeDesc *cones, const double *scal, double *K, long ldk, int base) {
+                                                     const ConeDesc *cones, const double *scal, double *K, long ldk, int base, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO8(cb, trp, tci, tv, rp, ci, av, scal, K);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     for (int q = trp[i]; q < trp[i + 1]; ++q) {
@@ -72,7 +80,9 @@ __global__ __launch_bounds__(256) void k_schur_rows(int n, const int *trp, const
 // A in ascending r; the rows of one cone are consecutive)
 __global__ __launch_bounds__(256) void k_schur_qcols(int n, const int *trp, const int *tci, const double *tv,
                                                       const int *row_cone, const ConeDesc *cones, const double *scal,
-                                                      double *Gm, long ldgm) {
+                                                      double *Gm, long ldgm, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO5(cb, trp, tci, tv, scal, Gm);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     int cur = -1;
@@ -97,7 +107,9 @@ __global__ __launch_bounds__(256) void k_schur_qcols(int n, const int *trp, cons
 
 // ---------------------------------------------------------------- full 3x3 route: -F'F block
 __global__ __launch_bounds__(256) void k_fill_ftf(const ConeDesc *cones, const WorkItem *items, const double *scal,
-                                                   double *K, long ldk) {
+                                                   double *K, long ldk, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO2(cb, scal, K);
     const WorkItem it = items[blockIdx.x];
     const ConeDesc cd = cones[it.cone];
     const int tid = threadIdx.x;
@@ -129,13 +141,17 @@ __global__ __launch_bounds__(256) void k_fill_ftf(const ConeDesc *cones, const W
     }
 }
 __global__ __launch_bounds__(256) void k_scatter_negA(int nrowsT, const int *trp, const int *tci, const double *tv,
-                                                       double *K, long ldk, int r0) {
+                                                       double *K, long ldk, int r0, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO4(cb, trp, tci, tv, K);
     // CSR of A' (row i = variable, column = constraint r):  K[r0 + i, r] = -A[r, i]
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nrowsT) return;
     for (int q = trp[i]; q < trp[i + 1]; ++q) K[(r0 + i) + (long)tci[q] * ldk] = -tv[q];
 }
-__global__ __launch_bounds__(256) void k_pad_identity(double *K, long ldk, int N, int Npad) {
+__global__ __launch_bounds__(256) void k_pad_identity(double *K, long ldk, int N, int Npad, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO1(cb, K);
     const int i = N + blockIdx.x * 256 + threadIdx.x;
     if (i < Npad) K[i + (long)i * ldk] = 1.0;
 }
@@ -153,21 +169,21 @@ static int assemble_schur(cip_handle *h) {
         if ((rc = cip_launch_gemm(s, EPI_SYRKQ, g))) return rc;
     } else {
         if (n > 0) {
-            hipLaunchKernelGGL(k_copy_block_lower, dim3((n + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, 0, h->Q,
+            cip_launch_b(k_copy_block_lower, dim3((n + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, 0, h->Q,
                                (long)n, n, 1.0);
         }
         if (h->m > 0) {
-            hipLaunchKernelGGL(k_schur_rows, dim3((n + 255) / 256), dim3(256), 0, s, n, h->T_rp, h->T_ci, h->T_v, h->A_rp, h->A_ci,
+            cip_launch_b(k_schur_rows, dim3((n + 255) / 256), dim3(256), 0, s, n, h->T_rp, h->T_ci, h->T_v, h->A_rp, h->A_ci,
                                h->A_v, h->row_cone, h->cs.d_cones, h->cs.d_scal, h->K, h->ldk, 0);
             if (h->nq > 0) {
-                CIP_HIP_CHECK(hipMemsetAsync(h->Gm, 0, sizeof(double) * (size_t)h->npad * h->nqpad, s));
-                hipLaunchKernelGGL(k_schur_qcols, dim3((n + 255) / 256), dim3(256), 0, s, n, h->T_rp, h->T_ci, h->T_v,
+                if ((rc = cip_zero(s, (long)h->npad * h->nqpad, h->Gm))) return rc;
+                cip_launch_b(k_schur_qcols, dim3((n + 255) / 256), dim3(256), 0, s, n, h->T_rp, h->T_ci, h->T_v,
                                    h->row_cone, h->cs.d_cones, h->cs.d_scal, h->Gm, (long)h->npad);
             }
         }
     }
     if (h->Npad > n) {
-        hipLaunchKernelGGL(k_fill_rest, dim3((h->Npad + 255) / 256, (h->Npad - n) < 32768 ? (h->Npad - n) : 32768), dim3(256), 0, s, h->K, h->ldk, n, p,
+        cip_launch_b(k_fill_rest, dim3((h->Npad + 255) / 256, (h->Npad - n) < 32768 ? (h->Npad - n) : 32768), dim3(256), 0, s, h->K, h->ldk, n, p,
                            h->Npad, h->G, (long)p);
     }
     if (h->A_sparse && h->nq > 0 && h->m > 0) {
@@ -186,27 +202,27 @@ int cip_sdp_fill_ftf(hipStream_t s, const ConeSet &cs, double *K, long ldk);    
 static int assemble_full(cip_handle *h) {
     hipStream_t s = h->stream;
     const int n = h->n, m = h->m, p = h->p;
-    CIP_HIP_CHECK(hipMemsetAsync(h->K, 0, sizeof(double) * (size_t)h->ldk * h->Npad, s));
+    { int rcz = cip_zero(s, (long)h->ldk * h->Npad, h->K); if (rcz) return rcz; }
     if (h->cs.nitems > 0)
-        hipLaunchKernelGGL(k_fill_ftf, dim3(h->cs.nitems), dim3(256), 0, s, h->cs.d_cones, h->cs.d_items, h->cs.d_scal,
+        cip_launch_b(k_fill_ftf, dim3(h->cs.nitems), dim3(256), 0, s, h->cs.d_cones, h->cs.d_items, h->cs.d_scal,
                            h->K, h->ldk);
     if (h->cs.has_S) { int rc = cip_sdp_fill_ftf(s, h->cs, h->K, h->ldk); if (rc) return rc; }
     if (m > 0 && n > 0) {
         if (!h->A_sparse)
-            hipLaunchKernelGGL(k_copy_block, dim3((n + 255) / 256, m < 32768 ? m : 32768), dim3(256), 0, s, h->K, h->ldk, m, 0, h->At,
+            cip_launch_b(k_copy_block, dim3((n + 255) / 256, m < 32768 ? m : 32768), dim3(256), 0, s, h->K, h->ldk, m, 0, h->At,
                                (long)h->npad, n, m, -1.0);
         else
-            hipLaunchKernelGGL(k_scatter_negA, dim3((n + 255) / 256), dim3(256), 0, s, n, h->T_rp, h->T_ci, h->T_v,
+            cip_launch_b(k_scatter_negA, dim3((n + 255) / 256), dim3(256), 0, s, n, h->T_rp, h->T_ci, h->T_v,
                                h->K, h->ldk, m);
     }
     if (n > 0)
-        hipLaunchKernelGGL(k_copy_block_lower, dim3((n + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, m, h->Q, (long)n,
+        cip_launch_b(k_copy_block_lower, dim3((n + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, m, h->Q, (long)n,
                            n, 1.0);
     if (p > 0)
-        hipLaunchKernelGGL(k_copy_block, dim3((p + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, m + n, m, h->G,
+        cip_launch_b(k_copy_block, dim3((p + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, m + n, m, h->G,
                            (long)p, p, n, 1.0);
     if (h->Npad > h->N)
-        hipLaunchKernelGGL(k_pad_identity, dim3((h->Npad - h->N + 255) / 256), dim3(256), 0, s, h->K, h->ldk, h->N, h->Npad);
+        cip_launch_b(k_pad_identity, dim3((h->Npad - h->N + 255) / 256), dim3(256), 0, s, h->K, h->ldk, h->N, h->Npad);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -215,7 +231,9 @@ static int assemble_full(cip_handle *h) {
 // row part j <= i and its column part below the diagonal), s_i = +1 on the positive-pivot block [p0, p1), -1 elsewhere.
 // Late interior-point iterates spread the diagonal of S over 20 orders of magnitude; one global delta either drowns
 // the small rows or does nothing for the large ones.
-__global__ __launch_bounds__(256) void k_rowmax_lower(const double *K, long ldk, int N, double *rowmax) {
+__global__ __launch_bounds__(256) void k_rowmax_lower(const double *K, long ldk, int N, double *rowmax, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO2(cb, K, rowmax);
     // thread <-> row i: the row part K[i, 0..i] (coalesced across the threads of a workgroup)
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
@@ -223,7 +241,9 @@ __global__ __launch_bounds__(256) void k_rowmax_lower(const double *K, long ldk,
     for (int j = 0; j <= i; ++j) mx = fmax(mx, fabs(K[i + (long)j * ldk]));
     rowmax[i] = mx;
 }
-__global__ __launch_bounds__(256) void k_regularize_rows(double *K, long ldk, int N, int p0, int p1, double rel, const double *rowmax) {
+__global__ __launch_bounds__(256) void k_regularize_rows(double *K, long ldk, int N, int p0, int p1, double rel, const double *rowmax, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO2(cb, K, rowmax);
     // workgroup <-> column i: the column part K[i+1.., i], then the diagonal update
     __shared__ double red[4];
     const int i = blockIdx.x;
@@ -243,8 +263,8 @@ int cip_assemble(cip_handle *h) {
     if (rc == 0 && h->reg_rel > 0.0) {
         // (the diagonal is modified only after every row / column maximum has been read: the second kernel reads
         //  column i strictly below the diagonal, the first one has finished before it starts)
-        hipLaunchKernelGGL(k_rowmax_lower, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->K, h->ldk, h->N, h->rhs);
-        hipLaunchKernelGGL(k_regularize_rows, dim3(h->N), dim3(256), 0, h->stream, h->K, h->ldk, h->N, h->ws.signs.p0,
+        cip_launch_b(k_rowmax_lower, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->K, h->ldk, h->N, h->rhs);
+        cip_launch_b(k_regularize_rows, dim3(h->N), dim3(256), 0, h->stream, h->K, h->ldk, h->N, h->ws.signs.p0,
                            h->ws.signs.p1, h->reg_rel, h->rhs);
         CIP_HIP_CHECK(hipGetLastError());
     }

@@ -10,6 +10,12 @@ struct cip_handle {
     int nq = 0, nqpad = 0;          // number of Q cones, rounded up to 16 (>= 16)
     hipStream_t stream = nullptr;
     int device = 0;
+    // Device memory of the handle.  Normally one hipMalloc per buffer; a handle of a lock-step batch carves its buffers,
+    // in creation order, out of its slab of the batch's arena (api.hip: cip_handle_alloc) so that problem z's buffers
+    // sit at problem 0's addresses + z * stride.  alloc_bytes counts what creation asked for (256-byte granules).
+    char *arena = nullptr;
+    size_t arena_cap = 0, arena_used = 0, alloc_bytes = 0;
+    bool arena_overflow = false;
 
     // ---- problem data, device resident for the lifetime of the handle (level 1)
     double *Q = nullptr;            // n x n, ld n
@@ -69,6 +75,9 @@ struct cip_handle {
 };
 
 int cip_assemble(cip_handle *h);     // assemble.hip
+int cip_handle_alloc(cip_handle *h, void **out, size_t bytes);      // api.hip
+int cip_create_in_arena(const struct cip_problem *pr, char *slab, size_t cap, hipStream_t stream, cip_handle **out);   // api.hip
+size_t cip_driver_bytes(const cip_handle *h);                        // driver.hip: vectors of the interior-point loop
 // api.hip: resolve the pivot flag of the last factorisation (wait = 0: only if its read-back has already landed)
 int cip_factor_resolve(cip_handle *h, int wait);
 

@@ -47,6 +47,42 @@ inline void cip_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t s
     b->last = node; b->have_last = true;
 }
 
+// ---------------------------------------------------------------- lock-step batches (batch dimension = blockIdx.z)
+// A lock-step batch (csrc/lockstep.hip) holds B problems of identical shape whose device buffers were carved, in the
+// same order, out of equally sized slabs of ONE arena: whatever pointer problem 0 uses, problem z uses the same pointer
+// + z * stride.  The host code of the library therefore runs ONCE, on problem 0's handle, while a thread-local batch
+// context is active: cip_launch_b multiplies grid.z by B and appends a CipBatch argument; the kernel drops out when its
+// problem is masked off and shifts its pointer arguments (CIP_BOFF).  Outside a batch the context is {B = 1}: stride 0,
+// mask 1 -- the same kernels, bit for bit.
+struct CipBatch { long stride; unsigned long long mask; };            // stride in BYTES; bit z of mask: problem z takes part
+struct CipBatchCtx {
+    int B; long stride; unsigned long long mask;
+    double *gather_dev; double *gather_host;       // B x CIP_GATHER doubles (device / pinned host): per-problem scalar results
+};
+#define CIP_GATHER 64
+#define CIP_BATCH_MAX 64
+struct CipScal64 { double v[CIP_BATCH_MAX]; };     // one scalar per problem, passed by value
+extern thread_local CipBatchCtx cip_tl_bz;
+inline bool cip_in_batch() { return cip_tl_bz.B > 1; }
+template <typename T>
+__device__ __forceinline__ T *cip_bo(T *p, const CipBatch &cb) { return p ? (T *)((char *)p + (long)blockIdx.z * cb.stride) : p; }
+#define CIP_BATCH_GUARD(cb) do { if (!(((cb).mask >> blockIdx.z) & 1ull)) return; } while (0)
+#define CIP_BO1(cb, a) a = cip_bo(a, cb)
+#define CIP_BO2(cb, a, b) CIP_BO1(cb, a); CIP_BO1(cb, b)
+#define CIP_BO3(cb, a, b, c) CIP_BO2(cb, a, b); CIP_BO1(cb, c)
+#define CIP_BO4(cb, a, b, c, d) CIP_BO2(cb, a, b); CIP_BO2(cb, c, d)
+#define CIP_BO5(cb, a, b, c, d, e) CIP_BO4(cb, a, b, c, d); CIP_BO1(cb, e)
+#define CIP_BO6(cb, a, b, c, d, e, f) CIP_BO4(cb, a, b, c, d); CIP_BO2(cb, e, f)
+#define CIP_BO7(cb, a, b, c, d, e, f, g) CIP_BO4(cb, a, b, c, d); CIP_BO3(cb, e, f, g)
+#define CIP_BO8(cb, a, b, c, d, e, f, g, h) CIP_BO4(cb, a, b, c, d); CIP_BO4(cb, e, f, g, h)
+template <typename... KArgs, typename... Args>
+inline void cip_launch_b(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t s, Args... args) {
+    const CipBatchCtx &c = cip_tl_bz;
+    CipBatch cb{c.B > 1 ? c.stride : 0, c.B > 1 ? c.mask : 1ull};
+    if (c.B > 1) grid.z *= (unsigned)c.B;
+    cip_launch(kernel, grid, block, shmem, s, args..., cb);
+}
+
 // ---------------------------------------------------------------- GEMM (gemm_f64.hip)
 enum { EPI_ACCUM = 0, EPI_SYRKQ = 2, EPI_STORE = 3 };
 
@@ -102,6 +138,8 @@ struct LdltWorkspace {        // carved out of one device allocation
 int cip_kernels_init(void);                // diag.hip: one-time kernel attributes (before any hipGraph capture)
 int cip_ldlt_set_lookahead(int on);
 int cip_solve_block(int Npad);
+int cip_solve_block_max_set(int b);              // 128 | 256 | 512 | 1024 (0: query); returns the previous limit
+extern thread_local int cip_tl_solve_block_max;  // > 0: this thread's limit for handles it creates
 size_t cip_ldlt_ws_bytes(int Npad);
 void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws);
 int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws);
@@ -184,3 +222,6 @@ int cip_dots(hipStream_t s, int count, const double *const *x_host, const double
              const int *len_host, double *scratch_dev, void *ptrs_dev, double *out_host);
 int cip_axpby(hipStream_t s, int len, double alpha, const double *x, double beta, double *y);
 int cip_copy_neg(hipStream_t s, int len, const double *x, double *y, double scale);   // y = scale * x
+int cip_axpby_ps(hipStream_t s, int len, const double *alpha_host, const double *x, double beta, double *y);   // batch: alpha per problem
+int cip_zero(hipStream_t s, long len, double *y);                     // batch-aware memset(0) of doubles
+int cip_copy(hipStream_t s, long len, const double *x, double *y);    // batch-aware device-to-device copy

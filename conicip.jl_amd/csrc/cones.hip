@@ -69,7 +69,9 @@ __device__ __forceinline__ void team_sync(int T) { if (T == 256) __syncthreads()
 
 // ------------------------------------------------------------------ NT scaling
 __global__ __launch_bounds__(256) void k_nt_scaling(const ConeDesc *cones, const WorkItem *items, const double *v,
-                                                     const double *s, double *scal, double *lambda) {
+                                                     const double *s, double *scal, double *lambda, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO4(cb, v, s, scal, lambda);
     __shared__ double sh[12];
     const WorkItem it = items[blockIdx.x];
     const ConeDesc cd = cones[it.cone];
@@ -119,7 +121,9 @@ __global__ __launch_bounds__(256) void k_nt_scaling(const ConeDesc *cones, const
     }
 }
 
-__global__ __launch_bounds__(256) void k_identity_scaling(const ConeDesc *cones, const WorkItem *items, double *scal) {
+__global__ __launch_bounds__(256) void k_identity_scaling(const ConeDesc *cones, const WorkItem *items, double *scal, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO1(cb, scal);
     const WorkItem it = items[blockIdx.x];
     const ConeDesc cd = cones[it.cone];
     const int tid = threadIdx.x;
@@ -144,7 +148,9 @@ __global__ __launch_bounds__(256) void k_identity_scaling(const ConeDesc *cones,
 
 // ------------------------------------------------------------------ F, F', F^-1, F^-T on a vector
 __global__ __launch_bounds__(256) void k_apply(const ConeDesc *cones, const WorkItem *items, const double *scal,
-                                                int mode, const double *x, double *out) {
+                                                int mode, const double *x, double *out, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO3(cb, scal, x, out);
     __shared__ double sh[12];
     const WorkItem it = items[blockIdx.x];
     const ConeDesc cd = cones[it.cone];
@@ -186,7 +192,9 @@ __global__ __launch_bounds__(256) void k_apply(const ConeDesc *cones, const Work
 
 // Wt[i, off + e] = (F^-T a_i)_e,  a_i = At[i, off:off+k]   (thread per row i of At, coalesced along i)
 __global__ __launch_bounds__(256) void k_scale_At(const ConeDesc *cones, const WorkItem *items, const double *scal,
-                                                   int n, const double *At, long ldat, double *Wt, long ldwt) {
+                                                   int n, const double *At, long ldat, double *Wt, long ldwt, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO3(cb, scal, At, Wt);
     const WorkItem it = items[blockIdx.y];
     const ConeDesc cd = cones[it.cone];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -217,7 +225,9 @@ __global__ __launch_bounds__(256) void k_scale_At(const ConeDesc *cones, const W
 
 // ------------------------------------------------------------------ Jordan product / division
 __global__ __launch_bounds__(256) void k_cone_prod(const ConeDesc *cones, const WorkItem *items, const double *x,
-                                                    const double *y, double *out) {
+                                                    const double *y, double *out, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO3(cb, x, y, out);
     __shared__ double sh[12];
     const WorkItem it = items[blockIdx.x];
     const ConeDesc cd = cones[it.cone];
@@ -244,7 +254,9 @@ __global__ __launch_bounds__(256) void k_cone_prod(const ConeDesc *cones, const 
 
 // out = x (./) y : solves y o out = x   (cone_div!(o, x, y) src/ConicIP.jl:622-635)
 __global__ __launch_bounds__(256) void k_cone_div(const ConeDesc *cones, const WorkItem *items, const double *x,
-                                                   const double *y, double *out) {
+                                                   const double *y, double *out, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO3(cb, x, y, out);
     __shared__ double sh[12];
     const WorkItem it = items[blockIdx.x];
     const ConeDesc cd = cones[it.cone];
@@ -276,7 +288,9 @@ __global__ __launch_bounds__(256) void k_cone_div(const ConeDesc *cones, const W
 // partial[item] = largest alpha with x - alpha*(scale*d) in the cone (d != NULL), or the
 // `nothing` variant (distance into the cone, <= 0) when d == NULL.
 __global__ __launch_bounds__(256) void k_maxstep(const ConeDesc *cones, const WorkItem *items, const double *x,
-                                                  const double *d, double scale, double *partial) {
+                                                  const double *d, double scale, double *partial, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO3(cb, x, d, partial);
     __shared__ double sh[12];
     const WorkItem it = items[blockIdx.x];
     const ConeDesc cd = cones[it.cone];
@@ -332,7 +346,9 @@ __global__ __launch_bounds__(256) void k_maxstep(const ConeDesc *cones, const Wo
     }
 }
 
-__global__ __launch_bounds__(256) void k_min_reduce(const double *partial, int n, double *out) {
+__global__ __launch_bounds__(256) void k_min_reduce(const double *partial, int n, double *out, double *gather, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO2(cb, partial, out);
     __shared__ double sh[12];
     double mn = __builtin_inf();
     int nan_seen = 0;
@@ -343,10 +359,15 @@ __global__ __launch_bounds__(256) void k_min_reduce(const double *partial, int n
     // NaN-propagating block min (Julia's min propagates NaN, src/ConicIP.jl:582)
     const double m2 = block_min(mn, sh);
     const int bad = __syncthreads_or(nan_seen);
-    if (threadIdx.x == 0) out[0] = bad ? __builtin_nan("") : m2;
+    if (threadIdx.x == 0) {
+        out[0] = bad ? __builtin_nan("") : m2;
+        if (gather) gather[blockIdx.z * CIP_GATHER] = out[0];        // lock-step batch: one read-back for all problems
+    }
 }
 
-__global__ __launch_bounds__(256) void k_cone_identity(const ConeDesc *cones, const WorkItem *items, double *e) {
+__global__ __launch_bounds__(256) void k_cone_identity(const ConeDesc *cones, const WorkItem *items, double *e, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO1(cb, e);
     const WorkItem it = items[blockIdx.x];
     const ConeDesc cd = cones[it.cone];
     const int tid = threadIdx.x;
@@ -374,58 +395,66 @@ int cip_sdp_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, 
 
 int cip_cones_nt_scaling(hipStream_t s, const ConeSet &cs, const double *v, const double *sv, double *lambda) {
     if (cs.nitems == 0) return 0;
-    hipLaunchKernelGGL(k_nt_scaling, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, v, sv, cs.d_scal, lambda);
+    cip_launch_b(k_nt_scaling, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, v, sv, cs.d_scal, lambda);
     CIP_HIP_CHECK(hipGetLastError());
     if (cs.has_S) return cip_sdp_nt_scaling(s, cs, v, sv, lambda);
     return 0;
 }
 int cip_cones_identity_scaling(hipStream_t s, const ConeSet &cs) {
     if (cs.nitems == 0) return 0;
-    hipLaunchKernelGGL(k_identity_scaling, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, cs.d_scal);
+    cip_launch_b(k_identity_scaling, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, cs.d_scal);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 int cip_cones_apply(hipStream_t s, const ConeSet &cs, int mode, const double *x, double *out) {
     if (cs.nitems == 0) return 0;
-    hipLaunchKernelGGL(k_apply, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, cs.d_scal, mode, x, out);
+    cip_launch_b(k_apply, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, cs.d_scal, mode, x, out);
     CIP_HIP_CHECK(hipGetLastError());
     if (cs.has_S) return cip_sdp_apply(s, cs, mode, x, out);
     return 0;
 }
 int cip_cones_prod(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out) {
     if (cs.nitems == 0) return 0;
-    hipLaunchKernelGGL(k_cone_prod, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x, y, out);
+    cip_launch_b(k_cone_prod, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x, y, out);
     CIP_HIP_CHECK(hipGetLastError());
     if (cs.has_S) return cip_sdp_prod(s, cs, x, y, out);
     return 0;
 }
 int cip_cones_div(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out) {
     if (cs.nitems == 0) return 0;
-    hipLaunchKernelGGL(k_cone_div, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x, y, out);
+    cip_launch_b(k_cone_div, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x, y, out);
     CIP_HIP_CHECK(hipGetLastError());
     if (cs.has_S) return cip_sdp_div(s, cs, x, y, out);
     return 0;
 }
 int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const double *d, double scale, double *alpha_host) {
-    if (cs.nitems == 0) { *alpha_host = __builtin_inf(); return 0; }
-    hipLaunchKernelGGL(k_maxstep, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x, d, scale, cs.d_partial);
+    if (cs.nitems == 0) { for (int z = 0; z < (cip_tl_bz.B > 1 ? cip_tl_bz.B : 1); ++z) alpha_host[z] = __builtin_inf(); return 0; }
+    cip_launch_b(k_maxstep, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x, d, scale, cs.d_partial);
     CIP_HIP_CHECK(hipGetLastError());
     if (cs.has_S) { int rc = cip_sdp_maxstep(s, cs, x, d, scale, cs.d_partial); if (rc) return rc; }
-    hipLaunchKernelGGL(k_min_reduce, dim3(1), dim3(256), 0, s, cs.d_partial, cs.nslots, cs.d_scalar);
+    const CipBatchCtx &bc = cip_tl_bz;
+    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)cs.d_partial, cs.nslots, cs.d_scalar,
+                 bc.B > 1 ? bc.gather_dev : (double *)nullptr);
     CIP_HIP_CHECK(hipGetLastError());
+    if (bc.B > 1) {                          // alpha_host: B values
+        CIP_HIP_CHECK(hipMemcpyAsync(bc.gather_host, bc.gather_dev, sizeof(double) * bc.B * CIP_GATHER, hipMemcpyDeviceToHost, s));
+        CIP_HIP_CHECK(hipStreamSynchronize(s));
+        for (int z = 0; z < bc.B; ++z) alpha_host[z] = bc.gather_host[z * CIP_GATHER];
+        return 0;
+    }
     CIP_HIP_CHECK(hipMemcpyAsync(alpha_host, cs.d_scalar, sizeof(double), hipMemcpyDeviceToHost, s));
     CIP_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
 }
 int cip_cones_identity(hipStream_t s, const ConeSet &cs, double *e) {
     if (cs.nitems == 0) return 0;
-    hipLaunchKernelGGL(k_cone_identity, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, e);
+    cip_launch_b(k_cone_identity, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, e);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 int cip_cones_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, long ldat, double *Wt, long ldwt) {
     if (cs.nitems == 0 || n == 0) return 0;
-    hipLaunchKernelGGL(k_scale_At, dim3((n + 255) / 256, cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items,
+    cip_launch_b(k_scale_At, dim3((n + 255) / 256, cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items,
                        cs.d_scal, n, At, ldat, Wt, ldwt);
     CIP_HIP_CHECK(hipGetLastError());
     if (cs.has_S) return cip_sdp_scale_At(s, cs, n, At, ldat, Wt, ldwt);

@@ -213,7 +213,9 @@ __device__ __forceinline__ void diag_store_panel(const double *a, double *Kb, lo
 // Factor-only diagonal kernel: L (strictly lower) and d back into K, d / 1/d vectors, and the 8 micro
 // inverses Xm (xm_out[kb][k*16 + jj] = inv(L11_kb)[jj][k]) for the TRSM and the block-inverse kernels.
 __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
-                                                          int *info, int col0, PivotSigns sg) {
+                                                          int *info, int col0, PivotSigns sg, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO5(cb, Kb, xm_out, dvec, dinv, info);
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *a = sm;
     double *xm = sm + XM_OFF;
@@ -276,7 +278,9 @@ __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, do
 // independent, so this is ONE launch after the factorisation instead of a serial link in it).  Only the
 // solves use X (gemv with the block inverses).
 __global__ __launch_bounds__(256) void k_diag_inverse_batched(const double *K, long ld, const double *xm_all, double *Linv,
-                                                               double *LinvT) {
+                                                               double *LinvT, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO4(cb, K, xm_all, Linv, LinvT);
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *a = sm;
     double *xm = sm + XM_OFF;
@@ -325,7 +329,9 @@ __global__ __launch_bounds__(256) void k_diag_inverse_batched(const double *K, l
 __device__ __forceinline__ int trsm_tile_index(int kb, int qq) { return kb * (kb - 1) / 2 + qq; }        // qq < kb
 __global__ __launch_bounds__(256) void k_trsm_subst(double *__restrict__ Ap, long ld, const double *__restrict__ L11,
                                                         const double *__restrict__ xm, const double *__restrict__ dinv,
-                                                        double *__restrict__ W, long ldw) {
+                                                        double *__restrict__ W, long ldw, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO5(cb, Ap, L11, xm, dinv, W);
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *lt = sm, *xs = sm + 28 * 256, *ds = xs + 8 * 256;
     __builtin_amdgcn_s_setprio(3);       // panel chain is latency-critical: win issue arbitration against co-resident GEMM waves
@@ -403,14 +409,14 @@ int cip_kernels_init(void) {
 int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
                        PivotSigns sg) {
     if (cip_kernels_init()) return -3;
-    cip_launch(k_ldlt_diag128_v2, dim3(1), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg);
+    cip_launch_b(k_ldlt_diag128_v2, dim3(1), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 int cip_launch_diag_inverse(hipStream_t s, const double *K, long ld, int nblk, const double *xm_all, double *Linv,
                             double *LinvT) {
     if (cip_kernels_init()) return -3;
-    cip_launch(k_diag_inverse_batched, dim3(nblk), dim3(256), DIAG2_LDS_BYTES, s, K, ld, xm_all, Linv, LinvT);
+    cip_launch_b(k_diag_inverse_batched, dim3(nblk), dim3(256), DIAG2_LDS_BYTES, s, K, ld, xm_all, Linv, LinvT);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -418,7 +424,7 @@ int cip_launch_trsm_subst(hipStream_t s, double *Ap, long ld, int rows, const do
                           const double *dinv, double *W, long ldw) {
     if (rows <= 0) return 0;
     if (cip_kernels_init()) return -3;
-    cip_launch(k_trsm_subst, dim3(rows / 64), dim3(256), TRSM_LDS_DOUBLES * sizeof(double), s, Ap, ld, L11, xm, dinv, W, ldw);
+    cip_launch_b(k_trsm_subst, dim3(rows / 64), dim3(256), TRSM_LDS_DOUBLES * sizeof(double), s, Ap, ld, L11, xm, dinv, W, ldw);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }

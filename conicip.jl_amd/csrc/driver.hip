@@ -9,52 +9,29 @@
 // Quirks of the reference are kept: a factorisation also happens in the terminating
 // iteration (:737 precedes :786), rPr ignores the equality residual (:765), norm(v4x1) is the sum of the
 // block 2-norms (:61), the returned (y, w, v) is the last iterate.
-#include "cip_handle.h"
-#include "../../include/cipkkt.h"
+#include "cip_driver.h"
 #include <chrono>
-#include <cmath>
 #include <vector>
 
+using namespace cipdrv;
+
+size_t cip_driver_bytes(const cip_handle *h) { return sizeof(double) * driver_doubles(h->n, h->m, h->p); }
+
 namespace {
-
-inline double jlmax(double a, double b) { return (a != a || b != b) ? NAN : (a > b ? a : b); }   // Julia max propagates NaN
-inline double jlmax(double a, double b, double c) { return jlmax(jlmax(a, b), c); }
-inline double nrm(double x2) { return x2 >= 0 ? std::sqrt(x2) : NAN; }
-
-struct Vec4 {          // (y[n], w[p], v[m], s[m]) stored contiguously
-    double *base = nullptr, *y = nullptr, *w = nullptr, *v = nullptr, *s = nullptr;
-};
 
 struct Driver {
     cip_handle *h;
     int n, m, p, NT;
-    double *next = nullptr;      // bump pointer into h->drv (one allocation per handle, kept for later calls)
     int rc = 0;
 
-    static size_t pad(size_t c) { return (c + 31) & ~(size_t)31; }      // 256-byte alignment of every vector
-    size_t total() const {
-        return 9 * pad(NT) + pad(n) + pad(m) + pad(p) + 5 * pad(m) + 2 * pad(n) + pad(m) + pad(p) + 32;
-    }
     int init() {
         if (!h->drv) {
             void *ptr = nullptr;
-            if (hipMalloc(&ptr, sizeof(double) * total()) != hipSuccess) { rc = CIP_E_HIP; return rc; }
+            if (cip_handle_alloc(h, &ptr, cip_driver_bytes(h)) != 0) { rc = CIP_E_HIP; return rc; }
             h->drv = (double *)ptr;
         }
-        if (hipMemsetAsync(h->drv, 0, sizeof(double) * total(), h->stream) != hipSuccess) { rc = CIP_E_HIP; return rc; }
-        next = h->drv;
+        if (hipMemsetAsync(h->drv, 0, cip_driver_bytes(h), h->stream) != hipSuccess) { rc = CIP_E_HIP; return rc; }
         return 0;
-    }
-    double *dalloc(size_t count) {
-        double *ptr = next;
-        next += pad(count);
-        return ptr;
-    }
-    Vec4 vec4() {
-        Vec4 v;
-        v.base = dalloc(NT);
-        v.y = v.base; v.w = v.y + n; v.v = v.w + p; v.s = v.v + m;
-        return v;
     }
 
     // y <- alpha x + beta y
@@ -62,8 +39,10 @@ struct Driver {
     int copy(int len, const double *x, double *y) { return axpby(len, 1.0, x, 0.0, y); }
 
     // out.y = Q x.y + G' x.w - A' x.v ; out.w = G x.y ; out.v = A x.y - x.s     (:747-749, :912-914)
-    int kkt_apply(const Vec4 &x, Vec4 &out) {
-        int e = cip_gemv_dev(h, CIP_MAT_Q, 0, 1.0, x.y, 0.0, out.y);
+    // Qx != NULL: Q x.y has already been computed (the certificates need it on its own): copied instead of a second
+    // pass over Q -- the same bits, 8 n^2 bytes of HBM traffic less per iteration
+    int kkt_apply(const Vec4 &x, Vec4 &out, const double *Qx = nullptr) {
+        int e = Qx ? copy(n, Qx, out.y) : cip_gemv_dev(h, CIP_MAT_Q, 0, 1.0, x.y, 0.0, out.y);
         if (p > 0) {
             e |= cip_gemv_dev(h, CIP_MAT_G, 1, 1.0, x.w, 1.0, out.y);
             e |= cip_gemv_dev(h, CIP_MAT_G, 0, 1.0, x.y, 0.0, out.w);
@@ -85,35 +64,23 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
     if (!h || !res || !c_host || (h->m > 0 && !b_host) || (h->p > 0 && !d_host) || !y_out || (h->p > 0 && !w_out) ||
         (h->m > 0 && !v_out)) { cip_set_error("cip_conicip: null argument"); return CIP_E_INVALID; }
     const auto t_start = std::chrono::steady_clock::now();
-    cip_options o;
-    o.optTol = 1e-6; o.DTB = 0.01; o.infeasTol = -1.0; o.refinementThreshold = -1.0;
-    o.maxRefinementSteps = 3; o.maxIters = 100; o.verbose = 0;                       // src/ConicIP.jl:498-509
-    if (opt_in) o = *opt_in;
-    if (o.infeasTol < 0) o.infeasTol = o.optTol;
-    if (o.refinementThreshold < 0) o.refinementThreshold = o.optTol / 1e7;
+    const cip_options o = resolve_options(opt_in);
     CIP_HIP_CHECK(hipSetDevice(h->device));
 
     Driver D{h, h->n, h->m, h->p, h->n + h->p + 2 * h->m};
     const int n = D.n, m = D.m, p = D.p;
     if (D.init()) { cip_set_error("cip_conicip: device allocation failed"); return CIP_E_HIP; }
-    double *c_d = D.dalloc(n), *b_d = D.dalloc(m), *d_d = D.dalloc(p);
-    Vec4 z = D.vec4(), r0 = D.vec4(), rleft = D.vec4(), r = D.vec4(), daff = D.vec4(), dz = D.vec4(), dzr = D.vec4(),
-         rIr = D.vec4(), rkkt = D.vec4();
-    double *e = D.dalloc(m), *lam = D.dalloc(m), *mb1 = D.dalloc(m), *mb2 = D.dalloc(m), *mb3 = D.dalloc(m);
-    double *Qy = D.dalloc(n), *pinf = D.dalloc(n), *Ays = D.dalloc(m), *Gy = D.dalloc(p);
+    Vectors V;
+    V.carve(h->drv, n, m, p);
+    double *c_d = V.c_d, *b_d = V.b_d, *d_d = V.d_d;
+    Vec4 &z = V.z, &r0 = V.r0, &rleft = V.rleft, &r = V.r, &daff = V.daff, &dz = V.dz, &dzr = V.dzr, &rIr = V.rIr, &rkkt = V.rkkt;
+    double *e = V.e, *lam = V.lam, *mb1 = V.mb1, *mb2 = V.mb2, *mb3 = V.mb3;
+    double *Qy = V.Qy, *pinf = V.pinf, *Ays = V.Ays, *Gy = V.Gy;
     CIP_HIP_CHECK(hipMemcpyAsync(c_d, c_host, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
     if (m > 0) CIP_HIP_CHECK(hipMemcpyAsync(b_d, b_host, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
     if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(d_d, d_host, sizeof(double) * p, hipMemcpyHostToDevice, h->stream));
-    double normc = 0, normb = 0, normd = -INFINITY;
-    for (int i = 0; i < n; ++i) normc += c_host[i] * c_host[i];
-    normc = std::sqrt(normc);
-    for (int i = 0; i < m; ++i) normb += b_host[i] * b_host[i];
-    normb = std::sqrt(normb);
-    if (p > 0) { normd = 0; for (int i = 0; i < p; ++i) normd += d_host[i] * d_host[i]; normd = std::sqrt(normd); }
-
-    // conedim (:547-552) and e (:559-565)
-    double conedim = 0;
-    for (const ConeDesc &cd : h->h_cones) conedim += cd.type == CIP_CONE_R ? cd.dim : (cd.type == CIP_CONE_Q ? 1 : cd.r);
+    const Norms nm = host_norms(n, m, p, c_host, b_host, d_host);
+    const double conedim = cone_degree(h);                                          // (:547-552); e (:559-565) below
     int rc;
 #define CK(x) do { if ((rc = (x)) != 0) return rc; } while (0)
     if (m > 0) CK(cip_cone_identity_dev(h, e));
@@ -155,9 +122,8 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
         if (m > 0) CK(cip_set_scaling_from_iterate_dev(h, z.v, z.s, lam));             // :732-735 (F, lambda = F v)
         CK(cip_factor(h)); ++n_factor;                                                 // :737 -> :682
         if (m > 0) CK(cip_cone_prod_dev(h, lam, lam, rleft.s));                        // :746
-        CK(D.kkt_apply(z, rleft));                                                     // :747-750
-        // pieces needed by the certificates
-        CK(cip_gemv_dev(h, CIP_MAT_Q, 0, 1.0, z.y, 0.0, Qy));
+        CK(cip_gemv_dev(h, CIP_MAT_Q, 0, 1.0, z.y, 0.0, Qy));                          // needed by the certificates
+        CK(D.kkt_apply(z, rleft, Qy));                                                 // :747-750
         CIP_HIP_CHECK(hipMemsetAsync(pinf, 0, sizeof(double) * n, h->stream));
         if (p > 0) { CK(cip_gemv_dev(h, CIP_MAT_G, 1, 1.0, z.w, 0.0, pinf)); CK(D.copy(p, rleft.w, Gy)); }
         if (m > 0) { CK(cip_gemv_dev(h, CIP_MAT_A, 1, -1.0, z.v, 1.0, pinf)); CK(D.copy(m, rleft.v, Ays)); }
@@ -176,65 +142,16 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
         // non-finite) pivot even after regularisation is where the reference's LU hands back NaNs and the loop ends
         // with :Error at its next residual check (src/ConicIP.jl:870-873)
         if ((rc = cip_factor_resolve(h, 1)) != 0) { if (rc == CIP_E_SINGULAR) return finish(CIP_STATUS_ERROR); return rc; }
-        const double mubar = dt[0], cTy = dt[1], r0y2 = dt[2], r0v2 = dt[3], r0s2 = dt[4], yQy = dt[5], wr0w = dt[6],
-                     vr0v = dt[7], dTw = dt[8], bTv = dt[9], pinf2 = dt[10], yy = dt[11], vv = dt[12], ays2 = dt[13],
-                     gy2 = dt[14], qy2 = dt[15];
-        const double mu = conedim > 0 ? mubar / conedim : NAN;                         // :756-757
-        const double rDu = nrm(r0y2) / (1 + normc);                                    // :764
-        const double rPr = (m > 0 ? nrm(r0v2) : 0.0) / (1 + normb);                    // :765
-        const double rCp = (m > 0 ? nrm(r0s2) : 0.0) / (1 + std::fabs(cTy));           // :766
-        const double worst = jlmax(rDu, rPr, rCp);
-        if (worst < optBest) {                                                         // :768-773
-            res->iter = Iter; res->mu = mu; res->duFeas = rDu; res->prFeas = rPr; res->muFeas = rCp;
-            optBest = worst;
-        }
-        const double pobj = 0.5 * yQy - cTy;                                           // :775
-        const double dobj = pobj + wr0w + vr0v - mubar;                                // :776
-        res->pobj = pobj; res->dobj = dobj;
+        IterDots dd;
+        for (int i = 0; i < 16; ++i) dd.v[i] = dt[i];
         double *tr = (trace && Iter <= trace_cap) ? trace + (size_t)(Iter - 1) * CIP_TRACE_COLS : nullptr;
-        if (tr) { tr[0] = Iter; tr[1] = mu; tr[2] = rDu; tr[3] = rPr; tr[4] = rCp; tr[5] = pobj; tr[6] = dobj; tr[7] = NAN; tr[8] = NAN; }
-        res->trace_rows = tr ? Iter : res->trace_rows;
-        if (o.verbose) printf(" %6d | %-8.1e %-8.1e %-8.1e | % -8.1e % -8.1e\n", Iter, rDu, rPr, rCp, pobj, dobj);
-
-        int status = CIP_STATUS_NONE;
-        if (worst < o.optTol) status = CIP_STATUS_OPTIMAL;                             // :786
-        if (!(p == 0 && m == 0)) {                                                     // :790
-            const double dTy_bTv = dTw - bTv;                                          // :808
-            double p_infeas = NAN;
-            if (dTy_bTv < 0) {
-                const double p_unscaled = nrm(pinf2);                                  // :810
-                const double den = nrm(yy) + (m > 0 ? nrm(vv) : 0.0);
-                const double p_cvx = den != 0 ? p_unscaled / den : INFINITY;           // :811
-                const double p_ecos = p_unscaled / (std::fmax(1.0, normc) * std::fabs(dTy_bTv));   // :812
-                p_infeas = jlmax(p_cvx, p_ecos);
-            }
-            if (p_infeas < o.infeasTol) {                                              // :815-818
-                CK(finish(CIP_STATUS_INFEASIBLE));
-                for (int i = 0; i < n; ++i) y_out[i] = NAN;
-                for (int i = 0; i < p; ++i) w_out[i] /= -dTy_bTv;
-                for (int i = 0; i < m; ++i) v_out[i] /= -dTy_bTv;
-                return 0;
-            }
-            const double d1 = m == 0 ? -INFINITY : nrm(ays2);                          // :839
-            const double d2 = p == 0 ? -INFINITY : nrm(gy2);                           // :840
-            const double d3 = nrm(qy2);                                                // :841
-            double d_infeas = NAN;
-            if (cTy > 0) {
-                const double d_cvx = jlmax(d1 / std::fmax(1.0, normb), d2 / std::fmax(1.0, normd), d3 / std::fmax(1.0, normc)) / std::fabs(cTy);   // :843
-                const double ny = nrm(yy);
-                const double d_ecos = ny != 0 ? jlmax(d1, d2, d3) / ny : INFINITY;     // :844
-                d_infeas = std::fabs(jlmax(d_cvx, d_ecos));
-            }
-            if (d_infeas < o.infeasTol) {                                              // :847-850
-                CK(finish(CIP_STATUS_UNBOUNDED));
-                for (int i = 0; i < n; ++i) y_out[i] /= std::fabs(cTy);
-                for (int i = 0; i < m; ++i) v_out[i] = NAN;
-                for (int i = 0; i < p; ++i) w_out[i] = NAN;
-                return 0;
-            }
+        const IterOutcome oc = evaluate_iteration(dd, nm, conedim, m, p, o, Iter, res, optBest, tr);
+        const double mubar = oc.mubar, mu = oc.mu;
+        if (oc.status != CIP_STATUS_NONE) {
+            CK(finish(oc.status));
+            apply_certificate(oc, n, m, p, y_out, w_out, v_out);
+            return 0;
         }
-        if (status != CIP_STATUS_NONE) return finish(status);                          // :867
-        if (!(std::isfinite(mu) && std::isfinite(rDu) && std::isfinite(rPr) && std::isfinite(rCp))) return finish(CIP_STATUS_ERROR);   // :870-873
 
         // ------------------------------------------------------------ predictor (:879-887)
         CK(cip_solve4x4_dev(h, lam, r0.base, daff.base)); ++n_solve;

@@ -45,6 +45,29 @@ __device__ __forceinline__ void tile_coords(int t, int lower, int tm, int &bi, i
     }
 }
 
+// Lock-step batches (cip_internal.h): grid.z = (own batch count, >= 1) x (problems); returns the launch's own z index
+// after shifting every operand pointer by the problem's slab offset; live = false: the problem is masked off.
+__device__ __forceinline__ unsigned gemm_batch_prologue(GemmArgs &g, const CipBatch &cb, bool &live) {
+    const unsigned gz = g.bz > 0 ? (unsigned)g.bz : 1u;
+    const unsigned pz = blockIdx.z / gz;
+    live = ((cb.mask >> pz) & 1ull) != 0;
+    const long off = (long)pz * cb.stride;
+    g.A = (const double *)((const char *)g.A + off);
+    g.B = (const double *)((const char *)g.B + off);
+    g.C = (double *)((char *)g.C + off);
+    if (g.Ct) g.Ct = (double *)((char *)g.Ct + off);
+    if (g.Qin) g.Qin = (const double *)((const char *)g.Qin + off);
+    if (g.dk) g.dk = (const double *)((const char *)g.dk + off);
+    return blockIdx.z - pz * gz;
+}
+// the launch's own (grid.y, grid.z) batching: pointer strides in doubles
+__device__ __forceinline__ void gemm_own_batch(GemmArgs &g, unsigned oz) {
+    g.A += blockIdx.y * g.sAy + oz * g.sAz;
+    g.B += blockIdx.y * g.sBy + oz * g.sBz;
+    g.C += blockIdx.y * g.sCy + oz * g.sCz;
+    if (g.Ct) g.Ct += blockIdx.y * g.sCty + oz * g.sCtz;
+}
+
 template <int EPI>
 __device__ __forceinline__ void gemm_tile_128(GemmArgs &g, double *lds, int bi, int bj) {
 
@@ -55,13 +78,6 @@ __device__ __forceinline__ void gemm_tile_128(GemmArgs &g, double *lds, int bi, 
     const int l15 = lane & 15, l4 = lane >> 4;
 
     const long i0 = (long)bi * CIP_NB, j0 = (long)bj * CIP_NB;
-    if (EPI == EPI_ACCUM) {       // batched problems: grid.y x grid.z
-        g.A += blockIdx.y * g.sAy + blockIdx.z * g.sAz;
-        g.B += blockIdx.y * g.sBy + blockIdx.z * g.sBz;
-        g.C += blockIdx.y * g.sCy + blockIdx.z * g.sCz;
-        if (g.Ct) g.Ct += blockIdx.y * g.sCty + blockIdx.z * g.sCtz;
-    }
-
     const double *Ap = g.A + i0 + 2 * lane;
     const double *Bp = g.B + j0 + 2 * lane;
 
@@ -154,8 +170,12 @@ __device__ __forceinline__ void gemm_tile_128(GemmArgs &g, double *lds, int bi, 
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void k_gemm_nt_128(GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_128(GemmArgs g, CipBatch cb) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 2 * LDS_TILE];   // 64 KB
+    bool live;
+    const unsigned oz = gemm_batch_prologue(g, cb, live);
+    if (!live) return;
+    if (EPI == EPI_ACCUM) gemm_own_batch(g, oz);       // batched problems: grid.y x grid.z
     int bi, bj;
     tile_coords(xcd_remap(blockIdx.x, gridDim.x), g.lower, g.M / CIP_NB, bi, bj);   // grid may cover only the first tiles
     gemm_tile_128<EPI>(g, lds, bi, bj);
@@ -284,8 +304,11 @@ __device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, lon
         }
 }
 
-__global__ __launch_bounds__(256, 4) void k_gemm_nt_64(GemmArgs g) {
+__global__ __launch_bounds__(256, 4) void k_gemm_nt_64(GemmArgs g, CipBatch cb) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
+    bool live;
+    (void)gemm_batch_prologue(g, cb, live);
+    if (!live) return;
     __builtin_amdgcn_s_setprio(3);       // skinny critical-path updates: priority over co-resident waves
     const int tm = g.M / SB;
     const int t = xcd_remap(blockIdx.x, gridDim.x);
@@ -297,8 +320,11 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_64(GemmArgs g) {
 // 5 workgroups (20 waves) per CU; measured against the 128x128-tile kernel at 2 workgroups per CU:
 // 55.0 vs 52.4 TFLOP/s at r = 8192, K = 512 and 53.1 vs 44.0 at K = 256 (tools/gemm_bench.hip, same session).
 template <bool SCALEA>
-__global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64(GemmArgs g) {
+__global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64(GemmArgs g, CipBatch cb) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
+    bool live;
+    (void)gemm_batch_prologue(g, cb, live);
+    if (!live) return;
     __builtin_amdgcn_s_setprio(3);       // measured: 58.0 vs 56.6 TFLOP/s without
     int bi, bj;
     tile_coords((int)(blockIdx.x >> 2), 1, g.M / CIP_NB, bi, bj);
@@ -310,19 +336,22 @@ __global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64(GemmArgs g) {
 }
 
 // Batched small products (block-inverse doubling): grid.y x grid.z independent problems, C = alpha A B' (overwrite)
-__global__ __launch_bounds__(256, 4) void k_gemm_nt_64_batched(GemmArgs g) {
+__global__ __launch_bounds__(256, 4) void k_gemm_nt_64_batched(GemmArgs g, CipBatch cb) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
-    g.A += blockIdx.y * g.sAy + blockIdx.z * g.sAz;
-    g.B += blockIdx.y * g.sBy + blockIdx.z * g.sBz;
-    g.C += blockIdx.y * g.sCy + blockIdx.z * g.sCz;
-    if (g.Ct) g.Ct += blockIdx.y * g.sCty + blockIdx.z * g.sCtz;
+    bool live;
+    const unsigned oz = gemm_batch_prologue(g, cb, live);
+    if (!live) return;
+    gemm_own_batch(g, oz);
     const int tm = g.M / SB;
     gemm_tile_64<EPI_STORE>(g, lds, (long)(blockIdx.x % tm) * SB, (long)(blockIdx.x / tm) * SB);
 }
 
 // Schur formation S = Q + Wt Wt' (lower tiles) in quarter tiles: the long-K (K = m) counterpart of the trailing update
-__global__ __launch_bounds__(256, 4) void k_syrkq_64(GemmArgs g) {
+__global__ __launch_bounds__(256, 4) void k_syrkq_64(GemmArgs g, CipBatch cb) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
+    bool live;
+    (void)gemm_batch_prologue(g, cb, live);
+    if (!live) return;
     int bi, bj;
     tile_coords((int)(blockIdx.x >> 2), 1, g.M / CIP_NB, bi, bj);
     const int sub = blockIdx.x & 3;
@@ -333,8 +362,11 @@ __global__ __launch_bounds__(256, 4) void k_syrkq_64(GemmArgs g) {
 // XCD-aware order (optional, CIP_TRAIL_PATCH): workgroups are dealt round-robin to the 8 XCDs, so XCD x is handed whole
 // p x p patches of quarter tiles (patches x, x+8, ...): the 2p half-panels of a patch are then fetched into that
 // XCD's L2 once for p^2 tiles instead of once per tile.
-__global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64p(GemmArgs g, int psz, int npatch, int P) {
+__global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64p(GemmArgs g, int psz, int npatch, int P, CipBatch cb) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
+    bool live;
+    (void)gemm_batch_prologue(g, cb, live);
+    if (!live) return;
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.x, x = b & 7, sq = b >> 3, per = psz * psz;
     const int patch = x + 8 * (sq / per), w = sq % per;
@@ -659,11 +691,11 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     if (by * bz > 1 || (g.overwrite && epi == EPI_ACCUM && !g.lower)) {
         if (epi != EPI_ACCUM || g.lower) { cip_set_error("gemm: batching needs the plain accumulate form"); return -1; }
         if (g.overwrite) {
-            cip_launch(k_gemm_nt_64_batched, dim3((unsigned)(4 * tiles), by, bz), dim3(256), 0, s, g);
+            cip_launch_b(k_gemm_nt_64_batched, dim3((unsigned)(4 * tiles), by, bz), dim3(256), 0, s, g);
             CIP_HIP_CHECK(hipGetLastError());
             return 0;
         }
-        cip_launch(k_gemm_nt_128<EPI_ACCUM>, dim3((unsigned)tiles, by, bz), dim3(256), 0, s, g);
+        cip_launch_b(k_gemm_nt_128<EPI_ACCUM>, dim3((unsigned)tiles, by, bz), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -681,31 +713,31 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
         if (psz > 0) {
             const int nq = g.M / SB, P = (nq + psz - 1) / psz, npatch = P * (P + 1) / 2;
             const long grid = (long)((npatch + 7) / 8) * 8 * psz * psz;
-            cip_launch(k_ldlt_trailing_64p, dim3((unsigned)grid), dim3(256), 0, s, g, psz, npatch, P);
+            cip_launch_b(k_ldlt_trailing_64p, dim3((unsigned)grid), dim3(256), 0, s, g, psz, npatch, P);
             CIP_HIP_CHECK(hipGetLastError());
             return 0;
         }
-        if (g.dk) cip_launch(k_ldlt_trailing_64<true>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
-        else cip_launch(k_ldlt_trailing_64<false>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
+        if (g.dk) cip_launch_b(k_ldlt_trailing_64<true>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
+        else cip_launch_b(k_ldlt_trailing_64<false>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
     if (epi == EPI_SYRKQ && g.lower && g_tile == 64) {
-        cip_launch(k_syrkq_64, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
+        cip_launch_b(k_syrkq_64, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
     if (epi == EPI_ACCUM && !g.lower && !g.overwrite && tiles < 256 && g.M % SB == 0 && g.N % SB == 0) {
         // skinny, latency-critical: quarter-size tiles
         const long t64 = (long)(g.M / SB) * (g.N / SB);
-        cip_launch(k_gemm_nt_64, dim3((unsigned)t64), dim3(256), 0, s, g);
+        cip_launch_b(k_gemm_nt_64, dim3((unsigned)t64), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
     dim3 grid((unsigned)tiles), block(256);
     switch (epi) {
-        case EPI_ACCUM: cip_launch(k_gemm_nt_128<EPI_ACCUM>, grid, block, 0, s, g); break;
-        case EPI_SYRKQ: cip_launch(k_gemm_nt_128<EPI_SYRKQ>, grid, block, 0, s, g); break;
+        case EPI_ACCUM: cip_launch_b(k_gemm_nt_128<EPI_ACCUM>, grid, block, 0, s, g); break;
+        case EPI_SYRKQ: cip_launch_b(k_gemm_nt_128<EPI_SYRKQ>, grid, block, 0, s, g); break;
         default: cip_set_error("gemm: bad epilogue"); return -1;
     }
     CIP_HIP_CHECK(hipGetLastError());

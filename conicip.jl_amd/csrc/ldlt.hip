@@ -16,6 +16,8 @@
 // Solves (HBM-bound, L read once per sweep): blocked substitution using the stored
 // inverses of the diagonal blocks, one launch per 128-column block and sweep.
 #include "cip_internal.h"
+#include <stdlib.h>
+#include <string.h>
 
 static int g_nbo = 512;       // measured best at n = 8192 (A/B in one session: 256/384/512 -> 107.7/107.0/109.1 KKT solves/s)
 int cip_ldlt_outer_block(void) { return g_nbo; }
@@ -68,9 +70,23 @@ int cip_ldlt_profile_collect(LdltProfile *p, double *launches, double *ms, doubl
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // solve block: largest of {1024, 512, 256, 128} that divides the (128-padded) order
+// Upper limit: process-wide knob (cip_set_solve_block_max / CIP_SOLVE_BLOCK, default 1024) or, when set, the calling
+// thread's override (lock-step batches create their handles with 256: in a batch a block step is one launch for all
+// problems, so launches are cheap and the doubled inverses -- 1.5 GFLOP per n = 2048 factorisation on top of its 2.9 --
+// and the half-empty 1024-wide triangular blocks the solves stream are what cost).
+static int g_solve_block_max = -1;
+thread_local int cip_tl_solve_block_max = 0;
+int cip_solve_block_max_set(int b) {
+    if (g_solve_block_max < 0) { const char *e = getenv("CIP_SOLVE_BLOCK"); g_solve_block_max = e ? atoi(e) : 1024; }
+    const int prev = g_solve_block_max;
+    if (b == 128 || b == 256 || b == 512 || b == 1024) g_solve_block_max = b;
+    return prev;
+}
 int cip_solve_block(int Npad) {
+    int mx = cip_tl_solve_block_max > 0 ? cip_tl_solve_block_max : cip_solve_block_max_set(0);
+    if (mx < CIP_NB) mx = CIP_NB;
     for (int b = 1024; b > CIP_NB; b >>= 1)
-        if (Npad % b == 0) return b;
+        if (b <= mx && Npad % b == 0) return b;
     return CIP_NB;
 }
 
@@ -129,8 +145,6 @@ int cip_launch_diag_inverse(hipStream_t s, const double *K, long ld, int nblk, c
                             double *LinvT);
 int cip_launch_trsm_subst(hipStream_t s, double *Ap, long ld, int rows, const double *L11, const double *xm,
                           const double *dinv, double *W, long ldw);
-#include <stdlib.h>
-#include <string.h>
 
 // right-looking update inside the outer block: after inner panel t, the remaining panel columns of the block
 //   K[c0+128:, c0+128 : C0+wblk] -= W_t[c0+128:, :] * L_t[c0+128 : C0+wblk, :]'        (K = 128, wide and short:
@@ -227,7 +241,9 @@ int cip_la_finish(hipStream_t s, void *ctrl_dev, int *info);
 // zero fill as a kernel: these fills sit inside the launch sequences that small systems replay as hipGraphs, and a
 // captured hipMemsetAsync node left the flag words of ws.info unset on ROCm 7.0 (the factorisation then reported a
 // scheduler error out of uninitialised memory)
-__global__ __launch_bounds__(256) void k_zero_words(unsigned *p, size_t nwords) {
+__global__ __launch_bounds__(256) void k_zero_words(unsigned *p, size_t nwords, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO1(cb, p);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) p[i] = 0u;
 }
 static int zero_fill(hipStream_t s, void *p, size_t bytes) {
@@ -235,14 +251,16 @@ static int zero_fill(hipStream_t s, void *p, size_t bytes) {
     size_t nb = (nw + 255) / 256;
     if (nb > 2048) nb = 2048;
     if (nb == 0) return 0;
-    cip_launch(k_zero_words, dim3((unsigned)nb), dim3(256), 0, s, (unsigned *)p, nw);
+    cip_launch_b(k_zero_words, dim3((unsigned)nb), dim3(256), 0, s, (unsigned *)p, nw);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 // upper triangle <- (strictly lower triangle)': gives the forward sweep the same coalesced
 // "column-dot" access as the backward sweep (U[k, i] = L[i, k])
-__global__ __launch_bounds__(256) void k_mirror_lower(double *K, long ld) {
+__global__ __launch_bounds__(256) void k_mirror_lower(double *K, long ld, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO1(cb, K);
     __shared__ double t[32][33];
     const int bi = blockIdx.x, bj = blockIdx.y;      // 32x32 tile (row tile bi, column tile bj), bi >= bj
     if (bi < bj) return;
@@ -256,7 +274,9 @@ __global__ __launch_bounds__(256) void k_mirror_lower(double *K, long ld) {
 }
 // X/XT diagonal 128-blocks <- Linv/LinvT
 __global__ __launch_bounds__(256) void k_seed_block_inverse(const double *Linv, const double *LinvT, double *X, double *XT,
-                                                             int Bs) {
+                                                             int Bs, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO4(cb, Linv, LinvT, X, XT);
     const int jb = blockIdx.x;                       // 128-block index
     const int per = Bs / CIP_NB;
     const int q = jb / per, o = (jb % per) * CIP_NB;
@@ -277,15 +297,15 @@ static int build_solve_blocks(hipStream_t s, double *K, int Npad, long ld, const
     const int Bs = ws.Bs;
     const int nbk = Npad / Bs;
     int rc;
-    cip_launch(k_mirror_lower, dim3(Npad / 32, Npad / 32), dim3(256), 0, s, K, ld);
+    cip_launch_b(k_mirror_lower, dim3(Npad / 32, Npad / 32), dim3(256), 0, s, K, ld);
     if (Bs == CIP_NB) { CIP_HIP_CHECK(hipGetLastError()); return 0; }   // X == Linv, XT == LinvT
     if (!ws.x_zeroed || !*ws.x_zeroed) {
         // the strictly upper blocks of X (lower of XT) are never written afterwards: zero them once per workspace
         if ((rc = zero_fill(s, ws.X, sizeof(double) * (size_t)nbk * Bs * Bs))) return rc;
         if ((rc = zero_fill(s, ws.XT, sizeof(double) * (size_t)nbk * Bs * Bs))) return rc;
-        if (ws.x_zeroed) *ws.x_zeroed = 1;
+        if (ws.x_zeroed && (!cip_in_batch() || cip_tl_bz.mask == (cip_tl_bz.B >= 64 ? ~0ull : ((1ull << cip_tl_bz.B) - 1)))) *ws.x_zeroed = 1;
     }
-    cip_launch(k_seed_block_inverse, dim3(Npad / CIP_NB), dim3(256), 0, s, ws.Linv, ws.LinvT, ws.X, ws.XT, Bs);
+    cip_launch_b(k_seed_block_inverse, dim3(Npad / CIP_NB), dim3(256), 0, s, ws.Linv, ws.LinvT, ws.X, ws.XT, Bs);
     CIP_HIP_CHECK(hipGetLastError());
     const long bs2 = (long)Bs * Bs, tt2 = (long)(Bs / 2) * (Bs / 2);
     for (int h = CIP_NB; h < Bs; h *= 2) {
@@ -319,7 +339,7 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
     std::call_once(g_la_once, lookahead_env);
     if ((rc = zero_fill(s, ws.info, 64))) return rc;       // [0] bad pivot, [1] sweep bail-out, [2] dead pivot, [3] look-ahead scheduler
     bool la = g_lookahead == 1 && Npad >= g_la_min && Npad > 2 * NBO && NBO % 64 == 0;
-    if (cip_tl_builder) la = false;                           // recording a hipGraph: the single-stream schedule
+    if (cip_tl_builder || cip_in_batch()) la = false;         // recording a hipGraph / a lock-step batch: the single-stream schedule
     if (!la) {
         // serial right-looking schedule: panels of the outer block, then ONE trailing update
         for (int C0 = 0; C0 < Npad; C0 += NBO) {
@@ -379,7 +399,9 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
 
 // ---------------------------------------------------------------------------
 // Solves
-__global__ __launch_bounds__(256) void k_scale_vec(int n, const double *x, const double *d, double *y) {
+__global__ __launch_bounds__(256) void k_scale_vec(int n, const double *x, const double *d, double *y, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO3(cb, x, d, y);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) y[i] = x[i] * d[i];
 }
@@ -394,7 +416,7 @@ static int g_solve_steps = -1;
 
 int cip_ldlt_solve(hipStream_t s, const double *K, int Npad, long ld, const LdltWorkspace &ws, double *rhs) {
     if (g_solve_steps < 0) { const char *e = getenv("CIP_SOLVE"); g_solve_steps = (e && !strcmp(e, "sweeps")) ? 0 : 1; }
-    if (!g_solve_steps && !cip_tl_builder) return cip_ldlt_solve_sweeps(s, K, Npad, ld, ws, rhs);
+    if (!g_solve_steps && !cip_tl_builder && !cip_in_batch()) return cip_ldlt_solve_sweeps(s, K, Npad, ld, ws, rhs);
     const int Bs = ws.Bs;
     const int nbk = Npad / Bs;
     const double *X = (Bs == CIP_NB) ? ws.Linv : ws.X;
@@ -410,7 +432,7 @@ int cip_ldlt_solve(hipStream_t s, const double *K, int Npad, long ld, const Ldlt
             (rc = cip_gemv_t(s, Bs, below, -1.0, K + C0 + (C0 + Bs) * ld, ld, y + C0, 1.0, rhs + C0 + Bs)))
             return rc;
     }
-    cip_launch(k_scale_vec, dim3((Npad + 255) / 256), dim3(256), 0, s, Npad, y, ws.dinv, z);
+    cip_launch_b(k_scale_vec, dim3((Npad + 255) / 256), dim3(256), 0, s, Npad, y, ws.dinv, z);
     for (int J = nbk - 1; J >= 0; --J) {
         const long C0 = (long)J * Bs;
         if ((rc = cip_gemv_t(s, Bs, Bs, 1.0, X + J * bs2, Bs, z + C0, 0.0, rhs + C0))) return rc;

@@ -16,7 +16,9 @@ __device__ __forceinline__ double wsum(double v) {
 // one wave per column, 4 columns per workgroup; 4 x 16-byte loads of the matrix in flight per lane (the first version
 // had one: the triangular solves ran at 2.1 TB/s)
 __global__ __launch_bounds__(256) void k_gemv_t(int rows, int cols, double alpha, const double *A, long lda,
-                                                 const double *x, double beta, double *y) {
+                                                 const double *x, double beta, double *y, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO3(cb, A, x, y);
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= cols) return;
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void k_gemv_t(int rows, int cols, double alpha
 int cip_gemv_t(hipStream_t s, int rows, int cols, double alpha, const double *A, long lda, const double *x,
                double beta, double *y) {
     if (cols <= 0) return 0;
-    cip_launch(k_gemv_t, dim3((cols + 3) / 4), dim3(256), 0, s, rows, cols, alpha, A, lda, x, beta, y);
+    cip_launch_b(k_gemv_t, dim3((cols + 3) / 4), dim3(256), 0, s, rows, cols, alpha, A, lda, x, beta, y);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -60,7 +62,9 @@ int cip_gemv_t(hipStream_t s, int rows, int cols, double alpha, const double *A,
 // CSR spmv, one wave per row group: rows are short in the KKT use (identity-like A), so use
 // thread-per-row for simplicity (coalescing over rows of rowptr; gathers from x).
 __global__ __launch_bounds__(256) void k_spmv_csr(int rows, const int *rowptr, const int *colind, const double *val,
-                                                   double alpha, const double *x, double beta, double *y) {
+                                                   double alpha, const double *x, double beta, double *y, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO5(cb, rowptr, colind, val, x, y);
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= rows) return;
     double s = 0;
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256) void k_spmv_csr(int rows, const int *rowptr, c
 int cip_spmv_csr(hipStream_t s, int rows, const int *rowptr, const int *colind, const double *val, double alpha,
                  const double *x, double beta, double *y) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(k_spmv_csr, dim3((rows + 255) / 256), dim3(256), 0, s, rows, rowptr, colind, val, alpha, x, beta, y);
+    cip_launch_b(k_spmv_csr, dim3((rows + 255) / 256), dim3(256), 0, s, rows, rowptr, colind, val, alpha, x, beta, y);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -80,9 +84,12 @@ int cip_spmv_csr(hipStream_t s, int rows, const int *rowptr, const int *colind, 
 #define DOT_NB 32
 struct DotPtrs { const double *x; const double *y; int len; int pad; };
 
-__global__ __launch_bounds__(256) void k_dots1(const DotPtrs *p, double *partial) {
+// In a batch the pointer table is problem 0's (shared): the vectors it names and the partial sums are shifted.
+__global__ __launch_bounds__(256) void k_dots1(const DotPtrs *p, double *partial, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
     __shared__ double sh[4];
-    const DotPtrs d = p[blockIdx.y];
+    DotPtrs d = p[blockIdx.y];
+    CIP_BO3(cb, d.x, d.y, partial);
     double s = 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < d.len; i += (long)DOT_NB * 256) s += d.x[i] * d.y[i];
     s = wsum(s);
@@ -90,10 +97,16 @@ __global__ __launch_bounds__(256) void k_dots1(const DotPtrs *p, double *partial
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.y * DOT_NB + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
-__global__ __launch_bounds__(64) void k_dots2(const double *partial, double *out) {
+// gather != NULL (batch): the result of problem z also goes to gather[z * CIP_GATHER + dot] (one read-back for all)
+__global__ __launch_bounds__(64) void k_dots2(const double *partial, double *out, double *gather, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO2(cb, partial, out);
     double s = (threadIdx.x < DOT_NB) ? partial[blockIdx.x * DOT_NB + threadIdx.x] : 0.0;
     s = wsum(s);
-    if (threadIdx.x == 0) out[blockIdx.x] = s;
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = s;
+        if (gather) gather[blockIdx.z * CIP_GATHER + blockIdx.x] = s;
+    }
 }
 
 #define DOT_MAX 32
@@ -108,15 +121,26 @@ int cip_dots(hipStream_t s, int count, const double *const *x_host, const double
     // synchronise below anyway (the result comes back to the host).
     double *partial = scratch_dev;
     double *out = scratch_dev + DOT_MAX * DOT_NB;
-    hipLaunchKernelGGL(k_dots1, dim3(DOT_NB, count), dim3(256), 0, s, (const DotPtrs *)ptrs_dev, partial);
-    hipLaunchKernelGGL(k_dots2, dim3(count), dim3(64), 0, s, partial, out);
+    const CipBatchCtx &bc = cip_tl_bz;
+    cip_launch_b(k_dots1, dim3(DOT_NB, count), dim3(256), 0, s, (const DotPtrs *)ptrs_dev, partial);
+    cip_launch_b(k_dots2, dim3(count), dim3(64), 0, s, (const double *)partial, out, bc.B > 1 ? bc.gather_dev : (double *)nullptr);
     CIP_HIP_CHECK(hipGetLastError());
+    if (bc.B > 1) {
+        // out_host: B x count, problem-major; masked-off problems keep whatever the gather buffer held (callers ignore them)
+        CIP_HIP_CHECK(hipMemcpyAsync(bc.gather_host, bc.gather_dev, sizeof(double) * bc.B * CIP_GATHER, hipMemcpyDeviceToHost, s));
+        CIP_HIP_CHECK(hipStreamSynchronize(s));
+        for (int z = 0; z < bc.B; ++z)
+            for (int i = 0; i < count; ++i) out_host[z * count + i] = bc.gather_host[z * CIP_GATHER + i];
+        return 0;
+    }
     CIP_HIP_CHECK(hipMemcpyAsync(out_host, out, sizeof(double) * count, hipMemcpyDeviceToHost, s));
     CIP_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
 }
 
-__global__ __launch_bounds__(256) void k_axpby(int len, double alpha, const double *x, double beta, double *y) {
+__global__ __launch_bounds__(256) void k_axpby(int len, double alpha, const double *x, double beta, double *y, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO2(cb, x, y);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < len; i += (long)gridDim.x * 256)
         y[i] = alpha * x[i] + (beta == 0.0 ? 0.0 : beta * y[i]);
 }
@@ -124,10 +148,50 @@ int cip_axpby(hipStream_t s, int len, double alpha, const double *x, double beta
     if (len <= 0) return 0;
     int nb = (len + 255) / 256;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(k_axpby, dim3(nb), dim3(256), 0, s, len, alpha, x, beta, y);
+    cip_launch_b(k_axpby, dim3(nb), dim3(256), 0, s, len, alpha, x, beta, y);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 int cip_copy_neg(hipStream_t s, int len, const double *x, double *y, double scale) {
     return cip_axpby(s, len, scale, x, 0.0, y);
+}
+
+// y = alpha[z] x + beta y with one alpha per problem of a lock-step batch (step lengths, sigma mu)
+__global__ __launch_bounds__(256) void k_axpby_ps(int len, CipScal64 alpha, const double *x, double beta, double *y, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO2(cb, x, y);
+    const double a = alpha.v[blockIdx.z];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < len; i += (long)gridDim.x * 256)
+        y[i] = a * x[i] + (beta == 0.0 ? 0.0 : beta * y[i]);
+}
+int cip_axpby_ps(hipStream_t s, int len, const double *alpha_host, const double *x, double beta, double *y) {
+    if (len <= 0) return 0;
+    CipScal64 a;
+    for (int z = 0; z < CIP_BATCH_MAX; ++z) a.v[z] = z < cip_tl_bz.B ? alpha_host[z] : 0.0;
+    int nb = (len + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    cip_launch_b(k_axpby_ps, dim3(nb), dim3(256), 0, s, len, a, x, beta, y);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// memset / device-to-device copy that follow the batch dimension (hipMemsetAsync / hipMemcpyAsync would touch problem 0 only)
+__global__ __launch_bounds__(256) void k_fill(long len, double value, double *y, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO1(cb, y);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < len; i += (long)gridDim.x * 256) y[i] = value;
+}
+int cip_zero(hipStream_t s, long len, double *y) {
+    if (len <= 0) return 0;
+    if (!cip_in_batch() && !cip_tl_builder) { CIP_HIP_CHECK(hipMemsetAsync(y, 0, sizeof(double) * len, s)); return 0; }
+    long nb = (len + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    cip_launch_b(k_fill, dim3((unsigned)nb), dim3(256), 0, s, len, 0.0, y);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int cip_copy(hipStream_t s, long len, const double *x, double *y) {
+    if (len <= 0) return 0;
+    if (!cip_in_batch() && !cip_tl_builder) { CIP_HIP_CHECK(hipMemcpyAsync(y, x, sizeof(double) * len, hipMemcpyDeviceToDevice, s)); return 0; }
+    return cip_axpby(s, (int)len, 1.0, x, 0.0, y);
 }

@@ -199,6 +199,18 @@ int cip_batch_conicip(cip_batch *b, const double *const *c, const double *const 
 int cip_conicip_problems(int count, const cip_problem *probs, const double *const *c, const double *const *bvec,
                          const double *const *d, const cip_options *opt, double *const *y, double *const *w,
                          double *const *v, cip_result *res, int in_flight);
+/* the same, in LOCK-STEP: the problems must have identical shape (n, m, p, cone list, route, dense-or-CSR A) and no S
+ * cones; they advance through the loop together, every step ONE launch with the problem index in the grid (groups of up
+ * to 64).  Results are bit-identical to cip_conicip on each problem.  Returns CIP_E_UNSUPPORTED (nothing written) when
+ * the batch does not qualify -- fall back to cip_conicip_problems.  A problem whose factorisation meets a bad pivot leaves
+ * the group and is solved by the one-problem loop afterwards. */
+int cip_conicip_lockstep(int count, const cip_problem *probs, const double *const *c, const double *const *bvec,
+                         const double *const *d, const cip_options *opt, double *const *y, double *const *w,
+                         double *const *v, cip_result *res);
+/* the arena of the last lock-step group is kept for the next call (allocation of several GB is slow); this frees it */
+int cip_release_cached_memory(void);
+/* diagnostics of the calling thread's last cip_conicip_lockstep: {groups, problems, problems that left their group} */
+int cip_lockstep_stats(int *out3);
 int cip_conicip_many(cip_handle *const *handles, int count, const double *const *c, const double *const *bvec,
                      const double *const *d, const cip_options *opt, double *const *y, double *const *w,
                      double *const *v, cip_result *res, int in_flight);
@@ -221,6 +233,9 @@ int cip_assemble_only(cip_handle *h);                                   /* level
 int cip_stats(cip_handle *h, double *out8);
 int cip_set_timing(cip_handle *h, int enabled);
 int cip_set_ldlt_outer_block(int nbo);
+/* tuning knob: widest block of the triangular solves' block-step form (128, 256, 512 or 1024; 0 = query).  Applies to
+ * handles created afterwards; returns the previous value.  Lock-step batches use min(this, 256) for their handles. */
+int cip_set_solve_block_max(int b);
 /* schedule of the blocked LDL': 0 = serial single-stream (default), 1 = deep look-ahead for orders >= 4096 (also
  * CIP_LOOKAHEAD=1: every trailing update in one persistent launch, the panel chain of each outer block on a side
  * stream behind a gate on its own column strip), 2 = serial with the look-ahead's operand form (bit-identical to 1; tests).

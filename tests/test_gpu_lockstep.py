@@ -1,0 +1,164 @@
+"""Lock-step batches (csrc/lockstep.hip, `cip_conicip_lockstep`): B problems of one shape advance through the
+interior-point loop together, one launch per step with the problem index in blockIdx.z.  The kernels and their
+arithmetic are those of the one-problem path, so the bar is BIT-identity with `cip_conicip` on each problem
+(iterates, iteration / factorisation / solve counts, status) -- through mixed cones, both routes, dense and CSR A,
+problems that finish at different iterations or with different statuses, problems that leave the group because their
+factorisation needs the regularised retry, and more than 64 problems (two groups)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(prs, mode, in_flight=4):
+    """the thread-pool reference runs with the solve-block limit the lock-step groups use for their handles (256): the
+    block size changes the summation order of the triangular solves, and the comparison below is bit for bit"""
+    from cipkkt import _lib as L
+    from cipkkt.batch import _solve_problems_native
+    lib = L.load()
+    prev = lib.cip_set_solve_block_max(256) if mode == "threads" else None
+    try:
+        return _solve_problems_native(prs, torch.device("cuda:0"), in_flight, mode)
+    finally:
+        if prev is not None:
+            lib.cip_set_solve_block_max(prev)
+
+
+def _as_problem(t, **kw):
+    Q, c, A, b, cone_dims, G, d = t[:7]
+    return dict(Q=Q.toarray() if sp.issparse(Q) else Q, c=c, A=A, b=b, cone_dims=cone_dims, G=G, d=d, kwargs=dict(kw))
+
+
+def _assert_identical(a, b):
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x.status == y.status, (i, x.status, y.status)
+        assert (x.Iter, x.n_factor, x.n_solve) == (y.Iter, y.n_factor, y.n_solve), i
+        for f in ("y", "w", "v"):
+            assert np.array_equal(getattr(x, f), getattr(y, f), equal_nan=True), (i, f)
+        for f in ("Mu", "prFeas", "duFeas", "muFeas", "pobj", "dobj"):
+            assert getattr(x, f) == getattr(y, f) or (getattr(x, f) != getattr(x, f) and getattr(y, f) != getattr(y, f)), (i, f)
+
+
+@pytest.mark.parametrize("route", ["schur", "full3x3"])
+@pytest.mark.parametrize("dense_A", [True, False], ids=["denseA", "csrA"])
+def test_mixed_cones_bit_identical(route, dense_A):
+    prs = []
+    for seed in range(7):
+        t = P.random_mixed(n=40, nq=3, kq=6, p=4, seed=100 + seed, dense_A=dense_A)
+        pr = _as_problem(t, kktsolver=route)
+        if not dense_A:
+            pr["A"] = sp.csr_matrix(pr["A"])
+        prs.append(pr)
+    one = _solve(prs, "threads", in_flight=1)
+    lock = _solve(prs, "lockstep")
+    assert all(s.status == "Optimal" for s in one)
+    assert len({s.Iter for s in one}) >= 1
+    _assert_identical(lock, one)
+
+
+def test_dense_qps_finishing_at_different_iterations():
+    """config-5 family at n = 384: the problems of a group need 8-11 iterations; the ones that are done stop taking part"""
+    from cipkkt.workloads import c5_batch
+    prs = c5_batch(count=12, n=384, seed=4000)
+    # spread the iteration counts: different tolerances are not allowed inside one batch, scale the data instead
+    for i, pr in enumerate(prs):
+        pr["c"] = pr["c"] * (10.0 ** (i % 4))
+    one = _solve(prs, "threads", in_flight=1)
+    lock = _solve(prs, "lockstep")
+    assert len({s.Iter for s in one}) > 1, "the case is meant to have problems finishing at different iterations"
+    _assert_identical(lock, one)
+    assert all(s.status == "Optimal" for s in lock)
+
+
+def test_statuses_differ_inside_one_group():
+    """feasible, infeasible and unbounded problems of one shape in one group"""
+    n = 10
+    prs = []
+    for seed in range(3):
+        prs.append(_as_problem(P.infeasible_box(n, seed)))                       # y >= 1 and y <= -1
+    rng = np.random.default_rng(3)
+    for _ in range(3):                                                           # same shape, feasible: -5 <= y <= 5
+        h = rng.standard_normal(n)
+        H = np.outer(h, h) + 0.1 * np.eye(n)
+        A = sp.vstack([sp.identity(n), -sp.identity(n)]).tocsr()
+        prs.append(dict(Q=H, c=rng.standard_normal(n), A=A, b=-5 * np.ones(2 * n), cone_dims=[("R", 2 * n)], G=None, d=None, kwargs={}))
+    one = _solve(prs, "threads", in_flight=1)
+    lock = _solve(prs, "lockstep")
+    assert {s.status for s in one} == {"Infeasible", "Optimal"}
+    _assert_identical(lock, one)
+
+
+def test_problems_that_need_the_regularised_factorisation_leave_the_group():
+    """LPs (Q = 0): the Schur block A'(F'F)^-1 A of the free-variable part is singular in the static order for some of
+    them -> bad pivot -> the problem is solved by the one-problem loop on its own handle; the others stay in lock-step."""
+    n = 12
+    prs = []
+    rng = np.random.default_rng(5)
+    for k in range(6):
+        if k % 2 == 0:      # LP with a free direction in Q and A (rank-deficient S): needs regularisation
+            Q = np.zeros((n, n))
+            A = np.zeros((n, n))
+            A[:n - 2, :n - 2] = np.eye(n - 2)
+            A[n - 2, 0] = 1.0
+            A[n - 1, 1] = 1.0
+            G = np.zeros((2, n))
+            G[0, n - 2] = 1.0
+            G[1, n - 1] = 1.0
+            d = np.array([1.0, 2.0])
+            c = np.concatenate([rng.random(n - 2) + 0.5, [0.0, 0.0]])
+        else:
+            M = rng.standard_normal((n, n))
+            Q = M @ M.T / n + 0.1 * np.eye(n)
+            A = np.eye(n)
+            G = rng.standard_normal((2, n))
+            d = G @ np.ones(n)
+            c = rng.standard_normal(n)
+        prs.append(dict(Q=Q, c=c, A=A, b=np.zeros(n), cone_dims=[("R", n)], G=G, d=d, kwargs={}))
+    one = _solve(prs, "threads", in_flight=1)
+    lock = _solve(prs, "lockstep")
+    _assert_identical(lock, one)
+    assert [s.status for s in lock[1::2]] == ["Optimal"] * 3
+    import ctypes as C
+    from cipkkt import _lib as L
+    st = (C.c_int * 3)()
+    L.check(L.load().cip_lockstep_stats(st))
+    assert (st[0], st[1]) == (1, 6) and st[2] >= 1, list(st)      # at least one LP met a bad pivot and left the group
+
+
+def test_more_than_64_problems_two_groups():
+    prs = []
+    for seed in range(70):
+        prs.append(_as_problem(P.random_mixed(n=16, nq=1, kq=4, p=2, seed=300 + seed)))
+    one = _solve(prs, "threads", in_flight=4)
+    lock = _solve(prs, "lockstep")
+    _assert_identical(lock, one)
+
+
+def test_unsupported_batches_fall_back():
+    from cipkkt import _lib as L
+    a = _as_problem(P.random_mixed(n=16, nq=1, kq=4, p=2, seed=1))
+    b = _as_problem(P.random_mixed(n=18, nq=1, kq=4, p=2, seed=2))
+    with pytest.raises(L.CipError) as ei:
+        _solve([a, b], "lockstep")
+    assert ei.value.code == L.E_UNSUPPORTED
+    sols = _solve([a, b], "auto")                       # falls back to the thread pool
+    assert [s.status for s in sols] == ["Optimal", "Optimal"]
+    s1 = _as_problem(P.psd_projection())
+    with pytest.raises(L.CipError) as ei:
+        _solve([s1, s1], "lockstep")
+    assert ei.value.code == L.E_UNSUPPORTED
+
+
+def test_config5_reduced_lockstep_matches_threads():
+    """BASELINE config 5 at reduced count: 8 x n = 2048 dense QPs generated in HBM; lock-step == thread pool, bit for bit"""
+    from cipkkt.workloads import c5_batch
+    prs = c5_batch(count=8, n=2048, seed=4000, device=torch.device("cuda:0"))
+    one = _solve(prs, "threads", in_flight=4)
+    lock = _solve(prs, "lockstep")
+    _assert_identical(lock, one)
+    assert all(s.status == "Optimal" for s in lock)
