@@ -15,7 +15,9 @@ inputs are resident in HBM before the timed region.
 N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) measures the north-star's
 multi-GPU configuration, BASELINE.json configs[4]: 64 independent dense QPs with n = 2048
 (seeds 4000 + i), problem i -> rank i mod N, each rank running its shard through the library's
-batch entry point (cip_conicip_problems); no data-path collective, one all-reduce of the
+batch entry point -- in LOCK-STEP (cip_conicip_lockstep: the rank's problems advance through the loop
+together, every step one launch with the problem index in the grid; `--batch-mode threads` selects the
+thread pool of cip_conicip_problems instead); no data-path collective, one all-reduce of the
 counts (SUM) and of the wall time (MAX).  A step is then one pass over the whole batch and
 `value` = KKT solves (factorisations) of all ranks per second; total work is fixed as N grows
 (`"scaling": "strong"`).  `--workload c5` runs that workload on one GPU; the default N = 1 line
@@ -189,6 +191,8 @@ def main():
     ap.add_argument("--workload", default=None, choices=["c2", "c5"],
                     help="c2: dense QP n=8192 (default at --gpus 1); c5: 64 x n=2048 batch (default at --gpus > 1)")
     ap.add_argument("--in-flight", type=int, default=8, help="c5: problems in flight per GPU (measured on one GPU: 4 -> 1703, 8 -> 2024 KKT solves/s)")
+    ap.add_argument("--batch-mode", default="lockstep", choices=["lockstep", "threads"],
+                    help="c5: lock-step batch (one launch per step for all problems of the rank) or host threads + streams")
     ap.add_argument("--no-c5", action="store_true", help="c2: skip the single-GPU config-5 figure")
     ap.add_argument("--compare-lookahead", action="store_true",
                     help="also time the same steps under the opt-in deep look-ahead schedule (slower than the serial one: "
@@ -214,6 +218,7 @@ def main():
     if args.nbo:
         cipkkt._lib.load().cip_set_ldlt_outer_block(args.nbo)
     workload = args.workload or ("c5" if world > 1 else "c2")
+    os.environ["CIP_BATCH"] = "auto" if args.batch_mode == "lockstep" else "threads"
 
     def config5(steps, warmup):
         stats, el = run_config5(rank, world, dist, device, steps, warmup, count=64, n=2048, seed=4000,
@@ -221,9 +226,10 @@ def main():
         return dict(value=stats["n_factor"] * steps / el, unit="KKT solves/s", ms_per_pass=el / steps * 1e3,
                     problems_per_s=64 * steps / el, n_optimal=stats["n_optimal"], n_problems=stats["n_problems"],
                     iters=stats["iters"], n_factor=stats["n_factor"], n_solve=stats["n_solve"],
-                    in_flight_per_gpu=args.in_flight,
+                    batch_mode=args.batch_mode, in_flight_per_gpu=args.in_flight if args.batch_mode == "threads" else None,
                     note="64 dense QPs n=m=2048 (seeds 4000+i), problem i -> rank i mod N, level-1 upload included, "
-                         "cip_conicip_problems; KKT solves = factorisations")
+                         "%s; KKT solves = factorisations" % ("cip_conicip_lockstep (one launch per step for the rank's whole shard)"
+                                                              if args.batch_mode == "lockstep" else "cip_conicip_problems (host threads)"))
 
     if workload == "c5":
         c5 = config5(args.steps, args.warmup)
@@ -235,7 +241,8 @@ def main():
                    "config": {"workload": "config 5: 64 x dense QP n=m=2048 p=0 K=[(R,2048)] Q=M'M/n A=I(sparse) b=0 "
                                           "optTol=1e-6, seeds 4000+i (SplitMix64), problem i -> rank i mod %d; "
                                           "step = one pass over the batch" % world,
-                              "parallelism": "problem-per-GPU x%d, %d in flight per GPU" % (world, args.in_flight)},
+                              "parallelism": ("problem-per-GPU x%d, lock-step batch per GPU" % world) if args.batch_mode == "lockstep"
+                                             else "problem-per-GPU x%d, %d in flight per GPU" % (world, args.in_flight)},
                    "batch": c5}
             print(json.dumps(out), flush=True)
         if dist is not None:

@@ -14,6 +14,7 @@ ROUTE_SCHUR, ROUTE_FULL3X3 = 0, 1
 OP_F, OP_FT, OP_FINV, OP_FINVT = 0, 1, 2, 3
 MAT_Q, MAT_A, MAT_G = 0, 1, 2
 FLAG_DEVICE_PTRS = 1
+FLAG_CSR_HOST = 2
 E_SINGULAR = -5
 E_UNSUPPORTED = -6
 

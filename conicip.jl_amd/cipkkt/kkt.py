@@ -111,20 +111,23 @@ def make_problem(Q, A, G, cone_dims, route, device):
 
     pr.Q, pr.ldq = dense(Q, n, n), n
     a_sparse = False
+    csr_host = False
     if m > 0 and _is_sparse(A) and not any(t == "S" for t, _ in cone_dims):
         csr = A.tocsr()
         csr.sort_indices()
-        rp_t, ci_t, av_t = (torch.as_tensor(np.ascontiguousarray(x, dtype=dt), device=device)
+        # the CSR arrays stay on the host (CIP_FLAG_CSR_HOST): the library builds the CSR of A' there and uploads both
+        rp_h, ci_h, av_h = (np.ascontiguousarray(x, dtype=dt)
                             for x, dt in ((csr.indptr, np.int32), (csr.indices, np.int32), (csr.data, np.float64)))
-        keep += [rp_t, ci_t, av_t]
-        pr.A_rowptr, pr.A_colind, pr.A_val = _ptr(rp_t), _ptr(ci_t), _ptr(av_t)
+        keep += [rp_h, ci_h, av_h]
+        pr.A_rowptr, pr.A_colind, pr.A_val = (C.c_void_p(x.ctypes.data) for x in (rp_h, ci_h, av_h))
         pr.A = None
         a_sparse = True
+        csr_host = True
     else:
         pr.A, pr.lda = (dense(A, m, n) if m > 0 else None), max(m, 1)
     pr.G, pr.ldg = (dense(G, p, n) if p > 0 else None), max(p, 1)
     pr.route = L.ROUTE_SCHUR if route in ("schur", L.ROUTE_SCHUR) else L.ROUTE_FULL3X3
-    pr.flags = L.FLAG_DEVICE_PTRS
+    pr.flags = L.FLAG_DEVICE_PTRS | (L.FLAG_CSR_HOST if csr_host else 0)
     return pr, keep, a_sparse
 
 

@@ -134,16 +134,21 @@ static int upload_problem(cip_handle *h, const cip_problem *pr) {
         }
         return 0;
     }
-    // CSR of A (given) and of A' (built here on the host)
-    std::vector<int> rp(m + 1);
-    if (dev) CIP_HIP_CHECK(hipMemcpy(rp.data(), pr->A_rowptr, sizeof(int) * (m + 1), hipMemcpyDeviceToHost));
+    // CSR of A (given) and of A' (built here on the host).  The host arrays live in the handle: the uploads below are
+    // asynchronous and nothing here waits for them (a previous upload from the same vectors is waited for first).
+    if (h->staging_live) CIP_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<int> &rp = h->st_rp, &ci = h->st_ci, &trp = h->st_trp, &tci = h->st_tci;
+    std::vector<double> &av = h->st_av, &tv = h->st_tv;
+    rp.assign(m + 1, 0);
+    const bool csr_dev = dev && !(pr->flags & CIP_FLAG_CSR_HOST);
+    if (csr_dev) CIP_HIP_CHECK(hipMemcpy(rp.data(), pr->A_rowptr, sizeof(int) * (m + 1), hipMemcpyDeviceToHost));
     else memcpy(rp.data(), pr->A_rowptr, sizeof(int) * (m + 1));
     const int nnz = rp[m];
     if (rp[0] != 0 || nnz != h->A_nnz) { cip_set_error("bad CSR row pointer (nnz %d, handle holds %d)", nnz, h->A_nnz); return CIP_E_INVALID; }
-    std::vector<int> ci(nnz > 0 ? nnz : 1);
-    std::vector<double> av(nnz > 0 ? nnz : 1);
+    ci.assign(nnz > 0 ? nnz : 1, 0);
+    av.assign(nnz > 0 ? nnz : 1, 0.0);
     if (nnz > 0) {
-        if (dev) {
+        if (csr_dev) {
             CIP_HIP_CHECK(hipMemcpy(ci.data(), pr->A_colind, sizeof(int) * nnz, hipMemcpyDeviceToHost));
             CIP_HIP_CHECK(hipMemcpy(av.data(), pr->A_val, sizeof(double) * nnz, hipMemcpyDeviceToHost));
         } else {
@@ -153,8 +158,8 @@ static int upload_problem(cip_handle *h, const cip_problem *pr) {
     }
     for (int q = 0; q < nnz; ++q)
         if (ci[q] < 0 || ci[q] >= n) { cip_set_error("CSR column index out of range"); return CIP_E_INVALID; }
-    std::vector<int> trp(n + 1, 0), tci(nnz > 0 ? nnz : 1);
-    std::vector<double> tv(nnz > 0 ? nnz : 1);
+    trp.assign(n + 1, 0); tci.assign(nnz > 0 ? nnz : 1, 0);
+    tv.assign(nnz > 0 ? nnz : 1, 0.0);
     for (int q = 0; q < nnz; ++q) trp[ci[q] + 1]++;
     for (int i = 0; i < n; ++i) trp[i + 1] += trp[i];
     {
@@ -170,11 +175,11 @@ static int upload_problem(cip_handle *h, const cip_problem *pr) {
         CIP_HIP_CHECK(hipMemcpyAsync(h->T_ci, tci.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, s));
         CIP_HIP_CHECK(hipMemcpyAsync(h->T_v, tv.data(), sizeof(double) * nnz, hipMemcpyHostToDevice, s));
     }
-    CIP_HIP_CHECK(hipStreamSynchronize(s));          // the host vectors above die with this frame
+    h->staging_live = true;
     return 0;
 }
 
-static int create_impl(const cip_problem *pr, cip_handle *h) {
+static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = true) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         cip_set_error("no HIP device available (libcipkkt has no CPU fallback)");
@@ -258,7 +263,8 @@ static int create_impl(const cip_problem *pr, cip_handle *h) {
     h->cs.ns_small = 0; h->cs.nlarge = 0; h->cs.lg = nullptr; h->cs.d_sidx_small = nullptr;
     h->cs.h_cones = h->h_cones.data();
     if (has_S) {
-        std::vector<int> small;
+        std::vector<int> &small = h->st_small;
+        small.clear();
         int rmax_large = 0;
         for (int c : sidx) {
             if (h->h_cones[c].r >= CIP_LARGE_S_MIN) {
@@ -269,23 +275,24 @@ static int create_impl(const cip_problem *pr, cip_handle *h) {
         }
         h->cs.ns_small = (int)small.size();
         DMALLOC(h->cs.d_sidx_small, sizeof(int) * (small.size() + 1));
-        if (!small.empty()) CIP_HIP_CHECK(hipMemcpy(h->cs.d_sidx_small, small.data(), sizeof(int) * small.size(), hipMemcpyHostToDevice));
+        if (!small.empty()) CIP_HIP_CHECK(hipMemcpyAsync(h->cs.d_sidx_small, small.data(), sizeof(int) * small.size(), hipMemcpyHostToDevice, s));
         if (h->cs.nlarge > 0) { int rcl = cip_sdp_large_create(rmax_large, h->cs.nlarge, &h->cs.lg); if (rcl) return rcl; }
     }
     if (has_S) {
         const int per = n < 64 ? n : 64;
         h->cs.sdp_slots = h->cs.ns * (per > 0 ? per : 1);
         DMALLOC(h->cs.d_sidx, sizeof(int) * sidx.size());
-        CIP_HIP_CHECK(hipMemcpy(h->cs.d_sidx, sidx.data(), sizeof(int) * sidx.size(), hipMemcpyHostToDevice));
+        h->st_sidx = sidx;
+        CIP_HIP_CHECK(hipMemcpyAsync(h->cs.d_sidx, h->st_sidx.data(), sizeof(int) * sidx.size(), hipMemcpyHostToDevice, s));
         DMALLOC(h->cs.d_sdpws, sizeof(double) * (size_t)h->cs.sdp_slots * 6 * rmax * rmax);
         DMALLOC(h->cs.d_sdpvec, sizeof(double) * (size_t)h->cs.sdp_slots * 2 * kmax);
         DMALLOC(h->cs.d_sdpflag, sizeof(int) * 4);
-        CIP_HIP_CHECK(hipMemset(h->cs.d_sdpflag, 0, sizeof(int) * 4));
+        CIP_HIP_CHECK(hipMemsetAsync(h->cs.d_sdpflag, 0, sizeof(int) * 4, s));
     }
     if (!h->h_cones.empty())
-        CIP_HIP_CHECK(hipMemcpy(h->cs.d_cones, h->h_cones.data(), sizeof(ConeDesc) * h->h_cones.size(), hipMemcpyHostToDevice));
+        CIP_HIP_CHECK(hipMemcpyAsync(h->cs.d_cones, h->h_cones.data(), sizeof(ConeDesc) * h->h_cones.size(), hipMemcpyHostToDevice, s));
     if (!h->h_items.empty())
-        CIP_HIP_CHECK(hipMemcpy(h->cs.d_items, h->h_items.data(), sizeof(WorkItem) * h->h_items.size(), hipMemcpyHostToDevice));
+        CIP_HIP_CHECK(hipMemcpyAsync(h->cs.d_items, h->h_items.data(), sizeof(WorkItem) * h->h_items.size(), hipMemcpyHostToDevice, s));
 
     // ---- sizes
     h->npad = rup(n, CIP_NB);
@@ -310,17 +317,18 @@ static int create_impl(const cip_problem *pr, cip_handle *h) {
         }
     } else {
         int nnz = 0;
-        if (dev) CIP_HIP_CHECK(hipMemcpy(&nnz, pr->A_rowptr + m, sizeof(int), hipMemcpyDeviceToHost));
+        if (dev && !(pr->flags & CIP_FLAG_CSR_HOST)) CIP_HIP_CHECK(hipMemcpy(&nnz, pr->A_rowptr + m, sizeof(int), hipMemcpyDeviceToHost));
         else nnz = pr->A_rowptr[m];
         if (nnz < 0) { cip_set_error("bad CSR row pointer"); return CIP_E_INVALID; }
         h->A_nnz = nnz;
         DMALLOC(h->A_rp, sizeof(int) * (m + 1)); DMALLOC(h->A_ci, sizeof(int) * nnz); DMALLOC(h->A_v, sizeof(double) * nnz);
         DMALLOC(h->T_rp, sizeof(int) * (n + 1)); DMALLOC(h->T_ci, sizeof(int) * nnz); DMALLOC(h->T_v, sizeof(double) * nnz);
-        std::vector<int> rc_(m > 0 ? m : 1);
+        std::vector<int> &rc_ = h->st_rowcone;
+        rc_.assign(m > 0 ? m : 1, 0);
         for (size_t c = 0; c < h->h_cones.size(); ++c)
             for (int e = 0; e < h->h_cones[c].dim; ++e) rc_[h->h_cones[c].off + e] = (int)c;
         DMALLOC(h->row_cone, sizeof(int) * m);
-        if (m > 0) CIP_HIP_CHECK(hipMemcpy(h->row_cone, rc_.data(), sizeof(int) * m, hipMemcpyHostToDevice));
+        if (m > 0) CIP_HIP_CHECK(hipMemcpyAsync(h->row_cone, rc_.data(), sizeof(int) * m, hipMemcpyHostToDevice, s));
         if (h->route == CIP_ROUTE_SCHUR) DMALLOC(h->Gm, sizeof(double) * (size_t)h->npad * h->nqpad);
     }
     if ((rc = upload_problem(h, pr))) return rc;
@@ -345,7 +353,9 @@ static int create_impl(const cip_problem *pr, cip_handle *h) {
     memset(h->info_host, 0, 4 * sizeof(int));
     if ((rc = cip_cones_identity_scaling(s, h->cs))) return rc;
     if ((rc = cip_sdp_scaling_changed(s, h->cs))) return rc;
-    CIP_HIP_CHECK(hipStreamSynchronize(s));
+    // the caller's Q / A / G may go away as soon as a public create returns: wait for the uploads.  A lock-step group
+    // keeps its problems alive for the whole call and creates its 64 handles without a single host wait.
+    if (final_sync) CIP_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
 }
 
@@ -368,7 +378,7 @@ int cip_create_in_arena(const cip_problem *pr, char *slab, size_t cap, hipStream
     if (!h) { cip_set_error("out of host memory"); return CIP_E_INVALID; }
     h->arena = slab; h->arena_cap = cap; h->arena_used = 0;
     h->stream = stream;
-    const int rc = create_impl(pr, h);
+    const int rc = create_impl(pr, h, false);
     if (rc) { free_all(h); delete h; return rc; }
     *out = h;
     return 0;

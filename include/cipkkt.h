@@ -61,6 +61,8 @@ typedef struct cip_handle cip_handle;
 
 /* flags for cip_create_ex */
 #define CIP_FLAG_DEVICE_PTRS 1   /* Q/A/G arrays are device pointers */
+#define CIP_FLAG_CSR_HOST    2   /* ... except the CSR arrays of A, which are host pointers (the library needs them on the
+                                    host anyway, to build the CSR of A') */
 
 #define CIP_OK            0
 #define CIP_E_INVALID    -1
