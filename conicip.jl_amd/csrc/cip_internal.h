@@ -101,6 +101,8 @@ struct GemmArgs {
     int overwrite;               // EPI_ACCUM: C = alpha*acc instead of C += alpha*acc
     const double *dk;            // lower-triangular trailing update only, optional: A is scaled by dk[k] column-wise (A = L, dk = d)
     double *Ct; long ldct, sCty, sCtz;   // 128-tile EPI_ACCUM only, optional: the result is also stored transposed, Ct[j + i*ldct]
+    int lowprio;                 // lower-triangular trailing update: run its waves at s_setprio 0 (default 3)
+    int force64;                 // plain accumulate form: quarter tiles (k_gemm_nt_64) whatever the tile count
 };
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g);
 

@@ -59,7 +59,12 @@ __device__ __forceinline__ double bperm_d(double x, int byte_addr) {
 // right-looking by the same multipliers (lane (cc = l15, g) owns rows g+4q of column cc).
 // (A row-per-lane variant -- lane i holds row i and column i of X, pivot column broadcast with v_readlane only, no LDS
 // round trip -- was built and measured in round 2: 40.5 us per kernel against 30.9: with 16 useful lanes a pivot
-// issues (15-j) x 5 fp64 instructions instead of 4 x 3, and the issue time exceeds the bpermute latency it removes.)
+// issues (15-j) x 5 fp64 instructions instead of 4 x 3, and the issue time exceeds the bpermute latency it removes.
+// A third variant moved every per-pivot operand in registers -- own-row entry by v_permlane32_swap + v_permlane16_swap,
+// the pivot ROW (instead of the pivot column: the block is symmetric) by DPP row_newbcast -- no LDS at all: 31.2 us against
+// 30.6, and with steps B/C switched off 23.7 against 20.7: the chain is ISSUE-bound (one wave, ~40 instructions of ~5
+// cycles per pivot), not latency-bound; the swaps need copies and hazard nops and cost more issue slots than the 12
+// ds_bpermute they replace.  tools/diag_bench.hip measures such variants and checks them against a host LDL'.)
 __device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int lane, int *info, int col0, PivotSigns sg) {
     const int l15 = lane & 15, g = lane >> 4;
     const int c = kb * 16;

@@ -325,7 +325,8 @@ __global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64(GemmArgs g, CipBatc
     bool live;
     (void)gemm_batch_prologue(g, cb, live);
     if (!live) return;
-    __builtin_amdgcn_s_setprio(3);       // measured: 58.0 vs 56.6 TFLOP/s without
+    if (g.lowprio) __builtin_amdgcn_s_setprio(0);      // the bulk of the two-stream schedule: the chain's waves win issue arbitration
+    else __builtin_amdgcn_s_setprio(3);                // measured: 58.0 vs 56.6 TFLOP/s without
     int bi, bj;
     tile_coords((int)(blockIdx.x >> 2), 1, g.M / CIP_NB, bi, bj);
     const int sub = blockIdx.x & 3;
@@ -727,7 +728,7 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    if (epi == EPI_ACCUM && !g.lower && !g.overwrite && tiles < 256 && g.M % SB == 0 && g.N % SB == 0) {
+    if (epi == EPI_ACCUM && !g.lower && !g.overwrite && (tiles < 256 || g.force64) && g.M % SB == 0 && g.N % SB == 0) {
         // skinny, latency-critical: quarter-size tiles
         const long t64 = (long)(g.M / SB) * (g.N / SB);
         cip_launch_b(k_gemm_nt_64, dim3((unsigned)t64), dim3(256), 0, s, g);

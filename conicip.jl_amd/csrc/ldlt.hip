@@ -210,8 +210,14 @@ static std::once_flag g_la_once;
 static int g_lookahead = 0;
 static int g_la_min = 4096;               // below this order a factorisation is chain-bound whatever the schedule
 static int g_reserve = 2;                 // CUs per (XCD, SE) pair left to the chain: 1 -> 32 CUs, 2 -> 64
+static int g_la2_min = 3072;              // two-stream schedule: smallest trailing order whose bulk is overlapped
+static int g_la2_lowprio = 1;
+static int g_la2_reserve = 1;             // CUs per (XCD, SE) pair the bulk stream leaves to the chain (CU mask): 1 -> 32 CUs
 static void lookahead_env(void) {
-    if (const char *e = getenv("CIP_LOOKAHEAD")) g_lookahead = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("CIP_LOOKAHEAD")) { const int v = atoi(e); g_lookahead = (v >= 0 && v <= 3) ? v : 0; }
+    if (const char *e = getenv("CIP_LA2_MIN")) g_la2_min = atoi(e);
+    if (const char *e = getenv("CIP_LA2_RESERVE")) g_la2_reserve = atoi(e);
+    if (const char *e = getenv("CIP_LA2_LOWPRIO")) g_la2_lowprio = atoi(e);
     if (const char *e = getenv("CIP_RESERVE")) { const int r = atoi(e); if (r >= 0 && r <= 2) g_reserve = r; }
     if (const char *e = getenv("CIP_LA_MIN")) g_la_min = atoi(e);
 }
@@ -219,7 +225,7 @@ static void lookahead_env(void) {
 int cip_ldlt_set_lookahead(int on) {
     std::call_once(g_la_once, lookahead_env);
     const int prev = g_lookahead;
-    g_lookahead = (on == 2) ? 2 : (on ? 1 : 0);      // 2: serial schedule with the workers' operand form (tests)
+    g_lookahead = (on == 2 || on == 3) ? on : (on ? 1 : 0);      // 2: serial schedule with the workers' operand form (tests); 3: two streams
     return prev;
 }
 static int lookahead_init(void) {
@@ -231,6 +237,40 @@ static int lookahead_init(void) {
     CIP_HIP_CHECK(hipEventCreateWithFlags(&g_side.ev_chain, hipEventDisableTiming));
     return 0;
 }
+// ---- two-stream look-ahead (mode 3).  The trailing update of outer block J is cut into the STRIP (the next block's
+// columns: what the chain of block J+1 needs) and the BULK (everything to the right).  Chain and strips run on a
+// high-priority stream; the bulk runs on a second stream whose CU mask (hipExtStreamCreateWithCUMask; bit = cu * 32 +
+// se * 8 + xcc, probed with tools/cumask_probe.hip) leaves `reserve` CUs of every (XCD, SE) pair alone, so that the
+// single-workgroup diagonal kernel -- which needs a CU's whole LDS -- and part of the TRSM always find a free CU, while
+// the chain's wide kernels also take whatever slots the bulk frees.  Ordinary launches, ordinary stream order and events:
+// no in-launch hand-offs.  Two W-panel buffers alternate (the bulk of block J reads W_J while the chain writes W_{J+1}).
+struct BulkStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_strip = nullptr, ev_bulk = nullptr;
+    int reserve = -1;
+    ~BulkStream() {
+        if (ev_strip) (void)hipEventDestroy(ev_strip);
+        if (ev_bulk) (void)hipEventDestroy(ev_bulk);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+static thread_local BulkStream g_bulk;
+static int bulk_stream_init(void) {
+    if (g_bulk.stream && g_bulk.reserve == g_la2_reserve) return 0;
+    if (g_bulk.stream) { (void)hipStreamDestroy(g_bulk.stream); g_bulk.stream = nullptr; }
+    uint32_t mask[8];
+    for (int w = 0; w < 8; ++w) mask[w] = 0xffffffffu;
+    // reserve r (1..4) CUs per (xcc, se): clear bits of cu = 7, 6, ... ; r = 0 with CIP_LA2_RESERVE=0: half of the pairs (se 0, 2)
+    const int r = g_la2_reserve;
+    if (r > 0) for (int cu = 7; cu > 7 - r && cu >= 4; --cu) mask[cu] = 0u;
+    else for (int b = 0; b < 32; ++b) if (((b >> 3) & 1) == 0) mask[7] &= ~(1u << b);
+    CIP_HIP_CHECK(hipExtStreamCreateWithCUMask(&g_bulk.stream, 8, mask));
+    g_bulk.reserve = r;
+    if (!g_bulk.ev_strip) CIP_HIP_CHECK(hipEventCreateWithFlags(&g_bulk.ev_strip, hipEventDisableTiming));
+    if (!g_bulk.ev_bulk) CIP_HIP_CHECK(hipEventCreateWithFlags(&g_bulk.ev_bulk, hipEventDisableTiming));
+    return 0;
+}
+
 // gemm_f64.hip
 size_t cip_la_ctrl_bytes(int Npad);
 int cip_la_launch_workers(hipStream_t s, double *K, int Npad, long ld, const double *dvec, int nbo, void *ctrl_dev, int reserve);
@@ -340,6 +380,56 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
     if ((rc = zero_fill(s, ws.info, 64))) return rc;       // [0] bad pivot, [1] sweep bail-out, [2] dead pivot, [3] look-ahead scheduler
     bool la = g_lookahead == 1 && Npad >= g_la_min && Npad > 2 * NBO && NBO % 64 == 0;
     if (cip_tl_builder || cip_in_batch()) la = false;         // recording a hipGraph / a lock-step batch: the single-stream schedule
+    if (g_lookahead == 3 && !cip_tl_builder && !cip_in_batch() && Npad >= 2 * g_la2_min && !ws.prof) {
+        if ((rc = lookahead_init())) return rc;
+        if ((rc = bulk_stream_init())) return rc;
+        hipStream_t sc = g_side.stream, sb = g_bulk.stream;          // chain + strips (high priority), bulk (CU-masked)
+        CIP_HIP_CHECK(hipEventRecord(g_side.ev_start, s));
+        CIP_HIP_CHECK(hipStreamWaitEvent(sc, g_side.ev_start, 0));
+        bool bulk_pending = false;
+        const size_t wstride = (size_t)Npad * CIP_NBO_MAX;
+        int J = 0;
+        for (int C0 = 0; C0 < Npad; C0 += NBO, ++J) {
+            const int wblk = (Npad - C0 < NBO) ? (Npad - C0) : NBO;
+            double *Wb = ws.Wbuf + (size_t)(J & 1) * wstride;
+            if ((rc = factor_outer_panels(sc, K, Npad, ld, ws, Wb, C0, wblk))) return rc;
+            const int r0 = C0 + wblk;
+            if (r0 >= Npad) break;
+            const int r = Npad - r0;
+            const bool split = r - NBO >= g_la2_min;
+            // the bulk of this block needs the chain of this block (W, L panels) and the previous bulk (stream order): it
+            // starts NOW, beside the strip
+            if (split) { CIP_HIP_CHECK(hipEventRecord(g_bulk.ev_strip, sc)); CIP_HIP_CHECK(hipStreamWaitEvent(sb, g_bulk.ev_strip, 0)); }
+            // the strip (and an unsplit update) touch columns the previous bulk has written
+            if (bulk_pending) { CIP_HIP_CHECK(hipStreamWaitEvent(sc, g_bulk.ev_bulk, 0)); bulk_pending = false; }
+            GemmArgs g = {};
+            g.A = Wb + r0; g.lda = Npad;
+            g.B = K + r0 + (long)C0 * ld; g.ldb = ld;
+            g.C = K + r0 + (long)r0 * ld; g.ldc = ld;
+            g.K = wblk; g.alpha = -1.0;
+            if (split) {
+                GemmArgs gb = g;
+                gb.A = g.A + NBO; gb.B = g.B + NBO; gb.C = g.C + NBO + (long)NBO * ld; gb.M = gb.N = r - NBO; gb.lower = 1; gb.lowprio = g_la2_lowprio;
+                if ((rc = cip_launch_gemm(sb, EPI_ACCUM, gb))) return rc;
+                CIP_HIP_CHECK(hipEventRecord(g_bulk.ev_bulk, sb));
+                bulk_pending = true;
+                // strip: columns [r0, r0 + NBO) -- the lower triangle of the next diagonal block, then the rows below it
+                GemmArgs gs = g;
+                gs.M = NBO; gs.N = NBO; gs.lower = 1;
+                if ((rc = cip_launch_gemm(sc, EPI_ACCUM, gs))) return rc;
+                gs.A = g.A + NBO; gs.C = g.C + NBO; gs.M = r - NBO; gs.N = NBO; gs.lower = 0; gs.force64 = 1;
+                if ((rc = cip_launch_gemm(sc, EPI_ACCUM, gs))) return rc;
+            } else {
+                g.M = g.N = r; g.lower = 1;
+                if ((rc = cip_launch_gemm(sc, EPI_ACCUM, g))) return rc;
+            }
+        }
+        if (bulk_pending) CIP_HIP_CHECK(hipStreamWaitEvent(sc, g_bulk.ev_bulk, 0));
+        CIP_HIP_CHECK(hipEventRecord(g_side.ev_chain, sc));
+        CIP_HIP_CHECK(hipStreamWaitEvent(s, g_side.ev_chain, 0));
+        if ((rc = cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.Linv, ws.LinvT))) return rc;
+        return build_solve_blocks(s, K, Npad, ld, ws);
+    }
     if (!la) {
         // serial right-looking schedule: panels of the outer block, then ONE trailing update
         for (int C0 = 0; C0 < Npad; C0 += NBO) {

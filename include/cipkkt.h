@@ -240,7 +240,9 @@ int cip_set_ldlt_outer_block(int nbo);
 int cip_set_solve_block_max(int b);
 /* schedule of the blocked LDL': 0 = serial single-stream (default), 1 = deep look-ahead for orders >= 4096 (also
  * CIP_LOOKAHEAD=1: every trailing update in one persistent launch, the panel chain of each outer block on a side
- * stream behind a gate on its own column strip), 2 = serial with the look-ahead's operand form (bit-identical to 1; tests).
+ * stream behind a gate on its own column strip), 2 = serial with the look-ahead's operand form (bit-identical to 1; tests),
+ * 3 = two-stream look-ahead (CIP_LOOKAHEAD=3: chain and column strips on a high-priority stream, the bulk of every large
+ * trailing update on a second, CU-masked stream; ordinary launches and events, bit-identical to 0).
  * Process-wide; returns the previous setting. */
 int cip_set_ldlt_lookahead(int on);
 /* out4 = [100 MHz ticks the persistent workers of the last look-ahead factorisation spent inside tile computations

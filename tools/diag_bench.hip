@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cmath>
 void cip_set_error(const char *fmt, ...) {}
+thread_local CipGraphBuilder *cip_tl_builder = nullptr;
+thread_local CipBatchCtx cip_tl_bz = {1, 0, 1ull, nullptr, nullptr};
 int main() {
     const int N = 128;
     std::vector<double> K(N * N);
@@ -24,6 +26,21 @@ int main() {
     for (int r = 0; r < reps; ++r) cip_launch_diag_v2(0, dK, N, dLi, dd, ddi, dinfo, 0, PivotSigns{-1, 0, 0});
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
+    {   // correctness of one factorisation against a host LDL' of the same block
+        hipMemcpy(dK, dK0, N * N * 8, hipMemcpyDeviceToDevice);
+        cip_launch_diag_v2(0, dK, N, dLi, dd, ddi, dinfo, 0, PivotSigns{-1, 0, 0});
+        std::vector<double> G(N * N), dv(N), H = K;
+        hipMemcpy(G.data(), dK, N * N * 8, hipMemcpyDeviceToHost);
+        hipMemcpy(dv.data(), dd, N * 8, hipMemcpyDeviceToHost);
+        for (int j = 0; j < N; ++j) {
+            const double d = H[j + j * N];
+            for (int i = j + 1; i < N; ++i) H[i + j * N] /= d;
+            for (int c = j + 1; c < N; ++c) for (int i = c; i < N; ++i) H[i + c * N] -= H[i + j * N] * d * H[c + j * N];
+        }
+        double e = 0, ed = 0;
+        for (int j = 0; j < N; ++j) { ed = fmax(ed, fabs(dv[j] - H[j + j * N]) / fabs(H[j + j * N])); for (int i = j + 1; i < N; ++i) e = fmax(e, fabs(G[i + j * N] - H[i + j * N])); }
+        printf("max |L - L_host| %.3e, max rel |d - d_host| %.3e\n", e, ed);
+    }
     printf("DIAG_SKIP=%d avg %.2f us per launch\n",
 #ifdef DIAG_SKIP
            DIAG_SKIP,
