@@ -349,8 +349,8 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
     DMALLOC(h->stage, sizeof(double) * 2 * (size_t)(n + p + m));
     CIP_HIP_CHECK(hipEventCreate(&h->ev0)); CIP_HIP_CHECK(hipEventCreate(&h->ev1)); CIP_HIP_CHECK(hipEventCreate(&h->ev2));
     CIP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_info, hipEventDisableTiming));
-    CIP_HIP_CHECK(hipHostMalloc((void **)&h->info_host, 4 * sizeof(int), hipHostMallocDefault));
-    memset(h->info_host, 0, 4 * sizeof(int));
+    // (the pinned pivot-flag words are allocated by the first factorisation: pinned allocations cost ~0.1 ms each, and the
+    //  64 handles of a lock-step group never use theirs)
     if ((rc = cip_cones_identity_scaling(s, h->cs))) return rc;
     if ((rc = cip_sdp_scaling_changed(s, h->cs))) return rc;
     // the caller's Q / A / G may go away as soon as a public create returns: wait for the uploads.  A lock-step group
@@ -515,6 +515,10 @@ static int factor_enqueue(cip_handle *h) {
         if ((rc = graph_run(h, &h->gx_factor, [&]() { return cip_ldlt_factor(h->stream, h->K, h->Npad, h->ldk, h->ws); }))) return rc;
     }
     h->n_factor += 1;
+    if (!h->info_host) {
+        CIP_HIP_CHECK(hipHostMalloc((void **)&h->info_host, 4 * sizeof(int), hipHostMallocDefault));
+        memset(h->info_host, 0, 4 * sizeof(int));
+    }
     CIP_HIP_CHECK(hipMemcpyAsync(h->info_host, h->ws.info, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     CIP_HIP_CHECK(hipEventRecord(h->ev_info, h->stream));
     h->info_pending = true;

@@ -122,6 +122,11 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
     double t_probe = 0, t_arena = 0, t_create = 0, t_loop = 0;
     const cip_options o = resolve_options(opt_in);
     const int n = probs[0].n, m = probs[0].m, p = probs[0].p;
+    struct ExitTimer {            // reports what the destructors behind it (handles, arena) cost
+        bool on; std::chrono::steady_clock::time_point t0;
+        ~ExitTimer() { if (on) fprintf(stderr, "lockstep group: tear-down %.2f ms\n", 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+    };
+    ExitTimer exit_timer{false, std::chrono::steady_clock::now()};
     Group G;
     G.B = B;
     int rc;
@@ -422,6 +427,7 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
 #undef CK
     g_last_stats[0] += 1; g_last_stats[1] += B;
     for (int z = 0; z < B; ++z) g_last_stats[2] += ejected[z] ? 1 : 0;
+    exit_timer.on = timing; exit_timer.t0 = std::chrono::steady_clock::now();
     // ---- problems that left the group: the one-problem loop on their own handle (regularised factorisation and all)
     {
         BatchScope single(CipBatchCtx{1, 0, 1ull, nullptr, nullptr});
