@@ -1,0 +1,231 @@
+// Device pieces of the fp64 MFMA GEMM shared by gemm_f64.hip and the fused diagonal + in-block-update kernel of diag.hip:
+// the 64x64 tile computation (gemm_tile_64) and the lock-step batch prologue of GEMM kernels.
+#pragma once
+#include "cip_internal.h"
+
+// Lock-step batches (cip_internal.h): grid.z = (own batch count, >= 1) x (problems); returns the launch's own z index
+// after shifting every operand pointer by the problem's slab offset; live = false: the problem is masked off.
+__device__ __forceinline__ unsigned gemm_batch_prologue(GemmArgs &g, const CipBatch &cb, bool &live) {
+    const unsigned gz = g.bz > 0 ? (unsigned)g.bz : 1u;
+    const unsigned pz = blockIdx.z / gz;
+    live = ((cb.mask >> pz) & 1ull) != 0;
+    const long off = (long)pz * cb.stride;
+    g.A = (const double *)((const char *)g.A + off);
+    g.B = (const double *)((const char *)g.B + off);
+    g.C = (double *)((char *)g.C + off);
+    if (g.Ct) g.Ct = (double *)((char *)g.Ct + off);
+    if (g.Qin) g.Qin = (const double *)((const char *)g.Qin + off);
+    if (g.dk) g.dk = (const double *)((const char *)g.dk + off);
+    return blockIdx.z - pz * gz;
+}
+// the launch's own (grid.y, grid.z) batching: pointer strides in doubles
+__device__ __forceinline__ void gemm_own_batch(GemmArgs &g, unsigned oz) {
+    g.A += blockIdx.y * g.sAy + oz * g.sAz;
+    g.B += blockIdx.y * g.sBy + oz * g.sBz;
+    g.C += blockIdx.y * g.sCy + oz * g.sCz;
+    if (g.Ct) g.Ct += blockIdx.y * g.sCty + oz * g.sCtz;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small-tile variant (64x64 C tile, wave = 32x32 = 2x2 MFMA tiles) for the latency-critical skinny
+// updates on the factorisation's critical path (look-ahead column strip, in-block strip update):
+// 4x the workgroups and a quarter of the per-tile latency of the 128x128 kernel, at twice the LDS
+// traffic per flop -- these launches carry < 10 % of the flops.  Accumulate epilogue only.
+#define SB 64
+// SC1C: the C tile is read with L1-bypassing loads and written through (`sc1`): tiles handed from workgroup to
+// workgroup inside one launch (k_ldlt_workers).  SCALEA: the A operand is column-scaled on its way into LDS,
+// A[i,k] * dk[k] -- the trailing update then reads W = L D as L (from K itself) times d, no separate W panel.
+template <int EPI = EPI_ACCUM, bool SC1C = false, bool SCALEA = false>
+__device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, long i0, long j0, const double *dk = nullptr) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    // staging: 64 rows x 16 k per operand = 512 double2 -> 2 per thread: e = q*256 + tid, k = e >> 5, rp = e & 31
+    const int k_ld = tid >> 5, rp = tid & 31;
+    const double *Ap = g.A + i0 + 2 * rp;
+    const double *Bp = g.B + j0 + 2 * rp;
+    v2d ra[2], rb[2];
+    double rd[2] = {1.0, 1.0};
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const long k = (long)kt * CIP_KT + q * 8 + k_ld;
+            ra[q] = *(const v2d *)(Ap + k * g.lda);
+            rb[q] = *(const v2d *)(Bp + k * g.ldb);
+            if (SCALEA) rd[q] = dk[k];
+        }
+    };
+    auto lstore = [&](int buf) {
+        double *la = lds + buf * (2 * CIP_KT * SB);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (SCALEA) ra[q] *= rd[q];
+            *(v2d *)(la + (q * 8 + k_ld) * SB + 2 * rp) = ra[q];
+            *(v2d *)(la + CIP_KT * SB + (q * 8 + k_ld) * SB + 2 * rp) = rb[q];
+        }
+    };
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int KT = g.K / CIP_KT;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) gload(kt + 1);
+        const double *la = lds + buf * (2 * CIP_KT * SB) + wm * 32 + 2 * l15;
+        const double *lb = lds + buf * (2 * CIP_KT * SB) + CIP_KT * SB + wn * 32 + 2 * l15;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kk = ks * 4 + l4;
+            const v2d fi = *(const v2d *)(la + kk * SB);
+            const v2d fj = *(const v2d *)(lb + kk * SB);
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.x, fi.x, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.x, fi.y, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.y, fi.x, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.y, fi.y, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < KT) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // lane holds, for tile (ti,tj), reg q: row = i0 + wm*32 + 2*l15 + ti, col = j0 + wn*32 + 2*(l4 + 4q) + tj
+    if (SC1C) {
+        // agent-scope relaxed atomics = `global_load/store_dwordx2 ... sc1` the compiler schedules and waits for itself
+        // (a hand-written asm load is invisible to its s_waitcnt / spill logic: the first version of this epilogue
+        // produced garbage whenever the register allocator moved an asm result before the manual wait)
+        // four passes of 4 loads in flight: the register budget of five workgroups per CU (102) leaves no room for more
+        const long rowo = i0 + wm * 32 + 2 * l15;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {
+                double cv[2][2];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const double *cp = g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * (2 * qh + qq)) + tj) * g.ldc;
+                    cv[qq][0] = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cv[qq][1] = __hip_atomic_load(cp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int q = 2 * qh + qq;
+                    double *cp = g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * q) + tj) * g.ldc;
+                    __hip_atomic_store(cp, cv[qq][0] + g.alpha * acc[0][tj][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cp + 1, cv[qq][1] + g.alpha * acc[1][tj][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long col = j0 + wn * 32 + 2 * (l4 + 4 * q) + tj;
+            const long row = i0 + wm * 32 + 2 * l15;
+            double *cp = g.C + row + col * g.ldc;
+            const v2d val = (v2d){acc[0][tj][q], acc[1][tj][q]};
+            if (EPI == EPI_ACCUM) {
+                v2d c = *(v2d *)cp;
+                c += g.alpha * val;
+                *(v2d *)cp = c;
+            } else if (EPI == EPI_STORE) {    // C = alpha acc, optionally also stored transposed
+                const v2d c = g.alpha * val;
+                *(v2d *)cp = c;
+                if (g.Ct) { g.Ct[col + row * g.ldct] = c.x; g.Ct[col + (row + 1) * g.ldct] = c.y; }
+            } else if (col < g.nvalid) {      // EPI_SYRKQ: C = Qin + alpha acc inside the valid n x n corner
+                if (row + 1 < g.nvalid) {
+                    const double *qp = g.Qin + row + col * g.ldq;       // Q keeps the caller's (possibly odd) pitch
+                    *(v2d *)cp = (v2d){qp[0], qp[1]} + g.alpha * val;
+                } else if (row < g.nvalid) {
+                    *cp = g.Qin[row + col * g.ldq] + g.alpha * val.x;
+                }
+            }
+        }
+}
+
+
+// K = 128 with the WHOLE of both operands resident in LDS (128 KB): one global round trip, one barrier, then 32 MFMA
+// steps -- for launches that own a CU's LDS anyway (diag.hip: k_ldlt_diag_upd).  The k-loop of gemm_tile_64 waits for a
+// global load in each of its eight iterations (~1 us each when the tile is alone on its CU).  Same accumulation order
+// as gemm_tile_64: bit-identical results.  Accumulate epilogue; SC1C as above.
+template <bool SC1C>
+__device__ __forceinline__ void gemm_tile_64_k128(const GemmArgs &g, double *lds, long i0, long j0) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int k_ld = tid >> 5, rp = tid & 31;
+    const double *Ap = g.A + i0 + 2 * rp;
+    const double *Bp = g.B + j0 + 2 * rp;
+    double *la = lds, *lb = lds + 128 * SB;                     // [k][row], 128 x 64 each
+    {
+        v2d ra[16], rb[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const long k = q * 8 + k_ld;
+            ra[q] = *(const v2d *)(Ap + k * g.lda);
+            rb[q] = *(const v2d *)(Bp + k * g.ldb);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            *(v2d *)(la + (q * 8 + k_ld) * SB + 2 * rp) = ra[q];
+            *(v2d *)(lb + (q * 8 + k_ld) * SB + 2 * rp) = rb[q];
+        }
+    }
+    __syncthreads();
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double *pa = la + wm * 32 + 2 * l15, *pb = lb + wn * 32 + 2 * l15;
+#pragma unroll 8
+    for (int ks = 0; ks < 32; ++ks) {
+        const int kk = ks * 4 + l4;
+        const v2d fi = *(const v2d *)(pa + kk * SB);
+        const v2d fj = *(const v2d *)(pb + kk * SB);
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.x, fi.x, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.x, fi.y, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.y, fi.x, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.y, fi.y, acc[1][1], 0, 0, 0);
+    }
+    const long rowo = i0 + wm * 32 + 2 * l15;
+    if (SC1C) {
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {
+                double cv[2][2];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const double *cp = g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * (2 * qh + qq)) + tj) * g.ldc;
+                    cv[qq][0] = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cv[qq][1] = __hip_atomic_load(cp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int q = 2 * qh + qq;
+                    double *cp = g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * q) + tj) * g.ldc;
+                    __hip_atomic_store(cp, cv[qq][0] + g.alpha * acc[0][tj][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cp + 1, cv[qq][1] + g.alpha * acc[1][tj][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double *cp = g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * q) + tj) * g.ldc;
+            v2d c = *(v2d *)cp;
+            c += g.alpha * (v2d){acc[0][tj][q], acc[1][tj][q]};
+            *(v2d *)cp = c;
+        }
+}

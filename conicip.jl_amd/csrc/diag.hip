@@ -18,6 +18,8 @@
 // lane groups are bank-conflict free), the 8 micro inverses, and d / 1/d in the pitch padding:
 // 160 KiB exactly (one workgroup per CU, which is all a serial kernel needs).
 #include "cip_internal.h"
+#include "cip_gemm_tile.h"
+#include <stdlib.h>
 
 #define DP 144
 #ifndef DIAG_SKIP
@@ -217,18 +219,42 @@ __device__ __forceinline__ void diag_store_panel(const double *a, double *Kb, lo
 
 // Factor-only diagonal kernel: L (strictly lower) and d back into K, d / 1/d vectors, and the 8 micro
 // inverses Xm (xm_out[kb][k*16 + jj] = inv(L11_kb)[jj][k]) for the TRSM and the block-inverse kernels.
-__global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
-                                                          int *info, int col0, PivotSigns sg, CipBatch cb) {
-    CIP_BATCH_GUARD(cb);
-    CIP_BO5(cb, Kb, xm_out, dvec, dinv, info);
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+// WAIT: the block is being updated by three other workgroups of the SAME launch (k_ldlt_diag_upd: the quarter tiles of the
+// previous panel's in-block update that make up this block's lower triangle, written with agent-scope stores); thread 0
+// polls their completion counter, one acquire fence, then the block is read with agent-scope loads.
+template <bool WAIT>
+__device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
+                                          int *info, int col0, PivotSigns sg, const unsigned *ready) {
     double *a = sm;
     double *xm = sm + XM_OFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
 
     __builtin_amdgcn_s_setprio(3);
-    if (!(DIAG_SKIP & 16)) diag_load_block(a, Kb, ld, tid);
+    if (WAIT) {
+        if (tid == 0) {
+            const long t0 = __builtin_amdgcn_s_memtime();
+            while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 3u) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memtime() - t0 > 100000000L) { atomicCAS(info + 3, 0, -9); break; }   // ~1 s: never hang the GPU
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        double t[64];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+            const int e = q * 256 + tid;                         // element: row e & 127, column e >> 7
+            t[q] = __hip_atomic_load(Kb + (e & 127) + (long)(e >> 7) * ld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+            const int e = q * 256 + tid;
+            const int i = e & 127, j = e >> 7;
+            a[i + j * DP] = (i < j) ? 0.0 : t[q];                // strictly upper part -> 0
+        }
+    } else if (!(DIAG_SKIP & 16)) diag_load_block(a, Kb, ld, tid);
     __syncthreads();
 
     // Schedule per 16-column micro-panel kb (A(0) first):
@@ -277,6 +303,56 @@ __global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, do
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) xm_out[q * 256 + tid] = xm[q * 256 + tid];
+}
+
+__global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
+                                                          int *info, int col0, PivotSigns sg, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO5(cb, Kb, xm_out, dvec, dinv, info);
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    diag_body<false>(sm, Kb, ld, xm_out, dvec, dinv, info, col0, sg, nullptr);
+}
+
+// The diagonal kernel of inner panel t >= 1 FUSED with the in-block update of panel t-1: one launch instead of two on the
+// serial chain (diag -> TRSM -> update -> diag became [update tiles || diag] -> TRSM):
+//   workgroup 0        waits for the three quarter tiles of the update that are its block's lower triangle, then its LDL'
+//   workgroups 1..3    those three tiles, C read and written with agent-scope accesses (gemm_tile_64<.., SC1C>), then
+//                      one atomicAdd on the launch's `ready` counter
+//   the others         the remaining 64x64 tiles of C -= W L'.  The launch's 160 KB per workgroup limits them to one per CU;
+//                      they use it: all of K = 128 staged at once (gemm_tile_64_k128: one global round trip per tile)
+// WAIT = false is the timing experiment CIP_FUSE_DIAG=2 (workgroup 0 does not wait: wrong results).
+template <bool WAIT>
+__global__ __launch_bounds__(256) void k_ldlt_diag_upd(double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
+                                                        int *info, int col0, PivotSigns sg, unsigned *ready, GemmArgs g,
+                                                        CipBatch cb) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (blockIdx.x == 0) {
+        CIP_BATCH_GUARD(cb);
+        CIP_BO6(cb, Kb, xm_out, dvec, dinv, info, ready);
+        diag_body<WAIT>(sm, Kb, ld, xm_out, dvec, dinv, info, col0, sg, ready);
+        return;
+    }
+    bool live;
+    (void)gemm_batch_prologue(g, cb, live);
+    if (!live) return;
+    ready = cip_bo(ready, cb);
+    __builtin_amdgcn_s_setprio(3);
+    const int tm = g.M / SB;
+    const int b = (int)blockIdx.x;
+    if (b <= 3) {
+        // (0,0), (64,0), (64,64): the block's lower triangle, dispatched first
+        const long i0 = (b == 1) ? 0 : SB, j0 = (b == 3) ? SB : 0;
+        gemm_tile_64_k128<true>(g, sm, i0, j0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(ready, 1u);
+        return;
+    }
+    // the other tiles in column-major order, skipping t = 0, 1, tm, tm + 1 (the block's four quarter tiles; the
+    // strictly-upper one, t = tm, is never referenced)
+    const int tq = b - 4;
+    const int t = (tq < tm - 2) ? tq + 2 : tq + 4;
+    gemm_tile_64_k128<false>(g, sm, (long)(t % tm) * SB, (long)(t / tm) * SB);
 }
 
 // X = inv(L) for every 128x128 diagonal block of a factored matrix, one workgroup per block (they are
@@ -402,6 +478,8 @@ static std::once_flag g_attr_once;
 static hipError_t g_attr_err = hipSuccess;
 static void diag_attr_init(void) {
     hipError_t e = hipFuncSetAttribute((const void *)k_ldlt_diag128_v2, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ldlt_diag_upd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ldlt_diag_upd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_diag_inverse_batched, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_trsm_subst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TRSM_LDS_DOUBLES * sizeof(double)));
     g_attr_err = e;
@@ -415,6 +493,21 @@ int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *xm_out, doubl
                        PivotSigns sg) {
     if (cip_kernels_init()) return -3;
     cip_launch_b(k_ldlt_diag128_v2, dim3(1), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+// diag of a block + the in-block update `g` (C -= A B', plain accumulate form, M, N multiples of 64, M >= 128) whose first
+// 128x128 tile IS that block; `ready`: a zeroed device word of this launch's own
+int cip_launch_diag_upd(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
+                        PivotSigns sg, unsigned *ready, const GemmArgs &g) {
+    if (cip_kernels_init()) return -3;
+    const long nt = (long)(g.M / SB) * (g.N / SB) - 1;          // every tile but the block's strictly-upper quarter
+    static int nowait = -1;                     // CIP_FUSE_DIAG=2: timing experiment, workgroup 0 does not wait (wrong results)
+    if (nowait < 0) { const char *e = getenv("CIP_FUSE_DIAG"); nowait = (e && atoi(e) == 2) ? 1 : 0; }
+    if (nowait) cip_launch_b(k_ldlt_diag_upd<false>, dim3((unsigned)(1 + nt)), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv,
+                             info, col0, sg, ready, g);
+    else cip_launch_b(k_ldlt_diag_upd<true>, dim3((unsigned)(1 + nt)), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv,
+                      info, col0, sg, ready, g);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -106,7 +106,7 @@ size_t cip_ldlt_ws_bytes(int Npad) {
     }
     b += al256((size_t)Npad * 8) * 4;                    // dinv, dvec, tmp, ybuf
     b += al256(4 * 2 * (2 + 2 * nblk + (size_t)Npad / 8));  // sweep counters / flags (solve.hip)
-    b += al256(64);                                      // info
+    b += al256(64 + 4 * nblk);                           // info (16 ints) + one `ready` counter per 128-block (fused diag + update launches)
     b += al256(cip_la_ctrl_bytes(Npad));                 // look-ahead control block (gemm_f64.hip: LaCtrl + done[])
     return b;
 }
@@ -131,7 +131,7 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     ws->tmp = (double *)p;   p += al256((size_t)Npad * 8);
     ws->ybuf = (double *)p;  p += al256((size_t)Npad * 8);
     ws->sweep_ctr = (unsigned *)p; p += al256(4 * 2 * (2 + 2 * nblk + (size_t)Npad / 8));
-    ws->info = (int *)p;     p += al256(64);
+    ws->info = (int *)p;     p += al256(64 + 4 * nblk);
     ws->la_ctrl = (void *)p;
     ws->prof = nullptr;
     ws->signs = PivotSigns{-1, 0, 0};
@@ -141,6 +141,8 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
 // diag.hip
 int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
                        PivotSigns sg);
+int cip_launch_diag_upd(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
+                        PivotSigns sg, unsigned *ready, const GemmArgs &g);
 int cip_launch_diag_inverse(hipStream_t s, const double *K, long ld, int nblk, const double *xm_all, double *Linv,
                             double *LinvT);
 int cip_launch_trsm_subst(hipStream_t s, double *Ap, long ld, int rows, const double *L11, const double *xm,
@@ -149,21 +151,28 @@ int cip_launch_trsm_subst(hipStream_t s, double *Ap, long ld, int rows, const do
 // right-looking update inside the outer block: after inner panel t, the remaining panel columns of the block
 //   K[c0+128:, c0+128 : C0+wblk] -= W_t[c0+128:, :] * L_t[c0+128 : C0+wblk, :]'        (K = 128, wide and short:
 // many quarter tiles, one short k-loop -- the latency-critical shape; the left-looking form had K up to 384)
-static int update_rest_of_block(hipStream_t s, double *K, int Npad, long ld, double *Wb, int C0, int wblk, int t) {
+static bool rest_of_block_args(double *K, int Npad, long ld, double *Wb, int C0, int wblk, int t, GemmArgs &g) {
     const int c1 = C0 + (t + 1) * CIP_NB;            // first row / column still to be factored in this block
     const int ncols = C0 + wblk - c1;
-    if (ncols <= 0 || c1 >= Npad) return 0;
-    GemmArgs g = {};
+    if (ncols <= 0 || c1 >= Npad) return false;
+    g = GemmArgs{};
     g.A = Wb + c1 + (long)(t * CIP_NB) * Npad; g.lda = Npad;
     g.B = K + c1 + (long)(c1 - CIP_NB) * ld; g.ldb = ld;
     g.C = K + c1 + (long)c1 * ld; g.ldc = ld;
     g.M = Npad - c1; g.N = ncols; g.K = CIP_NB; g.alpha = -1.0; g.lower = 0;
+    return true;
+}
+static int update_rest_of_block(hipStream_t s, double *K, int Npad, long ld, double *Wb, int C0, int wblk, int t) {
+    GemmArgs g;
+    if (!rest_of_block_args(K, Npad, ld, Wb, C0, wblk, t, g)) return 0;
     return cip_launch_gemm(s, EPI_ACCUM, g);
 }
+// CIP_FUSE_DIAG=0: the unfused chain (diag -> TRSM -> update per panel), for A/B runs
+static int g_fuse_diag = -1;
 
 // one inner-panel sweep of an outer block: [strip update] -> diagonal kernel -> TRSM, for each 128 columns
 static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws, double *Wb, int C0,
-                               int wblk) {
+                               int wblk, bool alone = false) {
     int rc;
     const int T = wblk / CIP_NB;
     for (int t = 0; t < T; ++t) {
@@ -171,15 +180,25 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
         const int jb = c0 / CIP_NB;
         const int r = Npad - c0 - CIP_NB;
         // MFMA micro-blocked diagonal kernel + substitution TRSM (the block inverses the solves
-        // need are produced by one batched launch after the factorisation)
-        if ((rc = cip_launch_diag_v2(s, K + c0 + (long)c0 * ld, ld, ws.Xm + (size_t)jb * 2048, ws.dvec + c0,
-                                     ws.dinv + c0, ws.info, c0, ws.signs)))
+        // need are produced by one batched launch after the factorisation).  From the second panel of the block on, the
+        // diagonal kernel's launch also carries the previous panel's in-block update (diag.hip: k_ldlt_diag_upd).
+        GemmArgs gu;
+        if (g_fuse_diag < 0) { const char *e = getenv("CIP_FUSE_DIAG"); g_fuse_diag = (e && atoi(e) == 0) ? 0 : 1; }
+        // fused only when the chain has the chip to itself: a lock-step batch is throughput-bound and beside a look-ahead's
+        // bulk the fused launch's update tiles (160 KB of LDS per workgroup: one per CU) would queue on the few free CUs
+        const bool fuse = g_fuse_diag && alone && !cip_in_batch();
+        if (fuse && t > 0 && rest_of_block_args(K, Npad, ld, Wb, C0, wblk, t - 1, gu)) {
+            if ((rc = cip_launch_diag_upd(s, K + c0 + (long)c0 * ld, ld, ws.Xm + (size_t)jb * 2048, ws.dvec + c0, ws.dinv + c0,
+                                          ws.info, c0, ws.signs, (unsigned *)(ws.info + 16) + jb, gu)))
+                return rc;
+        } else if ((rc = cip_launch_diag_v2(s, K + c0 + (long)c0 * ld, ld, ws.Xm + (size_t)jb * 2048, ws.dvec + c0,
+                                            ws.dinv + c0, ws.info, c0, ws.signs)))
             return rc;
         if ((rc = cip_launch_trsm_subst(s, K + (c0 + CIP_NB) + (long)c0 * ld, ld, r, K + c0 + (long)c0 * ld,
                                         ws.Xm + (size_t)jb * 2048, ws.dinv + c0,
                                         Wb + (c0 + CIP_NB) + (long)(t * CIP_NB) * Npad, Npad)))
             return rc;
-        if ((rc = update_rest_of_block(s, K, Npad, ld, Wb, C0, wblk, t))) return rc;
+        if (!fuse && (rc = update_rest_of_block(s, K, Npad, ld, Wb, C0, wblk, t))) return rc;
     }
     return 0;
 }
@@ -377,7 +396,8 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
     const int NBO = g_nbo;
     int rc;
     std::call_once(g_la_once, lookahead_env);
-    if ((rc = zero_fill(s, ws.info, 64))) return rc;       // [0] bad pivot, [1] sweep bail-out, [2] dead pivot, [3] look-ahead scheduler
+    // [0] bad pivot, [1] sweep bail-out, [2] dead pivot, [3] look-ahead scheduler / fused-launch wait; from word 16: `ready` counters
+    if ((rc = zero_fill(s, ws.info, 64 + 4 * (size_t)(Npad / CIP_NB)))) return rc;
     bool la = g_lookahead == 1 && Npad >= g_la_min && Npad > 2 * NBO && NBO % 64 == 0;
     if (cip_tl_builder || cip_in_batch()) la = false;         // recording a hipGraph / a lock-step batch: the single-stream schedule
     if (g_lookahead == 3 && !cip_tl_builder && !cip_in_batch() && Npad >= 2 * g_la2_min && !ws.prof) {
@@ -434,7 +454,7 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
         // serial right-looking schedule: panels of the outer block, then ONE trailing update
         for (int C0 = 0; C0 < Npad; C0 += NBO) {
             const int wblk = (Npad - C0 < NBO) ? (Npad - C0) : NBO;
-            if ((rc = factor_outer_panels(s, K, Npad, ld, ws, ws.Wbuf, C0, wblk))) return rc;
+            if ((rc = factor_outer_panels(s, K, Npad, ld, ws, ws.Wbuf, C0, wblk, true))) return rc;
             const int r0 = C0 + wblk;
             if (r0 < Npad) {
                 GemmArgs g = {};
