@@ -26,7 +26,16 @@ python3 $R/tools/la_time.py 8192 01 > $OUT/lookahead_time.log 2>/dev/null
 rocprofv3 --kernel-trace --output-format csv -d $OUT/la -o la -- python3 $R/tools/la_time.py 8192 1 > /dev/null 2>&1
 python3 $R/tools/la_trace.py $OUT/la > $OUT/lookahead_trace_summary.txt 2>&1
 CIP_LA_DBG=64 python3 $R/tools/la_time.py 8192 1 > $OUT/lookahead_chain_only.log 2>/dev/null
-# config 5 on one GPU (the multi-GPU workload of bench.py)
-python3 $R/bench.py --workload c5 --steps 3 --warmup 1 > $OUT/bench_c5.json 2> /dev/null
-python3 $R/bench.py --workload c5 --steps 3 --warmup 1 --in-flight 8 > $OUT/bench_c5_inflight8.json 2> /dev/null
+# the opt-in two-stream look-ahead: timing (bit-identity checked in the same run) + overlap timeline
+python3 $R/tools/la2_time.py 8192 > $OUT/lookahead2_time.log 2>/dev/null
+CIP_LOOKAHEAD=3 rocprofv3 --kernel-trace --output-format csv -d $OUT/la2 -o la2 -- python3 $R/tools/la2_time.py 8192 > /dev/null 2>&1
+python3 $R/tools/la2_trace.py $OUT/la2 > $OUT/lookahead2_trace_summary.txt 2>&1
+# fused vs unfused panel chain (diag + in-block update in one launch)
+for f in 0 1; do echo "CIP_FUSE_DIAG=$f"; CIP_FUSE_DIAG=$f python3 $R/tools/la_time.py 8192 0 2>/dev/null | tail -1; done > $OUT/fused_chain_time.log
+# config 5 on one GPU (the multi-GPU workload of bench.py): lock-step (default) and the thread pool
+python3 $R/bench.py --workload c5 --steps 5 --warmup 1 > $OUT/bench_c5.json 2> /dev/null
+python3 $R/bench.py --workload c5 --batch-mode threads --steps 3 --warmup 1 > $OUT/bench_c5_threads.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5ls -o c5ls -- python3 $R/tools/lockstep_time.py 64 2048 1 lockstep > $OUT/c5_lockstep_time.log 2>&1
+cp $OUT/c5ls/c5ls_kernel_stats.csv $OUT/c5_lockstep_kernel_stats.csv
+for c in 8 16 32 64; do CIP_LOCKSTEP_TIMING=1 python3 $R/tools/lockstep_time.py $c 2048 2 both 2>&1 | tail -5; done > $OUT/c5_shard_sizes.log
 ls -la $OUT
