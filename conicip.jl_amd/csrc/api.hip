@@ -954,5 +954,6 @@ extern "C" int cip_profile_lookahead(cip_handle *h, double *out4) {
     return rc;
 }
 extern "C" int cip_set_ldlt_lookahead(int on) { return cip_ldlt_set_lookahead(on); }
+extern "C" int cip_set_ldlt_fused_chain(int on) { return cip_ldlt_set_fused_chain(on); }
 extern "C" int cip_set_solve_block_max(int b) { return cip_solve_block_max_set(b); }
 extern "C" int cip_set_ldlt_outer_block(int nbo) { cip_ldlt_set_outer_block(nbo); return cip_ldlt_outer_block(); }

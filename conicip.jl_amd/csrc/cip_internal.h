@@ -139,6 +139,7 @@ struct LdltWorkspace {        // carved out of one device allocation
 };
 int cip_kernels_init(void);                // diag.hip: one-time kernel attributes (before any hipGraph capture)
 int cip_ldlt_set_lookahead(int on);
+int cip_ldlt_set_fused_chain(int on);     // 1 (default): diag + previous in-block update in one launch; returns the previous setting
 int cip_solve_block(int Npad);
 int cip_solve_block_max_set(int b);              // 128 | 256 | 512 | 1024 (0: query); returns the previous limit
 extern thread_local int cip_tl_solve_block_max;  // > 0: this thread's limit for handles it creates

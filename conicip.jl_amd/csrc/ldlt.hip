@@ -167,8 +167,10 @@ static int update_rest_of_block(hipStream_t s, double *K, int Npad, long ld, dou
     if (!rest_of_block_args(K, Npad, ld, Wb, C0, wblk, t, g)) return 0;
     return cip_launch_gemm(s, EPI_ACCUM, g);
 }
-// CIP_FUSE_DIAG=0: the unfused chain (diag -> TRSM -> update per panel), for A/B runs
+// CIP_FUSE_DIAG=0 / cip_set_ldlt_fused_chain(0): the unfused chain (diag -> TRSM -> update per panel), for A/B runs and tests
 static int g_fuse_diag = -1;
+static void fuse_env(void) { if (g_fuse_diag < 0) { const char *e = getenv("CIP_FUSE_DIAG"); g_fuse_diag = (e && atoi(e) == 0) ? 0 : 1; } }
+int cip_ldlt_set_fused_chain(int on) { fuse_env(); const int prev = g_fuse_diag; if (on == 0 || on == 1) g_fuse_diag = on; return prev; }
 
 // one inner-panel sweep of an outer block: [strip update] -> diagonal kernel -> TRSM, for each 128 columns
 static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws, double *Wb, int C0,
@@ -183,7 +185,7 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
         // need are produced by one batched launch after the factorisation).  From the second panel of the block on, the
         // diagonal kernel's launch also carries the previous panel's in-block update (diag.hip: k_ldlt_diag_upd).
         GemmArgs gu;
-        if (g_fuse_diag < 0) { const char *e = getenv("CIP_FUSE_DIAG"); g_fuse_diag = (e && atoi(e) == 0) ? 0 : 1; }
+        fuse_env();
         // fused only when the chain has the chip to itself: a lock-step batch is throughput-bound and beside a look-ahead's
         // bulk the fused launch's update tiles (160 KB of LDS per workgroup: one per CU) would queue on the few free CUs
         const bool fuse = g_fuse_diag && alone && !cip_in_batch();

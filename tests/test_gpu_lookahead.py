@@ -81,6 +81,39 @@ def test_two_stream_lookahead_bitwise_equals_serial(lib, N, quasi):
         assert torch.equal(torch.tril(got.t()), torch.tril(ref.t())), "repetition %d differs from the serial schedule" % rep
 
 
+@pytest.mark.parametrize("N,quasi", [(1024, 0), (2048, 0), (4608, 512), (8192, 0)])
+def test_fused_panel_chain_bitwise_equals_unfused(lib, N, quasi):
+    """From the second panel of an outer block on, the diagonal kernel's launch carries the previous panel's in-block
+    update and waits, INSIDE the launch, for the three tiles that are its own block (diag.hip: k_ldlt_diag_upd).  Same
+    arithmetic in the same order as the three-launch chain: identical bits -- also repeated under a concurrent 1-GiB copy
+    load, which is when a missing fence or a stale line would show."""
+    from cipkkt import _lib as L
+    nbytes = C.c_size_t()
+    L.check(lib.cip_ldlt_workspace_bytes(N, C.byref(nbytes)))
+    ws = torch.zeros(nbytes.value // 8 + 8, dtype=torch.float64, device="cuda")
+    K0 = _spd(N, N + quasi + 11, quasi)
+    prev = lib.cip_set_ldlt_fused_chain(0)
+    try:
+        ref = _factor(lib, K0, N, 0, ws)
+        lib.cip_set_ldlt_fused_chain(1)
+        for rep in range(3):
+            got = _factor(lib, K0, N, 0, ws)
+            assert torch.equal(torch.tril(got.t()), torch.tril(ref.t())), "repetition %d differs from the unfused chain" % rep
+        side = torch.cuda.Stream()
+        a = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+        b = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+        for rep in range(3):
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    b.copy_(a, non_blocking=True)
+                    a.copy_(b, non_blocking=True)
+            got = _factor(lib, K0, N, 0, ws)
+            assert torch.equal(torch.tril(got.t()), torch.tril(ref.t())), "under load, repetition %d differs" % rep
+        side.synchronize()
+    finally:
+        lib.cip_set_ldlt_fused_chain(prev)
+
+
 def test_lookahead_under_memory_streaming_load(lib):
     """The hand-offs must survive an uneven, L1-warm, bandwidth-loaded chip: a second stream copies 1 GiB buffers
     back and forth while the factorisation runs."""
