@@ -923,7 +923,7 @@ extern "C" int cip_get_kkt_matrix(cip_handle *h, double *K_host) {
 extern "C" int cip_stats(cip_handle *h, double *out8) {
     if (!h || !out8) return CIP_E_INVALID;
     out8[0] = h->n_factor; out8[1] = h->n_solve; out8[2] = h->ms_assemble; out8[3] = h->ms_ldlt; out8[4] = h->flops_ldlt;
-    out8[5] = cip_ldlt_outer_block(); out8[6] = h->N; out8[7] = h->Npad;
+    out8[5] = cip_ldlt_outer_block_for(h->Npad); out8[6] = h->N; out8[7] = h->Npad;
     return 0;
 }
 extern "C" int cip_set_timing(cip_handle *h, int enabled) {

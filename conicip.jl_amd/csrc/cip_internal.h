@@ -147,7 +147,8 @@ size_t cip_ldlt_ws_bytes(int Npad);
 void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws);
 int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws);
 int cip_ldlt_solve(hipStream_t s, const double *K, int Npad, long ld, const LdltWorkspace &ws, double *rhs);
-int cip_ldlt_outer_block(void);          // NBO currently in use
+int cip_ldlt_outer_block(void);          // the knob: 0 = automatic
+int cip_ldlt_outer_block_for(int Npad);  // NBO a factorisation of this order uses
 void cip_ldlt_set_outer_block(int nbo);
 
 // ---------------------------------------------------------------- cones (cones.hip)

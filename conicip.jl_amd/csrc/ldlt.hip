@@ -19,10 +19,21 @@
 #include <stdlib.h>
 #include <string.h>
 
-static int g_nbo = 512;       // measured best at n = 8192 (A/B in one session: 256/384/512 -> 107.7/107.0/109.1 KKT solves/s)
+// Outer block.  0 = automatic: 768 from order 4096 on when the panel chain is fused (the in-block updates, K = 128 tiles
+// that a wider block has more of, then run beside the diagonal kernels and a trailing update with K = 768 passes over C
+// less often: same-session A/B at n = 8192, 512 / 768 / 1024 -> 130.6-132.0 / 134.5 / 133.9 KKT solves/s), else 512 (unfused
+// chain, round 1: 256 / 384 / 512 -> 107.7 / 107.0 / 109.1; 1024 -> 125 against 128).
+static int g_nbo = 0;
+static int g_fuse_diag = -1;
+static void fuse_env(void) { if (g_fuse_diag < 0) { const char *e = getenv("CIP_FUSE_DIAG"); g_fuse_diag = (e && atoi(e) == 0) ? 0 : 1; } }
+int cip_ldlt_outer_block_for(int Npad) {
+    if (g_nbo > 0) return g_nbo;
+    fuse_env();
+    return (Npad >= 4096 && g_fuse_diag && cip_tl_bz.B <= 1) ? 768 : 512;
+}
 int cip_ldlt_outer_block(void) { return g_nbo; }
 void cip_ldlt_set_outer_block(int nbo) {
-    if (nbo >= CIP_NB && nbo % CIP_NB == 0 && nbo <= 1024) g_nbo = nbo;
+    if (nbo == 0 || (nbo >= CIP_NB && nbo % CIP_NB == 0 && nbo <= 1024)) g_nbo = nbo;
 }
 #define CIP_NBO_MAX 1024
 
@@ -168,8 +179,6 @@ static int update_rest_of_block(hipStream_t s, double *K, int Npad, long ld, dou
     return cip_launch_gemm(s, EPI_ACCUM, g);
 }
 // CIP_FUSE_DIAG=0 / cip_set_ldlt_fused_chain(0): the unfused chain (diag -> TRSM -> update per panel), for A/B runs and tests
-static int g_fuse_diag = -1;
-static void fuse_env(void) { if (g_fuse_diag < 0) { const char *e = getenv("CIP_FUSE_DIAG"); g_fuse_diag = (e && atoi(e) == 0) ? 0 : 1; } }
 int cip_ldlt_set_fused_chain(int on) { fuse_env(); const int prev = g_fuse_diag; if (on == 0 || on == 1) g_fuse_diag = on; return prev; }
 
 // one inner-panel sweep of an outer block: [strip update] -> diagonal kernel -> TRSM, for each 128 columns
@@ -395,7 +404,7 @@ static int build_solve_blocks(hipStream_t s, double *K, int Npad, long ld, const
 
 int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws) {
     if (Npad % CIP_NB) { cip_set_error("ldlt: N must be a multiple of 128"); return -1; }
-    const int NBO = g_nbo;
+    const int NBO = cip_ldlt_outer_block_for(Npad);
     int rc;
     std::call_once(g_la_once, lookahead_env);
     // [0] bad pivot, [1] sweep bail-out, [2] dead pivot, [3] look-ahead scheduler / fused-launch wait; from word 16: `ready` counters
