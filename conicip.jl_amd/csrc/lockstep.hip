@@ -25,9 +25,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
-#include <cstring>
 #include <mutex>
-#include <string>
 #include <vector>
 
 using namespace cipdrv;
@@ -236,9 +234,10 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
         for (int z = 0; z < B; ++z) if ((cip_tl_bz.mask >> z) & 1ull) ++n_factor[z];
         return 0;
     };
-    // pivot flags of the last factorisation -> problems that met a bad pivot leave the group.  Must be called with the
-    // mask the factorisation ran under, after something has drained the stream (or it drains it itself).
-    auto gather_info = [&]() -> int {       // enqueue only
+    // pivot flags of the last factorisation: gather_info enqueues their copy into the gather buffer (launched under the mask
+    // the factorisation ran under; the words then ride on the next read-back of that buffer, normally the dots'), and
+    // eject_bad_pivots takes the problems that met a bad pivot out of the group (read_back: fetch the buffer itself)
+    auto gather_info = [&]() -> int {
         cip_launch_b(k_gather_info, dim3(1), dim3(64), 0, s, (const int *)h->ws.info, G.gather_dev);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
