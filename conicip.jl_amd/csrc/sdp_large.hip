@@ -534,10 +534,186 @@ static int lg_set_attr(const void *fn, size_t bytes) {
     CIP_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return 0;
 }
+// ---- Householder tridiagonalisation of a symmetric matrix of order r <= 256 by ONE workgroup, the matrix in REGISTERS.
+// The cooperative kernel above pays a grid barrier and two coherent global round trips per column (5.7 us x 255 columns
+// at r = 256: 76 % of a max-step).  A CU's register file holds what its LDS cannot: 512 threads (two waves per SIMD: 256
+// registers each) as a 32 x 16 grid, thread (tr, tc) owning the entries (i, j) with i = tr (mod 32), j = tc (mod 16) of the
+// blocks on or below the block diagonal -- 72 of the 128 blocks of 32 x 16, the 32 x 32 diagonal blocks whole -- in 72
+// doubles.  A Householder step is then
+//   column k -> LDS, norm, v (zero outside the active rows), p = A v as 8 row + 16 column partial sums per thread reduced
+//   through two LDS images (row parts over tc, column parts over tr), w = p - (beta v'p / 2) v, rank-2 update from LDS
+//   copies of v and w (zero-padded: finished rows and columns take no part, no index tests in the inner loops)
+// with workgroup barriers only.  Same reflectors as k_lg_tridiag; d and e go to the same Sturm kernel.
+// Measured at r = 256: 1.17 ms against 1.45 ms for the cooperative kernel (max-step 1.45 against 1.75 ms).  Phases switched off
+// one at a time: barriers + norm + scalars 1.3 us per column, rank-2 update 1.4, A v 1.0, the reduction of its partial sums 0.7,
+// column extraction 0.15 -- the arithmetic of a column (2.6e5 flop) is now one CU's (0.85 + 0.43 us at its fp64 rate), which
+// is the floor of this form.  (A 1024-thread version with 36 doubles per thread was built first: at four waves per SIMD the
+// budget is 128 registers, 23 of the 36 spilled, 22 us per column; and `break` / `continue` inside the column loop made the
+// compiler spill the register matrix around the exits even at 256 registers: 16 us per column.)
+#define T1_LDS_DOUBLES (256 * 17 + 32 * 256 + 4 * 256 + 64)     // row parts, column parts, 2 column buffers, v, p, reduction scratch
+template <int KB>
+__device__ __forceinline__ void t1_extract(const double (&a)[8][16], double *xs, int tr) {      // column block KB (16 wide)
+#pragma unroll
+    for (int ai = KB / 2; ai < 8; ++ai) xs[32 * ai + tr] = a[ai][KB];
+}
+__global__ __launch_bounds__(512) void k_lg_tridiag1(const double *M, int ldm, const double *dscale, int r, double *dg, double *of) {
+    extern __shared__ double sh[];
+    double *rowp = sh, *colp = sh + 256 * 17;                 // partial sums: [i][tc] (pitch 17) and [tr][j]
+    double *xs0 = colp + 32 * 256, *vs = xs0 + 512, *red = vs + 512;
+    const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
+    double a[8][16];                                           // blocks bj <= 2 ai + 1 only
+#pragma unroll
+    for (int ai = 0; ai < 8; ++ai)
+#pragma unroll
+        for (int bj = 0; bj < 16; ++bj) {
+            if (bj <= 2 * ai + 1) {
+                a[ai][bj] = 0.0;
+                const int i = 32 * ai + tr, j = 16 * bj + tc;
+                if (i < r && j < r) {
+                    double x = 0.5 * (M[i + (long)j * ldm] + M[j + (long)i * ldm]);
+                    if (dscale) x *= rsqrt(dscale[i]) * rsqrt(dscale[j]);
+                    a[ai][bj] = x;
+                }
+            }
+        }
+    double *ps = vs + 256;                                     // p, read back by everybody
+    // columns 0 .. r-2 (the last one only hands out d and e: its "reflector" is 1 x 1).  Five barriers per column; the column
+    // buffer alternates, so the next column's extraction may start while slower waves still read this one's
+    for (int k = 0; k + 1 < r; ++k) {
+        const int kb = k >> 4, kc = k & 15;
+        double *xs = xs0 + (k & 1) * 256;
+        // ---- column k -> xs (rows of the stored blocks: everything below the diagonal, and d_k); readers mask by index
+        if (tc == kc) {
+            switch (kb) {
+                case 0: t1_extract<0>(a, xs, tr); break;
+                case 1: t1_extract<1>(a, xs, tr); break;
+                case 2: t1_extract<2>(a, xs, tr); break;
+                case 3: t1_extract<3>(a, xs, tr); break;
+                case 4: t1_extract<4>(a, xs, tr); break;
+                case 5: t1_extract<5>(a, xs, tr); break;
+                case 6: t1_extract<6>(a, xs, tr); break;
+                case 7: t1_extract<7>(a, xs, tr); break;
+                case 8: t1_extract<8>(a, xs, tr); break;
+                case 9: t1_extract<9>(a, xs, tr); break;
+                case 10: t1_extract<10>(a, xs, tr); break;
+                case 11: t1_extract<11>(a, xs, tr); break;
+                case 12: t1_extract<12>(a, xs, tr); break;
+                case 13: t1_extract<13>(a, xs, tr); break;
+                case 14: t1_extract<14>(a, xs, tr); break;
+                default: t1_extract<15>(a, xs, tr); break;
+            }
+        }
+        __syncthreads();                                                                        // (1)
+        if (tid == 0) dg[k] = xs[k];
+        // ---- sigma = |x(k+1:)|^2
+        double part = 0.0;
+        if (tid < 256 && tid > k && tid < r) part = xs[tid] * xs[tid];
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (tid < 256 && (tid & 63) == 0) red[(k & 1) * 4 + (tid >> 6)] = part;
+        __syncthreads();                                                                        // (2)
+        const double *rs = red + (k & 1) * 4;
+        const double sigma = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+        const double x0 = xs[k + 1];
+        // flat: already tridiagonal in this column (always so for the last one); the reflector is then the identity:
+        // beta = 0 makes p, w and the update vanish -- one code path, no divergent loop exits around the register matrix
+        const bool flat = !(sigma - x0 * x0 > 0.0);
+        const double alpha = flat ? x0 : -copysign(sqrt(sigma), x0);
+        const double beta = flat ? 0.0 : 1.0 / (sigma - x0 * alpha);        // 2 / |v|^2 with v = x - alpha e1
+        if (tid == 0) of[k] = alpha;
+        if (tid < 256) vs[tid] = (tid > k && tid < r && !flat) ? (tid == k + 1 ? x0 - alpha : xs[tid]) : 0.0;
+        __syncthreads();                                                                        // (3)
+        // ---- p = A v: row parts (all stored blocks) and column parts (blocks strictly below the 32 x 32 diagonal blocks)
+        {
+            double t16[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t16[q] = vs[16 * q + tc];
+#pragma unroll
+            for (int ai = 0; ai < 8; ++ai) {
+                double pr = 0.0;
+#pragma unroll
+                for (int bj = 0; bj <= 2 * ai + 1; ++bj) pr = fma(a[ai][bj], t16[bj], pr);
+                rowp[(32 * ai + tr) * 17 + tc] = pr;
+            }
+            double t8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t8[q] = vs[32 * q + tr];
+#pragma unroll
+            for (int bj = 0; bj < 16; ++bj) {
+                double pc = 0.0;
+#pragma unroll
+                for (int ai = bj / 2 + 1; ai < 8; ++ai) pc = fma(a[ai][bj], t8[ai], pc);
+                colp[tr * 256 + 16 * bj + tc] = pc;
+            }
+        }
+        __syncthreads();                                                                        // (4)
+        {
+            double pj = 0.0;
+            if (tid < 256) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) s0 += rowp[tid * 17 + q];
+#pragma unroll 8
+                for (int q = 0; q < 32; ++q) s1 += colp[q * 256 + tid];
+                pj = (tid > k && tid < r) ? beta * (s0 + s1) : 0.0;
+                ps[tid] = pj;
+            }
+            part = (tid < 256) ? pj * vs[tid] : 0.0;
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+            if (tid < 256 && (tid & 63) == 0) red[8 + (k & 1) * 4 + (tid >> 6)] = part;
+        }
+        __syncthreads();                                                                        // (5)
+        const double *rk = red + 8 + (k & 1) * 4;
+        const double kk = 0.5 * beta * ((rk[0] + rk[1]) + (rk[2] + rk[3]));
+        // ---- A -= v w' + w v',  w = p - kk v
+        {
+            double t16[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const int j = 16 * q + tc; t16[q] = ps[j] - kk * vs[j]; }
+#pragma unroll
+            for (int ai = 0; ai < 8; ++ai) {                    // - v w'
+                const double vi = vs[32 * ai + tr];
+#pragma unroll
+                for (int bj = 0; bj <= 2 * ai + 1; ++bj) a[ai][bj] = fma(-vi, t16[bj], a[ai][bj]);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t16[q] = vs[16 * q + tc];
+#pragma unroll
+            for (int ai = 0; ai < 8; ++ai) {                    // - w v'
+                const int i = 32 * ai + tr;
+                const double wi = ps[i] - kk * vs[i];
+#pragma unroll
+                for (int bj = 0; bj <= 2 * ai + 1; ++bj) a[ai][bj] = fma(-wi, t16[bj], a[ai][bj]);
+            }
+        }
+        // (no barrier here: the next column's extraction writes the OTHER column buffer; vs, ps and red are next written
+        //  behind barriers (2), (4) and (1) of the next column, which every reader of this column's values has passed by then)
+    }
+    __syncthreads();
+    // the last diagonal entry
+    if (tr == ((r - 1) & 31) && tc == ((r - 1) & 15)) {
+        double dlast = 0.0;
+#pragma unroll
+        for (int ai = 0; ai < 8; ++ai)
+#pragma unroll
+            for (int bj = 2 * ai; bj <= 2 * ai + 1; ++bj)
+                if (ai == ((r - 1) >> 5) && bj == ((r - 1) >> 4)) dlast = a[ai][bj];
+        dg[r - 1] = dlast; of[r - 1] = 0.0;
+    }
+}
+
 static int lg_tridiag(hipStream_t s, LargeWs *w, const double *M, const double *dscale, int r) {
+    int rc;
+    static int one_wg = -1;                                   // CIP_LG_TRIDIAG1=0: the cooperative kernel at every order (A/B runs)
+    if (one_wg < 0) { const char *e = getenv("CIP_LG_TRIDIAG1"); one_wg = (e && atoi(e) == 0) ? 0 : 1; }
+    if (one_wg && r <= 256) {
+        const size_t shm1 = T1_LDS_DOUBLES * sizeof(double);
+        if ((rc = lg_set_attr((const void *)k_lg_tridiag1, shm1))) return rc;
+        hipLaunchKernelGGL(k_lg_tridiag1, dim3(1), dim3(512), shm1, s, M, w->rp, dscale, r, w->vec + 1 * w->rp, w->vec + 2 * w->rp);
+        CIP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const int nwg = (r + LG_SLAB - 1) / LG_SLAB;
     const size_t shm = ((size_t)LG_SLAB * (r | 1) + 3 * (size_t)r + 64) * sizeof(double);
-    int rc;
     if ((rc = lg_set_attr((const void *)k_lg_tridiag, shm))) return rc;
     CIP_HIP_CHECK(hipMemsetAsync(w->ctr, 0, 1024, s));
     double *dg = w->vec + 1 * w->rp, *of = w->vec + 2 * w->rp, *xbuf = w->vec + 3 * w->rp, *pbuf = w->vec + 5 * w->rp;   // 2 x rp each
