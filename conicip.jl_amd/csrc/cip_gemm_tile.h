@@ -165,6 +165,14 @@ __device__ __forceinline__ void gemm_tile_64_k128(const GemmArgs &g, double *lds
     const double *Ap = g.A + i0 + 2 * rp;
     const double *Bp = g.B + j0 + 2 * rp;
     double *la = lds, *lb = lds + 128 * SB;                     // [k][row], 128 x 64 each
+    // the C tile is fetched FIRST, beside the operands: nobody else writes it in this launch and earlier launches are
+    // complete, so plain 16-byte loads do; only the stores of an SC1C tile must be write-through (its reader is another CU)
+    const long rowo = i0 + wm * 32 + 2 * l15;
+    v2d cpre[2][4];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cpre[tj][q] = *(const v2d *)(g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * q) + tj) * g.ldc);
     {
         v2d ra[16], rb[16];
 #pragma unroll
@@ -196,36 +204,18 @@ __device__ __forceinline__ void gemm_tile_64_k128(const GemmArgs &g, double *lds
         acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.y, fi.x, acc[0][1], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.y, fi.y, acc[1][1], 0, 0, 0);
     }
-    const long rowo = i0 + wm * 32 + 2 * l15;
-    if (SC1C) {
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int qh = 0; qh < 2; ++qh) {
-                double cv[2][2];
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq) {
-                    const double *cp = g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * (2 * qh + qq)) + tj) * g.ldc;
-                    cv[qq][0] = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    cv[qq][1] = __hip_atomic_load(cp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq) {
-                    const int q = 2 * qh + qq;
-                    double *cp = g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * q) + tj) * g.ldc;
-                    __hip_atomic_store(cp, cv[qq][0] + g.alpha * acc[0][tj][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(cp + 1, cv[qq][1] + g.alpha * acc[1][tj][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        return;
-    }
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             double *cp = g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * q) + tj) * g.ldc;
-            v2d c = *(v2d *)cp;
+            v2d c = cpre[tj][q];
             c += g.alpha * (v2d){acc[0][tj][q], acc[1][tj][q]};
-            *(v2d *)cp = c;
+            if (SC1C) {
+                __hip_atomic_store(cp, c.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cp + 1, c.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                *(v2d *)cp = c;
+            }
         }
 }
