@@ -242,17 +242,24 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        double t[64];
+        // 16-byte loads that bypass the non-coherent caches (buffer load with the sc1 policy bit = agent scope)
+        typedef int v4i_t __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)Kb, 0, 0x7fffffff, 0x00020000);
+        v4i_t t[32];
 #pragma unroll
-        for (int q = 0; q < 64; ++q) {
-            const int e = q * 256 + tid;                         // element: row e & 127, column e >> 7
-            t[q] = __hip_atomic_load(Kb + (e & 127) + (long)(e >> 7) * ld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < 32; ++q) {
+            const int e = q * 256 + tid;                         // pair index: rows 2*(e&63), +1 ; column e>>6
+            const long off = (2 * (e & 63) + (long)(e >> 6) * ld) * 8;
+            t[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);
         }
 #pragma unroll
-        for (int q = 0; q < 64; ++q) {
+        for (int q = 0; q < 32; ++q) {
             const int e = q * 256 + tid;
-            const int i = e & 127, j = e >> 7;
-            a[i + j * DP] = (i < j) ? 0.0 : t[q];                // strictly upper part -> 0
+            const int i = 2 * (e & 63), j = e >> 6;
+            v2d v = __builtin_bit_cast(v2d, t[q]);
+            if (i < j) v.x = 0.0;                                // strictly upper part -> 0
+            if (i + 1 < j) v.y = 0.0;
+            *(v2d *)(a + i + j * DP) = v;
         }
     } else if (!(DIAG_SKIP & 16)) diag_load_block(a, Kb, ld, tid);
     __syncthreads();
