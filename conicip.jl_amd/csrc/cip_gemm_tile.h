@@ -212,8 +212,10 @@ __device__ __forceinline__ void gemm_tile_64_k128(const GemmArgs &g, double *lds
             v2d c = cpre[tj][q];
             c += g.alpha * (v2d){acc[0][tj][q], acc[1][tj][q]};
             if (SC1C) {
-                __hip_atomic_store(cp, c.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(cp + 1, c.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // one 16-byte write-through store (buffer store with the sc1 policy bit = agent scope)
+                typedef int v4i_t __attribute__((ext_vector_type(4)));
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)g.C, 0, 0x7fffffff, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, c), rs, (int)((cp - g.C) * 8), 0, 16);
             } else {
                 *(v2d *)cp = c;
             }
