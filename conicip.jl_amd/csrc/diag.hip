@@ -82,18 +82,28 @@ __device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int l
 #pragma unroll
     for (int j = 0; j < ((DIAG_SKIP & 8) ? 0 : 16); ++j) {
         const int gj = j & 3, qj = j >> 2;
+        // every cross-lane operand of the step is requested before any of them is used: ONE LDS round trip per pivot (the
+        // first version interleaved permutes, waits and predicated updates: three to four dependent round trips), and the
+        // updates are selects, not branches
         const double d = rlane(u[qj], 16 * gj + j);
-        const double di = fast_rcp(d);
         const double wi = bperm_d(u[qj], addr_r + 64 * gj);    // a[i][j], own row
         const double xj = bperm_d(x[qj], addr_r + 64 * gj);    // X[j][cc], own column
+        double cjv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)                            // a[g+4q][j] where some lane group still has column g+4q > j
+            cjv[q] = (4 * q + 3 > j) ? bperm_d(u[qj], addr_c[q] + 64 * gj) : 0.0;
+        const double di = fast_rcp(d);
         const double ti = wi * di;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (4 * q + 3 > j) {                               // some lane group still has column g+4q > j
-                const double cj = bperm_d(u[qj], addr_c[q] + 64 * gj);           // a[g+4q][j]
-                if (g + 4 * q > j) {
-                    u[q] -= ti * cj;
-                    x[q] -= (cj * di) * xj;
+            if (4 * q + 3 > j) {
+                const double nu = u[q] - ti * cjv[q];
+                const double nx = x[q] - (cjv[q] * di) * xj;
+                if (4 * q > j) { u[q] = nu; x[q] = nx; }       // every lane group's column g + 4q is beyond j (known at compile time)
+                else {                                          // the one register whose columns straddle j: per-lane select
+                    const bool act = g + 4 * q > j;
+                    u[q] = act ? nu : u[q];
+                    x[q] = act ? nx : x[q];
                 }
             }
         }
