@@ -162,3 +162,33 @@ def test_config5_reduced_lockstep_matches_threads():
     lock = _solve(prs, "lockstep")
     _assert_identical(lock, one)
     assert all(s.status == "Optimal" for s in lock)
+
+
+def test_config5_all_64_problems_lockstep_matches_threads():
+    """BASELINE config 5 at its stated size: 64 x n = 2048, one full lock-step group, against the thread pool bit for bit"""
+    from cipkkt.workloads import c5_batch
+    prs = c5_batch(count=64, n=2048, seed=4000, device=torch.device("cuda:0"))
+    one = _solve(prs, "threads", in_flight=8)
+    lock = _solve(prs, "lockstep")
+    _assert_identical(lock, one)
+    assert all(s.status == "Optimal" for s in lock)
+    assert sum(s.n_factor for s in lock) == 627                 # the count bench.py divides by
+
+
+def test_lockstep_against_the_oracle():
+    """not only against the product's own one-problem loop: a lock-step group of mixed-cone problems against the numpy
+    restatement of the reference (same status, iteration count, factorisations; iterates to 1e-6)"""
+    from oracle.conicip import conicIP as oracle_conicIP
+    from oracle.kktsolvers import kktsolver_2x2, pivot
+    prs, refs = [], []
+    for seed in range(5):
+        Q, c, A, b, cone_dims, G, d, _ = P.random_mixed(n=30, nq=2, kq=5, p=3, seed=700 + seed)
+        prs.append(dict(Q=Q, c=c, A=A, b=b, cone_dims=cone_dims, G=G, d=d, kwargs={}))
+        refs.append(oracle_conicIP(Q, c, A, b, cone_dims, G, d, kktsolver=pivot(kktsolver_2x2)))
+    lock = _solve(prs, "lockstep")
+    for got, ref in zip(lock, refs):
+        assert got.status == ref.status == "Optimal"
+        assert got.Iter == ref.Iter
+        for f in ("y", "w", "v"):
+            a, bb = getattr(got, f), np.asarray(getattr(ref, f)).reshape(-1)
+            assert np.linalg.norm(a - bb) <= 1e-6 * (1.0 + np.linalg.norm(bb)), f
