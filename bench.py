@@ -178,6 +178,36 @@ def pmc_traffic_per_launch():
         return None
 
 
+def pmc_solve_traffic(N):
+    """HBM-side bytes of ONE solve4x4 from the committed PMC passes: the k_gemv_t dispatches of the triangular sweeps
+    (1024-row column-dot gemvs; the Q gemvs of the loop have 8192 rows and a larger grid), 2*FETCH_SIZE + WRITE_SIZE as for
+    the trailing update.  A solve has 2 * (N/1024 + 1) dispatches of the 1024-column grid.  None when absent / other N."""
+    import csv
+    try:
+        if N % 1024:
+            return None
+        pdir = next(d for d in (os.path.join(ROOT, "profiles", r) for r in ("r2", "r1"))
+                    if os.path.exists(os.path.join(d, "final_pmc_fetch.csv")))
+        small, big = 256 * 256, 256 * ((N - 1024) // 4)
+
+        def load(name, counter):
+            tot, nsmall = 0.0, 0
+            with open(os.path.join(pdir, name)) as f:
+                for r in csv.DictReader(f):
+                    if r["Counter_Name"] == counter and r["Kernel"].startswith("k_gemv_t") and int(r["Grid_Size"]) <= big:
+                        tot += float(r["Counter_Value"])
+                        nsmall += int(r["Grid_Size"]) == small
+            return tot, nsmall
+        fe, n1 = load("final_pmc_fetch.csv", "FETCH_SIZE")
+        wr, n2 = load("final_pmc_write.csv", "WRITE_SIZE")
+        per = 2 * (N // 1024 + 1)
+        if n1 == 0 or n1 != n2 or n1 % per:
+            return None
+        return (2.0 * fe + wr) * 1024.0 / (n1 // per)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -380,7 +410,7 @@ def main():
                                "achieved": (8.0 * N * (N + 1) + 16.0 * N * min(1024, ks.Npad)) / (solve_ms * 1e-3) / 1e9,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": (8.0 * N * (N + 1) + 16.0 * N * min(1024, ks.Npad)) / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "traffic": None,
+                               "traffic": pmc_solve_traffic(ks.Npad),
                                "note": "algorithmic bytes of one solve = L read once per sweep (8 N (N+1)) + the 1024-wide block "
                                        "inverses (16 N Bs); time = whole cip_solve4x4 call (cone division, A'/A products, "
                                        "two sweeps), host-timed average of 5"},

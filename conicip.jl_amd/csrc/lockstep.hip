@@ -19,8 +19,8 @@
 // factorisation meets a bad pivot (it would switch to the regularised factorisation: LPs, singular Q with free
 // variables) is taken out of the lock-step group and solved afterwards by cip_conicip on its own handle.
 //
-// Not supported in lock-step (the caller falls back to the thread pool of batch.hip): S cones, problems of differing
-// shape.
+// Not supported in lock-step (the caller falls back to the thread pool of batch.hip): S cones of order >= 133 (their
+// chip-wide kernels own one workspace), problems of differing shape.
 #include "cip_driver.h"
 #include <chrono>
 #include <cstdio>
@@ -151,9 +151,9 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
         cip_handle *probe = nullptr;
         if ((rc = cip_create_ex(&probs[0], &probe))) return rc;
         slab = probe->alloc_bytes + ((cip_driver_bytes(probe) + 255) & ~(size_t)255);
-        const bool has_S = probe->cs.has_S != 0;
+        const bool large_S = probe->cs.nlarge > 0;
         cip_destroy(probe);
-        if (has_S) { cip_set_error("lock-step batch: S cones are not supported"); return CIP_E_UNSUPPORTED; }
+        if (large_S) { cip_set_error("lock-step batch: S cones of order >= %d are not supported", CIP_LARGE_S_MIN); return CIP_E_UNSUPPORTED; }
         std::lock_guard<std::mutex> lk(g_cache.mu);
         g_cache.sig = sig; g_cache.slab = slab;
     }
@@ -452,8 +452,11 @@ extern "C" int cip_conicip_lockstep(int count, const cip_problem *probs, const d
     if ((probs[0].m > 0 && (!b || !v)) || (probs[0].p > 0 && (!d || !w))) { cip_set_error("cip_conicip_lockstep: null argument"); return CIP_E_INVALID; }
     for (int i = 1; i < count; ++i)
         if (!same_shape(probs[0], probs[i])) { cip_set_error("lock-step batch: problem %d differs in shape from problem 0", i); return CIP_E_UNSUPPORTED; }
-    for (int c0 = 0; c0 < probs[0].ncones; ++c0)
-        if (probs[0].cone_type[c0] == CIP_CONE_S) { cip_set_error("lock-step batch: S cones are not supported"); return CIP_E_UNSUPPORTED; }
+    for (int c0 = 0; c0 < probs[0].ncones; ++c0)       // S cones of order >= 133 take chip-wide kernels with a single workspace (sdp_large.hip)
+        if (probs[0].cone_type[c0] == CIP_CONE_S && probs[0].cone_dim[c0] >= CIP_LARGE_S_MIN * (CIP_LARGE_S_MIN + 1) / 2) {
+            cip_set_error("lock-step batch: S cones of order >= %d are not supported", CIP_LARGE_S_MIN);
+            return CIP_E_UNSUPPORTED;
+        }
     if (cip_tl_builder) { cip_set_error("lock-step batch inside a graph recording"); return CIP_E_INVALID; }
     g_last_stats[0] = g_last_stats[1] = g_last_stats[2] = 0;
     for (int g0 = 0; g0 < count; g0 += CIP_BATCH_MAX) {

@@ -667,7 +667,9 @@ __device__ __forceinline__ void sd_nt_body(const ConeDesc &cd, const double *v, 
 }
 __global__ __launch_bounds__(SD_TMAX) void k_sdp_nt_scaling(const ConeDesc *cones, const int *sidx, const double *v,
                                                           const double *s, double *scal, double *lambda, double *wsb,
-                                                          int *flag, int cap) {
+                                                          int *flag, int cap, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO6(cb, v, s, scal, lambda, wsb, flag);
     extern __shared__ double sh[];
     __shared__ int sflag;
     const ConeDesc cd = cones[sidx[blockIdx.x]];
@@ -693,7 +695,9 @@ __device__ void sd_congruence(const double *R, const double *Ri, int mode, const
 }
 
 __global__ __launch_bounds__(SD_TMAX) void k_sdp_apply(const ConeDesc *cones, const int *sidx, const double *scal, int mode,
-                                                     const double *x, double *out, double *wsb) {
+                                                     const double *x, double *out, double *wsb, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO4(cb, scal, x, out, wsb);
     const ConeDesc cd = cones[sidx[blockIdx.x]];
     const int r = cd.r;
     const double *R = scal + cd.soff;
@@ -703,7 +707,9 @@ __global__ __launch_bounds__(SD_TMAX) void k_sdp_apply(const ConeDesc *cones, co
 
 // Wt[i, off+e] = (F^-T a_i)_e for rows i of At (grid.x loops over i, grid.y = S cone)
 __global__ __launch_bounds__(SD_TMAX) void k_sdp_scale_At(const ConeDesc *cones, const int *sidx, const double *scal, int n,
-                                                        const double *At, long ldat, double *Wt, long ldwt, double *wsb) {
+                                                        const double *At, long ldat, double *Wt, long ldwt, double *wsb, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO4(cb, scal, At, Wt, wsb);
     const ConeDesc cd = cones[sidx[blockIdx.y]];
     const int r = cd.r;
     const double *R = scal + cd.soff;
@@ -715,7 +721,9 @@ __global__ __launch_bounds__(SD_TMAX) void k_sdp_scale_At(const ConeDesc *cones,
 
 // column c of -(F'F) for the literal 3x3 assembly: K[off+e, off+c] = -(F'(F e_c))_e  (lower part)
 __global__ __launch_bounds__(SD_TMAX) void k_sdp_fill_ftf(const ConeDesc *cones, const int *sidx, const double *scal, double *K,
-                                                        long ldk, double *wsb, double *vtmp) {
+                                                        long ldk, double *wsb, double *vtmp, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO4(cb, scal, K, wsb, vtmp);
     const ConeDesc cd = cones[sidx[blockIdx.y]];
     const int r = cd.r, k = cd.dim;
     const double *R = scal + cd.soff;
@@ -735,7 +743,9 @@ __global__ __launch_bounds__(SD_TMAX) void k_sdp_fill_ftf(const ConeDesc *cones,
 
 // ---------------------------------------------------------------------------------- Jordan product / division
 __global__ __launch_bounds__(SD_TMAX) void k_sdp_prod(const ConeDesc *cones, const int *sidx, const double *x, const double *y,
-                                                    double *out, double *wsb) {
+                                                    double *out, double *wsb, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO4(cb, x, y, out, wsb);
     const ConeDesc cd = cones[sidx[blockIdx.x]];
     const int r = cd.r;
     double *X = sd_ws(wsb, blockIdx.x, r, 0), *Y = sd_ws(wsb, blockIdx.x, r, 1), *T = sd_ws(wsb, blockIdx.x, r, 2);
@@ -749,7 +759,9 @@ __global__ __launch_bounds__(SD_TMAX) void k_sdp_prod(const ConeDesc *cones, con
 
 // out: Y O + O Y = X  (dsdc! = vecm(lyap(Y, -X)) src/ConicIP.jl:347-353)
 __global__ __launch_bounds__(SD_TMAX) void k_sdp_div(const ConeDesc *cones, const int *sidx, const double *x, const double *y,
-                                                   double *out, double *wsb, int cap) {
+                                                   double *out, double *wsb, int cap, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO4(cb, x, y, out, wsb);
     extern __shared__ double sh[];
     const ConeDesc cd = cones[sidx[blockIdx.x]];
     const int r = cd.r;
@@ -830,7 +842,9 @@ __device__ __forceinline__ void sd_maxstep_body(const ConeDesc &cd, const double
     if (threadIdx.x == 0) partial[cd.item] = (mx < 0.0) ? INF : 1.0 / mx;
 }
 __global__ __launch_bounds__(SD_TMAX) void k_sdp_maxstep(const ConeDesc *cones, const int *sidx, const double *x, const double *d,
-                                                       double scale, double *partial, double *wsb, int cap) {
+                                                       double scale, double *partial, double *wsb, int cap, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO4(cb, x, d, partial, wsb);
     extern __shared__ double sh[];
     __shared__ int sflag;
     const ConeDesc cd = cones[sidx[blockIdx.x]];
@@ -858,7 +872,7 @@ static int sd_set_lds_attr(const void *fn, int rmax, int nmat) {
 int cip_sdp_nt_scaling(hipStream_t s, const ConeSet &cs, const double *v, const double *sv, double *lambda) {
     if (cs.ns_small > 0) {
         if (sd_set_lds_attr((const void *)k_sdp_nt_scaling, cs.rmax, 1)) return -3;
-        hipLaunchKernelGGL(k_sdp_nt_scaling, dim3(cs.ns_small), dim3(sd_threads(cs.rmax)), sd_shmem(cs.rmax, 1), s, cs.d_cones,
+        cip_launch_b(k_sdp_nt_scaling, dim3(cs.ns_small), dim3(sd_threads(cs.rmax)), sd_shmem(cs.rmax, 1), s, cs.d_cones,
                            cs.d_sidx_small, v, sv, cs.d_scal, lambda, cs.d_sdpws, cs.d_sdpflag, sd_cap(cs.rmax, 1) + SD_SCRATCH(cs.rmax));
         CIP_HIP_CHECK(hipGetLastError());
     }
@@ -878,7 +892,7 @@ int cip_sdp_scaling_changed(hipStream_t s, const ConeSet &cs) {
 }
 int cip_sdp_apply(hipStream_t s, const ConeSet &cs, int mode, const double *x, double *out) {
     if (cs.ns_small > 0) {
-        hipLaunchKernelGGL(k_sdp_apply, dim3(cs.ns_small), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx_small, cs.d_scal, mode, x,
+        cip_launch_b(k_sdp_apply, dim3(cs.ns_small), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx_small, cs.d_scal, mode, x,
                            out, cs.d_sdpws);
         CIP_HIP_CHECK(hipGetLastError());
     }
@@ -890,7 +904,7 @@ int cip_sdp_apply(hipStream_t s, const ConeSet &cs, int mode, const double *x, d
 }
 int cip_sdp_prod(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out) {
     if (cs.ns_small > 0) {
-        hipLaunchKernelGGL(k_sdp_prod, dim3(cs.ns_small), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx_small, x, y, out, cs.d_sdpws);
+        cip_launch_b(k_sdp_prod, dim3(cs.ns_small), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx_small, x, y, out, cs.d_sdpws);
         CIP_HIP_CHECK(hipGetLastError());
     }
     for (int li = 0; li < cs.nlarge; ++li) {
@@ -901,7 +915,7 @@ int cip_sdp_prod(hipStream_t s, const ConeSet &cs, const double *x, const double
 }
 int cip_sdp_div(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out) {
     if (sd_set_lds_attr((const void *)k_sdp_div, cs.rmax, 2)) return -3;
-    hipLaunchKernelGGL(k_sdp_div, dim3(cs.ns), dim3(sd_threads(cs.rmax)), sd_shmem(cs.rmax, 2), s, cs.d_cones, cs.d_sidx, x, y, out, cs.d_sdpws,
+    cip_launch_b(k_sdp_div, dim3(cs.ns), dim3(sd_threads(cs.rmax)), sd_shmem(cs.rmax, 2), s, cs.d_cones, cs.d_sidx, x, y, out, cs.d_sdpws,
                        sd_cap(cs.rmax, 2));
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
@@ -913,7 +927,7 @@ int cip_sdp_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const dou
     const size_t shm = ((size_t)SD_SCRATCH_TRI(cs.rmax) + cap) * sizeof(double);
     if (cs.ns_small > 0) {
         CIP_HIP_CHECK(hipFuncSetAttribute((const void *)k_sdp_maxstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        hipLaunchKernelGGL(k_sdp_maxstep, dim3(cs.ns_small), dim3(sd_threads(cs.rmax)), shm, s, cs.d_cones, cs.d_sidx_small, x, d, scale,
+        cip_launch_b(k_sdp_maxstep, dim3(cs.ns_small), dim3(sd_threads(cs.rmax)), shm, s, cs.d_cones, cs.d_sidx_small, x, d, scale,
                            partial, cs.d_sdpws, cap);
         CIP_HIP_CHECK(hipGetLastError());
     }
@@ -926,7 +940,7 @@ int cip_sdp_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const dou
 int cip_sdp_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, long ldat, double *Wt, long ldwt) {
     if (cs.ns_small > 0) {
         const int gx = n < cs.sdp_slots / cs.ns ? n : cs.sdp_slots / cs.ns;
-        hipLaunchKernelGGL(k_sdp_scale_At, dim3(gx, cs.ns_small), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx_small, cs.d_scal, n,
+        cip_launch_b(k_sdp_scale_At, dim3(gx, cs.ns_small), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx_small, cs.d_scal, n,
                            At, ldat, Wt, ldwt, cs.d_sdpws);
         CIP_HIP_CHECK(hipGetLastError());
     }
@@ -938,7 +952,7 @@ int cip_sdp_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, 
 }
 int cip_sdp_fill_ftf(hipStream_t s, const ConeSet &cs, double *K, long ldk) {
     const int gx = cs.sdp_slots / cs.ns;
-    hipLaunchKernelGGL(k_sdp_fill_ftf, dim3(gx, cs.ns), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx, cs.d_scal, K, ldk, cs.d_sdpws,
+    cip_launch_b(k_sdp_fill_ftf, dim3(gx, cs.ns), dim3(sd_threads(cs.rmax)), 0, s, cs.d_cones, cs.d_sidx, cs.d_scal, K, ldk, cs.d_sdpws,
                        cs.d_sdpvec);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;

@@ -202,7 +202,7 @@ int cip_conicip_problems(int count, const cip_problem *probs, const double *cons
                          const double *const *d, const cip_options *opt, double *const *y, double *const *w,
                          double *const *v, cip_result *res, int in_flight);
 /* the same, in LOCK-STEP: the problems must have identical shape (n, m, p, cone list, route, dense-or-CSR A) and no S
- * cones; they advance through the loop together, every step ONE launch with the problem index in the grid (groups of up
+ * cone of matrix order >= 133; they advance through the loop together, every step ONE launch with the problem index in the grid (groups of up
  * to 64).  Results are bit-identical to cip_conicip on each problem.  Returns CIP_E_UNSUPPORTED (nothing written) when
  * the batch does not qualify -- fall back to cip_conicip_problems.  A problem whose factorisation meets a bad pivot leaves
  * the group and is solved by the one-problem loop afterwards. */

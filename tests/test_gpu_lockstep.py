@@ -148,10 +148,42 @@ def test_unsupported_batches_fall_back():
     assert ei.value.code == L.E_UNSUPPORTED
     sols = _solve([a, b], "auto")                       # falls back to the thread pool
     assert [s.status for s in sols] == ["Optimal", "Optimal"]
-    s1 = _as_problem(P.psd_projection())
+    # S cones of matrix order >= 133 take chip-wide kernels with one workspace: not in lock-step
+    r = 133
+    k = r * (r + 1) // 2
+    big = dict(Q=np.eye(4), c=np.ones(4), A=np.zeros((k, 4)), b=-P_vecm_identity(r), cone_dims=[("S", k)], G=None, d=None, kwargs={})
     with pytest.raises(L.CipError) as ei:
-        _solve([s1, s1], "lockstep")
+        _solve([big, big], "lockstep")
     assert ei.value.code == L.E_UNSUPPORTED
+
+
+def P_vecm_identity(r):
+    from cipkkt.workloads import vecm_identity
+    return vecm_identity(r)
+
+
+def test_s_cones_in_lockstep():
+    """small S cones (one workgroup per cone, sdp.hip) follow the batch dimension too: SDPs of one shape, mixed with R and Q
+    cones, bit-identical to the one-problem loop"""
+    from oracle.cones import vecm
+    prs = []
+    for seed in range(6):
+        rng = np.random.default_rng(900 + seed)
+        n, r1, r2 = 12, 6, 9
+        k1, k2 = r1 * (r1 + 1) // 2, r2 * (r2 + 1) // 2
+        cone_dims = [("S", k1), ("R", 5), ("Q", 4), ("S", k2)]
+        m = k1 + 5 + 4 + k2
+        M = rng.standard_normal((n, n))
+        Q = M @ M.T / n + 0.1 * np.eye(n)
+        A = rng.standard_normal((m, n)) * 0.3
+        # strictly feasible at y = 0: b = -(interior point of every cone)
+        b = -np.concatenate([vecm(np.eye(r1)), np.ones(5), np.array([2.0, 0.3, -0.2, 0.1]), vecm(np.eye(r2))])
+        G = rng.standard_normal((2, n))
+        prs.append(dict(Q=Q, c=rng.standard_normal(n), A=A, b=b, cone_dims=cone_dims, G=G, d=np.zeros(2), kwargs={}))
+    one = _solve(prs, "threads", in_flight=1)
+    lock = _solve(prs, "lockstep")
+    assert all(s.status == "Optimal" for s in one), [s.status for s in one]
+    _assert_identical(lock, one)
 
 
 def test_config5_reduced_lockstep_matches_threads():
