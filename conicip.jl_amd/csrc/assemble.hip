@@ -43,6 +43,18 @@ __global__ __launch_bounds__(256) void k_copy_block(double *K, long ldk, int r0,
 __global__ __launch_bounds__(256) void k_copy_block_lower(double *K, long ldk, int r0, const double *M, long ldm, int n, double sign, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO2(cb, K, M);
+    // two rows per thread (16-byte accesses) when everything is even and 16-byte aligned -- 0.56 GB per factorisation at
+    // n = 8192 is 2.4 % of a step at the 3.2 TB/s of the 8-byte form
+    if (!(n & 1) && !(r0 & 1) && !(ldk & 1) && !(ldm & 1) && !(((uintptr_t)K | (uintptr_t)M) & 15)) {
+        const int i = 2 * (blockIdx.x * 256 + threadIdx.x);
+        if (i >= n) return;
+        const int jend = min(n, (((r0 + i) >> 7) + 1) * 128 - r0);  // columns up to the end of this row pair's diagonal tile
+        for (int j = blockIdx.y; j < jend; j += gridDim.y) {
+            const v2d v = *(const v2d *)(M + i + (long)j * ldm);
+            *(v2d *)(K + (r0 + i) + (long)(r0 + j) * ldk) = sign * v;
+        }
+        return;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int jend = min(n, (((r0 + i) >> 7) + 1) * 128 - r0);      // columns up to the end of this row's diagonal tile
