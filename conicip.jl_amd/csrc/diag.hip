@@ -218,12 +218,33 @@ __device__ __forceinline__ void diag_load_block(double *a, const double *Kb, lon
 }
 
 // columns [c, c+16) of the LDS image -> K (L strictly lower, d on the diagonal), 16-byte stores where aligned pairs
-// lie below the diagonal; `t` of `nt` threads
+// lie below the diagonal; `t` of `nt` threads.  PUB: write-through (`sc1`) stores -- the readers are other workgroups of
+// the same launch (k_ldlt_panel's TRSM strips)
+__device__ __forceinline__ void st_pub(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_pub(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool PUB = false>
 __device__ __forceinline__ void diag_store_panel(const double *a, double *Kb, long ld, int c, int t, int nt) {
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)Kb, 0, 0x7fffffff, 0x00020000);
     for (int e = t; e < 16 * 64; e += nt) {
         const int i = 2 * (e & 63), j = c + (e >> 6);
-        if (i >= j) *(v2d *)(Kb + i + (long)j * ld) = *(const v2d *)(a + i + j * DP);
-        else if (i + 1 == j) Kb[i + 1 + (long)j * ld] = a[i + 1 + j * DP];
+        if (i >= j) {
+            const v2d v = *(const v2d *)(a + i + j * DP);
+            if (PUB) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, v), rs, (int)((i + (long)j * ld) * 8), 0, 16);
+            else *(v2d *)(Kb + i + (long)j * ld) = v;
+        } else if (i + 1 == j) {
+            if (PUB) st_pub(Kb + i + 1 + (long)j * ld, a[i + 1 + j * DP]);
+            else Kb[i + 1 + (long)j * ld] = a[i + 1 + j * DP];
+        }
+    }
+}
+// micro-panel kb's inverse, d and 1/d -> global, write-through (PUB launches publish them per micro-panel)
+__device__ __forceinline__ void diag_publish_micro(const double *a, const double *xm, double *xm_out, double *dvec, double *dinv,
+                                                   int kb, int t, int nt) {
+    for (int i = t; i < 256; i += nt) st_pub(xm_out + kb * 256 + i, xm[kb * 256 + i]);
+    if (t < 16) {
+        st_pub(dvec + kb * 16 + t, a[128 + (kb * 16 + t) * DP]);
+        st_pub(dinv + kb * 16 + t, a[129 + (kb * 16 + t) * DP]);
     }
 }
 
@@ -232,9 +253,12 @@ __device__ __forceinline__ void diag_store_panel(const double *a, double *Kb, lo
 // WAIT: the block is being updated by three other workgroups of the SAME launch (k_ldlt_diag_upd: the quarter tiles of the
 // previous panel's in-block update that make up this block's lower triangle, written with agent-scope stores); thread 0
 // polls their completion counter, one acquire fence, then the block is read with agent-scope loads.
-template <bool WAIT>
+// PUB: every micro-panel is published as soon as it is final -- its columns of L, its micro inverse, d and 1/d written
+// through by waves 1-3 under wave 0's next serial step, then one count per wave on `stage`: stage >= 3 (kb + 1) <=> micro-
+// panels 0..kb are readable by the other workgroups of the launch (24 at the end).
+template <bool WAIT, bool PUB = false>
 __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
-                                          int *info, int col0, PivotSigns sg, const unsigned *ready) {
+                                          int *info, int col0, PivotSigns sg, const unsigned *ready, unsigned *stage = nullptr) {
     double *a = sm;
     double *xm = sm + XM_OFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -300,7 +324,8 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
         } else if (!(DIAG_SKIP & 4)) {
             // micro-panel kb is final (A(kb) and B(kb) are behind the barrier): waves 1-3 write it back now, under
             // wave 0's serial step, instead of in a store phase at the end of the kernel
-            if (!(DIAG_SKIP & 16)) diag_store_panel(a, Kb, ld, c, tid - 64, 192);
+            if (!(DIAG_SKIP & 16)) diag_store_panel<PUB>(a, Kb, ld, c, tid - 64, 192);
+            if (PUB) diag_publish_micro(a, xm, xm_out, dvec, dinv, kb, tid - 64, 192);
             int idx = 0;
             for (int it = kb + 1; it < 8; ++it)
                 for (int jt = kb + 1; jt <= it; ++jt) {
@@ -308,8 +333,20 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
                     if (idx % 3 == wave - 1) diag_step_c(a, it, jt, c, l15, g, d4);
                     ++idx;
                 }
+            if (PUB) {                                            // the wave's stores have landed -> its count
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) atomicAdd(stage, 1u);
+            }
         }
         __syncthreads();
+    }
+    if (PUB) {
+        diag_store_panel<true>(a, Kb, ld, 112, tid, 256);
+        diag_publish_micro(a, xm, xm_out, dvec, dinv, 7, tid, 256);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) atomicAdd(stage, 3u);
+        return;
     }
 
     // ---- last micro-panel, d and the micro inverses out; the strictly upper part of K is left untouched
@@ -370,6 +407,133 @@ __global__ __launch_bounds__(256) void k_ldlt_diag_upd(double *Kb, long ld, doub
     const int tq = b - 4;
     const int t = (tq < tm - 2) ? tq + 2 : tq + 4;
     gemm_tile_64_k128<false>(g, sm, (long)(t % tm) * SB, (long)(t / tm) * SB);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One launch per panel: the diagonal kernel, the previous panel's in-block update AND this panel's TRSM, the TRSM running
+// BEHIND the diagonal kernel micro-panel by micro-panel instead of after it (k_trsm_subst needs ~11.5 us after the last
+// pivot: a launch, one memory round trip and 144 dependent MFMAs per wave; here all but the last 4 MFMAs of every wave are
+// done when the last pivot is):
+//   workgroup 0          diag_body<WAIT, PUB>: publishes each 16-column micro-panel (L columns, micro inverse, 1/d) as
+//                        soon as it is final and counts on `stage`
+//   workgroups 1..3      (UPD) the quarter tiles of the in-block update that workgroup 0 waits for, as in k_ldlt_diag_upd
+//   the next `strips`    one 64-row strip of the rows below the block: (UPD) its two update tiles of this panel's columns,
+//                        then the substitution of k_trsm_subst with the operands of stage kb fetched (agent-scope loads)
+//                        once stage >= 3 (kb + 1):  W[:,kb] = T_kb inv(L11[kb][kb])',  T_{kb+1} = A21[:,kb+1] - sum W[:,q] L11[kb+1][q]'
+//   the others           (UPD) the remaining tiles of the in-block update
+// The same operations on the same operands in the same order as the separate launches: bit-identical factors.
+// Every wait is for a workgroup with a lower index in the same launch (dispatched earlier); waits are bounded (~1 s).
+struct TrsmStrips {
+    double *Ap; long ld;              // rows below the diagonal block, this panel's 128 columns
+    const double *L11;                // the diagonal block (leading dimension ld)
+    const double *xm, *dinv;          // micro inverses / 1/d of the block (published by workgroup 0)
+    double *W; long ldw;
+    int strips;                       // rows / 64
+};
+__device__ __forceinline__ unsigned strip_wait(unsigned v, unsigned target, const unsigned *stage, unsigned *slot, int *info) {
+    if (v >= target) return v;
+    if (threadIdx.x == 0) {
+        const long t0 = __builtin_amdgcn_s_memtime();
+        unsigned x;
+        while ((x = __hip_atomic_load(stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memtime() - t0 > 100000000L) { atomicCAS(info + 3, 0, -9); x = 0xffffffffu; break; }   // never hang the GPU
+        }
+        *slot = x;
+    }
+    __syncthreads();
+    const unsigned r = *slot;
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ void trsm_strip_pipelined(const TrsmStrips &tr, int strip, const unsigned *stage, unsigned *slot, int *info) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const long row = (long)strip * 64 + wave * 16 + l15;
+    double *ap = tr.Ap + row + (long)g * tr.ld;
+    double *wp = tr.W + row + (long)g * tr.ldw;
+    double areg[8][4];
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) areg[kb][q] = ap[(long)(kb * 16 + 4 * q) * tr.ld];
+    double wneg[8][4];
+    unsigned v = 0;
+    v4d acc = (v4d){areg[0][0], areg[0][1], areg[0][2], areg[0][3]};
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        v = strip_wait(v, 3u * (kb + 1), stage, slot, info);
+        // one batch of loads per stage: the micro inverse and 1/d of kb, row block kb + 1 of L11
+        double xo[4], dv[4], lo[7][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            xo[s] = ld_pub(tr.xm + kb * 256 + (g + 4 * s) * 16 + l15);
+            dv[s] = ld_pub(tr.dinv + kb * 16 + 4 * s + g);
+        }
+#pragma unroll
+        for (int qq = 0; qq < 7; ++qq)
+            if (qq <= kb && kb < 7) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) lo[qq][s] = ld_pub(tr.L11 + (kb + 1) * 16 + l15 + (long)(qq * 16 + 4 * s + g) * tr.ld);
+            }
+        v4d w = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) w = MFMA(xo[s], acc[s], w);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long col = kb * 16 + 4 * q;
+            wneg[kb][q] = -w[q];
+            wp[col * tr.ldw] = w[q];
+            ap[col * tr.ld] = w[q] * dv[q];
+        }
+        if (kb < 7) {
+            acc = (v4d){areg[kb + 1][0], areg[kb + 1][1], areg[kb + 1][2], areg[kb + 1][3]};
+#pragma unroll
+            for (int qq = 0; qq < 7; ++qq)
+                if (qq <= kb) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc = MFMA(lo[qq][s], wneg[qq][s], acc);
+                }
+        }
+    }
+}
+template <bool UPD>
+__global__ __launch_bounds__(256) void k_ldlt_panel(double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info,
+                                                     int col0, PivotSigns sg, unsigned *ready, unsigned *stage, GemmArgs g,
+                                                     TrsmStrips tr, CipBatch cb) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int b = (int)blockIdx.x;
+    if (b == 0) {
+        diag_body<UPD, true>(sm, Kb, ld, xm_out, dvec, dinv, info, col0, sg, ready, stage);
+        return;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    const int first = UPD ? 4 : 1;
+    if (UPD && b <= 3) {
+        const long i0 = (b == 1) ? 0 : SB, j0 = (b == 3) ? SB : 0;
+        gemm_tile_64_k128<true>(g, sm, i0, j0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(ready, 1u);
+        return;
+    }
+    if (b - first < tr.strips) {
+        const int strip = b - first;
+        if (UPD) {
+            // the strip's rows of this panel's columns first receive the previous panel's update (tiles (2 + strip, 0), (2 + strip, 1))
+            gemm_tile_64_k128<false>(g, sm, (long)(2 + strip) * SB, 0);
+            __syncthreads();
+            gemm_tile_64_k128<false>(g, sm, (long)(2 + strip) * SB, SB);
+            __syncthreads();
+        }
+        trsm_strip_pipelined(tr, strip, stage, (unsigned *)sm, info);
+        return;
+    }
+    if (UPD) {
+        const int tm = g.M / SB;
+        const int t = 2 * tm + (b - first - tr.strips);           // column-major, from tile column 2 on
+        gemm_tile_64_k128<false>(g, sm, (long)(t % tm) * SB, (long)(t / tm) * SB);
+    }
 }
 
 // X = inv(L) for every 128x128 diagonal block of a factored matrix, one workgroup per block (they are
@@ -497,6 +661,8 @@ static void diag_attr_init(void) {
     hipError_t e = hipFuncSetAttribute((const void *)k_ldlt_diag128_v2, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ldlt_diag_upd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ldlt_diag_upd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ldlt_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ldlt_panel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_diag_inverse_batched, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_trsm_subst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TRSM_LDS_DOUBLES * sizeof(double)));
     g_attr_err = e;
@@ -525,6 +691,26 @@ int cip_launch_diag_upd(hipStream_t s, double *Kb, long ld, double *xm_out, doub
                              info, col0, sg, ready, g);
     else cip_launch_b(k_ldlt_diag_upd<true>, dim3((unsigned)(1 + nt)), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv,
                       info, col0, sg, ready, g);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+// one launch per panel (k_ldlt_panel): diag of the block at Kb, the in-block update `g` of the previous panel when `g` is
+// given (as cip_launch_diag_upd), and the TRSM of the `rows` rows below the block; `ready` / `stage`: zeroed device words
+// of this launch's own
+int cip_launch_panel(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
+                     PivotSigns sg, unsigned *ready, unsigned *stage, const GemmArgs *g, int rows, double *W, long ldw) {
+    if (cip_kernels_init()) return -3;
+    TrsmStrips tr = {Kb + CIP_NB, ld, Kb, xm_out, dinv, W, ldw, rows / 64};
+    if (g) {
+        const int tm = g->M / SB, tn = g->N / SB;
+        if (tm != tr.strips + 2 || tn < 2) { cip_set_error("panel launch: update / TRSM shapes disagree"); return -1; }
+        const long grid = 4 + tr.strips + (long)tm * (tn - 2);
+        cip_launch_b(k_ldlt_panel<true>, dim3((unsigned)grid), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg,
+                     ready, stage, *g, tr);
+    } else {
+        cip_launch_b(k_ldlt_panel<false>, dim3((unsigned)(1 + tr.strips)), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv,
+                     info, col0, sg, ready, stage, GemmArgs{}, tr);
+    }
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -25,11 +25,19 @@
 // chain, round 1: 256 / 384 / 512 -> 107.7 / 107.0 / 109.1; 1024 -> 125 against 128).
 static int g_nbo = 0;
 static int g_fuse_diag = -1;
-static void fuse_env(void) { if (g_fuse_diag < 0) { const char *e = getenv("CIP_FUSE_DIAG"); g_fuse_diag = (e && atoi(e) == 0) ? 0 : 1; } }
+// 0: diag -> TRSM -> in-block update, three launches per panel; 1: the update inside the next diagonal kernel's launch
+// (k_ldlt_diag_upd); 3: one launch per panel, the TRSM pipelined behind the diagonal kernel (k_ldlt_panel)
+#define CIP_FUSE_DEFAULT 3
+static void fuse_env(void) {
+    if (g_fuse_diag >= 0) return;
+    const char *e = getenv("CIP_FUSE_DIAG");
+    const int v = e ? atoi(e) : CIP_FUSE_DEFAULT;
+    g_fuse_diag = (v == 0) ? 0 : (v == 3) ? 3 : 1;
+}
 int cip_ldlt_outer_block_for(int Npad) {
     if (g_nbo > 0) return g_nbo;
     fuse_env();
-    return (Npad >= 4096 && g_fuse_diag && cip_tl_bz.B <= 1) ? 768 : 512;
+    return (Npad >= 4096 && g_fuse_diag) ? 768 : 512;    // not a function of the batch: lock-step groups reproduce the one-problem loop bit for bit
 }
 int cip_ldlt_outer_block(void) { return g_nbo; }
 void cip_ldlt_set_outer_block(int nbo) {
@@ -117,7 +125,7 @@ size_t cip_ldlt_ws_bytes(int Npad) {
     }
     b += al256((size_t)Npad * 8) * 4;                    // dinv, dvec, tmp, ybuf
     b += al256(4 * 2 * (2 + 2 * nblk + (size_t)Npad / 8));  // sweep counters / flags (solve.hip)
-    b += al256(64 + 4 * nblk);                           // info (16 ints) + one `ready` counter per 128-block (fused diag + update launches)
+    b += al256(64 + 8 * nblk);                           // info (16 ints) + a `ready` and a `stage` counter per 128-block (fused panel launches)
     b += al256(cip_la_ctrl_bytes(Npad));                 // look-ahead control block (gemm_f64.hip: LaCtrl + done[])
     return b;
 }
@@ -142,7 +150,7 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     ws->tmp = (double *)p;   p += al256((size_t)Npad * 8);
     ws->ybuf = (double *)p;  p += al256((size_t)Npad * 8);
     ws->sweep_ctr = (unsigned *)p; p += al256(4 * 2 * (2 + 2 * nblk + (size_t)Npad / 8));
-    ws->info = (int *)p;     p += al256(64 + 4 * nblk);
+    ws->info = (int *)p;     p += al256(64 + 8 * nblk);
     ws->la_ctrl = (void *)p;
     ws->prof = nullptr;
     ws->signs = PivotSigns{-1, 0, 0};
@@ -156,6 +164,8 @@ int cip_launch_diag_upd(hipStream_t s, double *Kb, long ld, double *xm_out, doub
                         PivotSigns sg, unsigned *ready, const GemmArgs &g);
 int cip_launch_diag_inverse(hipStream_t s, const double *K, long ld, int nblk, const double *xm_all, double *Linv,
                             double *LinvT);
+int cip_launch_panel(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
+                     PivotSigns sg, unsigned *ready, unsigned *stage, const GemmArgs *g, int rows, double *W, long ldw);
 int cip_launch_trsm_subst(hipStream_t s, double *Ap, long ld, int rows, const double *L11, const double *xm,
                           const double *dinv, double *W, long ldw);
 
@@ -179,7 +189,7 @@ static int update_rest_of_block(hipStream_t s, double *K, int Npad, long ld, dou
     return cip_launch_gemm(s, EPI_ACCUM, g);
 }
 // CIP_FUSE_DIAG=0 / cip_set_ldlt_fused_chain(0): the unfused chain (diag -> TRSM -> update per panel), for A/B runs and tests
-int cip_ldlt_set_fused_chain(int on) { fuse_env(); const int prev = g_fuse_diag; if (on == 0 || on == 1) g_fuse_diag = on; return prev; }
+int cip_ldlt_set_fused_chain(int on) { fuse_env(); const int prev = g_fuse_diag; if (on == 0 || on == 1 || on == 3) g_fuse_diag = on; return prev; }
 
 // one inner-panel sweep of an outer block: [strip update] -> diagonal kernel -> TRSM, for each 128 columns
 static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws, double *Wb, int C0,
@@ -198,6 +208,15 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
         // fused only when the chain has the chip to itself: a lock-step batch is throughput-bound and beside a look-ahead's
         // bulk the fused launch's update tiles (160 KB of LDS per workgroup: one per CU) would queue on the few free CUs
         const bool fuse = g_fuse_diag && alone && !cip_in_batch();
+        if (fuse && g_fuse_diag == 3) {
+            const bool upd = t > 0 && rest_of_block_args(K, Npad, ld, Wb, C0, wblk, t - 1, gu);
+            unsigned *ctr = (unsigned *)(ws.info + 16);
+            if ((rc = cip_launch_panel(s, K + c0 + (long)c0 * ld, ld, ws.Xm + (size_t)jb * 2048, ws.dvec + c0, ws.dinv + c0, ws.info, c0,
+                                       ws.signs, ctr + jb, ctr + Npad / CIP_NB + jb, upd ? &gu : nullptr, r,
+                                       Wb + (c0 + CIP_NB) + (long)(t * CIP_NB) * Npad, Npad)))
+                return rc;
+            continue;
+        }
         if (fuse && t > 0 && rest_of_block_args(K, Npad, ld, Wb, C0, wblk, t - 1, gu)) {
             if ((rc = cip_launch_diag_upd(s, K + c0 + (long)c0 * ld, ld, ws.Xm + (size_t)jb * 2048, ws.dvec + c0, ws.dinv + c0,
                                           ws.info, c0, ws.signs, (unsigned *)(ws.info + 16) + jb, gu)))
@@ -408,7 +427,7 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
     int rc;
     std::call_once(g_la_once, lookahead_env);
     // [0] bad pivot, [1] sweep bail-out, [2] dead pivot, [3] look-ahead scheduler / fused-launch wait; from word 16: `ready` counters
-    if ((rc = zero_fill(s, ws.info, 64 + 4 * (size_t)(Npad / CIP_NB)))) return rc;
+    if ((rc = zero_fill(s, ws.info, 64 + 8 * (size_t)(Npad / CIP_NB)))) return rc;
     bool la = g_lookahead == 1 && Npad >= g_la_min && Npad > 2 * NBO && NBO % 64 == 0;
     if (cip_tl_builder || cip_in_batch()) la = false;         // recording a hipGraph / a lock-step batch: the single-stream schedule
     if (g_lookahead == 3 && !cip_tl_builder && !cip_in_batch() && Npad >= 2 * g_la2_min && !ws.prof) {

@@ -81,21 +81,27 @@ def test_two_stream_lookahead_bitwise_equals_serial(lib, N, quasi):
         assert torch.equal(torch.tril(got.t()), torch.tril(ref.t())), "repetition %d differs from the serial schedule" % rep
 
 
+@pytest.mark.parametrize("mode", [1, 3], ids=["diag+update", "one-launch-panel"])
 @pytest.mark.parametrize("N,quasi", [(1024, 0), (2048, 0), (4608, 512), (8192, 0)])
-def test_fused_panel_chain_bitwise_equals_unfused(lib, N, quasi):
-    """From the second panel of an outer block on, the diagonal kernel's launch carries the previous panel's in-block
+def test_fused_panel_chain_bitwise_equals_unfused(lib, N, quasi, mode):
+    """Mode 1: from the second panel of an outer block on, the diagonal kernel's launch carries the previous panel's in-block
     update and waits, INSIDE the launch, for the three tiles that are its own block (diag.hip: k_ldlt_diag_upd).  Same
     arithmetic in the same order as the three-launch chain: identical bits -- also repeated under a concurrent 1-GiB copy
-    load, which is when a missing fence or a stale line would show."""
+    load, which is when a missing fence or a stale line would show.  Mode 3: that launch also carries the panel's TRSM,
+    which follows the diagonal kernel micro-panel by micro-panel through agent-scope stores, loads and a stage counter
+    (diag.hip: k_ldlt_panel) -- same bar."""
     from cipkkt import _lib as L
     nbytes = C.c_size_t()
     L.check(lib.cip_ldlt_workspace_bytes(N, C.byref(nbytes)))
     ws = torch.zeros(nbytes.value // 8 + 8, dtype=torch.float64, device="cuda")
     K0 = _spd(N, N + quasi + 11, quasi)
     prev = lib.cip_set_ldlt_fused_chain(0)
+    # the automatic outer block depends on the chain mode (768 fused, 512 not) and the block width changes the summation
+    # order: pin the production width for both sides of the comparison
+    lib.cip_set_ldlt_outer_block(768 if N >= 4096 else 512)
     try:
         ref = _factor(lib, K0, N, 0, ws)
-        lib.cip_set_ldlt_fused_chain(1)
+        lib.cip_set_ldlt_fused_chain(mode)
         for rep in range(3):
             got = _factor(lib, K0, N, 0, ws)
             assert torch.equal(torch.tril(got.t()), torch.tril(ref.t())), "repetition %d differs from the unfused chain" % rep
@@ -112,6 +118,7 @@ def test_fused_panel_chain_bitwise_equals_unfused(lib, N, quasi):
         side.synchronize()
     finally:
         lib.cip_set_ldlt_fused_chain(prev)
+        lib.cip_set_ldlt_outer_block(0)
 
 
 def test_lookahead_under_memory_streaming_load(lib):
@@ -152,6 +159,7 @@ def test_lookahead_through_the_kkt_path_n8192():
     rhs = torch.randn(3 * n, generator=g, dtype=torch.float64, device="cuda")
     lam = torch.zeros(n, dtype=torch.float64, device="cuda")
     outs = []
+    lib.cip_set_ldlt_outer_block(512)           # the tile count below is the one of 512-wide outer blocks
     for mode in (0, 1):
         prev = lib.cip_set_ldlt_lookahead(mode)
         dz = torch.zeros(3 * n, dtype=torch.float64, device="cuda")
@@ -165,6 +173,7 @@ def test_lookahead_through_the_kkt_path_n8192():
             assert st["err"] == 0 and st["workers"] >= 5 * 128 and st["tiles"] == sum(
                 (128 - 8 * (J + 1)) * (128 - 8 * (J + 1) + 1) // 2 for J in range(15))
         lib.cip_set_ldlt_lookahead(prev)
+    lib.cip_set_ldlt_outer_block(0)
     np.testing.assert_allclose(outs[1], outs[0], rtol=1e-9, atol=1e-11)
     ks.close()
 
