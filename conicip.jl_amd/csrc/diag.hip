@@ -258,7 +258,8 @@ __device__ __forceinline__ void diag_publish_micro(const double *a, const double
 // panels 0..kb are readable by the other workgroups of the launch (24 at the end).
 template <bool WAIT, bool PUB = false>
 __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
-                                          int *info, int col0, PivotSigns sg, const unsigned *ready, unsigned *stage = nullptr) {
+                                          int *info, int col0, PivotSigns sg, const unsigned *ready, unsigned *stage = nullptr,
+                                          unsigned ready_target = 3u) {
     double *a = sm;
     double *xm = sm + XM_OFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -268,7 +269,7 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
     if (WAIT) {
         if (tid == 0) {
             const long t0 = __builtin_amdgcn_s_memtime();
-            while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 3u) {
+            while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ready_target) {
                 __builtin_amdgcn_s_sleep(1);
                 if (__builtin_amdgcn_s_memtime() - t0 > 100000000L) { atomicCAS(info + 3, 0, -9); break; }   // ~1 s: never hang the GPU
             }
@@ -416,7 +417,8 @@ __global__ __launch_bounds__(256) void k_ldlt_diag_upd(double *Kb, long ld, doub
 // done when the last pivot is):
 //   workgroup 0          diag_body<WAIT, PUB>: publishes each 16-column micro-panel (L columns, micro inverse, 1/d) as
 //                        soon as it is final and counts on `stage`
-//   workgroups 1..3      (UPD) the quarter tiles of the in-block update that workgroup 0 waits for, as in k_ldlt_diag_upd
+//   workgroups 1..9      (UPD) the in-block update of the block itself, which workgroup 0 waits for: one 16x16 tile per wave
+//                        (diag_block_producer)
 //   the next `strips`    one 64-row strip of the rows below the block: (UPD) its two update tiles of this panel's columns,
 //                        then the substitution of k_trsm_subst with the operands of stage kb fetched (agent-scope loads)
 //                        once stage >= 3 (kb + 1):  W[:,kb] = T_kb inv(L11[kb][kb])',  T_{kb+1} = A21[:,kb+1] - sum W[:,q] L11[kb+1][q]'
@@ -497,6 +499,36 @@ __device__ __forceinline__ void trsm_strip_pipelined(const TrsmStrips &tr, int s
         }
     }
 }
+// One 16x16 tile (it >= jt) of the diagonal block's update C -= W L' (K = 128) per WAVE, operands straight from L2 into
+// registers, 32 dependent MFMAs: the producer side of workgroup 0's wait in k_ldlt_panel, 36 waves in 9 workgroups instead
+// of three 64x64 tiles (3.4 us of MFMAs per wave behind an LDS staging pass).  Same k order from a zero accumulator and the
+// same C + alpha acc as gemm_tile_64_k128: identical bits (the 16x16 tiles above the diagonal, which nobody reads, are
+// left alone).  Written through; one count per wave on `ready` (36 = complete).
+__device__ __forceinline__ void diag_block_producer(const GemmArgs &g, int tile, unsigned *ready) {
+    const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    int it = 0;
+    while ((it + 1) * (it + 2) / 2 <= tile) ++it;              // row-major over the lower triangle of the 8 x 8 tile grid
+    const int jt = tile - it * (it + 1) / 2;
+    const double *ap = g.A + it * 16 + l15 + (long)l4 * g.lda;   // W rows of the tile's rows
+    const double *bp = g.B + jt * 16 + l15 + (long)l4 * g.ldb;   // L rows of the tile's columns
+    double *cp = g.C + (it * 16 + l15) + (long)(jt * 16 + l4) * g.ldc;
+    double wa[32], lb[32], cpre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cpre[q] = cp[(long)(4 * q) * g.ldc];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+        wa[ks] = ap[(long)(4 * ks) * g.lda];
+        lb[ks] = bp[(long)(4 * ks) * g.ldb];
+    }
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) acc = MFMA(lb[ks], wa[ks], acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st_pub(cp + (long)(4 * q) * g.ldc, cpre[q] + g.alpha * acc[q]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) atomicAdd(ready, 1u);
+}
+#define PANEL_PRODUCERS 9
 template <bool UPD>
 __global__ __launch_bounds__(256) void k_ldlt_panel(double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info,
                                                      int col0, PivotSigns sg, unsigned *ready, unsigned *stage, GemmArgs g,
@@ -504,17 +536,13 @@ __global__ __launch_bounds__(256) void k_ldlt_panel(double *Kb, long ld, double 
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = (int)blockIdx.x;
     if (b == 0) {
-        diag_body<UPD, true>(sm, Kb, ld, xm_out, dvec, dinv, info, col0, sg, ready, stage);
+        diag_body<UPD, true>(sm, Kb, ld, xm_out, dvec, dinv, info, col0, sg, ready, stage, 36u);
         return;
     }
     __builtin_amdgcn_s_setprio(3);
-    const int first = UPD ? 4 : 1;
-    if (UPD && b <= 3) {
-        const long i0 = (b == 1) ? 0 : SB, j0 = (b == 3) ? SB : 0;
-        gemm_tile_64_k128<true>(g, sm, i0, j0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(ready, 1u);
+    const int first = UPD ? 1 + PANEL_PRODUCERS : 1;
+    if (UPD && b <= PANEL_PRODUCERS) {
+        diag_block_producer(g, (b - 1) * 4 + (int)(threadIdx.x >> 6), ready);
         return;
     }
     if (b - first < tr.strips) {
@@ -704,7 +732,7 @@ int cip_launch_panel(hipStream_t s, double *Kb, long ld, double *xm_out, double 
     if (g) {
         const int tm = g->M / SB, tn = g->N / SB;
         if (tm != tr.strips + 2 || tn < 2) { cip_set_error("panel launch: update / TRSM shapes disagree"); return -1; }
-        const long grid = 4 + tr.strips + (long)tm * (tn - 2);
+        const long grid = 1 + PANEL_PRODUCERS + tr.strips + (long)tm * (tn - 2);
         cip_launch_b(k_ldlt_panel<true>, dim3((unsigned)grid), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg,
                      ready, stage, *g, tr);
     } else {

@@ -81,7 +81,7 @@ def test_two_stream_lookahead_bitwise_equals_serial(lib, N, quasi):
         assert torch.equal(torch.tril(got.t()), torch.tril(ref.t())), "repetition %d differs from the serial schedule" % rep
 
 
-@pytest.mark.parametrize("mode", [1, 3], ids=["diag+update", "one-launch-panel"])
+@pytest.mark.parametrize("mode", [1, 3, 4], ids=["diag+update", "one-launch-panel", "panel+heir"])
 @pytest.mark.parametrize("N,quasi", [(1024, 0), (2048, 0), (4608, 512), (8192, 0)])
 def test_fused_panel_chain_bitwise_equals_unfused(lib, N, quasi, mode):
     """Mode 1: from the second panel of an outer block on, the diagonal kernel's launch carries the previous panel's in-block
