@@ -25,6 +25,12 @@
 #ifndef DIAG_SKIP
 #define DIAG_SKIP 0        // development switch (tools/diag_bench.hip): bit mask of phases to skip
 #endif
+#ifdef DIAG_TIMING
+__device__ long g_diag_t[8 * 8];                 // [kb][slot]: s_memtime stamps (tools/diag_bench.hip)
+#define DIAG_STAMP(kb, slot, cond) do { if (cond) g_diag_t[(kb) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DIAG_STAMP(kb, slot, cond) do { } while (0)
+#endif
 #define XM_OFF (CIP_NB * DP)             // 8 x 256 doubles: xm[kb][k*16 + jj] = Xm_kb[jj][k]
 #define DIAG2_LDS_BYTES ((CIP_NB * DP + 8 * 256) * 8)
 
@@ -153,6 +159,43 @@ __device__ __forceinline__ void diag_step_c(double *a, int it, int jt, int c, in
     for (int q = 0; q < 4; ++q) cp[4 * q * DP] = acc[q];
 }
 
+// step C for up to three tiles at once (tiles idx, idx + st, idx + 2 st of step kb in row-major order over rows
+// it = kb+2..7, jt = kb+1..it): every operand read is issued before the first MFMA and the three accumulation chains
+// interleave -- one tile at a time is an LDS round trip plus four DEPENDENT 64-cycle MFMAs, and the compiler cannot
+// overlap consecutive tiles (it must assume that a tile's write-back aliases the next tile's reads).  The helper waves'
+// tiles were the diagonal kernel's critical path at the first micro-panels (tools/diag_bench: 30.4 -> 23.8 us with the
+// tiles switched off).  Same MFMAs on the same operands: identical results.
+__device__ __forceinline__ void diag_tile_of(int kb, int idx, int &it, int &jt) {
+    int r = 0;
+    while ((r + 1) * (r + 4) / 2 <= idx) ++r;                // row r holds r + 2 tiles, r (r + 3) / 2 before it
+    it = kb + 2 + r;
+    jt = kb + 1 + idx - r * (r + 3) / 2;
+}
+template <int NT>
+__device__ __forceinline__ void diag_step_c_multi(double *a, int kb, int idx, int st, int c, int l15, int g, const double (&d4)[4]) {
+    double *cp[NT];
+    v4d acc[NT];
+    double lj[NT][4], li[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int it, jt;
+        diag_tile_of(kb, idx + st * t, it, jt);
+        cp[t] = a + (it * 16 + l15) + (jt * 16 + g) * DP;
+        const double *pj = a + (jt * 16 + l15) + (c + g) * DP, *pi = a + (it * 16 + l15) + (c + g) * DP;
+        acc[t] = (v4d){cp[t][0], cp[t][4 * DP], cp[t][8 * DP], cp[t][12 * DP]};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { lj[t][s] = pj[4 * s * DP]; li[t][s] = pi[4 * s * DP]; }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = MFMA(lj[t][s], -(li[t][s] * d4[s]), acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cp[t][4 * q * DP] = acc[t][q];
+}
+
 // X block row `it` (runtime, wave-uniform): tiles kept in registers, statically indexed
 __device__ __forceinline__ void diag_inverse_row(double *a, const double *xm, int it, int l15, int g) {
     double XT[8][4];
@@ -256,7 +299,8 @@ __device__ __forceinline__ void diag_publish_micro(const double *a, const double
 // PUB: every micro-panel is published as soon as it is final -- its columns of L, its micro inverse, d and 1/d written
 // through by waves 1-3 under wave 0's next serial step, then one count per wave on `stage`: stage >= 3 (kb + 1) <=> micro-
 // panels 0..kb are readable by the other workgroups of the launch (24 at the end).
-template <bool WAIT, bool PUB = false>
+// NW: waves of the workgroup (all of them call this); wave 0 is the serial one, the other NW - 1 are its helpers.
+template <bool WAIT, bool PUB = false, int NW = 4>
 __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
                                           int *info, int col0, PivotSigns sg, const unsigned *ready, unsigned *stage = nullptr,
                                           unsigned ready_target = 3u) {
@@ -265,6 +309,11 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
 
+    // NW > 4: waves 4, 8, .. would share wave 0's SIMD (waves are dealt round-robin to the four SIMDs) and slow the serial
+    // wave by 30 % (measured, whatever the priorities): they idle at the barriers, the others are the helpers
+    constexpr int NH = NW - NW / 4;
+    const bool idle = wave != 0 && (wave & 3) == 0;
+    const int hid = wave - 1 - (wave >> 2);                    // helper index 0 .. NH - 1
     __builtin_amdgcn_s_setprio(3);
     if (WAIT) {
         if (tid == 0) {
@@ -280,23 +329,25 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
         // 16-byte loads that bypass the non-coherent caches (buffer load with the sc1 policy bit = agent scope)
         typedef int v4i_t __attribute__((ext_vector_type(4)));
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)Kb, 0, 0x7fffffff, 0x00020000);
-        v4i_t t[32];
+        if (NW == 4 || tid < 256) {
+            v4i_t t[32];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const int e = q * 256 + tid;                         // pair index: rows 2*(e&63), +1 ; column e>>6
-            const long off = (2 * (e & 63) + (long)(e >> 6) * ld) * 8;
-            t[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);
-        }
+            for (int q = 0; q < 32; ++q) {
+                const int e = q * 256 + tid;                         // pair index: rows 2*(e&63), +1 ; column e>>6
+                const long off = (2 * (e & 63) + (long)(e >> 6) * ld) * 8;
+                t[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);
+            }
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const int e = q * 256 + tid;
-            const int i = 2 * (e & 63), j = e >> 6;
-            v2d v = __builtin_bit_cast(v2d, t[q]);
-            if (i < j) v.x = 0.0;                                // strictly upper part -> 0
-            if (i + 1 < j) v.y = 0.0;
-            *(v2d *)(a + i + j * DP) = v;
+            for (int q = 0; q < 32; ++q) {
+                const int e = q * 256 + tid;
+                const int i = 2 * (e & 63), j = e >> 6;
+                v2d v = __builtin_bit_cast(v2d, t[q]);
+                if (i < j) v.x = 0.0;                                // strictly upper part -> 0
+                if (i + 1 < j) v.y = 0.0;
+                *(v2d *)(a + i + j * DP) = v;
+            }
         }
-    } else if (!(DIAG_SKIP & 16)) diag_load_block(a, Kb, ld, tid);
+    } else if (!(DIAG_SKIP & 16) && (NW == 4 || tid < 256)) diag_load_block(a, Kb, ld, tid);
     __syncthreads();
 
     // Schedule per 16-column micro-panel kb (A(0) first):
@@ -316,24 +367,37 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
             di4[s] = a[129 + (c + g + 4 * s) * DP];
             d4[s] = a[128 + (c + g + 4 * s) * DP];
         }
+        DIAG_STAMP(kb, 0, tid == 0);                                  // wave 0: past the barrier that follows A(kb)
+        DIAG_STAMP(kb, 4, tid == 64);
         if (!(DIAG_SKIP & 4))
-            for (int it = kb + 1 + wave; it < 8; it += 4) diag_step_b(a, it, c, l15, g, xa, di4);
+        {
+            if (NW == 4) { for (int it = kb + 1 + wave; it < 8; it += 4) diag_step_b(a, it, c, l15, g, xa, di4); }
+            else if (wave == 0) diag_step_b(a, kb + 1, c, l15, g, xa, di4);
+            else if (!idle) { for (int it = kb + 2 + hid; it < 8; it += NH) diag_step_b(a, it, c, l15, g, xa, di4); }
+        }
+        DIAG_STAMP(kb, 1, tid == 0);                                  // B done
+        DIAG_STAMP(kb, 5, tid == 64);
         __syncthreads();
+        DIAG_STAMP(kb, 2, tid == 0);                                  // past the B barrier
         if (wave == 0) {
             if (!(DIAG_SKIP & 4)) diag_step_c(a, kb + 1, kb + 1, c, l15, g, d4);
             diag_step_a(a, xm, kb + 1, lane, info, col0, sg);
-        } else if (!(DIAG_SKIP & 4)) {
+            DIAG_STAMP(kb, 3, tid == 0);                              // C11 + A(kb+1) done
+        } else if (!(DIAG_SKIP & 4) && !idle) {
             // micro-panel kb is final (A(kb) and B(kb) are behind the barrier): waves 1-3 write it back now, under
             // wave 0's serial step, instead of in a store phase at the end of the kernel
-            if (!(DIAG_SKIP & 16)) diag_store_panel<PUB>(a, Kb, ld, c, tid - 64, 192);
-            if (PUB) diag_publish_micro(a, xm, xm_out, dvec, dinv, kb, tid - 64, 192);
-            int idx = 0;
-            for (int it = kb + 1; it < 8; ++it)
-                for (int jt = kb + 1; jt <= it; ++jt) {
-                    if (it == kb + 1) continue;                   // (kb+1, kb+1) belongs to wave 0
-                    if (idx % 3 == wave - 1) diag_step_c(a, it, jt, c, l15, g, d4);
-                    ++idx;
-                }
+            if (!(DIAG_SKIP & 16)) diag_store_panel<PUB>(a, Kb, ld, c, hid * 64 + lane, 64 * NH);
+            if (PUB) diag_publish_micro(a, xm, xm_out, dvec, dinv, kb, hid * 64 + lane, 64 * NH);
+            DIAG_STAMP(kb, 6, tid == 64);                             // helper: panel stores issued
+            // the tiles of rows kb+2.. ((kb+1, kb+1) is wave 0's), dealt round-robin to the three helper waves, three at a time
+            const int ntile = (6 - kb) * (9 - kb) / 2;
+            for (int idx = hid; idx < ntile; idx += 3 * NH) {
+                const int left = (ntile - idx + NH - 1) / NH;      // tiles idx, idx + NH, idx + 2 NH that exist
+                if (left >= 3) diag_step_c_multi<3>(a, kb, idx, NH, c, l15, g, d4);
+                else if (left == 2) diag_step_c_multi<2>(a, kb, idx, NH, c, l15, g, d4);
+                else diag_step_c_multi<1>(a, kb, idx, NH, c, l15, g, d4);
+            }
+            DIAG_STAMP(kb, 7, tid == 64);                             // helper: C tiles done
             if (PUB) {                                            // the wave's stores have landed -> its count
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) atomicAdd(stage, 1u);
@@ -342,30 +406,35 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
         __syncthreads();
     }
     if (PUB) {
-        diag_store_panel<true>(a, Kb, ld, 112, tid, 256);
-        diag_publish_micro(a, xm, xm_out, dvec, dinv, 7, tid, 256);
+        diag_store_panel<true>(a, Kb, ld, 112, tid, 64 * NW);
+        diag_publish_micro(a, xm, xm_out, dvec, dinv, 7, tid, 64 * NW);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) atomicAdd(stage, 3u);
+        if (tid == 0) atomicAdd(stage, (unsigned)NH);
         return;
     }
 
     // ---- last micro-panel, d and the micro inverses out; the strictly upper part of K is left untouched
-    if (!(DIAG_SKIP & 16)) diag_store_panel(a, Kb, ld, 112, tid, 256);
+    if (!(DIAG_SKIP & 16)) diag_store_panel(a, Kb, ld, 112, tid, 64 * NW);
     if (tid < CIP_NB) {
         dvec[tid] = a[128 + tid * DP];
         dinv[tid] = a[129 + tid * DP];
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) xm_out[q * 256 + tid] = xm[q * 256 + tid];
+    for (int q = 0; q < 8; ++q)
+        if (NW == 4 || tid < 256) xm_out[q * 256 + tid] = xm[q * 256 + tid];
 }
 
-__global__ __launch_bounds__(256) void k_ldlt_diag128_v2(double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
-                                                          int *info, int col0, PivotSigns sg, CipBatch cb) {
+// NW waves: 8 by default (CIP_DIAG_WAVES = 4 / 8 / 12).  The serial wave was waiting for its three helpers at the first
+// micro-panels (tools/diag_bench, per-phase clocks: at kb = 0 the helpers' panel stores + 9 trailing tiles each take twice
+// wave 0's C + A); with six or nine helpers it no longer does: 29.3 -> 24.0 / 23.4 us per launch.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_ldlt_diag128_v2(double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
+                                                             int *info, int col0, PivotSigns sg, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO5(cb, Kb, xm_out, dvec, dinv, info);
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    diag_body<false>(sm, Kb, ld, xm_out, dvec, dinv, info, col0, sg, nullptr);
+    diag_body<false, false, NW>(sm, Kb, ld, xm_out, dvec, dinv, info, col0, sg, nullptr);
 }
 
 // The diagonal kernel of inner panel t >= 1 FUSED with the in-block update of panel t-1: one launch instead of two on the
@@ -425,6 +494,8 @@ __global__ __launch_bounds__(256) void k_ldlt_diag_upd(double *Kb, long ld, doub
 //   the others           (UPD) the remaining tiles of the in-block update
 // The same operations on the same operands in the same order as the separate launches: bit-identical factors.
 // Every wait is for a workgroup with a lower index in the same launch (dispatched earlier); waits are bounded (~1 s).
+#define PANEL_WAVES 8                   // waves of a k_ldlt_panel workgroup: the diagonal kernel's; the other roles use the first four
+#define PANEL_NH (PANEL_WAVES - PANEL_WAVES / 4)
 struct TrsmStrips {
     double *Ap; long ld;              // rows below the diagonal block, this panel's 128 columns
     const double *L11;                // the diagonal block (leading dimension ld)
@@ -454,19 +525,20 @@ __device__ __forceinline__ void trsm_strip_pipelined(const TrsmStrips &tr, int s
     const long row = (long)strip * 64 + wave * 16 + l15;
     double *ap = tr.Ap + row + (long)g * tr.ld;
     double *wp = tr.W + row + (long)g * tr.ldw;
-    double areg[8][4];
-#pragma unroll
-    for (int kb = 0; kb < 8; ++kb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) areg[kb][q] = ap[(long)(kb * 16 + 4 * q) * tr.ld];
     double wneg[8][4];
     unsigned v = 0;
-    v4d acc = (v4d){areg[0][0], areg[0][1], areg[0][2], areg[0][3]};
+    v4d acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = ap[(long)(4 * q) * tr.ld];
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
-        v = strip_wait(v, 3u * (kb + 1), stage, slot, info);
-        // one batch of loads per stage: the micro inverse and 1/d of kb, row block kb + 1 of L11
-        double xo[4], dv[4], lo[7][4];
+        v = strip_wait(v, (unsigned)PANEL_NH * (kb + 1), stage, slot, info);
+        // one batch of loads per stage: the micro inverse and 1/d of kb, row block kb + 1 of L11, the wave's own next columns
+        double xo[4], dv[4], lo[7][4], an[4];
+        if (kb < 7) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) an[q] = ap[(long)((kb + 1) * 16 + 4 * q) * tr.ld];
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             xo[s] = ld_pub(tr.xm + kb * 256 + (g + 4 * s) * 16 + l15);
@@ -489,7 +561,7 @@ __device__ __forceinline__ void trsm_strip_pipelined(const TrsmStrips &tr, int s
             ap[col * tr.ld] = w[q] * dv[q];
         }
         if (kb < 7) {
-            acc = (v4d){areg[kb + 1][0], areg[kb + 1][1], areg[kb + 1][2], areg[kb + 1][3]};
+            acc = (v4d){an[0], an[1], an[2], an[3]};
 #pragma unroll
             for (int qq = 0; qq < 7; ++qq)
                 if (qq <= kb) {
@@ -528,23 +600,24 @@ __device__ __forceinline__ void diag_block_producer(const GemmArgs &g, int tile,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) atomicAdd(ready, 1u);
 }
-#define PANEL_PRODUCERS 9
+#define PANEL_PRODUCERS 9               // 36 tiles, one per wave, four waves per workgroup: one wave per SIMD (two would share its MFMA pipe)
 template <bool UPD>
-__global__ __launch_bounds__(256) void k_ldlt_panel(double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info,
-                                                     int col0, PivotSigns sg, unsigned *ready, unsigned *stage, GemmArgs g,
-                                                     TrsmStrips tr, CipBatch cb) {
+__global__ __launch_bounds__(64 * PANEL_WAVES) void k_ldlt_panel(double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
+                                                                  int *info, int col0, PivotSigns sg, unsigned *ready, unsigned *stage,
+                                                                  GemmArgs g, TrsmStrips tr, CipBatch cb) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = (int)blockIdx.x;
     if (b == 0) {
-        diag_body<UPD, true>(sm, Kb, ld, xm_out, dvec, dinv, info, col0, sg, ready, stage, 36u);
+        diag_body<UPD, true, PANEL_WAVES>(sm, Kb, ld, xm_out, dvec, dinv, info, col0, sg, ready, stage, 36u);
         return;
     }
     __builtin_amdgcn_s_setprio(3);
     const int first = UPD ? 1 + PANEL_PRODUCERS : 1;
     if (UPD && b <= PANEL_PRODUCERS) {
-        diag_block_producer(g, (b - 1) * 4 + (int)(threadIdx.x >> 6), ready);
+        if (threadIdx.x < 256) diag_block_producer(g, (b - 1) * 4 + (int)(threadIdx.x >> 6), ready);
         return;
     }
+    if (threadIdx.x >= 256) return;                 // strips and update tiles are four-wave jobs (barriers count live waves only)
     if (b - first < tr.strips) {
         const int strip = b - first;
         if (UPD) {
@@ -686,7 +759,9 @@ __global__ __launch_bounds__(256) void k_trsm_subst(double *__restrict__ Ap, lon
 static std::once_flag g_attr_once;
 static hipError_t g_attr_err = hipSuccess;
 static void diag_attr_init(void) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_ldlt_diag128_v2, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void *)k_ldlt_diag128_v2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ldlt_diag128_v2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ldlt_diag128_v2<12>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ldlt_diag_upd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ldlt_diag_upd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_ldlt_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
@@ -703,7 +778,11 @@ int cip_kernels_init(void) {
 int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
                        PivotSigns sg) {
     if (cip_kernels_init()) return -3;
-    cip_launch_b(k_ldlt_diag128_v2, dim3(1), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg);
+    static int nw = -1;
+    if (nw < 0) { const char *e = getenv("CIP_DIAG_WAVES"); nw = e ? atoi(e) : 8; }
+    if (nw == 4) cip_launch_b(k_ldlt_diag128_v2<4>, dim3(1), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg);
+    else if (nw == 12) cip_launch_b(k_ldlt_diag128_v2<12>, dim3(1), dim3(768), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg);
+    else cip_launch_b(k_ldlt_diag128_v2<8>, dim3(1), dim3(512), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -733,10 +812,10 @@ int cip_launch_panel(hipStream_t s, double *Kb, long ld, double *xm_out, double 
         const int tm = g->M / SB, tn = g->N / SB;
         if (tm != tr.strips + 2 || tn < 2) { cip_set_error("panel launch: update / TRSM shapes disagree"); return -1; }
         const long grid = 1 + PANEL_PRODUCERS + tr.strips + (long)tm * (tn - 2);
-        cip_launch_b(k_ldlt_panel<true>, dim3((unsigned)grid), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg,
+        cip_launch_b(k_ldlt_panel<true>, dim3((unsigned)grid), dim3(64 * PANEL_WAVES), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg,
                      ready, stage, *g, tr);
     } else {
-        cip_launch_b(k_ldlt_panel<false>, dim3((unsigned)(1 + tr.strips)), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv,
+        cip_launch_b(k_ldlt_panel<false>, dim3((unsigned)(1 + tr.strips)), dim3(64 * PANEL_WAVES), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv,
                      info, col0, sg, ready, stage, GemmArgs{}, tr);
     }
     CIP_HIP_CHECK(hipGetLastError());

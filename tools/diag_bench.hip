@@ -41,6 +41,18 @@ int main() {
         for (int j = 0; j < N; ++j) { ed = fmax(ed, fabs(dv[j] - H[j + j * N]) / fabs(H[j + j * N])); for (int i = j + 1; i < N; ++i) e = fmax(e, fabs(G[i + j * N] - H[i + j * N])); }
         printf("max |L - L_host| %.3e, max rel |d - d_host| %.3e\n", e, ed);
     }
+#ifdef DIAG_TIMING
+    {
+        long t[64];
+        hipMemcpyFromSymbol(t, HIP_SYMBOL(g_diag_t), sizeof(t));
+        printf("per micro-panel, 100 MHz ticks x10 = ns: w0: B, wait, C11+A | helper(w1): B, wait@B-barrier, stores, C tiles | iteration\n");
+        for (int kb = 0; kb < 7; ++kb) {
+            const long *r = t + kb * 8;
+            printf("kb %d  w0 %5ld %5ld %6ld | w1 %5ld %5ld %5ld %6ld | iter %6ld\n", kb, (r[1] - r[0]) * 10, (r[2] - r[1]) * 10, (r[3] - r[2]) * 10,
+                   (r[5] - r[4]) * 10, (r[2] - r[5]) * 10, (r[6] - r[2]) * 10, (r[7] - r[6]) * 10, kb < 6 ? (t[(kb + 1) * 8] - r[0]) * 10 : 0L);
+        }
+    }
+#endif
     printf("DIAG_SKIP=%d avg %.2f us per launch\n",
 #ifdef DIAG_SKIP
            DIAG_SKIP,
