@@ -45,7 +45,7 @@ int main() {
     {
         long t[64];
         hipMemcpyFromSymbol(t, HIP_SYMBOL(g_diag_t), sizeof(t));
-        printf("per micro-panel, 100 MHz ticks x10 = ns: w0: B, wait, C11+A | helper(w1): B, wait@B-barrier, stores, C tiles | iteration\n");
+        printf("s_memtime ticks x10 per micro-panel: wave 0: B, wait, C11 + A | helper (wave 1): B, wait at the B barrier, panel stores, trailing tiles | iteration\n");
         for (int kb = 0; kb < 7; ++kb) {
             const long *r = t + kb * 8;
             printf("kb %d  w0 %5ld %5ld %6ld | w1 %5ld %5ld %5ld %6ld | iter %6ld\n", kb, (r[1] - r[0]) * 10, (r[2] - r[1]) * 10, (r[3] - r[2]) * 10,

@@ -30,8 +30,10 @@ CIP_LA_DBG=64 python3 $R/tools/la_time.py 8192 1 > $OUT/lookahead_chain_only.log
 python3 $R/tools/la2_time.py 8192 > $OUT/lookahead2_time.log 2>/dev/null
 CIP_LOOKAHEAD=3 rocprofv3 --kernel-trace --output-format csv -d $OUT/la2 -o la2 -- python3 $R/tools/la2_time.py 8192 > /dev/null 2>&1
 python3 $R/tools/la2_trace.py $OUT/la2 > $OUT/lookahead2_trace_summary.txt 2>&1
-# fused vs unfused panel chain (diag + in-block update in one launch)
-for f in 0 1; do echo "CIP_FUSE_DIAG=$f"; CIP_FUSE_DIAG=$f python3 $R/tools/la_time.py 8192 0 2>/dev/null | tail -1; done > $OUT/fused_chain_time.log
+# the panel chain's three forms: three launches per panel / diag + in-block update / one launch per panel with the TRSM
+# pipelined behind the diagonal kernel (default); the diagonal kernel with 4 / 8 / 12 waves
+for f in 0 1 3; do echo "CIP_FUSE_DIAG=$f"; CIP_FUSE_DIAG=$f python3 $R/tools/la_time.py 8192 0 2>/dev/null | tail -1; done > $OUT/fused_chain_time.log
+for w in 4 8 12; do echo "CIP_DIAG_WAVES=$w (standalone diagonal kernel, chain form 0)"; CIP_FUSE_DIAG=0 CIP_DIAG_WAVES=$w python3 $R/tools/la_time.py 8192 0 2>/dev/null | tail -1; done >> $OUT/fused_chain_time.log
 # config 5 on one GPU (the multi-GPU workload of bench.py): lock-step (default) and the thread pool
 python3 $R/bench.py --workload c5 --steps 5 --warmup 1 > $OUT/bench_c5.json 2> /dev/null
 python3 $R/bench.py --workload c5 --batch-mode threads --steps 3 --warmup 1 > $OUT/bench_c5_threads.json 2> /dev/null
