@@ -7,14 +7,15 @@
 // whose LDL' exists for the static pivot order (S > 0, G full row rank).
 //
 // Blocked right-looking algorithm, two levels:
-//   outer block NBO (default 256) = NBO/128 inner panels of 128 columns
-//   per inner panel:  diag 128x128 LDL' (1 workgroup, LDS) -> TRSM -> update of the block's remaining panel columns
-//                     ->  TRSM as MFMA GEMM with the explicit inverse (W = A21 inv(L11)', L = W D^-1)
+//   outer block NBO (512, 768 from order 4096 on) = NBO/128 inner panels of 128 columns
+//   per inner panel:  diag 128x128 LDL' (1 workgroup, LDS) -> substitution TRSM (W = A21 inv(L11)', L = W D^-1) -> update of
+//                     the block's remaining panel columns; on the serial schedule these are ONE launch per panel
+//                     (diag.hip: k_ldlt_panel), in lock-step batches and beside a look-ahead three
 //   per outer block:  trailing update  C -= W L'  (lower tiles, K = NBO, MFMA GEMM)
-// >99% of the N^3/3 flops are in the trailing-update GEMM (gemm_f64.hip).
+// 3/4 of the N^3/3 flops at n = 8192 are in the trailing-update GEMM (gemm_f64.hip), the rest in the K = 128 in-block tiles.
 //
-// Solves (HBM-bound, L read once per sweep): blocked substitution using the stored
-// inverses of the diagonal blocks, one launch per 128-column block and sweep.
+// Solves (HBM-bound, L read once per sweep): blocked substitution with the stored inverses of the diagonal blocks
+// (doubled up to 1024 wide), one gemv launch per block step and sweep (solve.hip).
 #include "cip_internal.h"
 #include <stdlib.h>
 #include <string.h>

@@ -245,9 +245,10 @@ int cip_set_solve_block_max(int b);
  * trailing update on a second, CU-masked stream; ordinary launches and events, bit-identical to 0).
  * Process-wide; returns the previous setting. */
 int cip_set_ldlt_lookahead(int on);
-/* panel chain of the serial schedule: 1 (default) = from the second panel of an outer block on, the diagonal kernel's launch
- * also carries the previous panel's in-block update (in-launch hand-off of the block's own tiles); 0 = one launch each
- * (CIP_FUSE_DIAG=0).  Same factor bit for bit.  Process-wide; returns the previous setting (other values: query). */
+/* panel chain of the serial schedule (also CIP_FUSE_DIAG): 3 (default) = one launch per 128-column panel -- diagonal kernel,
+ * the previous panel's in-block update and this panel's TRSM, the TRSM following the diagonal kernel micro-panel by
+ * micro-panel through a stage counter; 1 = diagonal kernel + previous panel's update in one launch, TRSM in its own;
+ * 0 = three launches per panel.  Same factor bit for bit.  Process-wide; returns the previous setting (other values: query). */
 int cip_set_ldlt_fused_chain(int on);
 /* out4 = [100 MHz ticks the persistent workers of the last look-ahead factorisation spent inside tile computations
  * (summed over workers), tiles computed, workers, scheduler error flag] */

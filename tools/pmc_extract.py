@@ -1,7 +1,7 @@
 """Reduce a rocprofv3 counter_collection.csv to the rows of the LDL' kernels and of the solves' gemv (one line per dispatch and counter).
 usage: pmc_extract.py <counter_collection.csv> <out.csv>"""
 import csv, sys
-KEEP = ("k_ldlt_trailing_64", "k_gemm_nt_64", "k_ldlt_diag128_v2", "k_ldlt_diag_upd", "k_trsm_subst", "k_gemv_t")
+KEEP = ("k_ldlt_trailing_64", "k_gemm_nt_64", "k_ldlt_panel", "k_ldlt_diag128_v2", "k_ldlt_diag_upd", "k_trsm_subst", "k_gemv_t")
 rows = list(csv.DictReader(open(sys.argv[1])))
 with open(sys.argv[2], "w", newline="") as f:
     w = csv.writer(f)
