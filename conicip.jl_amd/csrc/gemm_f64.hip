@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64(GemmArgs g, CipBatc
     if (bi == bj && sub == 2) return;            // strictly-upper quadrant of a diagonal tile: never referenced
     // SCALEA: A = L (from K) scaled by d on its way into LDS -- the operand form of the look-ahead schedule's workers,
     // on the serial schedule (bit-identical results: the cross-check of the in-launch hand-offs, tests/test_gpu_lookahead.py)
-    gemm_tile_64<EPI_ACCUM, false, SCALEA>(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB, g.dk);
+    gemm_tile_64<EPI_ACCUM, false, SCALEA, !SCALEA>(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB, g.dk);
 }
 
 // Batched small products (block-inverse doubling): grid.y x grid.z independent problems, C = alpha A B' (overwrite)
