@@ -1,18 +1,19 @@
-// Diagonal-block kernel of the blocked LDL' (v2): in-LDS LDL' of one 128x128 block and the
-// explicit inverse of its unit-lower factor, one 256-thread workgroup, micro-blocked by 16 with
-// v_mfma_f64_16x16x4_f64.
+// Diagonal-block kernel of the blocked LDL' (v2): in-LDS LDL' of one 128x128 block, one workgroup of NW waves (8 by
+// default), micro-blocked by 16 with v_mfma_f64_16x16x4_f64 -- and the launches built around it: the standalone kernel
+// (k_ldlt_diag128_v2), diagonal kernel + previous panel's in-block update (k_ldlt_diag_upd), and the one launch per panel
+// of the serial schedule (k_ldlt_panel: + this panel's TRSM, pipelined behind the diagonal kernel).
 //
 // This is the serial link of the factorisation chain (N/128 of these run back to back), so it is
 // organised around latency, not throughput:
 //   for each 16-column micro-panel kb:
-//     A. wave 0: LDL' of the 16x16 diagonal micro-block + inverse of its unit-lower factor, rows held
-//        one per lane, pivot rows broadcast with v_readlane (no LDS round trip in the 16-step chain)
-//     B. every wave, for its row tiles below: W = U * inv(L11)' as 4 MFMAs (the accumulator layout of
-//        f64 16x16x4 is also its operand layout, so W feeds step C straight from registers); L = W D^-1
-//     C. every wave: trailing tiles C[it][jt] -= W[it] L[jt]'  (4 MFMAs per 16x16 tile, tiles in LDS)
-//   then X = inv(L) by block rows (X[it][jt] = -(sum_kt X[it][kt] L[kt][jt]) inv(L[jt][jt])), a chain of
-//   MFMAs whose running tiles stay in registers.
-// Row tiles are dealt to the 4 waves as pairs (w, 7-w), which balances the triangular work.
+//     A. wave 0: LDL' of the 16x16 diagonal micro-block + inverse of its unit-lower factor, the tile held in the MFMA
+//        accumulator layout, pivots broadcast with v_readlane, pivot row / column entries moved with ds_bpermute
+//     B. every working wave, for its row tiles below: W = U * inv(L11)' as 4 MFMAs (the accumulator layout of
+//        f64 16x16x4 is also its operand layout); L = W D^-1 written back to the LDS image
+//     C. the helper waves: trailing tiles C[it][jt] -= (L[it] D) L[jt]' (4 MFMAs per 16x16 tile, three tiles at a time per
+//        wave) and the write-back of micro-panel kb -- while wave 0 is already in step A of micro-panel kb+1
+//   The explicit inverses of the 128x128 unit-lower factors (X = inv(L) by block rows, a chain of MFMAs whose running tiles
+//   stay in registers) are not on the chain: one batched launch after the factorisation (k_diag_inverse_batched).
 //
 // LDS image: a[row + col*144] (pitch 144 doubles: fragment reads with rows on lanes 0-15 and k on the
 // lane groups are bank-conflict free), the 8 micro inverses, and d / 1/d in the pitch padding:
@@ -293,13 +294,15 @@ __device__ __forceinline__ void diag_publish_micro(const double *a, const double
 
 // Factor-only diagonal kernel: L (strictly lower) and d back into K, d / 1/d vectors, and the 8 micro
 // inverses Xm (xm_out[kb][k*16 + jj] = inv(L11_kb)[jj][k]) for the TRSM and the block-inverse kernels.
-// WAIT: the block is being updated by three other workgroups of the SAME launch (k_ldlt_diag_upd: the quarter tiles of the
-// previous panel's in-block update that make up this block's lower triangle, written with agent-scope stores); thread 0
-// polls their completion counter, one acquire fence, then the block is read with agent-scope loads.
+// WAIT: the block is being updated by other workgroups of the SAME launch (the previous panel's in-block update of this
+// block's lower triangle: three quarter tiles in k_ldlt_diag_upd, 36 one-per-wave tiles in k_ldlt_panel, written with
+// agent-scope stores and counted on `ready`); thread 0 polls the counter up to `ready_target`, one acquire fence, then the
+// block is read with agent-scope loads.
 // PUB: every micro-panel is published as soon as it is final -- its columns of L, its micro inverse, d and 1/d written
-// through by waves 1-3 under wave 0's next serial step, then one count per wave on `stage`: stage >= 3 (kb + 1) <=> micro-
-// panels 0..kb are readable by the other workgroups of the launch (24 at the end).
-// NW: waves of the workgroup (all of them call this); wave 0 is the serial one, the other NW - 1 are its helpers.
+// through by the helper waves under wave 0's next serial step, then one count per helper wave on `stage`: stage >= NH (kb + 1)
+// <=> micro-panels 0..kb are readable by the other workgroups of the launch (8 NH at the end).
+// NW: waves of the workgroup (all of them call this); wave 0 is the serial one, waves 4, 8, .. idle (they would share its
+// SIMD), the others are its NH = NW - NW / 4 helpers.
 template <bool WAIT, bool PUB = false, int NW = 4>
 __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
                                           int *info, int col0, PivotSigns sg, const unsigned *ready, unsigned *stage = nullptr,
@@ -354,7 +357,7 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
     //   B(kb)   all waves   : L tiles of the panel rows below (round-robin over the waves)
     //   barrier
     //   wave 0              : trailing update of the NEXT diagonal micro-block, then A(kb+1)      } overlapped
-    //   waves 1-3           : all other trailing tiles of step kb (any tile, operands from LDS)   }
+    //   the helper waves    : all other trailing tiles of step kb (any tile, operands from LDS)   }
     //   barrier
     if (wave == 0) diag_step_a(a, xm, 0, lane, info, col0, sg);
     __syncthreads();
@@ -384,12 +387,12 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
             diag_step_a(a, xm, kb + 1, lane, info, col0, sg);
             DIAG_STAMP(kb, 3, tid == 0);                              // C11 + A(kb+1) done
         } else if (!(DIAG_SKIP & 4) && !idle) {
-            // micro-panel kb is final (A(kb) and B(kb) are behind the barrier): waves 1-3 write it back now, under
+            // micro-panel kb is final (A(kb) and B(kb) are behind the barrier): the helper waves write it back now, under
             // wave 0's serial step, instead of in a store phase at the end of the kernel
             if (!(DIAG_SKIP & 16)) diag_store_panel<PUB>(a, Kb, ld, c, hid * 64 + lane, 64 * NH);
             if (PUB) diag_publish_micro(a, xm, xm_out, dvec, dinv, kb, hid * 64 + lane, 64 * NH);
             DIAG_STAMP(kb, 6, tid == 64);                             // helper: panel stores issued
-            // the tiles of rows kb+2.. ((kb+1, kb+1) is wave 0's), dealt round-robin to the three helper waves, three at a time
+            // the tiles of rows kb+2.. ((kb+1, kb+1) is wave 0's), dealt round-robin to the helper waves, three at a time
             const int ntile = (6 - kb) * (9 - kb) / 2;
             for (int idx = hid; idx < ntile; idx += 3 * NH) {
                 const int left = (ntile - idx + NH - 1) / NH;      // tiles idx, idx + NH, idx + 2 NH that exist
