@@ -943,7 +943,7 @@ extern "C" int cip_profile_get(cip_handle *h, double *out3) {
     if (!h || !out3 || !h->ws.prof) { cip_set_error("profiling not enabled"); return CIP_E_INVALID; }
     return cip_ldlt_profile_collect(h->ws.prof, &out3[0], &out3[1], &out3[2]);
 }
-// out4 = [ticks (100 MHz) the persistent workers of the LAST factorisation spent inside tile computations (summed over
+// out4 = [s_memtime ticks (shader cycles) the persistent workers of the LAST factorisation spent inside tile computations (summed over
 // workers), tiles computed, workers, scheduler error flag]
 int cip_la_read_stats(void *ctrl_dev, hipStream_t s, double *busy_ticks, double *tiles, double *workers, int *err);
 extern "C" int cip_profile_lookahead(cip_handle *h, double *out4) {

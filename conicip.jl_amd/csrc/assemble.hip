@@ -43,23 +43,39 @@ __global__ __launch_bounds__(256) void k_copy_block(double *K, long ldk, int r0,
 __global__ __launch_bounds__(256) void k_copy_block_lower(double *K, long ldk, int r0, const double *M, long ldm, int n, double sign, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO2(cb, K, M);
-    // two rows per thread (16-byte accesses) when everything is even and 16-byte aligned -- 0.56 GB per factorisation at
-    // n = 8192 is 2.4 % of a step at the 3.2 TB/s of the 8-byte form
-    if (!(n & 1) && !(r0 & 1) && !(ldk & 1) && !(ldm & 1) && !(((uintptr_t)K | (uintptr_t)M) & 15)) {
-        const int i = 2 * (blockIdx.x * 256 + threadIdx.x);
-        if (i >= n) return;
-        const int jend = min(n, (((r0 + i) >> 7) + 1) * 128 - r0);  // columns up to the end of this row pair's diagonal tile
-        for (int j = blockIdx.y; j < jend; j += gridDim.y) {
-            const v2d v = *(const v2d *)(M + i + (long)j * ldm);
-            *(v2d *)(K + (r0 + i) + (long)(r0 + j) * ldk) = sign * v;
-        }
-        return;
-    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int jend = min(n, (((r0 + i) >> 7) + 1) * 128 - r0);      // columns up to the end of this row's diagonal tile
     for (int j = blockIdx.y; j < jend; j += gridDim.y)
         K[(r0 + i) + (long)(r0 + j) * ldk] = sign * M[i + (long)j * ldm];
+}
+// The 16-byte form for even n, r0 and leading dimensions and 16-byte-aligned bases: a workgroup moves 512 rows x 8 columns
+// per step, a thread's eight loads in flight before its first store (one column of 512 rows per workgroup -- the first
+// 16-byte version, 262144 workgroups at n = 8192 -- ran at 2.8 TB/s: 0.19 ms of a 6.1-ms step).
+#define COPY_COLS 8
+__global__ __launch_bounds__(256) void k_copy_block_lower_v(double *K, long ldk, int r0, const double *M, long ldm, int n, double sign, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO2(cb, K, M);
+    const int i = 2 * (blockIdx.x * 256 + threadIdx.x);
+    if (i >= n) return;
+    const int jend = min(n, (((r0 + i) >> 7) + 1) * 128 - r0);      // columns up to the end of this row pair's diagonal tile
+    for (int j0 = blockIdx.y * COPY_COLS; j0 < jend; j0 += gridDim.y * COPY_COLS) {
+        v2d v[COPY_COLS];
+#pragma unroll
+        for (int u = 0; u < COPY_COLS; ++u)
+            if (j0 + u < jend) v[u] = *(const v2d *)(M + i + (long)(j0 + u) * ldm);
+#pragma unroll
+        for (int u = 0; u < COPY_COLS; ++u)
+            if (j0 + u < jend) *(v2d *)(K + (r0 + i) + (long)(r0 + j0 + u) * ldk) = sign * v[u];
+    }
+}
+static void launch_copy_block_lower(hipStream_t s, double *K, long ldk, int r0, const double *M, long ldm, int n, double sign) {
+    if (!(n & 1) && !(r0 & 1) && !(ldk & 1) && !(ldm & 1) && !(((uintptr_t)K | (uintptr_t)M) & 15)) {
+        const int gy = (n + COPY_COLS - 1) / COPY_COLS;
+        cip_launch_b(k_copy_block_lower_v, dim3((n + 511) / 512, gy < 32768 ? gy : 32768), dim3(256), 0, s, K, ldk, r0, M, ldm, n, sign);
+    } else {
+        cip_launch_b(k_copy_block_lower, dim3((n + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, K, ldk, r0, M, ldm, n, sign);
+    }
 }
 
 // ---------------------------------------------------------------- sparse-A Schur terms (R and Q cones)
@@ -181,8 +197,7 @@ static int assemble_schur(cip_handle *h) {
         if ((rc = cip_launch_gemm(s, EPI_SYRKQ, g))) return rc;
     } else {
         if (n > 0) {
-            cip_launch_b(k_copy_block_lower, dim3((n + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, 0, h->Q,
-                               (long)n, n, 1.0);
+            launch_copy_block_lower(s, h->K, h->ldk, 0, h->Q, (long)n, n, 1.0);
         }
         if (h->m > 0) {
             cip_launch_b(k_schur_rows, dim3((n + 255) / 256), dim3(256), 0, s, n, h->T_rp, h->T_ci, h->T_v, h->A_rp, h->A_ci,
@@ -228,8 +243,7 @@ static int assemble_full(cip_handle *h) {
                                h->K, h->ldk, m);
     }
     if (n > 0)
-        cip_launch_b(k_copy_block_lower, dim3((n + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, m, h->Q, (long)n,
-                           n, 1.0);
+        launch_copy_block_lower(s, h->K, h->ldk, m, h->Q, (long)n, n, 1.0);
     if (p > 0)
         cip_launch_b(k_copy_block, dim3((p + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, h->K, h->ldk, m + n, m, h->G,
                            (long)p, p, n, 1.0);

@@ -323,7 +323,7 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
             const long t0 = __builtin_amdgcn_s_memtime();
             while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ready_target) {
                 __builtin_amdgcn_s_sleep(1);
-                if (__builtin_amdgcn_s_memtime() - t0 > 100000000L) { atomicCAS(info + 3, 0, -9); break; }   // ~1 s: never hang the GPU
+                if (__builtin_amdgcn_s_memtime() - t0 > 2000000000L) { atomicCAS(info + 3, 0, -9); break; }   // ~1 s of shader clock: never hang the GPU
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
@@ -513,7 +513,7 @@ __device__ __forceinline__ unsigned strip_wait(unsigned v, unsigned target, cons
         unsigned x;
         while ((x = __hip_atomic_load(stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if (__builtin_amdgcn_s_memtime() - t0 > 100000000L) { atomicCAS(info + 3, 0, -9); x = 0xffffffffu; break; }   // never hang the GPU
+            if (__builtin_amdgcn_s_memtime() - t0 > 2000000000L) { atomicCAS(info + 3, 0, -9); x = 0xffffffffu; break; }   // never hang the GPU
         }
         *slot = x;
     }

@@ -251,7 +251,7 @@ __global__ void k_probe_cus(unsigned *out) {
         out[blockIdx.x] = (xcc << 8) | (((hw >> 13) & 0x3) << 4) | ((hw >> 8) & 0xf);
     }
     const long t0 = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t0 < 100000) __builtin_amdgcn_s_sleep(10);   // keep the CU busy: ~1 ms
+    while (__builtin_amdgcn_s_memtime() - t0 < 100000) __builtin_amdgcn_s_sleep(10);   // keep the CU busy: ~50 us of shader clock
 }
 static ReserveMap g_rmap;
 static int g_rmap_ready = 0;
@@ -321,7 +321,7 @@ struct LaCtrl {                                 // device, zeroed before every f
     unsigned crit_next, bulk_next;
     int err;
     unsigned workers_done;
-    unsigned long long busy_ticks, tiles;       // s_memtime ticks (100 MHz) inside tile computations, summed over workers
+    unsigned long long busy_ticks, tiles;       // s_memtime ticks (shader cycles) inside tile computations, summed over workers
     unsigned pad[8];
     unsigned flag[LA_MAX_ROUNDS + 1];
     unsigned stripdone[LA_MAX_ROUNDS + 1];
@@ -335,7 +335,7 @@ __device__ __forceinline__ bool la_wait_ge(const unsigned *p, unsigned target, L
     const long t0 = __builtin_amdgcn_s_memtime();
     while (la_load(p) < target) {
         __builtin_amdgcn_s_sleep(SLEEP);
-        if (__builtin_amdgcn_s_memtime() - t0 > 100000000L || la_load((const unsigned *)&ctrl->err) != 0) { atomicExch(&ctrl->err, -7); return false; }
+        if (__builtin_amdgcn_s_memtime() - t0 > 2000000000L || la_load((const unsigned *)&ctrl->err) != 0) { atomicExch(&ctrl->err, -7); return false; }
     }
     return true;
 }

@@ -250,7 +250,7 @@ int cip_set_ldlt_lookahead(int on);
  * micro-panel through a stage counter; 1 = diagonal kernel + previous panel's update in one launch, TRSM in its own;
  * 0 = three launches per panel.  Same factor bit for bit.  Process-wide; returns the previous setting (other values: query). */
 int cip_set_ldlt_fused_chain(int on);
-/* out4 = [100 MHz ticks the persistent workers of the last look-ahead factorisation spent inside tile computations
+/* out4 = [s_memtime ticks (shader cycles, ~2.1-2.4 GHz) the persistent workers of the last look-ahead factorisation spent inside tile computations
  * (summed over workers), tiles computed, workers, scheduler error flag] */
 int cip_profile_lookahead(cip_handle *h, double *out4);
 /* HIP-event timing of every LDL' trailing-update launch (bench.py roofline): enable, then read

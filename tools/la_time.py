@@ -25,9 +25,9 @@ for mode in modes:
     msg = "mode %d: assemble+factor ms %s" % (mode, " ".join("%.3f" % (t * 1e3) for t in ts))
     if mode == 1:
         st = ks.profile_lookahead()
-        per_tile_us = st["busy_ticks"] / max(st["tiles"], 1) / 100.0
+        per_tile_us = st["busy_ticks"] / max(st["tiles"], 1) / 2200.0      # s_memtime ticks are shader cycles (~2.2 GHz under load)
         flops = sum((n - 512 * (J + 1)) * (n - 512 * (J + 1) + 1) * 512.0 for J in range(n // 512 - 1))
-        busy_s = st["busy_ticks"] / 1e8 / max(st["workers"], 1)
+        busy_s = st["busy_ticks"] / 2.2e9 / max(st["workers"], 1)
         msg += " | workers %d tiles %d avg tile %.1f us, busy/worker %.3f ms -> %.1f TFLOP/s while busy" % (
             st["workers"], st["tiles"], per_tile_us, busy_s * 1e3, flops / busy_s / 1e12)
     print(msg, flush=True)
