@@ -4,6 +4,7 @@
 #include "../conicip.jl_amd/csrc/diag.hip"
 #include <vector>
 #include <cstdio>
+#include <cstdlib>
 #include <cmath>
 void cip_set_error(const char *fmt, ...) {}
 thread_local CipGraphBuilder *cip_tl_builder = nullptr;
@@ -13,6 +14,16 @@ int main() {
     std::vector<double> K(N * N);
     for (int j = 0; j < N; ++j)
         for (int i = 0; i < N; ++i) K[i + j * N] = (i == j ? 4.0 + 0.01 * i : 0.0) + 1.0 / (1.0 + abs(i - j));
+    if (getenv("DIAG_BENCH_MATRIX")) {          // 1: negative definite; 2: quasi-definite [-(SPD) C; C' SPD] (the full 3x3 KKT shape)
+        const int m = atoi(getenv("DIAG_BENCH_MATRIX"));
+        for (int j = 0; j < N; ++j)
+            for (int i = 0; i < N; ++i) {
+                if (m == 1) K[i + j * N] = -K[i + j * N];
+                else if (i < 44 && j < 44) K[i + j * N] = -K[i + j * N];
+                else if ((i < 44) != (j < 44)) K[i + j * N] = 0.3 * sin(1.0 + i * 0.37 + j * 0.91 + 0.01 * i * j) * 1.0;
+            }
+        for (int j = 0; j < N; ++j) for (int i = 0; i < j; ++i) K[i + j * N] = K[j + i * N];      // symmetric
+    }
     double *dK, *dLi, *dLt, *dd, *ddi, *dK0; int *dinfo;
     hipMalloc(&dK, N * N * 8); hipMalloc(&dK0, N * N * 8); hipMalloc(&dLi, N * N * 8); hipMalloc(&dLt, N * N * 8);
     hipMalloc(&dd, N * 8); hipMalloc(&ddi, N * 8); hipMalloc(&dinfo, 4);
