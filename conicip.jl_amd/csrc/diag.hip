@@ -781,8 +781,7 @@ int cip_kernels_init(void) {
 int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
                        PivotSigns sg) {
     if (cip_kernels_init()) return -3;
-    static int nw = -1;
-    if (nw < 0) { const char *e = getenv("CIP_DIAG_WAVES"); nw = e ? atoi(e) : 8; }
+    static const int nw = [] { const char *e = getenv("CIP_DIAG_WAVES"); return e ? atoi(e) : 8; }();     // thread-safe one-time read
     if (nw == 4) cip_launch_b(k_ldlt_diag128_v2<4>, dim3(1), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg);
     else if (nw == 12) cip_launch_b(k_ldlt_diag128_v2<12>, dim3(1), dim3(768), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg);
     else cip_launch_b(k_ldlt_diag128_v2<8>, dim3(1), dim3(512), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg);
@@ -795,8 +794,8 @@ int cip_launch_diag_upd(hipStream_t s, double *Kb, long ld, double *xm_out, doub
                         PivotSigns sg, unsigned *ready, const GemmArgs &g) {
     if (cip_kernels_init()) return -3;
     const long nt = (long)(g.M / SB) * (g.N / SB) - 1;          // every tile but the block's strictly-upper quarter
-    static int nowait = -1;                     // CIP_FUSE_DIAG=2: timing experiment, workgroup 0 does not wait (wrong results)
-    if (nowait < 0) { const char *e = getenv("CIP_FUSE_DIAG"); nowait = (e && atoi(e) == 2) ? 1 : 0; }
+    // CIP_FUSE_DIAG=2: timing experiment, workgroup 0 does not wait (wrong results)
+    static const int nowait = [] { const char *e = getenv("CIP_FUSE_DIAG"); return (e && atoi(e) == 2) ? 1 : 0; }();
     if (nowait) cip_launch_b(k_ldlt_diag_upd<false>, dim3((unsigned)(1 + nt)), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv,
                              info, col0, sg, ready, g);
     else cip_launch_b(k_ldlt_diag_upd<true>, dim3((unsigned)(1 + nt)), dim3(256), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv,

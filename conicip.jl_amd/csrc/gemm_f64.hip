@@ -528,7 +528,6 @@ int cip_la_read_stats(void *ctrl_dev, hipStream_t s, double *busy_ticks, double 
     return 0;
 }
 
-static int g_tile = -1;
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.M % CIP_NB || g.N % CIP_NB || g.K % CIP_KT || g.K <= 0) {
@@ -556,7 +555,7 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
         return 0;
     }
     // CIP_GEMM_TILE=128: the lower-triangular update on the 128x128 kernel (kept for A/B runs of tools/gemm_bench.hip)
-    if (g_tile < 0) g_tile = (getenv("CIP_GEMM_TILE") && atoi(getenv("CIP_GEMM_TILE")) == 128) ? 128 : 64;
+    static const int g_tile = [] { const char *e = getenv("CIP_GEMM_TILE"); return (e && atoi(e) == 128) ? 128 : 64; }();
     if (epi == EPI_ACCUM && g.lower && g_tile == 64) {
         // the LDL' trailing update: every 128-tile of the lower triangle as four 64x64 quarter tiles
         // Optional XCD-aware patch order (CIP_TRAIL_PATCH=4 or 8).  PMC at r = 8192, K = 512: 1.52 GB of L2-miss
@@ -564,8 +563,7 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
         // faster (standalone +1.5 % at r = 8192, -1 % at r = 2048) and the factorisation is 1-2 % SLOWER (same-session
         // A/B: 52.6 / 51.9 vs 51.0 / 50.4 TFLOP/s): the misses are served by the Infinity Cache and hidden by the 20
         // waves per CU, while a patch granularity costs load balance over the 8 XCDs.  Off by default.
-        static int psz = -1;
-        if (psz < 0) psz = getenv("CIP_TRAIL_PATCH") ? atoi(getenv("CIP_TRAIL_PATCH")) : 0;
+        static const int psz = [] { const char *e = getenv("CIP_TRAIL_PATCH"); return e ? atoi(e) : 0; }();
         if (psz > 0) {
             const int nq = g.M / SB, P = (nq + psz - 1) / psz, npatch = P * (P + 1) / 2;
             const long grid = (long)((npatch + 7) / 8) * 8 * psz * psz;

@@ -25,15 +25,19 @@
 // less often: same-session A/B at n = 8192, 512 / 768 / 1024 -> 130.6-132.0 / 134.5 / 133.9 KKT solves/s), else 512 (unfused
 // chain, round 1: 256 / 384 / 512 -> 107.7 / 107.0 / 109.1; 1024 -> 125 against 128).
 static int g_nbo = 0;
-static int g_fuse_diag = -1;
+#include <atomic>
+#include <mutex>
+static std::atomic<int> g_fuse_diag{-1};
+static std::once_flag g_fuse_once;
 // 0: diag -> TRSM -> in-block update, three launches per panel; 1: the update inside the next diagonal kernel's launch
 // (k_ldlt_diag_upd); 3: one launch per panel, the TRSM pipelined behind the diagonal kernel (k_ldlt_panel)
 #define CIP_FUSE_DEFAULT 3
 static void fuse_env(void) {
-    if (g_fuse_diag >= 0) return;
-    const char *e = getenv("CIP_FUSE_DIAG");
-    const int v = e ? atoi(e) : CIP_FUSE_DEFAULT;
-    g_fuse_diag = (v == 0) ? 0 : (v == 3) ? 3 : 1;
+    std::call_once(g_fuse_once, [] {
+        const char *e = getenv("CIP_FUSE_DIAG");
+        const int v = e ? atoi(e) : CIP_FUSE_DEFAULT;
+        g_fuse_diag = (v == 0) ? 0 : (v == 3) ? 3 : 1;
+    });
 }
 int cip_ldlt_outer_block_for(int Npad) {
     if (g_nbo > 0) return g_nbo;

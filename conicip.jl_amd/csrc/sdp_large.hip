@@ -703,8 +703,8 @@ __global__ __launch_bounds__(512) void k_lg_tridiag1(const double *M, int ldm, c
 
 static int lg_tridiag(hipStream_t s, LargeWs *w, const double *M, const double *dscale, int r) {
     int rc;
-    static int one_wg = -1;                                   // CIP_LG_TRIDIAG1=0: the cooperative kernel at every order (A/B runs)
-    if (one_wg < 0) { const char *e = getenv("CIP_LG_TRIDIAG1"); one_wg = (e && atoi(e) == 0) ? 0 : 1; }
+    // CIP_LG_TRIDIAG1=0: the cooperative kernel at every order (A/B runs)
+    static const int one_wg = [] { const char *e = getenv("CIP_LG_TRIDIAG1"); return (e && atoi(e) == 0) ? 0 : 1; }();
     if (one_wg && r <= 256) {
         const size_t shm1 = T1_LDS_DOUBLES * sizeof(double);
         if ((rc = lg_set_attr((const void *)k_lg_tridiag1, shm1))) return rc;
