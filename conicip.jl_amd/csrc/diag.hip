@@ -643,8 +643,10 @@ __global__ __launch_bounds__(64 * PANEL_WAVES) void k_ldlt_panel(double *Kb, lon
 // X = inv(L) for every 128x128 diagonal block of a factored matrix, one workgroup per block (they are
 // independent, so this is ONE launch after the factorisation instead of a serial link in it).  Only the
 // solves use X (gemv with the block inverses).
+// Output: block jb at Linv + jb 128^2 (leading dimension 128) when Bs == 128; else straight into the diagonal 128-block of
+// the Bs-wide block inverses the solves read (X / XT, leading dimension Bs: block jb / per, offset (jb % per) 128 (Bs + 1)).
 __global__ __launch_bounds__(256) void k_diag_inverse_batched(const double *K, long ld, const double *xm_all, double *Linv,
-                                                               double *LinvT, CipBatch cb) {
+                                                               double *LinvT, int Bs, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO4(cb, K, xm_all, Linv, LinvT);
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -660,7 +662,9 @@ __global__ __launch_bounds__(256) void k_diag_inverse_batched(const double *K, l
     diag_inverse_row(a, xm, wave, l15, g);
     diag_inverse_row(a, xm, 7 - wave, l15, g);
     __syncthreads();
-    double *Li = Linv + (size_t)jb * CIP_NB * CIP_NB, *Lt = LinvT + (size_t)jb * CIP_NB * CIP_NB;
+    const int per = Bs / CIP_NB;
+    const size_t ob = (size_t)(jb / per) * Bs * Bs + (size_t)(jb % per) * CIP_NB * (Bs + 1);
+    double *Li = Linv + ob, *Lt = LinvT + ob;
     for (int e = tid; e < CIP_NB * CIP_NB; e += 256) {
         const int r = e & 127, cc = e >> 7;
         const int tr = r >> 4, tc = cc >> 4;
@@ -672,8 +676,8 @@ __global__ __launch_bounds__(256) void k_diag_inverse_batched(const double *K, l
             x = (tr > tc) ? a[cc + r * DP] : 0.0;                    // X[r][cc]
             xt = (tc > tr) ? a[r + cc * DP] : 0.0;                   // X[cc][r]
         }
-        Li[r + cc * CIP_NB] = x;
-        Lt[r + cc * CIP_NB] = xt;
+        Li[r + (size_t)cc * Bs] = x;
+        Lt[r + (size_t)cc * Bs] = xt;
     }
 }
 
@@ -824,9 +828,9 @@ int cip_launch_panel(hipStream_t s, double *Kb, long ld, double *xm_out, double 
     return 0;
 }
 int cip_launch_diag_inverse(hipStream_t s, const double *K, long ld, int nblk, const double *xm_all, double *Linv,
-                            double *LinvT) {
+                            double *LinvT, int Bs) {
     if (cip_kernels_init()) return -3;
-    cip_launch_b(k_diag_inverse_batched, dim3(nblk), dim3(256), DIAG2_LDS_BYTES, s, K, ld, xm_all, Linv, LinvT);
+    cip_launch_b(k_diag_inverse_batched, dim3(nblk), dim3(256), DIAG2_LDS_BYTES, s, K, ld, xm_all, Linv, LinvT, Bs);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -168,7 +168,7 @@ int cip_launch_diag_v2(hipStream_t s, double *Kb, long ld, double *xm_out, doubl
 int cip_launch_diag_upd(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
                         PivotSigns sg, unsigned *ready, const GemmArgs &g);
 int cip_launch_diag_inverse(hipStream_t s, const double *K, long ld, int nblk, const double *xm_all, double *Linv,
-                            double *LinvT);
+                            double *LinvT, int Bs);
 int cip_launch_panel(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
                      PivotSigns sg, unsigned *ready, unsigned *stage, const GemmArgs *g, int rows, double *W, long ldw);
 int cip_launch_trsm_subst(hipStream_t s, double *Ap, long ld, int rows, const double *L11, const double *xm,
@@ -366,23 +366,6 @@ __global__ __launch_bounds__(256) void k_mirror_lower(double *K, long ld, CipBat
         if (c > r) K[(long)r + (long)c * ld] = t[tx][ty + q];
     }
 }
-// X/XT diagonal 128-blocks <- Linv/LinvT
-__global__ __launch_bounds__(256) void k_seed_block_inverse(const double *Linv, const double *LinvT, double *X, double *XT,
-                                                             int Bs, CipBatch cb) {
-    CIP_BATCH_GUARD(cb);
-    CIP_BO4(cb, Linv, LinvT, X, XT);
-    const int jb = blockIdx.x;                       // 128-block index
-    const int per = Bs / CIP_NB;
-    const int q = jb / per, o = (jb % per) * CIP_NB;
-    const double *li = Linv + (size_t)jb * CIP_NB * CIP_NB, *lt = LinvT + (size_t)jb * CIP_NB * CIP_NB;
-    double *x = X + (size_t)q * Bs * Bs + o + (size_t)o * Bs, *xt = XT + (size_t)q * Bs * Bs + o + (size_t)o * Bs;
-    for (int e = threadIdx.x; e < CIP_NB * CIP_NB / 2; e += 256) {
-        const int i = 2 * (e & 63), j = e >> 6;
-        *(v2d *)(x + i + (size_t)j * Bs) = *(const v2d *)(li + i + j * CIP_NB);
-        *(v2d *)(xt + i + (size_t)j * Bs) = *(const v2d *)(lt + i + j * CIP_NB);
-    }
-}
-
 // After the factorisation: inverses of the Bs x Bs unit-lower diagonal blocks by doubling,
 //   inv([L11 0; L21 L22]) = [X11 0; -X22 L21 X11  X22],
 // two batched MFMA GEMMs per level (Tt = X11' L21', then X21 = -X22 Tt' together with its transpose), so that a
@@ -392,15 +375,16 @@ static int build_solve_blocks(hipStream_t s, double *K, int Npad, long ld, const
     const int nbk = Npad / Bs;
     int rc;
     cip_launch_b(k_mirror_lower, dim3(Npad / 32, Npad / 32), dim3(256), 0, s, K, ld);
-    if (Bs == CIP_NB) { CIP_HIP_CHECK(hipGetLastError()); return 0; }   // X == Linv, XT == LinvT
+    if (Bs == CIP_NB)                                                   // X == Linv, XT == LinvT
+        return cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.Linv, ws.LinvT, CIP_NB);
     if (!ws.x_zeroed || !*ws.x_zeroed) {
         // the strictly upper blocks of X (lower of XT) are never written afterwards: zero them once per workspace
         if ((rc = zero_fill(s, ws.X, sizeof(double) * (size_t)nbk * Bs * Bs))) return rc;
         if ((rc = zero_fill(s, ws.XT, sizeof(double) * (size_t)nbk * Bs * Bs))) return rc;
         if (ws.x_zeroed && (!cip_in_batch() || cip_tl_bz.mask == (cip_tl_bz.B >= 64 ? ~0ull : ((1ull << cip_tl_bz.B) - 1)))) *ws.x_zeroed = 1;
     }
-    cip_launch_b(k_seed_block_inverse, dim3(Npad / CIP_NB), dim3(256), 0, s, ws.Linv, ws.LinvT, ws.X, ws.XT, Bs);
-    CIP_HIP_CHECK(hipGetLastError());
+    // the inverses of the 128-blocks, written straight into the diagonal of X / XT
+    if ((rc = cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.X, ws.XT, Bs))) return rc;
     const long bs2 = (long)Bs * Bs, tt2 = (long)(Bs / 2) * (Bs / 2);
     for (int h = CIP_NB; h < Bs; h *= 2) {
         const int P = Bs / (2 * h);                          // pairs per block
@@ -482,7 +466,6 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
         if (bulk_pending) CIP_HIP_CHECK(hipStreamWaitEvent(sc, g_bulk.ev_bulk, 0));
         CIP_HIP_CHECK(hipEventRecord(g_side.ev_chain, sc));
         CIP_HIP_CHECK(hipStreamWaitEvent(s, g_side.ev_chain, 0));
-        if ((rc = cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.Linv, ws.LinvT))) return rc;
         return build_solve_blocks(s, K, Npad, ld, ws);
     }
     if (!la) {
@@ -507,8 +490,6 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
                 if (ws.prof && (rc = prof_event(ws.prof, s))) return rc;
             }
         }
-        if ((rc = cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.Linv, ws.LinvT)))
-            return rc;
         return build_solve_blocks(s, K, Npad, ld, ws);
     }
     // Deep look-ahead (opt-in, Npad >= 4096): the persistent worker launch on the caller's stream carries all
@@ -537,8 +518,6 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
     CIP_HIP_CHECK(hipEventRecord(g_side.ev_chain, sp));
     CIP_HIP_CHECK(hipStreamWaitEvent(s, g_side.ev_chain, 0));
     if ((rc = cip_la_finish(s, ws.la_ctrl, ws.info))) return rc;
-    if ((rc = cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.Linv, ws.LinvT)))
-        return rc;
     return build_solve_blocks(s, K, Npad, ld, ws);
 }
 
