@@ -82,14 +82,15 @@ def test_two_stream_lookahead_bitwise_equals_serial(lib, N, quasi):
 
 
 @pytest.mark.parametrize("mode", [1, 3, 4], ids=["diag+update", "one-launch-panel", "panel+heir"])
-@pytest.mark.parametrize("N,quasi", [(1024, 0), (2048, 0), (4608, 512), (8192, 0)])
+@pytest.mark.parametrize("N,quasi", [(128, 0), (256, 0), (384, 38), (896, 0), (1024, 0), (2048, 0), (4608, 512), (8192, 0)])
 def test_fused_panel_chain_bitwise_equals_unfused(lib, N, quasi, mode):
     """Mode 1: from the second panel of an outer block on, the diagonal kernel's launch carries the previous panel's in-block
     update and waits, INSIDE the launch, for the three tiles that are its own block (diag.hip: k_ldlt_diag_upd).  Same
     arithmetic in the same order as the three-launch chain: identical bits -- also repeated under a concurrent 1-GiB copy
     load, which is when a missing fence or a stale line would show.  Mode 3: that launch also carries the panel's TRSM,
     which follows the diagonal kernel micro-panel by micro-panel through agent-scope stores, loads and a stage counter
-    (diag.hip: k_ldlt_panel) -- same bar."""
+    (diag.hip: k_ldlt_panel) -- same bar.  The small orders are the launch shapes without strips (one block), without
+    update tiles (last panel of an outer block) and with a single strip."""
     from cipkkt import _lib as L
     nbytes = C.c_size_t()
     L.check(lib.cip_ldlt_workspace_bytes(N, C.byref(nbytes)))
