@@ -609,6 +609,17 @@ __global__ __launch_bounds__(64 * PANEL_WAVES) void k_ldlt_panel(double *Kb, lon
                                                                   int *info, int col0, PivotSigns sg, unsigned *ready, unsigned *stage,
                                                                   GemmArgs g, TrsmStrips tr, CipBatch cb) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    // small lock-step groups (ldlt.hip: up to 8 problems): problem z's workgroups follow those of the problems before it in
+    // dispatch order, so every wait is still for a workgroup dispatched earlier
+    CIP_BATCH_GUARD(cb);
+    CIP_BO7(cb, Kb, xm_out, dvec, dinv, info, ready, stage);
+    {
+        const long off = (long)blockIdx.z * cb.stride;
+        g.A = (const double *)((const char *)g.A + off); g.B = (const double *)((const char *)g.B + off); g.C = (double *)((char *)g.C + off);
+        tr.Ap = (double *)((char *)tr.Ap + off); tr.L11 = (const double *)((const char *)tr.L11 + off);
+        tr.xm = (const double *)((const char *)tr.xm + off); tr.dinv = (const double *)((const char *)tr.dinv + off);
+        tr.W = (double *)((char *)tr.W + off);
+    }
     const int b = (int)blockIdx.x;
     if (b == 0) {
         diag_body<UPD, true, PANEL_WAVES>(sm, Kb, ld, xm_out, dvec, dinv, info, col0, sg, ready, stage, 36u);

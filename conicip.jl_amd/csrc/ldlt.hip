@@ -212,7 +212,14 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
         fuse_env();
         // fused only when the chain has the chip to itself: a lock-step batch is throughput-bound and beside a look-ahead's
         // bulk the fused launch's update tiles (160 KB of LDS per workgroup: one per CU) would queue on the few free CUs
-        const bool fuse = g_fuse_diag && alone && !cip_in_batch();
+        // ... except small lock-step groups, which take the one-launch-per-panel form too (grid.z = problems): while every
+        // problem's long-lived workgroups (diagonal kernel + strips: 1 + Npad / 64 at the first panel) fit on the chip at once
+        // the launch takes one round -- 4 / 8 / 12 problems of order 2048: 18.7 -> 16.4, 23.3 -> 21.0, 27.9 -> 27.0 ms per pass;
+        // 16 problems run in two rounds and lose against their three batched launches (31.6 -> 32.9)
+        static const int lsmax = [] { const char *e = getenv("CIP_LOCKSTEP_PANEL_MAX"); return e ? atoi(e) : 12; }();
+        static const int lscus = [] { const char *e = getenv("CIP_LOCKSTEP_PANEL_CUS"); return e ? atoi(e) : 400; }();
+        const bool small_group = cip_in_batch() && g_fuse_diag == 3 && cip_tl_bz.B <= lsmax && (long)cip_tl_bz.B * (1 + Npad / 64) <= lscus;
+        const bool fuse = g_fuse_diag && alone && (!cip_in_batch() || small_group);
         if (fuse && g_fuse_diag == 3) {
             const bool upd = t > 0 && rest_of_block_args(K, Npad, ld, Wb, C0, wblk, t - 1, gu);
             unsigned *ctr = (unsigned *)(ws.info + 16);
