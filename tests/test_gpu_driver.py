@@ -163,3 +163,19 @@ def test_degenerate_shapes(drv):
     assert np.abs(G @ s.y - d).max() < 1e-12
     s = cipkkt.conicIP(np.array([[2.0]]), np.array([-1.0]), np.array([[1.0]]), np.array([0.0]), [("R", 1)], driver=drv)
     assert s.status == "Optimal" and abs(s.y[0]) < 1e-5
+
+
+@pytest.mark.parametrize("route", ROUTES)
+def test_graph_replay_matches_plain_launches(route, monkeypatch):
+    """CIP_GRAPH=1 (opt-in): factor + solves of a handle are replayed from a captured hipGraph -- the one-launch-per-panel
+    chain with its in-launch counters included.  Same kernels on the same data: the iterates must be bit-identical."""
+    import cipkkt
+    Q, c, A, b, K, G, d, _ = P.random_mixed(n=200, nq=3, kq=6, p=4, seed=77)
+    monkeypatch.delenv("CIP_GRAPH", raising=False)
+    plain = cipkkt.conicIP(Q, c, A, b, K, G, d, kktsolver=route)
+    monkeypatch.setenv("CIP_GRAPH", "1")
+    graph = cipkkt.conicIP(Q, c, A, b, K, G, d, kktsolver=route)
+    assert plain.status == graph.status == "Optimal"
+    assert (plain.Iter, plain.n_factor, plain.n_solve) == (graph.Iter, graph.n_factor, graph.n_solve)
+    for f in ("y", "w", "v"):
+        assert np.array_equal(getattr(plain, f), getattr(graph, f)), f
