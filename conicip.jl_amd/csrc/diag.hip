@@ -493,12 +493,12 @@ __global__ __launch_bounds__(256) void k_ldlt_diag_upd(double *Kb, long ld, doub
 //                        (diag_block_producer)
 //   the next `strips`    one 64-row strip of the rows below the block: (UPD) its two update tiles of this panel's columns,
 //                        then the substitution of k_trsm_subst with the operands of stage kb fetched (agent-scope loads)
-//                        once stage >= 3 (kb + 1):  W[:,kb] = T_kb inv(L11[kb][kb])',  T_{kb+1} = A21[:,kb+1] - sum W[:,q] L11[kb+1][q]'
+//                        once stage >= PANEL_NH (kb + 1):  W[:,kb] = T_kb inv(L11[kb][kb])',  T_{kb+1} = A21[:,kb+1] - sum W[:,q] L11[kb+1][q]'
 //   the others           (UPD) the remaining tiles of the in-block update
 // The same operations on the same operands in the same order as the separate launches: bit-identical factors.
 // Every wait is for a workgroup with a lower index in the same launch (dispatched earlier); waits are bounded (~1 s).
 #define PANEL_WAVES 8                   // waves of a k_ldlt_panel workgroup: the diagonal kernel's; the other roles use the first four
-#define PANEL_NH (PANEL_WAVES - PANEL_WAVES / 4)
+#define PANEL_NH (PANEL_WAVES - PANEL_WAVES / 4)      // helper waves of the diagonal kernel = counts on `stage` per published micro-panel
 struct TrsmStrips {
     double *Ap; long ld;              // rows below the diagonal block, this panel's 128 columns
     const double *L11;                // the diagonal block (leading dimension ld)
@@ -609,8 +609,8 @@ __global__ __launch_bounds__(64 * PANEL_WAVES) void k_ldlt_panel(double *Kb, lon
                                                                   int *info, int col0, PivotSigns sg, unsigned *ready, unsigned *stage,
                                                                   GemmArgs g, TrsmStrips tr, CipBatch cb) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    // small lock-step groups (ldlt.hip: up to 8 problems): problem z's workgroups follow those of the problems before it in
-    // dispatch order, so every wait is still for a workgroup dispatched earlier
+    // small lock-step groups (ldlt.hip: factor_outer_panels, up to 12 problems): problem z's workgroups follow those of the
+    // problems before it in dispatch order, so every wait is still for a workgroup dispatched earlier
     CIP_BATCH_GUARD(cb);
     CIP_BO7(cb, Kb, xm_out, dvec, dinv, info, ready, stage);
     {
