@@ -141,9 +141,13 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
     } solve_block_scope;
     // ---- slab size: create problem 0 once with ordinary allocations and count what it asked for
     size_t slab = 0;
-    const bool csr = probs[0].A == nullptr && m > 0;         // CSR: the slab depends on the number of non-zeros -> always probe
-    const std::vector<long> sig = shape_signature(probs[0], cip_tl_solve_block_max);
-    if (!csr) {
+    // CSR: the slab depends on the number of non-zeros -- part of the signature when the row pointers are host memory
+    // (the probe is a full handle creation: 0.9 ms per call, 4 % of an 8-problem pass), else always probe
+    const bool csr = probs[0].A == nullptr && m > 0;
+    const bool csr_host = csr && probs[0].A_rowptr && ((probs[0].flags & CIP_FLAG_CSR_HOST) || !(probs[0].flags & CIP_FLAG_DEVICE_PTRS));
+    std::vector<long> sig = shape_signature(probs[0], cip_tl_solve_block_max);
+    if (csr_host) sig.push_back((long)probs[0].A_rowptr[m]);
+    if (!csr || csr_host) {
         std::lock_guard<std::mutex> lk(g_cache.mu);
         if (g_cache.sig == sig) slab = g_cache.slab;
     }
