@@ -72,7 +72,7 @@ static void free_all(cip_handle *h) {
     if (h->gx_factor) { (void)hipGraphExecDestroy(h->gx_factor); h->gx_factor = nullptr; }
     if (h->gx_solve) { (void)hipGraphExecDestroy(h->gx_solve); h->gx_solve = nullptr; }
     if (h->cs.lg) { cip_sdp_large_destroy(h->cs.lg); h->cs.lg = nullptr; }
-    void *ptrs[] = {h->cs.d_sidx_small, h->cs.d_sidx, h->cs.d_sdpws, h->cs.d_sdpvec, h->cs.d_sdpflag, h->Q, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->row_cone, h->G, h->Gt,
+    void *ptrs[] = {h->cs.d_sidx_small, h->cs.d_sidx, h->cs.d_sdpws, h->cs.d_sdpvec, h->cs.d_sdpflag, h->Q, h->symv_ws, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->row_cone, h->G, h->Gt,
                     h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->cs.d_partial, h->cs.d_scalar, h->K, h->Wt, h->Gm,
                     h->ws_base, h->rhs, h->mt1, h->mt2, h->mt3, h->nt1, h->pt1, h->dot_scratch, h->dot_ptrs, h->stage, h->drv, h->ref, h->c2x2};
     for (void *p : ptrs)
@@ -303,6 +303,7 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
 
     // ---- Q, G, A: buffers here, contents by upload_problem (also used by cip_update_problem)
     DMALLOC(h->Q, sizeof(double) * (size_t)n * n);
+    if (n >= 2048 && n % 128 == 0) DMALLOC(h->symv_ws, sizeof(double) * 2 * (size_t)(n / 128) * n);
     DMALLOC(h->G, sizeof(double) * (size_t)p * n);
     DMALLOC(h->Gt, sizeof(double) * (size_t)p * n);
     h->A_sparse = (pr->A == NULL && m > 0);
@@ -852,7 +853,9 @@ extern "C" int cip_gemv_dev(cip_handle *h, int which, int trans, double alpha, c
     if (!h) return CIP_E_INVALID;
     hipStream_t s = h->stream;
     switch (which) {
-        case CIP_MAT_Q: return cip_gemv_t(s, h->n, h->n, alpha, h->Q, h->n, x, beta, y);   // Q symmetric
+        case CIP_MAT_Q:                                                                     // Q symmetric
+            if (h->symv_ws && !(((uintptr_t)x) & 15)) return cip_symv_lower(s, h->n, alpha, h->Q, h->n, x, beta, y, h->symv_ws);
+            return cip_gemv_t(s, h->n, h->n, alpha, h->Q, h->n, x, beta, y);
         case CIP_MAT_A: return trans ? mul_At(h, alpha, x, beta, y) : mul_A(h, alpha, x, beta, y);
         case CIP_MAT_G:
             if (h->p == 0) {

@@ -19,6 +19,7 @@ struct cip_handle {
 
     // ---- problem data, device resident for the lifetime of the handle (level 1)
     double *Q = nullptr;            // n x n, ld n
+    double *symv_ws = nullptr;      // partial-sum tables of the symmetric mat-vec (n a multiple of 128, n >= 2048), else null
     bool A_sparse = false;
     double *A = nullptr;            // m x n, ld m            (dense A only)
     double *At = nullptr;           // npad x mpad, ld npad   (dense A only; zero padded)  At[i + r*npad] = A[r,i]

@@ -218,6 +218,7 @@ int cip_cones_identity(hipStream_t s, const ConeSet &cs, double *e);
 int cip_cones_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, long ldat, double *Wt, long ldwt);
 
 // ---------------------------------------------------------------- vector ops (vecops.hip)
+int cip_symv_lower(hipStream_t s, int n, double alpha, const double *Q, long ldq, const double *x, double beta, double *y, double *ws);
 int cip_gemv_t(hipStream_t s, int rows, int cols, double alpha, const double *A, long lda,
                const double *x, double beta, double *y);     // y[j] = alpha * sum_i A[i + j*lda] x[i] + beta y[j]
 int cip_spmv_csr(hipStream_t s, int rows, const int *rowptr, const int *colind, const double *val,

@@ -59,6 +59,88 @@ int cip_gemv_t(hipStream_t s, int rows, int cols, double alpha, const double *A,
     return 0;
 }
 
+// Symmetric mat-vec from the tiles on and below the diagonal only: y = alpha Q x + beta y for a dense symmetric Q of order
+// n (n a multiple of 128, even leading dimension, 16-byte aligned) with HALF the HBM traffic of the column-dot gemv -- Q x is
+// the residual product of every interior-point iteration (src/ConicIP.jl:747, :912), 0.54 GB at n = 8192 and three passes
+// over all 64 matrices per iteration of a config-5 batch.  Deterministic (no atomics), two launches:
+//   k_symv_tiles   one workgroup per 128 x 128 tile (I >= J), read once: the row sums  T x_J  (a piece of y_I) and, below the
+//                  diagonal, the column dots  T' x_I  (a piece of y_J) go to two partial-sum tables P1[J][i], P2[I][j]
+//   k_symv_reduce  y_i = alpha (sum_{J <= I(i)} P1[J][i] + sum_{I > I(i)} P2[I][i]) + beta y_i, fixed order
+__global__ __launch_bounds__(256) void k_symv_tiles(int n, const double *Q, long ldq, const double *x, double *P1, double *P2, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO4(cb, Q, x, P1, P2);
+    __shared__ double rs[4][128];
+    // tile index -> (I, J), row-major over the lower triangle
+    const int t = blockIdx.x;
+    int I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((long)I * (I + 1) / 2 > t) --I;
+    while ((long)(I + 1) * (I + 2) / 2 <= t) ++I;
+    const int J = t - (int)((long)I * (I + 1) / 2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double *q = Q + (long)I * 128 + 2 * lane + (long)(J * 128 + wave * 32) * ldq;      // rows 2 lane, 2 lane + 1; the wave's 32 columns
+    const v2d xi = *(const v2d *)(x + I * 128 + 2 * lane);
+    const double *xj = x + J * 128 + wave * 32;
+    v2d ra = {0.0, 0.0};
+    double cp[32];                                // this lane's two-row share of the 32 column dots
+    {
+        v2d v[32];                                // the wave's whole 128 x 32 slice in flight at once
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = *(const v2d *)(q + (long)u * ldq);
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const double xc = xj[u];
+            ra.x = fma(v[u].x, xc, ra.x);
+            ra.y = fma(v[u].y, xc, ra.y);
+            cp[u] = fma(v[u].x, xi.x, v[u].y * xi.y);
+        }
+    }
+    rs[wave][2 * lane] = ra.x;
+    rs[wave][2 * lane + 1] = ra.y;
+    if (I != J) {
+        // 32 sums over 64 lanes as ONE transposing butterfly (32 shuffles instead of 32 x 6): at offset o a lane keeps the
+        // half of its values that its bit o selects, hands the other half to lane ^ o and adds what it receives
+#pragma unroll
+        for (int o = 32, m = 32; o >= 2; o >>= 1, m >>= 1) {
+            const bool hi = (lane & o) != 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < m / 2) {
+                    const double give = hi ? cp[k] : cp[k + m / 2];
+                    const double keep = hi ? cp[k + m / 2] : cp[k];
+                    cp[k] = keep + __shfl_xor(give, o);
+                }
+        }
+        const double tot = cp[0] + __shfl_xor(cp[0], 1);
+        const int col = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+        if (!(lane & 1)) P2[(long)I * n + J * 128 + wave * 32 + col] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int r = threadIdx.x;
+        P1[(long)J * n + I * 128 + r] = ((rs[0][r] + rs[1][r]) + rs[2][r]) + rs[3][r];
+    }
+}
+__global__ __launch_bounds__(256) void k_symv_reduce(int n, const double *P1, const double *P2, double alpha, double beta, double *y, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO3(cb, P1, P2, y);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int Ii = i >> 7, nb = n >> 7;
+    double s = 0.0;
+    for (int J = 0; J <= Ii; ++J) s += P1[(long)J * n + i];
+    for (int I = Ii + 1; I < nb; ++I) s += P2[(long)I * n + i];
+    y[i] = alpha * s + (beta == 0.0 ? 0.0 : beta * y[i]);
+}
+// ws: 2 (n / 128) n doubles
+int cip_symv_lower(hipStream_t s, int n, double alpha, const double *Q, long ldq, const double *x, double beta, double *y, double *ws) {
+    const int nb = n / 128;
+    double *P1 = ws, *P2 = ws + (size_t)nb * n;
+    cip_launch_b(k_symv_tiles, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(256), 0, s, n, Q, ldq, x, P1, P2);
+    cip_launch_b(k_symv_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, (const double *)P1, (const double *)P2, alpha, beta, y);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // CSR spmv, one wave per row group: rows are short in the KKT use (identity-like A), so use
 // thread-per-row for simplicity (coalescing over rows of rowptr; gathers from x).
 __global__ __launch_bounds__(256) void k_spmv_csr(int rows, const int *rowptr, const int *colind, const double *val,

@@ -518,3 +518,29 @@ def test_single_entry_and_tiny_cones():
     d = rng.standard_normal(m)
     assert ks.maxstep(dev(v), dev(d)) == pytest.approx(maxstep(v, d), rel=1e-11)
     ks.close()
+
+
+def test_symmetric_matvec_from_lower_tiles(lib):
+    """Q x through cip_gemv_dev for n a multiple of 128 (>= 2048): the two-launch form that reads only the tiles on and below
+    the diagonal (vecops.hip: k_symv_tiles / k_symv_reduce) against numpy, with alpha / beta, twice (deterministic)."""
+    import cipkkt
+    from cipkkt import _lib as L
+    n = 2176
+    rng = np.random.default_rng(8)
+    M = rng.standard_normal((n, n))
+    Q = M @ M.T / n + np.eye(n)
+    A = np.eye(n)
+    ks = cipkkt.KKTSystem(Q, A, None, [("R", n)])
+    x = rng.standard_normal(n)
+    y0 = rng.standard_normal(n)
+    dx = dev(x)
+    outs = []
+    for rep in range(2):
+        dy = dev(y0)
+        L.check(lib.cip_gemv_dev(ks.h, L.MAT_Q, 0, -0.75, dx.data_ptr(), 0.5, dy.data_ptr()))
+        torch.cuda.synchronize()
+        outs.append(dy.cpu().numpy())
+    want = -0.75 * (Q @ x) + 0.5 * y0
+    assert np.abs(outs[0] - want).max() <= 1e-12 * (1 + np.abs(want).max())
+    assert np.array_equal(outs[0], outs[1])
+    ks.close()
