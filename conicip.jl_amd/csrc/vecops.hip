@@ -120,15 +120,24 @@ __global__ __launch_bounds__(256) void k_symv_tiles(int n, const double *Q, long
         P1[(long)J * n + I * 128 + r] = ((rs[0][r] + rs[1][r]) + rs[2][r]) + rs[3][r];
     }
 }
-__global__ __launch_bounds__(256) void k_symv_reduce(int n, const double *P1, const double *P2, double alpha, double beta, double *y, CipBatch cb) {
+__global__ __launch_bounds__(64) void k_symv_reduce(int n, const double *P1, const double *P2, double alpha, double beta, double *y, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO3(cb, P1, P2, y);
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 64 + threadIdx.x;                   // one wave per 64 outputs: n / 64 workgroups
     if (i >= n) return;
     const int Ii = i >> 7, nb = n >> 7;
+    // term k of y_i: P1[k][i] for k <= I(i), P2[k][i] above -- eight loads in flight, added in index order
     double s = 0.0;
-    for (int J = 0; J <= Ii; ++J) s += P1[(long)J * n + i];
-    for (int I = Ii + 1; I < nb; ++I) s += P2[(long)I * n + i];
+    for (int k0 = 0; k0 < nb; k0 += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u;
+            t[u] = k < nb ? (k <= Ii ? P1 : P2)[(long)k * n + i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (k0 + u < nb) s += t[u];
+    }
     y[i] = alpha * s + (beta == 0.0 ? 0.0 : beta * y[i]);
 }
 // ws: 2 (n / 128) n doubles
@@ -136,7 +145,7 @@ int cip_symv_lower(hipStream_t s, int n, double alpha, const double *Q, long ldq
     const int nb = n / 128;
     double *P1 = ws, *P2 = ws + (size_t)nb * n;
     cip_launch_b(k_symv_tiles, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(256), 0, s, n, Q, ldq, x, P1, P2);
-    cip_launch_b(k_symv_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, (const double *)P1, (const double *)P2, alpha, beta, y);
+    cip_launch_b(k_symv_reduce, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, n, (const double *)P1, (const double *)P2, alpha, beta, y);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
