@@ -12,7 +12,10 @@ with SOLVES_PER_FACTOR = the rounded mean the real solve used (predictor, correc
 refinement).  The scaling comes from a mid-trajectory iterate of the same problem; all
 inputs are resident in HBM before the timed region.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) measures the north-star's
+`--gpus N` with N > 1: run under `python -m torch.distributed.run --nproc-per-node N ...` (the driver's way: WORLD_SIZE
+must then equal N) or plainly as `python bench.py --gpus N` -- bench.py then starts that launcher itself as a CHILD
+process before anything touches the GPU and exits with its return code; fewer than N visible GPUs is an error.
+N > 1 (one rank per GPU over RCCL) measures the north-star's
 multi-GPU configuration, BASELINE.json configs[4]: 64 independent dense QPs with n = 2048
 (seeds 4000 + i), problem i -> rank i mod N, each rank running its shard through the library's
 batch entry point -- in LOCK-STEP (cip_conicip_lockstep: the rank's problems advance through the loop
@@ -21,7 +24,9 @@ thread pool of cip_conicip_problems instead); no data-path collective, one all-r
 counts (SUM) and of the wall time (MAX).  A step is then one pass over the whole batch and
 `value` = KKT solves (factorisations) of all ranks per second; total work is fixed as N grows
 (`"scaling": "strong"`).  `--workload c5` runs that workload on one GPU; the default N = 1 line
-(the n = 8192 headline) carries the same figure as `c5_single_gpu` for cross-checking a SCALE run.
+(the n = 8192 headline) carries the same figure as `c5_single_gpu`, and every N > 1 line carries its own
+`c5_single_gpu` (rank 0 alone on all 64 problems, timed before the sharded passes), `ranks_seen`, a `roofline` of the
+batch's trailing-update launches and a bounded `cpu_baseline`, so that a 1 -> N curve can be read off the N > 1 lines.
 
 Inputs come from the portable SplitMix64 generator (cipkkt/workloads.py), generated in HBM.
 
@@ -44,9 +49,39 @@ for _p in (ROOT, os.path.join(ROOT, "conicip.jl_amd")):
 import numpy as np
 import torch
 
-TRAILING_KERNELS = ("k_ldlt_trailing_64", "k_ldlt_workers")
+TRAILING_KERNELS = ("k_ldlt_trailing_64",)
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X vendor fp64 matrix peak (dense); see DESIGN.md §5
+# what the chip can issue at the clock it holds under this kernel: 256 CUs x 4 SIMDs x 2048 flop / 64 cycles x 2.17 GHz
+# (GRBM_GUI_ACTIVE / 8 / duration of profiles/r2/final_pmc_mfma.csv; tools/mfma_peak.hip measures 77.6 at 2.37 GHz unloaded)
+FP64_MFMA_CLOCK_LIMITED_TFLOPS = 256 * 4 * 32 * 2.17e9 / 1e12
 HBM_PEAK_GBS = 8000.0
+PMC_ROUNDS = ("r3", "r2", "r1")
+
+
+def pmc_dir():
+    for r in PMC_ROUNDS:
+        d = os.path.join(ROOT, "profiles", r)
+        if os.path.exists(os.path.join(d, "final_pmc_fetch.csv")) and os.path.exists(os.path.join(d, "final_pmc_write.csv")):
+            return d
+    return None
+
+
+def launch_ranks(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD process (never an
+    exec, and before this process has touched the GPU) and return its exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()            # counts devices without initialising the runtime
+    if have < n_gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this box" % (n_gpus, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def physical_cores():
@@ -159,8 +194,7 @@ def pmc_traffic_per_launch():
     the bytes of wide streaming reads -> doubled, MI355X_MICROARCH.md section HBM).  None when absent."""
     import csv
     try:
-        pdir = next(d for d in (os.path.join(ROOT, "profiles", r) for r in ("r2", "r1"))
-                    if os.path.exists(os.path.join(d, "final_pmc_fetch.csv")))
+        pdir = pmc_dir()
 
         def load(name, counter):
             out = {}
@@ -186,8 +220,7 @@ def pmc_solve_traffic(N):
     try:
         if N % 1024:
             return None
-        pdir = next(d for d in (os.path.join(ROOT, "profiles", r) for r in ("r2", "r1"))
-                    if os.path.exists(os.path.join(d, "final_pmc_fetch.csv")))
+        pdir = pmc_dir()
         small, big = 256 * 256, 256 * ((N - 1024) // 4)
 
         def load(name, counter):
@@ -208,6 +241,33 @@ def pmc_solve_traffic(N):
         return None
 
 
+def c5_cpu_baseline(seed=4000, n=2048):
+    """Bounded CPU leg of the batch workload: problem 0 of config 5 (n = 2048) through the oracle's conicIP with
+    pivot(kktsolver_2x2) (src/kktsolvers.jl:281-349) on the host cores -- a few seconds."""
+    from cipkkt import workloads
+    from oracle.conicip import conicIP as oracle_conicIP
+    from oracle import kktsolvers as ok
+    Q, c, A, b, K = workloads.c2_problem(n, seed)
+    t0 = time.perf_counter()
+    sol = oracle_conicIP(Q, c, A, b, K, optTol=1e-6, kktsolver=ok.pivot(ok.kktsolver_2x2))
+    dt = time.perf_counter() - t0
+    return dict(value=sol.n_factor / dt, unit="KKT solves/s", cores=os.cpu_count() or 1, kind="port",
+                sample="problem 0 of the batch (n=2048, seed %d) to convergence through the oracle's conicIP + "
+                       "pivot(kktsolver_2x2): %d factorisations, %d iterations, %s, %.2f s; BLAS threads = all logical CPUs"
+                       % (seed, sol.n_factor, sol.Iter, sol.status, dt),
+                iters=sol.Iter, status=sol.status)
+
+
+def fixture_iters(key):
+    """Iteration count of the ORACLE on the same inputs, from the committed full-size fixture
+    (tests/golden/fullsize_trajectories.json, generated by tests/golden/make_fullsize_fixtures.py)."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "fullsize_trajectories.json")) as f:
+            return json.load(f)[key]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,16 +284,22 @@ def main():
     ap.add_argument("--batch-mode", default="lockstep", choices=["lockstep", "threads"],
                     help="c5: lock-step batch (one launch per step for all problems of the rank) or host threads + streams")
     ap.add_argument("--no-c5", action="store_true", help="c2: skip the single-GPU config-5 figure")
-    ap.add_argument("--compare-lookahead", action="store_true",
-                    help="also time the same steps under the opt-in deep look-ahead schedule (slower than the serial one: "
-                         "DESIGN.md section 5; adds its kernels to a profile)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: start one rank per GPU as a child process -- before anything here touches the GPU
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the KKT path has no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -244,14 +310,15 @@ def main():
     import cipkkt
     from cipkkt import workloads
     from cipkkt.batch import run_config5
+    lib = cipkkt._lib.load()
     n = args.n
     if args.nbo:
-        cipkkt._lib.load().cip_set_ldlt_outer_block(args.nbo)
+        lib.cip_set_ldlt_outer_block(args.nbo)
     workload = args.workload or ("c5" if world > 1 else "c2")
     os.environ["CIP_BATCH"] = "auto" if args.batch_mode == "lockstep" else "threads"
 
-    def config5(steps, warmup):
-        stats, el = run_config5(rank, world, dist, device, steps, warmup, count=64, n=2048, seed=4000,
+    def config5(steps, warmup, rank_=rank, world_=world, dist_=None):
+        stats, el = run_config5(rank_, world_, dist_, device, steps, warmup, count=64, n=2048, seed=4000,
                                 in_flight=args.in_flight)
         return dict(value=stats["n_factor"] * steps / el, unit="KKT solves/s", ms_per_pass=el / steps * 1e3,
                     problems_per_s=64 * steps / el, n_optimal=stats["n_optimal"], n_problems=stats["n_problems"],
@@ -262,8 +329,45 @@ def main():
                                                               if args.batch_mode == "lockstep" else "cip_conicip_problems (host threads)"))
 
     if workload == "c5":
-        c5 = config5(args.steps, args.warmup)
+        # rank 0 alone on the whole batch first (the 1-GPU point of the scaling curve, measured in THIS run) ...
+        c5_one = None
+        if world > 1 and rank == 0:
+            c5_one = config5(2, 1, 0, 1, None)
+        if dist is not None:
+            dist.barrier()
+        # ... then the sharded passes
+        c5 = config5(args.steps, args.warmup, dist_=dist)
+        ranks_seen = 1
+        if dist is not None:
+            one = torch.ones(1, dtype=torch.float64, device=device)
+            dist.all_reduce(one, op=dist.ReduceOp.SUM)
+            ranks_seen = int(round(float(one.item())))
         if rank == 0:
+            # roofline of THIS workload's dominant MFMA kernel: one more (untimed) pass of rank 0's shard with HIP events
+            # around every trailing-update launch of the lock-step factorisations (launch = all live problems of the shard)
+            roof = None
+            if args.batch_mode == "lockstep":
+                lib.cip_profile_trailing_thread(1)
+                from cipkkt.batch import solve_batch
+                from cipkkt.workloads import c5_batch
+                mine = list(range(rank, 64, world))
+                probs = [None] * 64
+                for i, pr in zip(mine, c5_batch(64, 2048, 4000, device=device, indices=mine)):
+                    probs[i] = pr
+                solve_batch(probs, rank=rank, world=world, dist=None, device=device, native=True)
+                o3 = (cipkkt._lib.C.c_double * 3)()
+                cipkkt._lib.check(lib.cip_profile_thread_get(o3))
+                lib.cip_profile_trailing_thread(0)
+                if o3[1] > 0:
+                    ach = o3[2] / (o3[1] * 1e-3) / 1e12
+                    roof = {"bound": "mfma", "kernel": "LDL' trailing update of the lock-step batch: k_ldlt_trailing_64, "
+                                                       "grid.z = problems of rank 0's shard (%d at the start)" % len(mine),
+                            "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                            "clock_limited_peak": FP64_MFMA_CLOCK_LIMITED_TFLOPS, "traffic": None,
+                            "launches": o3[0], "avg_launch_ms": o3[1] / max(1.0, o3[0]),
+                            "algorithmic_flops_per_launch_avg": o3[2] / max(1.0, o3[0]),
+                            "note": "HIP events on the launch stream, one untimed extra pass of rank 0's shard; "
+                                    "flops = live problems x r(r+1) x outer block per launch"}
             out = {"metric": "KKT solves/sec, batch of 64 independent dense QPs n=2048 (BASELINE config 5), %d GPU(s)" % world,
                    "value": c5["value"], "unit": "KKT solves/s", "n_gpus": world, "steps": args.steps,
                    "warmup": args.warmup, "ms_per_step": c5["ms_per_pass"], "higher_is_better": True,
@@ -273,7 +377,17 @@ def main():
                                           "step = one pass over the batch" % world,
                               "parallelism": ("problem-per-GPU x%d, lock-step batch per GPU" % world) if args.batch_mode == "lockstep"
                                              else "problem-per-GPU x%d, %d in flight per GPU" % (world, args.in_flight)},
-                   "batch": c5}
+                   "ranks_seen": ranks_seen,
+                   "batch": c5, "roofline": roof}
+            if c5_one is not None:
+                out["c5_single_gpu"] = c5_one
+                out["speedup_vs_c5_single_gpu"] = c5["value"] / c5_one["value"]
+            fx = fixture_iters("c5_n2048_seed4000")
+            if fx is not None:
+                out["iters_cpu"] = sum(p_["Iter"] for p_ in fx["problems"].values())
+                out["iters_gpu"] = c5["iters"]
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = c5_cpu_baseline()
             print(json.dumps(out), flush=True)
         if dist is not None:
             dist.barrier()
@@ -317,7 +431,7 @@ def main():
 
     def step():
         ks.set_scaling_from_iterate(v_mid, s_mid, lam)
-        ks.factor()
+        ks.factor(check=False)                      # enqueue only, as the native loop does
         for _ in range(spf):
             ks.solve4x4_dev(lam, rhs, dz)
 
@@ -345,31 +459,6 @@ def main():
     ks.profile_trailing(False)
     ks.check_factor()
 
-    # the same steps under the opt-in look-ahead schedule (reported beside the headline, not as the headline: it
-    # trades trailing-update efficiency for overlap with the latency-bound panel chain -- DESIGN.md section 5)
-    la = None
-    if args.compare_lookahead and world == 1 and not os.environ.get("CIP_LOOKAHEAD"):
-        lib = cipkkt._lib.load()
-        lib.cip_set_ldlt_lookahead(1)
-        for _ in range(max(1, args.warmup)):
-            step()
-        ks.profile_trailing(True)
-        torch.cuda.synchronize()
-        t_la = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        e_la = time.perf_counter() - t_la
-        p_la = ks.profile_get()
-        ks.profile_trailing(False)
-        lib.cip_set_ldlt_lookahead(0)
-        step()
-        torch.cuda.synchronize()
-        la = {"value": args.steps / e_la, "ms_per_step": e_la / args.steps * 1e3,
-              "trailing_update_tflops": p_la["flops"] / (p_la["ms"] * 1e-3) / 1e12 if p_la["ms"] > 0 else None,
-              "note": "cip_set_ldlt_lookahead(1): every trailing update in one persistent worker launch (critical strip / "
-                      "bulk queues), panel chain on a side stream behind strip gates, 64 CUs left to it; same steps, same process"}
-
     # separate factor / solve split (untimed region, for the report)
     ks.set_timing(True)
     ks.factor()
@@ -391,6 +480,8 @@ def main():
         value = world * args.steps / elapsed
         ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
         N = ks.N
+        pdir = pmc_dir()
+        fx = fixture_iters("c2_n%d_seed1234" % n) if (args.route == "schur" and rank == 0) else None
         out = {
             "metric": "KKT solves/sec + wall-clock to converge, dense QP n=%d, 1 GPU" % n,
             "value": value, "unit": "KKT solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -400,9 +491,13 @@ def main():
                                    "step = NT scaling + assembly + LDL' + %d solve4x4" % (n, n, spf),
                        "route": args.route, "kkt_order": N, "solves_per_factor": spf,
                        "ldlt_outer_block": int(st["nbo"]), "parallelism": "problem-per-GPU x%d" % world},
-            "lookahead_schedule": la,
             "converge": {"wall_s": converge_s, "iters": iters, "status": status, "n_factor": n_factor,
                          "n_solve": n_solve},
+            # north-star: "at identical iteration count to convergence" -- the CPU side is the oracle's run on the same
+            # SplitMix64 inputs, committed as tests/golden/fullsize_trajectories.json (asserted equal, with mu / alpha per
+            # iteration at 1e-6, by tests/test_gpu_configs_full.py)
+            "iters_gpu": iters, "iters_cpu": fx["Iter"] if fx else None,
+            "iters_cpu_source": "tests/golden/fullsize_trajectories.json (oracle: pivot(kktsolver_2x2), same inputs)" if fx else None,
             "breakdown_ms": {"assemble": st["ms_assemble"], "ldlt_factor": st["ms_ldlt"], "solve4x4": solve_ms,
                              "ldlt_tflops_whole_factor": (N ** 3 / 3.0) / (st["ms_ldlt"] * 1e-3) / 1e12
                              if st["ms_ldlt"] > 0 else None},
@@ -417,10 +512,14 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": "LDL' trailing update: k_ldlt_trailing_64 (64x64 fp64-MFMA tiles, K = outer block)",
                          "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic_per_launch(),
+                         "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                         "clock_limited_peak": FP64_MFMA_CLOCK_LIMITED_TFLOPS,
+                         "frac_of_clock_limited_peak": ach / FP64_MFMA_CLOCK_LIMITED_TFLOPS,
+                         "traffic": pmc_traffic_per_launch(),
+                         "traffic_source": (os.path.relpath(pdir, ROOT) + "/final_pmc_{fetch,write}.csv: REPLAYED from the committed "
+                                            "rocprofv3 --pmc passes of this same command, not measured in this run") if pdir else None,
                          "traffic_note": "HBM-side bytes per trailing-update launch = (2*FETCH_SIZE + WRITE_SIZE) KiB of "
-                                         "k_ldlt_trailing_64, averaged over the launches of profiles/r2/final_pmc_*.csv (r1 when absent) "
-                                         "(separate rocprofv3 --pmc passes of this command; null if not present)",
+                                         "k_ldlt_trailing_64, averaged over its launches (separate --pmc passes; null if absent)",
                          "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(1.0, prof["launches"]),
                          "algorithmic_flops_per_launch_avg": prof["flops"] / max(1.0, prof["launches"])},
         }
@@ -432,7 +531,8 @@ def main():
             Qh = Q.cpu().numpy()
             cb = cpu_baseline(Qh, n, spf)
             out["cpu_baseline"] = cb
-            out["gpu_over_cpu"] = (value / world) / cb["value"]
+            out["gpu_over_cpu"] = (value / world) / cb["value"]                       # against the reference-faithful kktsolver_qr leg
+            out["gpu_over_strong_cpu"] = (value / world) / cb["strong_cpu_value"]     # against Schur + LAPACK Cholesky: the honest ratio
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -107,9 +107,9 @@ SIGNATURES = {
     "cip_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "cip_set_ldlt_outer_block": (C.c_int, [C.c_int]),
     "cip_set_solve_block_max": (C.c_int, [C.c_int]),
-    "cip_set_ldlt_lookahead": (C.c_int, [C.c_int]),
+    "cip_profile_trailing_thread": (C.c_int, [C.c_int]),
+    "cip_profile_thread_get": (C.c_int, [c_double_p]),
     "cip_set_ldlt_fused_chain": (C.c_int, [C.c_int]),
-    "cip_profile_lookahead": (C.c_int, [C.c_void_p, c_double_p]),
     "cip_profile_trailing": (C.c_int, [C.c_void_p, C.c_int]),
     "cip_profile_get": (C.c_int, [C.c_void_p, c_double_p]),
 }

@@ -196,7 +196,7 @@ def conicIP(Q, c, A, b, cone_dims, G=None, d=None, *,
     def factor(identity=False):                   # level 2 (:682)
         counts["factor"] += 1
         if plugin is None:
-            ks.factor()
+            ks.factor(check=False)                # enqueue only: the first solve resolves the pivot flag
             return
         if identity:
             I = _Block([_Diagonal(np.ones(k)) for _, k in ks.cone_dims])   # :704

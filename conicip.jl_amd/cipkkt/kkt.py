@@ -201,7 +201,9 @@ class KKTSystem:
     def assemble_only(self):
         L.check(self.lib.cip_assemble_only(self.h))
 
-    def factor(self, check=False):
+    def factor(self, check=True):
+        """Level 2.  check=True (default) waits for the factorisation and raises on a bad pivot; check=False only enqueues
+        it (the native loop's use: the flag is resolved by the next solve, see include/cipkkt.h: cip_factor)."""
         L.check(self.lib.cip_factor(self.h))
         if check:
             self.check_factor()
@@ -289,11 +291,6 @@ class KKTSystem:
         out = (C.c_double * 3)()
         L.check(self.lib.cip_profile_get(self.h, out))
         return dict(launches=out[0], ms=out[1], flops=out[2])
-
-    def profile_lookahead(self):
-        out = (C.c_double * 4)()
-        L.check(self.lib.cip_profile_lookahead(self.h, out))
-        return dict(busy_ticks=out[0], tiles=out[1], workers=out[2], err=out[3])
 
     def set_timing(self, on):
         L.check(self.lib.cip_set_timing(self.h, int(bool(on))))

@@ -548,17 +548,17 @@ static int factor_resolve(cip_handle *h, bool wait) {
     // info_host: [0] first bad pivot of any kind (1-based column), [1] bail-out flag of the sweep kernels,
     //            [2] first zero / non-finite pivot
     if (h->info_host[3] != 0 || h->info_host[1] != 0) {
-        cip_set_error("LDL': in-launch scheduler gave up waiting (look-ahead %d, sweeps %d)", h->info_host[3], h->info_host[1]);
+        cip_set_error("LDL': in-launch wait gave up (panel chain %d, sweeps %d)", h->info_host[3], h->info_host[1]);
         h->factored = false;
         return CIP_E_HIP;
     }
     int info = h->info_host[0];
-    if (info == 0) return 0;
+    if (info == 0) { h->pivots_verified = true; return 0; }
     const int spec = h->spec_solves;
     if (h->reg_rel > 0.0) {
         // regularised factor: a wrong-sign pivot (|d| ~ delta, rounding decides its sign) is harmless -- the refinement in
         // solve3x3 works against the true operator -- but a zero / non-finite one is not
-        if (h->info_host[2] == 0) return 0;
+        if (h->info_host[2] == 0) { h->pivots_verified = true; return 0; }
         info = h->info_host[2];
     } else if (h->auto_reg) {
         h->reg_rel = getenv("CIP_AUTO_REG") ? atof(getenv("CIP_AUTO_REG")) : CIP_AUTO_REG;
@@ -568,6 +568,7 @@ static int factor_resolve(cip_handle *h, bool wait) {
         CIP_HIP_CHECK(hipEventSynchronize(h->ev_info));
         h->info_pending = false;
         if (h->info_host[2] == 0) {
+            h->pivots_verified = true;
             if (spec > 0) {
                 cip_set_error("LDL': %d solve(s) were enqueued on a factorisation that met a bad pivot; the handle has switched "
                               "to the regularised factorisation -- repeat them", spec);
@@ -713,7 +714,9 @@ extern "C" int cip_solve3x3_dev(cip_handle *h, const double *x, const double *y,
     const int n = h->n, m = h->m, p = h->p;
     int rc;
     CipRange rg("cip:solve3x3");
-    if ((rc = factor_resolve(h, false))) return rc;      // no host wait: resolved only if the flag has already landed
+    // speculative (no host wait, the flag is resolved only if its read-back has landed) once a factorisation of this handle
+    // has been verified; before that the solve waits for the flag
+    if ((rc = factor_resolve(h, !h->pivots_verified))) return rc;
     if (h->info_pending) h->spec_solves += 1;
     h->n_solve += 1;
     if (h->reg_rel <= 0.0) return solve3x3_once(h, x, y, z, a, b, c);
@@ -774,7 +777,7 @@ extern "C" int cip_solve2x2_dev(cip_handle *h, const double *y, const double *w,
     if (h->route != CIP_ROUTE_SCHUR) { cip_set_error("cip_solve2x2: needs the Schur route"); return CIP_E_UNSUPPORTED; }
     if (!h->factored) { cip_set_error("cip_solve2x2: no factorisation (call cip_factor first)"); return CIP_E_NOTFACTORED; }
     int rc;
-    if ((rc = factor_resolve(h, false))) return rc;
+    if ((rc = factor_resolve(h, !h->pivots_verified))) return rc;
     if (h->reg_rel > 0.0 && h->m > 0) {
         // regularised factor: go through the refined 3x3 solve with z = 0 (its first two components are the 2x2 solution)
         { int rcc = cip_zero(h->stream, h->m, h->mt1); if (rcc) return rcc; }
@@ -946,17 +949,13 @@ extern "C" int cip_profile_get(cip_handle *h, double *out3) {
     if (!h || !out3 || !h->ws.prof) { cip_set_error("profiling not enabled"); return CIP_E_INVALID; }
     return cip_ldlt_profile_collect(h->ws.prof, &out3[0], &out3[1], &out3[2]);
 }
-// out4 = [s_memtime ticks (shader cycles) the persistent workers of the LAST factorisation spent inside tile computations (summed over
-// workers), tiles computed, workers, scheduler error flag]
-int cip_la_read_stats(void *ctrl_dev, hipStream_t s, double *busy_ticks, double *tiles, double *workers, int *err);
-extern "C" int cip_profile_lookahead(cip_handle *h, double *out4) {
-    if (!h || !out4) return CIP_E_INVALID;
-    int err = 0;
-    const int rc = cip_la_read_stats(h->ws.la_ctrl, h->stream, &out4[0], &out4[1], &out4[2], &err);
-    out4[3] = err;
-    return rc;
+// the calling thread's own trailing-update profile: covers factorisations of handles it does not hold (lock-step batches)
+extern "C" int cip_profile_trailing_thread(int enabled) { return cip_ldlt_profile_thread(enabled); }
+extern "C" int cip_profile_thread_get(double *out3) {
+    if (!out3) return CIP_E_INVALID;
+    if (cip_ldlt_profile_thread_collect(&out3[0], &out3[1], &out3[2])) { cip_set_error("thread profiling not enabled"); return CIP_E_INVALID; }
+    return 0;
 }
-extern "C" int cip_set_ldlt_lookahead(int on) { return cip_ldlt_set_lookahead(on); }
 extern "C" int cip_set_ldlt_fused_chain(int on) { return cip_ldlt_set_fused_chain(on); }
 extern "C" int cip_set_solve_block_max(int b) { return cip_solve_block_max_set(b); }
 extern "C" int cip_set_ldlt_outer_block(int nbo) { cip_ldlt_set_outer_block(nbo); return cip_ldlt_outer_block(); }

@@ -15,7 +15,6 @@ __device__ __forceinline__ unsigned gemm_batch_prologue(GemmArgs &g, const CipBa
     g.C = (double *)((char *)g.C + off);
     if (g.Ct) g.Ct = (double *)((char *)g.Ct + off);
     if (g.Qin) g.Qin = (const double *)((const char *)g.Qin + off);
-    if (g.dk) g.dk = (const double *)((const char *)g.dk + off);
     return blockIdx.z - pz * gz;
 }
 // the launch's own (grid.y, grid.z) batching: pointer strides in doubles
@@ -28,20 +27,17 @@ __device__ __forceinline__ void gemm_own_batch(GemmArgs &g, unsigned oz) {
 
 // ---------------------------------------------------------------------------------------------
 // Small-tile variant (64x64 C tile, wave = 32x32 = 2x2 MFMA tiles) for the latency-critical skinny
-// updates on the factorisation's critical path (look-ahead column strip, in-block strip update):
+// updates on the factorisation's critical path (in-block strip update):
 // 4x the workgroups and a quarter of the per-tile latency of the 128x128 kernel, at twice the LDS
 // traffic per flop -- these launches carry < 10 % of the flops.  Accumulate epilogue only.
 #define SB 64
-// SC1C: the C tile is read with L1-bypassing loads and written through (`sc1`): tiles handed from workgroup to
-// workgroup inside one launch (k_ldlt_workers).  SCALEA: the A operand is column-scaled on its way into LDS,
-// A[i,k] * dk[k] -- the trailing update then reads W = L D as L (from K itself) times d, no separate W panel.
 // GLDS: operands go global -> LDS directly (`global_load_lds_dwordx4`: no staging registers, no ds_write pass).  The
-// [k][64 rows] image is lane-linear for the staging pattern below -- a wave's 64 x 16 bytes are two consecutive k columns --
-// so the same image is produced.  Plain operand form only (no column scaling on the way in).  Used by the trailing update:
-// same-session A/B at n = 8192 54.0 -> 56.6 TFLOP/s (the kernel drops from 102 to 81 VGPRs and the ds_write pass of every
-// k-tile); the K = 128 in-block tiles and the batched / SYRK forms measured no different with it and keep register staging.
-template <int EPI = EPI_ACCUM, bool SC1C = false, bool SCALEA = false, bool GLDS = false>
-__device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, long i0, long j0, const double *dk = nullptr) {
+// [k][64 rows] LDS image is lane-linear for the staging pattern below -- a wave's 64 x 16 bytes are two consecutive k columns --
+// so the same image is produced.  Used by the trailing update: same-session A/B at n = 8192 54.0 -> 56.6 TFLOP/s (the
+// kernel drops from 102 to 81 VGPRs and the ds_write pass of every k-tile); the K = 128 in-block tiles and the batched /
+// SYRK forms measured no different with it and keep register staging.
+template <int EPI = EPI_ACCUM, bool GLDS = false>
+__device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, long i0, long j0) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -53,21 +49,18 @@ __device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, lon
     const double *Ap = g.A + i0 + 2 * rp;
     const double *Bp = g.B + j0 + 2 * rp;
     v2d ra[2], rb[2];
-    double rd[2] = {1.0, 1.0};
     auto gload = [&](int kt) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const long k = (long)kt * CIP_KT + q * 8 + k_ld;
             ra[q] = *(const v2d *)(Ap + k * g.lda);
             rb[q] = *(const v2d *)(Bp + k * g.ldb);
-            if (SCALEA) rd[q] = dk[k];
         }
     };
     auto lstore = [&](int buf) {
         double *la = lds + buf * (2 * CIP_KT * SB);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            if (SCALEA) ra[q] *= rd[q];
             *(v2d *)(la + (q * 8 + k_ld) * SB + 2 * rp) = ra[q];
             *(v2d *)(la + CIP_KT * SB + (q * 8 + k_ld) * SB + 2 * rp) = rb[q];
         }
@@ -111,33 +104,6 @@ __device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, lon
         __syncthreads();
     }
     // lane holds, for tile (ti,tj), reg q: row = i0 + wm*32 + 2*l15 + ti, col = j0 + wn*32 + 2*(l4 + 4q) + tj
-    if (SC1C) {
-        // agent-scope relaxed atomics = `global_load/store_dwordx2 ... sc1` the compiler schedules and waits for itself
-        // (a hand-written asm load is invisible to its s_waitcnt / spill logic: the first version of this epilogue
-        // produced garbage whenever the register allocator moved an asm result before the manual wait)
-        // four passes of 4 loads in flight: the register budget of five workgroups per CU (102) leaves no room for more
-        const long rowo = i0 + wm * 32 + 2 * l15;
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int qh = 0; qh < 2; ++qh) {
-                double cv[2][2];
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq) {
-                    const double *cp = g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * (2 * qh + qq)) + tj) * g.ldc;
-                    cv[qq][0] = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    cv[qq][1] = __hip_atomic_load(cp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq) {
-                    const int q = 2 * qh + qq;
-                    double *cp = g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * q) + tj) * g.ldc;
-                    __hip_atomic_store(cp, cv[qq][0] + g.alpha * acc[0][tj][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(cp + 1, cv[qq][1] + g.alpha * acc[1][tj][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        return;
-    }
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
@@ -169,7 +135,8 @@ __device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, lon
 // K = 128 with the WHOLE of both operands resident in LDS (128 KB): one global round trip, one barrier, then 32 MFMA
 // steps -- for launches that own a CU's LDS anyway (diag.hip: k_ldlt_diag_upd).  The k-loop of gemm_tile_64 waits for a
 // global load in each of its eight iterations (~1 us each when the tile is alone on its CU).  Same accumulation order
-// as gemm_tile_64: bit-identical results.  Accumulate epilogue; SC1C as above.
+// as gemm_tile_64: bit-identical results.  Accumulate epilogue.  SC1C: the C tile is written through (`sc1`): its reader
+// is another workgroup of the same launch (k_ldlt_diag_upd).
 template <bool SC1C>
 __device__ __forceinline__ void gemm_tile_64_k128(const GemmArgs &g, double *lds, long i0, long j0) {
     const int tid = threadIdx.x;

@@ -58,6 +58,11 @@ struct cip_handle {
     hipEvent_t ev_info = nullptr;
     bool info_pending = false;
     int spec_solves = 0;            // solves enqueued while the flag was still in flight
+    // true once a factorisation of this handle has been resolved clean (or the regularised mode is on): until then the
+    // *_dev solves WAIT for the pivot flag instead of going ahead speculatively -- the factorisation that meets a bad
+    // pivot is almost always the first one (LPs, singular Q with free variables), and a caller doing factor -> solve*_dev
+    // must not get rc 0 and a solution of a broken factor
+    bool pivots_verified = false;
 
     // ---- scratch
     double *rhs = nullptr;          // Npad

@@ -99,9 +99,7 @@ struct GemmArgs {
     int by, bz;
     long sAy, sAz, sBy, sBz, sCy, sCz;
     int overwrite;               // EPI_ACCUM: C = alpha*acc instead of C += alpha*acc
-    const double *dk;            // lower-triangular trailing update only, optional: A is scaled by dk[k] column-wise (A = L, dk = d)
     double *Ct; long ldct, sCty, sCtz;   // 128-tile EPI_ACCUM only, optional: the result is also stored transposed, Ct[j + i*ldct]
-    int lowprio;                 // lower-triangular trailing update: run its waves at s_setprio 0 (default 3)
     int force64;                 // plain accumulate form: quarter tiles (k_gemm_nt_64) whatever the tile count
 };
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g);
@@ -112,6 +110,8 @@ LdltProfile *cip_ldlt_profile_create(void);
 void cip_ldlt_profile_destroy(LdltProfile *p);
 // synchronises; adds the elapsed time of every recorded trailing-update launch to the totals
 int cip_ldlt_profile_collect(LdltProfile *p, double *launches, double *ms, double *flops);
+int cip_ldlt_profile_thread(int enabled);      // a profile of the calling host thread (lock-step batches: bench.py, config 5)
+int cip_ldlt_profile_thread_collect(double *launches, double *ms, double *flops);
 
 // Expected pivot signs of a quasi-definite matrix in its static order: positive for columns in [p0, p1) and for the
 // identity padding (>= N), negative elsewhere; p0 < 0: unknown, no sign check (stand-alone LDL' entry points)
@@ -134,11 +134,9 @@ struct LdltWorkspace {        // carved out of one device allocation
     unsigned *sweep_ctr;      // tickets / arrival counters / flags of the two sweep kernels
     int *info;                // device int: 0 ok, >0 = 1-based column of a bad pivot (zero, non-finite, or of the wrong sign)
     PivotSigns signs;
-    void *la_ctrl;            // device control block of the look-ahead schedule (gemm_f64.hip: LaCtrl + done[])
     LdltProfile *prof;        // host object or NULL
 };
 int cip_kernels_init(void);                // diag.hip: one-time kernel attributes (before any hipGraph capture)
-int cip_ldlt_set_lookahead(int on);
 int cip_ldlt_set_fused_chain(int on);     // 1 (default): diag + previous in-block update in one launch; returns the previous setting
 int cip_solve_block(int Npad);
 int cip_solve_block_max_set(int b);              // 128 | 256 | 512 | 1024 (0: query); returns the previous limit

@@ -10,7 +10,7 @@
 //   outer block NBO (512, 768 from order 4096 on) = NBO/128 inner panels of 128 columns
 //   per inner panel:  diag 128x128 LDL' (1 workgroup, LDS) -> substitution TRSM (W = A21 inv(L11)', L = W D^-1) -> update of
 //                     the block's remaining panel columns; on the serial schedule these are ONE launch per panel
-//                     (diag.hip: k_ldlt_panel), in lock-step batches and beside a look-ahead three
+//                     (diag.hip: k_ldlt_panel), in lock-step batches three
 //   per outer block:  trailing update  C -= W L'  (lower tiles, K = NBO, MFMA GEMM)
 // 3/4 of the N^3/3 flops at n = 8192 are in the trailing-update GEMM (gemm_f64.hip), the rest in the K = 128 in-block tiles.
 //
@@ -91,6 +91,19 @@ int cip_ldlt_profile_collect(LdltProfile *p, double *launches, double *ms, doubl
     return 0;
 }
 
+// A profile of the calling host thread, for factorisations whose workspace has none of its own: the handles of a
+// lock-step batch are created inside cip_conicip_lockstep, whose host code runs on the caller's thread (bench.py measures
+// config 5's trailing update this way).  One launch then covers every live problem of the batch: flops x popcount(mask).
+static thread_local LdltProfile *g_tl_prof = nullptr;
+int cip_ldlt_profile_thread(int enabled) {
+    if (enabled && !g_tl_prof) g_tl_prof = cip_ldlt_profile_create();
+    if (!enabled && g_tl_prof) { cip_ldlt_profile_destroy(g_tl_prof); g_tl_prof = nullptr; }
+    return 0;
+}
+int cip_ldlt_profile_thread_collect(double *launches, double *ms, double *flops) {
+    return cip_ldlt_profile_collect(g_tl_prof, launches, ms, flops);
+}
+
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // solve block: largest of {1024, 512, 256, 128} that divides the (128-padded) order
@@ -114,11 +127,10 @@ int cip_solve_block(int Npad) {
     return CIP_NB;
 }
 
-size_t cip_la_ctrl_bytes(int Npad);
 size_t cip_ldlt_ws_bytes(int Npad) {
     const size_t nblk = Npad / CIP_NB;
     size_t b = 0;
-    b += al256((size_t)Npad * CIP_NBO_MAX * 8) * 2;      // Wbuf (double buffered for the look-ahead)
+    b += al256((size_t)Npad * CIP_NBO_MAX * 8);          // Wbuf
     b += al256(nblk * CIP_NB * CIP_NB * 8) * 2;          // Linv, LinvT
     b += al256(nblk * 2048 * 8);                         // Xm
     {
@@ -131,14 +143,13 @@ size_t cip_ldlt_ws_bytes(int Npad) {
     b += al256((size_t)Npad * 8) * 4;                    // dinv, dvec, tmp, ybuf
     b += al256(4 * 2 * (2 + 2 * nblk + (size_t)Npad / 8));  // sweep counters / flags (solve.hip)
     b += al256(64 + 8 * nblk);                           // info (16 ints) + a `ready` and a `stage` counter per 128-block (fused panel launches)
-    b += al256(cip_la_ctrl_bytes(Npad));                 // look-ahead control block (gemm_f64.hip: LaCtrl + done[])
     return b;
 }
 
 void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     const size_t nblk = Npad / CIP_NB;
     char *p = (char *)base;
-    ws->Wbuf = (double *)p;  p += al256((size_t)Npad * CIP_NBO_MAX * 8) * 2;
+    ws->Wbuf = (double *)p;  p += al256((size_t)Npad * CIP_NBO_MAX * 8);
     ws->Linv = (double *)p;  p += al256(nblk * CIP_NB * CIP_NB * 8);
     ws->LinvT = (double *)p; p += al256(nblk * CIP_NB * CIP_NB * 8);
     ws->Xm = (double *)p;    p += al256(nblk * 2048 * 8);
@@ -156,7 +167,6 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     ws->ybuf = (double *)p;  p += al256((size_t)Npad * 8);
     ws->sweep_ctr = (unsigned *)p; p += al256(4 * 2 * (2 + 2 * nblk + (size_t)Npad / 8));
     ws->info = (int *)p;     p += al256(64 + 8 * nblk);
-    ws->la_ctrl = (void *)p;
     ws->prof = nullptr;
     ws->signs = PivotSigns{-1, 0, 0};
     ws->x_zeroed = nullptr;
@@ -198,7 +208,7 @@ int cip_ldlt_set_fused_chain(int on) { fuse_env(); const int prev = g_fuse_diag;
 
 // one inner-panel sweep of an outer block: [strip update] -> diagonal kernel -> TRSM, for each 128 columns
 static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws, double *Wb, int C0,
-                               int wblk, bool alone = false) {
+                               int wblk) {
     int rc;
     const int T = wblk / CIP_NB;
     for (int t = 0; t < T; ++t) {
@@ -210,8 +220,7 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
         // diagonal kernel's launch also carries the previous panel's in-block update (diag.hip: k_ldlt_diag_upd).
         GemmArgs gu;
         fuse_env();
-        // fused only when the chain has the chip to itself: a lock-step batch is throughput-bound and beside a look-ahead's
-        // bulk the fused launch's update tiles (160 KB of LDS per workgroup: one per CU) would queue on the few free CUs
+        // fused only when the chain has the chip to itself: a lock-step batch is throughput-bound and wants its tiles' occupancy
         // ... except small lock-step groups, which take the one-launch-per-panel form too (grid.z = problems): while every
         // problem's long-lived workgroups (diagonal kernel + strips: 1 + Npad / 64 at the first panel) fit on the chip at once
         // the launch takes one round -- 4 / 8 / 12 problems of order 2048: 18.7 -> 16.4, 23.3 -> 21.0, 27.9 -> 27.0 ms per pass;
@@ -219,7 +228,7 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
         static const int lsmax = [] { const char *e = getenv("CIP_LOCKSTEP_PANEL_MAX"); return e ? atoi(e) : 12; }();
         static const int lscus = [] { const char *e = getenv("CIP_LOCKSTEP_PANEL_CUS"); return e ? atoi(e) : 400; }();
         const bool small_group = cip_in_batch() && g_fuse_diag == 3 && cip_tl_bz.B <= lsmax && (long)cip_tl_bz.B * (1 + Npad / 64) <= lscus;
-        const bool fuse = g_fuse_diag && alone && (!cip_in_batch() || small_group);
+        const bool fuse = g_fuse_diag && (!cip_in_batch() || small_group);
         if (fuse && g_fuse_diag == 3) {
             const bool upd = t > 0 && rest_of_block_args(K, Npad, ld, Wb, C0, wblk, t - 1, gu);
             unsigned *ctr = (unsigned *)(ws.info + 16);
@@ -244,100 +253,6 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
     }
     return 0;
 }
-
-// Look-ahead plumbing.  The panel chain (diag -> TRSM -> in-block update, serial, small grids) runs on a high-priority
-// side stream; every trailing update of the factorisation is carried by ONE persistent launch on the caller's stream
-// (gemm_f64.hip: k_ldlt_workers) that leaves `reserve` CUs per (XCD, SE) pair to the chain.
-// The side stream and its events belong to the calling host thread (handles of a batch factor concurrently from
-// several threads; a thread's objects are destroyed when it exits); the process-wide switches are set once.
-#include <mutex>
-struct SideStream {
-    hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_chain = nullptr;
-    ~SideStream() {
-        if (ev_start) (void)hipEventDestroy(ev_start);
-        if (ev_chain) (void)hipEventDestroy(ev_chain);
-        if (stream) (void)hipStreamDestroy(stream);
-    }
-};
-static thread_local SideStream g_side;
-static std::once_flag g_la_once;
-// Opt-in (CIP_LOOKAHEAD=1 / cip_set_ldlt_lookahead(1)).  Measured at N = 8192 (profiles/r2/lookahead_*): 9.7 ms against
-// 7.05 ms for the serial schedule.  The hand-offs work (bit-identical factors, tests/test_gpu_lookahead.py) and the bulk
-// of every round does run beside the chain, but the chain is not the narrow latency-bound thing the schedule assumes:
-// at the top of the matrix its TRSM + in-block updates are 17 % of the factorisation's flops and want the whole chip --
-// on 64 reserved CUs the chain ALONE takes 6.0 ms (tile compute switched off: CIP_LA_DBG=64) against 3.5 ms on an idle
-// chip, 9.4 ms with the workers' memory traffic beside it -- and at the bottom there is no bulk left to overlap.
-static int g_lookahead = 0;
-static int g_la_min = 4096;               // below this order a factorisation is chain-bound whatever the schedule
-static int g_reserve = 2;                 // CUs per (XCD, SE) pair left to the chain: 1 -> 32 CUs, 2 -> 64
-static int g_la2_min = 3072;              // two-stream schedule: smallest trailing order whose bulk is overlapped
-static int g_la2_lowprio = 1;
-static int g_la2_reserve = 1;             // CUs per (XCD, SE) pair the bulk stream leaves to the chain (CU mask): 1 -> 32 CUs
-static void lookahead_env(void) {
-    if (const char *e = getenv("CIP_LOOKAHEAD")) { const int v = atoi(e); g_lookahead = (v >= 0 && v <= 3) ? v : 0; }
-    if (const char *e = getenv("CIP_LA2_MIN")) g_la2_min = atoi(e);
-    if (const char *e = getenv("CIP_LA2_RESERVE")) g_la2_reserve = atoi(e);
-    if (const char *e = getenv("CIP_LA2_LOWPRIO")) g_la2_lowprio = atoi(e);
-    if (const char *e = getenv("CIP_RESERVE")) { const int r = atoi(e); if (r >= 0 && r <= 2) g_reserve = r; }
-    if (const char *e = getenv("CIP_LA_MIN")) g_la_min = atoi(e);
-}
-// run-time switch of the schedule (bench.py measures both in one process); returns the previous setting
-int cip_ldlt_set_lookahead(int on) {
-    std::call_once(g_la_once, lookahead_env);
-    const int prev = g_lookahead;
-    g_lookahead = (on == 2 || on == 3) ? on : (on ? 1 : 0);      // 2: serial schedule with the workers' operand form (tests); 3: two streams
-    return prev;
-}
-static int lookahead_init(void) {
-    if (g_side.stream) return 0;
-    int lo = 0, hi = 0;
-    CIP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    CIP_HIP_CHECK(hipStreamCreateWithPriority(&g_side.stream, hipStreamNonBlocking, hi));
-    CIP_HIP_CHECK(hipEventCreateWithFlags(&g_side.ev_start, hipEventDisableTiming));
-    CIP_HIP_CHECK(hipEventCreateWithFlags(&g_side.ev_chain, hipEventDisableTiming));
-    return 0;
-}
-// ---- two-stream look-ahead (mode 3).  The trailing update of outer block J is cut into the STRIP (the next block's
-// columns: what the chain of block J+1 needs) and the BULK (everything to the right).  Chain and strips run on a
-// high-priority stream; the bulk runs on a second stream whose CU mask (hipExtStreamCreateWithCUMask; bit = cu * 32 +
-// se * 8 + xcc, probed with tools/cumask_probe.hip) leaves `reserve` CUs of every (XCD, SE) pair alone, so that the
-// single-workgroup diagonal kernel -- which needs a CU's whole LDS -- and part of the TRSM always find a free CU, while
-// the chain's wide kernels also take whatever slots the bulk frees.  Ordinary launches, ordinary stream order and events:
-// no in-launch hand-offs.  Two W-panel buffers alternate (the bulk of block J reads W_J while the chain writes W_{J+1}).
-struct BulkStream {
-    hipStream_t stream = nullptr;
-    hipEvent_t ev_strip = nullptr, ev_bulk = nullptr;
-    int reserve = -1;
-    ~BulkStream() {
-        if (ev_strip) (void)hipEventDestroy(ev_strip);
-        if (ev_bulk) (void)hipEventDestroy(ev_bulk);
-        if (stream) (void)hipStreamDestroy(stream);
-    }
-};
-static thread_local BulkStream g_bulk;
-static int bulk_stream_init(void) {
-    if (g_bulk.stream && g_bulk.reserve == g_la2_reserve) return 0;
-    if (g_bulk.stream) { (void)hipStreamDestroy(g_bulk.stream); g_bulk.stream = nullptr; }
-    uint32_t mask[8];
-    for (int w = 0; w < 8; ++w) mask[w] = 0xffffffffu;
-    // reserve r (1..4) CUs per (xcc, se): clear bits of cu = 7, 6, ... ; r = 0 with CIP_LA2_RESERVE=0: half of the pairs (se 0, 2)
-    const int r = g_la2_reserve;
-    if (r > 0) for (int cu = 7; cu > 7 - r && cu >= 4; --cu) mask[cu] = 0u;
-    else for (int b = 0; b < 32; ++b) if (((b >> 3) & 1) == 0) mask[7] &= ~(1u << b);
-    CIP_HIP_CHECK(hipExtStreamCreateWithCUMask(&g_bulk.stream, 8, mask));
-    g_bulk.reserve = r;
-    if (!g_bulk.ev_strip) CIP_HIP_CHECK(hipEventCreateWithFlags(&g_bulk.ev_strip, hipEventDisableTiming));
-    if (!g_bulk.ev_bulk) CIP_HIP_CHECK(hipEventCreateWithFlags(&g_bulk.ev_bulk, hipEventDisableTiming));
-    return 0;
-}
-
-// gemm_f64.hip
-size_t cip_la_ctrl_bytes(int Npad);
-int cip_la_launch_workers(hipStream_t s, double *K, int Npad, long ld, const double *dvec, int nbo, void *ctrl_dev, int reserve);
-int cip_la_signal(hipStream_t s, void *ctrl_dev, int J);
-int cip_la_gate(hipStream_t s, void *ctrl_dev, int Npad, int nbo, int S);
-int cip_la_finish(hipStream_t s, void *ctrl_dev, int *info);
 
 // zero fill as a kernel: these fills sit inside the launch sequences that small systems replay as hipGraphs, and a
 // captured hipMemsetAsync node left the flag words of ws.info unset on ROCm 7.0 (the factorisation then reported a
@@ -421,110 +336,30 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
     if (Npad % CIP_NB) { cip_set_error("ldlt: N must be a multiple of 128"); return -1; }
     const int NBO = cip_ldlt_outer_block_for(Npad);
     int rc;
-    std::call_once(g_la_once, lookahead_env);
-    // [0] bad pivot, [1] sweep bail-out, [2] dead pivot, [3] look-ahead scheduler / fused-launch wait; from word 16: `ready` counters
+    // [0] bad pivot, [1] sweep bail-out, [2] dead pivot, [3] fused-launch wait timed out; from word 16: `ready` counters
     if ((rc = zero_fill(s, ws.info, 64 + 8 * (size_t)(Npad / CIP_NB)))) return rc;
-    bool la = g_lookahead == 1 && Npad >= g_la_min && Npad > 2 * NBO && NBO % 64 == 0;
-    if (cip_tl_builder || cip_in_batch()) la = false;         // recording a hipGraph / a lock-step batch: the single-stream schedule
-    if (g_lookahead == 3 && !cip_tl_builder && !cip_in_batch() && Npad >= 2 * g_la2_min && !ws.prof) {
-        if ((rc = lookahead_init())) return rc;
-        if ((rc = bulk_stream_init())) return rc;
-        hipStream_t sc = g_side.stream, sb = g_bulk.stream;          // chain + strips (high priority), bulk (CU-masked)
-        CIP_HIP_CHECK(hipEventRecord(g_side.ev_start, s));
-        CIP_HIP_CHECK(hipStreamWaitEvent(sc, g_side.ev_start, 0));
-        bool bulk_pending = false;
-        const size_t wstride = (size_t)Npad * CIP_NBO_MAX;
-        int J = 0;
-        for (int C0 = 0; C0 < Npad; C0 += NBO, ++J) {
-            const int wblk = (Npad - C0 < NBO) ? (Npad - C0) : NBO;
-            double *Wb = ws.Wbuf + (size_t)(J & 1) * wstride;
-            if ((rc = factor_outer_panels(sc, K, Npad, ld, ws, Wb, C0, wblk))) return rc;
-            const int r0 = C0 + wblk;
-            if (r0 >= Npad) break;
-            const int r = Npad - r0;
-            const bool split = r - NBO >= g_la2_min;
-            // the bulk of this block needs the chain of this block (W, L panels) and the previous bulk (stream order): it
-            // starts NOW, beside the strip
-            if (split) { CIP_HIP_CHECK(hipEventRecord(g_bulk.ev_strip, sc)); CIP_HIP_CHECK(hipStreamWaitEvent(sb, g_bulk.ev_strip, 0)); }
-            // the strip (and an unsplit update) touch columns the previous bulk has written
-            if (bulk_pending) { CIP_HIP_CHECK(hipStreamWaitEvent(sc, g_bulk.ev_bulk, 0)); bulk_pending = false; }
+    // serial right-looking schedule: panels of the outer block, then ONE trailing update
+    for (int C0 = 0; C0 < Npad; C0 += NBO) {
+        const int wblk = (Npad - C0 < NBO) ? (Npad - C0) : NBO;
+        if ((rc = factor_outer_panels(s, K, Npad, ld, ws, ws.Wbuf, C0, wblk))) return rc;
+        const int r0 = C0 + wblk;
+        if (r0 < Npad) {
             GemmArgs g = {};
-            g.A = Wb + r0; g.lda = Npad;
+            g.A = ws.Wbuf + r0; g.lda = Npad;
             g.B = K + r0 + (long)C0 * ld; g.ldb = ld;
             g.C = K + r0 + (long)r0 * ld; g.ldc = ld;
-            g.K = wblk; g.alpha = -1.0;
-            if (split) {
-                GemmArgs gb = g;
-                gb.A = g.A + NBO; gb.B = g.B + NBO; gb.C = g.C + NBO + (long)NBO * ld; gb.M = gb.N = r - NBO; gb.lower = 1; gb.lowprio = g_la2_lowprio;
-                if ((rc = cip_launch_gemm(sb, EPI_ACCUM, gb))) return rc;
-                CIP_HIP_CHECK(hipEventRecord(g_bulk.ev_bulk, sb));
-                bulk_pending = true;
-                // strip: columns [r0, r0 + NBO) -- the lower triangle of the next diagonal block, then the rows below it
-                GemmArgs gs = g;
-                gs.M = NBO; gs.N = NBO; gs.lower = 1;
-                if ((rc = cip_launch_gemm(sc, EPI_ACCUM, gs))) return rc;
-                gs.A = g.A + NBO; gs.C = g.C + NBO; gs.M = r - NBO; gs.N = NBO; gs.lower = 0; gs.force64 = 1;
-                if ((rc = cip_launch_gemm(sc, EPI_ACCUM, gs))) return rc;
-            } else {
-                g.M = g.N = r; g.lower = 1;
-                if ((rc = cip_launch_gemm(sc, EPI_ACCUM, g))) return rc;
+            g.M = Npad - r0; g.N = Npad - r0; g.K = wblk; g.alpha = -1.0; g.lower = 1;
+            LdltProfile *prof = ws.prof ? ws.prof : (cip_tl_builder ? nullptr : g_tl_prof);
+            if (prof) {
+                if ((rc = prof_event(prof, s))) return rc;
+                const double r = (double)(Npad - r0);
+                const double live = cip_in_batch() ? (double)__builtin_popcountll(cip_tl_bz.mask) : 1.0;
+                prof->flops.push_back(live * r * (r + 1.0) * (double)wblk);   // 2 flop/MAC on the lower triangle
             }
+            if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
+            if (prof && (rc = prof_event(prof, s))) return rc;
         }
-        if (bulk_pending) CIP_HIP_CHECK(hipStreamWaitEvent(sc, g_bulk.ev_bulk, 0));
-        CIP_HIP_CHECK(hipEventRecord(g_side.ev_chain, sc));
-        CIP_HIP_CHECK(hipStreamWaitEvent(s, g_side.ev_chain, 0));
-        return build_solve_blocks(s, K, Npad, ld, ws);
     }
-    if (!la) {
-        // serial right-looking schedule: panels of the outer block, then ONE trailing update
-        for (int C0 = 0; C0 < Npad; C0 += NBO) {
-            const int wblk = (Npad - C0 < NBO) ? (Npad - C0) : NBO;
-            if ((rc = factor_outer_panels(s, K, Npad, ld, ws, ws.Wbuf, C0, wblk, true))) return rc;
-            const int r0 = C0 + wblk;
-            if (r0 < Npad) {
-                GemmArgs g = {};
-                g.A = ws.Wbuf + r0; g.lda = Npad;
-                g.B = K + r0 + (long)C0 * ld; g.ldb = ld;
-                g.C = K + r0 + (long)r0 * ld; g.ldc = ld;
-                g.M = Npad - r0; g.N = Npad - r0; g.K = wblk; g.alpha = -1.0; g.lower = 1;
-                if (g_lookahead == 2) { g.A = K + r0 + (long)C0 * ld; g.lda = ld; g.dk = ws.dvec + C0; }   // the workers' operand form
-                if (ws.prof) {
-                    if ((rc = prof_event(ws.prof, s))) return rc;
-                    const double r = (double)(Npad - r0);
-                    ws.prof->flops.push_back(r * (r + 1.0) * (double)wblk);   // 2 flop/MAC on the lower triangle
-                }
-                if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
-                if (ws.prof && (rc = prof_event(ws.prof, s))) return rc;
-            }
-        }
-        return build_solve_blocks(s, K, Npad, ld, ws);
-    }
-    // Deep look-ahead (opt-in, Npad >= 4096): the persistent worker launch on the caller's stream carries all
-    // trailing updates, the panel chain of every outer block runs on the side stream behind a gate that waits for its
-    // column strip only (see gemm_f64.hip: k_ldlt_workers for the dependency protocol).
-    if ((rc = lookahead_init())) return rc;
-    hipStream_t sp = g_side.stream;
-    CIP_HIP_CHECK(hipMemsetAsync(ws.la_ctrl, 0, cip_la_ctrl_bytes(Npad), s));
-    CIP_HIP_CHECK(hipEventRecord(g_side.ev_start, s));
-    CIP_HIP_CHECK(hipStreamWaitEvent(sp, g_side.ev_start, 0));
-    if (ws.prof) {
-        if ((rc = prof_event(ws.prof, s))) return rc;
-        double fl = 0;
-        for (int C0 = 0; C0 + NBO < Npad; C0 += NBO) { const double r = (double)(Npad - C0 - NBO); fl += r * (r + 1.0) * (double)NBO; }
-        ws.prof->flops.push_back(fl);
-    }
-    if ((rc = cip_la_launch_workers(s, K, Npad, ld, ws.dvec, NBO, ws.la_ctrl, g_reserve))) return rc;
-    if (ws.prof && (rc = prof_event(ws.prof, s))) return rc;
-    int J = 0;
-    for (int C0 = 0; C0 < Npad; C0 += NBO, ++J) {
-        const int wblk = (Npad - C0 < NBO) ? (Npad - C0) : NBO;
-        if (J > 0 && (rc = cip_la_gate(sp, ws.la_ctrl, Npad, NBO, J))) return rc;
-        if ((rc = factor_outer_panels(sp, K, Npad, ld, ws, ws.Wbuf, C0, wblk))) return rc;
-        if (C0 + wblk < Npad && (rc = cip_la_signal(sp, ws.la_ctrl, J))) return rc;
-    }
-    CIP_HIP_CHECK(hipEventRecord(g_side.ev_chain, sp));
-    CIP_HIP_CHECK(hipStreamWaitEvent(s, g_side.ev_chain, 0));
-    if ((rc = cip_la_finish(s, ws.la_ctrl, ws.info))) return rc;
     return build_solve_blocks(s, K, Npad, ld, ws);
 }
 

@@ -113,9 +113,12 @@ int cip_set_scaling_identity(cip_handle *h);                            /* F = I
 int cip_set_scaling_from_iterate_dev(cip_handle *h, const double *v, const double *s, double *lambda_out);
 int cip_get_scaling_packed(cip_handle *h, double *packedF);             /* host pointer (tests) */
 /* assemble + factor the KKT system for the current scaling.  Asynchronous on the handle's stream: nothing waits for
- * the GPU.  The pivot flag is read back into pinned host memory behind the factorisation and resolved lazily -- by
- * cip_check_factor, by the host-pointer solves (which are synchronous anyway), or by the next *_dev solve / the
- * interior-point loop once the read-back has landed.  A bad pivot then triggers the regularised re-factorisation
+ * the GPU.  The pivot flag is read back into pinned host memory behind the factorisation and resolved by
+ * cip_check_factor, by the host-pointer solves (which are synchronous anyway) and by the *_dev solves: those WAIT for
+ * the flag until one factorisation of the handle has been seen clean (the factorisation that meets a bad pivot is the
+ * first one: LPs, singular Q), afterwards they resolve it only if the read-back has already landed and go ahead
+ * speculatively otherwise (a later bad pivot then surfaces from the next resolving call as CIP_E_SINGULAR "repeat
+ * them"; cip_check_factor after cip_factor rules that out).  A bad pivot triggers the regularised re-factorisation
  * described below; if that fails too the resolving call returns CIP_E_SINGULAR. */
 int cip_factor(cip_handle *h);
 /* wait for the factorisation and report its status: CIP_OK or CIP_E_SINGULAR */
@@ -238,25 +241,19 @@ int cip_set_ldlt_outer_block(int nbo);    /* 0 = automatic (768 from order 4096 
 /* tuning knob: widest block of the triangular solves' block-step form (128, 256, 512 or 1024; 0 = query).  Applies to
  * handles created afterwards; returns the previous value.  Lock-step batches use min(this, 256) for their handles. */
 int cip_set_solve_block_max(int b);
-/* schedule of the blocked LDL': 0 = serial single-stream (default), 1 = deep look-ahead for orders >= 4096 (also
- * CIP_LOOKAHEAD=1: every trailing update in one persistent launch, the panel chain of each outer block on a side
- * stream behind a gate on its own column strip), 2 = serial with the look-ahead's operand form (bit-identical to 1; tests),
- * 3 = two-stream look-ahead (CIP_LOOKAHEAD=3: chain and column strips on a high-priority stream, the bulk of every large
- * trailing update on a second, CU-masked stream; ordinary launches and events, bit-identical to 0).
- * Process-wide; returns the previous setting. */
-int cip_set_ldlt_lookahead(int on);
 /* panel chain of the serial schedule (also CIP_FUSE_DIAG): 3 (default) = one launch per 128-column panel -- diagonal kernel,
  * the previous panel's in-block update and this panel's TRSM, the TRSM following the diagonal kernel micro-panel by
  * micro-panel through a stage counter; 1 = diagonal kernel + previous panel's update in one launch, TRSM in its own;
  * 0 = three launches per panel.  Same factor bit for bit.  Process-wide; returns the previous setting (other values: query). */
 int cip_set_ldlt_fused_chain(int on);
-/* out4 = [s_memtime ticks (shader cycles, ~2.1-2.4 GHz) the persistent workers of the last look-ahead factorisation spent inside tile computations
- * (summed over workers), tiles computed, workers, scheduler error flag] */
-int cip_profile_lookahead(cip_handle *h, double *out4);
 /* HIP-event timing of every LDL' trailing-update launch (bench.py roofline): enable, then read
  * out3 = [launches, total ms, total algorithmic flops (r(r+1)K per launch)] */
 int cip_profile_trailing(cip_handle *h, int enabled);
-int cip_profile_get(cip_handle *h, double *out3);   /* tuning knob: outer block of the blocked LDL' (multiple of 128); returns the value in use */
+int cip_profile_get(cip_handle *h, double *out3);
+/* the same for every factorisation the CALLING THREAD enqueues on handles without a profile of their own (the handles of
+ * cip_conicip_lockstep live inside the call): flops count every live problem of a lock-step launch */
+int cip_profile_trailing_thread(int enabled);
+int cip_profile_thread_get(double *out3);   /* tuning knob: outer block of the blocked LDL' (multiple of 128); returns the value in use */
 
 #ifdef __cplusplus
 }

@@ -36,3 +36,47 @@ def test_bench_line_has_the_contract_fields():
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
     assert d["converge"]["status"] == "Optimal"
+
+
+def _json_line(r):
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_gpus_flag_is_honoured():
+    """`--gpus N` must start N ranks or fail loudly (it was parsed and ignored).  On a box with fewer GPUs than
+    asked for the launcher path refuses before touching the GPU; a WORLD_SIZE that disagrees with --gpus is an error too."""
+    import torch
+    have = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 1), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode != 0 and "visible" in (r.stderr + r.stdout), (r.returncode, r.stderr[-500:])
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout), (r.returncode, r.stderr[-500:])
+
+
+def test_config5_line_through_rccl_on_one_rank():
+    """The N > 1 code path of bench.py -- config 5 in lock-step, process group on the nccl (= RCCL) backend, the SUM / MAX
+    all-reduces, `ranks_seen` -- driven with ONE rank (CIP_BENCH_FORCE_DIST=1), launched by torch.distributed.run exactly
+    as the driver launches it."""
+    env = dict(os.environ, CIP_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--workload", "c5", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    d = _json_line(r)
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["scaling"] == "strong" and d["dtype"] == "f64"
+    assert d["batch"]["n_problems"] == 64 and d["batch"]["n_optimal"] == 64
+    assert d["value"] > 0 and abs(d["value"] - d["batch"]["n_factor"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and rf["launches"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    # identical iteration counts to the oracle over the whole batch (tests/golden/fullsize_trajectories.json)
+    assert d["iters_cpu"] == d["iters_gpu"], (d["iters_cpu"], d["iters_gpu"])

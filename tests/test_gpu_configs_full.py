@@ -1,8 +1,13 @@
 """Every BASELINE.json configuration at its stated size on the GPU ("configs untested"), inputs from the
-portable generator (cipkkt/workloads.py).  At full size the checks are size-independent properties -- status, the
-optimality conditions of the returned point (src/ConicIP.jl:763-788), a KKT backward error -- and, at the largest size
-the oracle finishes in seconds, identity of the trajectory with the oracle (iteration count, factorisations, iterates:
-the north-star's "identical iteration count to convergence")."""
+portable generator (cipkkt/workloads.py).  At full size the checks are (1) IDENTITY OF THE TRAJECTORY WITH THE ORACLE --
+status, iteration count, factorisations, solves, per-iteration mu / alpha / residuals, sampled entries of the iterates:
+the north-star's "identical iteration count to convergence" -- against tests/golden/fullsize_trajectories.json, which
+tests/golden/make_fullsize_fixtures.py writes by running the oracle on the same SplitMix64 inputs in the build container
+(config 2 at n = 8192, config 3 at full size, all 64 problems of config 5), and (2) size-independent
+properties: the optimality conditions of the returned point (src/ConicIP.jl:763-788) and a KKT backward error."""
+import json
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -13,6 +18,31 @@ from oracle import kktsolvers as ok
 from test_gpu_configs import check_optimality
 
 pytestmark = pytest.mark.gpu
+
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_trajectories.json")) as _f:
+    FULLSIZE = json.load(_f)
+
+
+def assert_same_trajectory(sol, fx, what):
+    """`sol` (product) walked the oracle's trajectory `fx` (fixture record): equal status / Iter / n_factor / n_solve; mu
+    to 1e-6 relative and alpha to 1e-6 absolute in every iteration; the residual triples to 1e-6 of their scale (they are
+    norms of differences of O(1) vectors: absolute agreement 1e-9); the final iterate by its norms and 64 sampled entries."""
+    assert sol.status == fx["status"], (what, sol.status, fx["status"])
+    assert (sol.Iter, sol.n_factor, sol.n_solve) == (fx["Iter"], fx["n_factor"], fx["n_solve"]), \
+        (what, (sol.Iter, sol.n_factor, sol.n_solve), (fx["Iter"], fx["n_factor"], fx["n_solve"]))
+    if sol.trace:
+        assert len(sol.trace) == len(fx["trace"]), (what, len(sol.trace), len(fx["trace"]))
+        for it, (tg, tr) in enumerate(zip(sol.trace, fx["trace"])):
+            assert abs(tg["mu"] - tr["mu"]) <= 1e-6 * abs(tr["mu"]), (what, it, tg["mu"], tr["mu"])
+            if tr.get("alpha") is not None:
+                assert abs(tg["alpha"] - tr["alpha"]) <= 1e-6, (what, it, tg["alpha"], tr["alpha"])
+                assert abs(tg["sigma"] - tr["sigma"]) <= 1e-6, (what, it, tg["sigma"], tr["sigma"])
+            for k in ("rDu", "rPr", "rCp"):
+                assert abs(tg[k] - tr[k]) <= 1e-6 * abs(tr[k]) + 1e-9, (what, it, k, tg[k], tr[k])
+    ny, nv = np.linalg.norm(sol.y), np.linalg.norm(sol.v)
+    assert abs(ny - fx["norm_y"]) <= 1e-6 * fx["norm_y"] and abs(nv - fx["norm_v"]) <= 1e-6 * max(fx["norm_v"], 1e-300), what
+    np.testing.assert_allclose(sol.y[fx["idx_y"]], fx["y"], rtol=1e-6, atol=1e-8 * fx["norm_y"], err_msg=what)
+    np.testing.assert_allclose(sol.v[fx["idx_v"]], fx["v"], rtol=1e-6, atol=1e-8 * max(fx["norm_v"], 1.0), err_msg=what)
 
 
 def test_c1_readme_boxqp_n1000_vs_oracle_qr():
@@ -46,7 +76,8 @@ def test_c2_family_n2048_identical_trajectory_to_oracle():
 
 
 def test_c2_headline_n8192():
-    """Config 2 at full size, inputs generated in HBM: Optimal, optimality conditions, and the backward error of one
+    """Config 2 at full size, inputs generated in HBM: the ORACLE'S TRAJECTORY (fixture: pivot(kktsolver_2x2) on the same
+    inputs, 9 iterations) with both loops, the optimality conditions, and the backward error of one
     3x3 solve at a late-iteration scaling (||K x - rhs|| / (||K|| ||x|| + ||rhs||) < 1e-12, evaluated with the problem
     operators on the host)."""
     import torch
@@ -56,9 +87,11 @@ def test_c2_headline_n8192():
     ks = cipkkt.KKTSystem(Q, A, None, K)
     its = []
     sol = cipkkt.conicIP(Q, c, A, b, K, optTol=1e-6, system=ks, keep_iterates=its, driver="python")
-    assert sol.status == "Optimal" and 5 <= sol.Iter <= 20
+    fx = FULLSIZE["c2_n8192_seed1234"]
+    assert_same_trajectory(sol, fx, "c2 n=8192, per-operation loop")
     nat = cipkkt.conicIP(Q, c, A, b, K, optTol=1e-6, system=ks)
-    assert nat.status == "Optimal" and nat.Iter == sol.Iter and np.array_equal(nat.y, sol.y)
+    assert_same_trajectory(nat, fx, "c2 n=8192, native loop")
+    assert np.array_equal(nat.y, sol.y)
     Qh = Q.cpu().numpy()
     check_optimality(Qh, c, A, b, K, np.zeros((0, n)), np.zeros(0), sol, 1e-5)
     # a late-iteration NT scaling (two before the last), one solve3x3 through the host-pointer ABI
@@ -84,6 +117,8 @@ def test_c3_socp_full_size_portable_inputs():
     sol = cipkkt.conicIP(*prob, optTol=1e-6)
     assert sol.status == "Optimal"
     check_optimality(*prob, sol, 1e-5)
+    # the oracle's run with the reference's DEFAULT solver (kktsolver_qr restatement) on the same inputs
+    assert_same_trajectory(sol, FULLSIZE["c3_socp_seed11"], "c3 full size")
 
 
 @pytest.mark.parametrize("r,n,p", [(64, 96, 8), (140, 64, 4)])
@@ -110,13 +145,17 @@ def test_c4_sdp_r256_full_size():
 
 
 def test_c5_all_64_problems():
-    """Config 5 in full: 64 independent dense QPs, n = 2048, seeds 4000 + i, generated in HBM, 4 in flight."""
+    """Config 5 in full: 64 independent dense QPs, n = 2048, seeds 4000 + i, generated in HBM, through the batch entry
+    point (lock-step): every problem walks the oracle's trajectory (fixture: Iter / n_factor / n_solve equal per problem,
+    final iterates at 1e-6)."""
     from cipkkt.batch import solve_batch
     probs = W.c5_batch(64, 2048, seed=4000, device="cuda")
     sols, st = solve_batch(probs, concurrency=4, native=True)
     assert st["n_problems"] == 64 and st["n_optimal"] == 64
-    iters = [sols[i].Iter for i in range(64)]
-    assert min(iters) >= 5 and max(iters) <= 20
+    fx = FULLSIZE["c5_n2048_seed4000"]["problems"]
+    for i in range(64):
+        assert_same_trajectory(sols[i], fx[str(i)], "c5 problem %d" % i)
+    assert st["iters"] == sum(fx[str(i)]["Iter"] for i in range(64))
     for i in (0, 17, 63):                                       # spot-check optimality conditions
         pr = probs[i]
         check_optimality(pr["Q"].cpu().numpy(), pr["c"], pr["A"], pr["b"], pr["cone_dims"], np.zeros((0, 2048)),
