@@ -1,19 +1,61 @@
-# Reference-side binding of libcipkkt (include/cipkkt.h) -- the file a ConicIP.jl maintainer adds as
-# src/kktsolver_hip.jl and includes after kktsolvers.jl.  It cannot be executed in this repository's build
-# image (no Julia); INTEGRATION.md explains each call and the C-ABI entry point it binds.
-# src/kktsolver_hip.jl  -- include("kktsolver_hip.jl") after kktsolvers.jl
-const libcipkkt = get(ENV, "CONICIP_LIBCIPKKT", "libcipkkt")
+"""
+    ConicIPHIP
+
+MI355X back end for ConicIP's `kktsolver` plugin hook: the per-iteration Newton step (NT-scaled KKT assembly, dense LDLᵀ,
+triangular solves) runs in `libcipkkt.so` (hand-written HIP for gfx950, C ABI in `include/cipkkt.h`); ConicIP keeps its
+`conicIP` / MathOptInterface surface and its Mehrotra loop (`src/ConicIP.jl:730-934`).
+
+    using ConicIP, ConicIPHIP
+    sol = conicIP(Q, c, A, b, cone_dims, G, d; kktsolver = kktsolver_hip)              # block elimination on the device
+    sol = conicIP(Q, c, A, b, cone_dims, G, d; kktsolver = pivot(kktsolver_2x2_hip))   # the reference's own `pivot` around the 2×2 form
+    # JuMP, with integration/moi_kktsolver.patch applied to ConicIP's src/MOI_wrapper.jl:
+    model = Model(() -> ConicIP.Optimizer(kktsolver = kktsolver_hip))
+
+The library is looked up once, at module initialisation: `ENV["CONICIP_LIBCIPKKT"]` (a full path) if set, else
+`Libdl.find_library` over `libcipkkt` in `LD_LIBRARY_PATH` and in `<this package>/../../conicip.jl_amd/cipkkt` (the in-tree
+build of this repository).  This file cannot be executed in the repository's build image (no Julia): INTEGRATION.md walks
+through every `ccall` and the C-ABI entry point it binds; `tests/test_integration_files.py` checks the symbol names and
+argument counts used here against `include/cipkkt.h`.
+"""
+module ConicIPHIP
+
+using ConicIP
+using ConicIP: Block
+using Libdl
+using LinearAlgebra
+using SparseArrays
+
+export kktsolver_hip, kktsolver_hip_full3x3, kktsolver_2x2_hip, CIP_ROUTE_SCHUR, CIP_ROUTE_FULL3X3
+
+const _libpath = Ref{String}("")
+const _lib = Ref{Ptr{Cvoid}}(C_NULL)
+# function pointers are looked up in the handle opened by __init__ (a `ccall` through a pointer needs no constant library name)
+_sym(name::Symbol) = Libdl.dlsym(_lib[], name)
+
+function __init__()
+    path = get(ENV, "CONICIP_LIBCIPKKT", "")
+    if isempty(path)
+        here = normpath(joinpath(@__DIR__, "..", "..", "..", "conicip.jl_amd", "cipkkt"))
+        path = Libdl.find_library(["libcipkkt"], [here])
+    end
+    isempty(path) && error("ConicIPHIP: libcipkkt.so not found; build it (python conicip.jl_amd/build.py) and set " *
+                           "ENV[\"CONICIP_LIBCIPKKT\"] or LD_LIBRARY_PATH")
+    _lib[] = Libdl.dlopen(path)     # fails here, loudly, rather than in the first ccall
+    _libpath[] = path
+    return
+end
+
 const CIP_ROUTE_SCHUR, CIP_ROUTE_FULL3X3 = Cint(0), Cint(1)
 const _CONE_CODE = Dict("R" => Cint(0), "Q" => Cint(1), "S" => Cint(2))
 
 _cipcheck(rc) = rc == 0 ? nothing :
-    error("libcipkkt: " * unsafe_string(ccall((:cip_last_error, libcipkkt), Cstring, ())))
+    error("libcipkkt: " * unsafe_string(ccall(_sym(:cip_last_error), Cstring, ())))
 
 mutable struct CipHandle
     ptr::Ptr{Cvoid}
     function CipHandle(p)
         h = new(p)
-        finalizer(x -> ccall((:cip_destroy, libcipkkt), Cint, (Ptr{Cvoid},), x.ptr), h)
+        finalizer(x -> ccall(_sym(:cip_destroy), Cint, (Ptr{Cvoid},), x.ptr), h)
         h
     end
 end
@@ -39,7 +81,7 @@ function _pack_scaling(F::Block, F⁻ᵀ::Block, cone_dims)
             end
         else
             if Fi isa Diagonal                          # vecm(RᵀXR) = d·vecm(X)  ⇔  R = √d·I
-                d = _uniform(Fi); r = ord(zeros(k))
+                d = _uniform(Fi); r = ConicIP.ord(zeros(k))
                 append!(out, vec(Matrix(sqrt(d) * I, r, r))); append!(out, vec(Matrix(I / sqrt(d), r, r)))
             else
                 append!(out, vec(Fi.R))                 # VecCongurance(R)            ConicIP.jl:208
@@ -66,11 +108,11 @@ function kktsolver_hip(Q, A, G, cone_dims; route = CIP_ROUTE_SCHUR)
 
     function solve3x3gen(F, F⁻ᵀ)                                              # level 2
         packed = _pack_scaling(F, F⁻ᵀ, cone_dims)
-        _cipcheck(ccall((:cip_set_scaling_packed, libcipkkt), Cint, (Ptr{Cvoid}, Ptr{Float64}), h.ptr, packed))
-        _cipcheck(ccall((:cip_factor, libcipkkt), Cint, (Ptr{Cvoid},), h.ptr))   # asynchronous; cip_solve3x3 resolves it
+        _cipcheck(ccall(_sym(:cip_set_scaling_packed), Cint, (Ptr{Cvoid}, Ptr{Float64}), h.ptr, packed))
+        _cipcheck(ccall(_sym(:cip_factor), Cint, (Ptr{Cvoid},), h.ptr))   # asynchronous; cip_solve3x3 resolves it
         function solve3x3(x, y, z)                                            # level 3
             a, b, c = zeros(n), zeros(p), zeros(m)    # fresh, Julia-owned (they become fields of z / Δz, ConicIP.jl:690)
-            _cipcheck(ccall((:cip_solve3x3, libcipkkt), Cint,
+            _cipcheck(ccall(_sym(:cip_solve3x3), Cint,
                 (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
                 h.ptr, Vector{Float64}(x), Vector{Float64}(y), Vector{Float64}(z), a, b, c))
             return (a, b, c)
@@ -86,7 +128,7 @@ function _cip_create_dense(Q, A, G, cone_dims, route)
     ctype = Cint[_CONE_CODE[c[1]] for c in cone_dims]
     cdim  = Cint[c[2] for c in cone_dims]
     href = Ref{Ptr{Cvoid}}(C_NULL)
-    _cipcheck(ccall((:cip_create, libcipkkt), Cint,
+    _cipcheck(ccall(_sym(:cip_create), Cint,
         (Cint, Cint, Cint, Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Ref{Ptr{Cvoid}}),
         n, m, p, length(cone_dims), ctype, cdim, Qd, Ad, Gd, route, href))
     CipHandle(href[])
@@ -120,7 +162,7 @@ function _cip_create_sparse(Q, A::SparseMatrixCSC, G, cone_dims, route)
                               pointer(Qd), n, Ptr{Float64}(C_NULL), 0,
                               pointer(rowptr), pointer(colind), pointer(val),
                               p > 0 ? pointer(Gd) : Ptr{Float64}(C_NULL), max(p, 1), route, 0))
-        _cipcheck(ccall((:cip_create_ex, libcipkkt), Cint, (Ref{CipProblem}, Ref{Ptr{Cvoid}}), prob, href))
+        _cipcheck(ccall(_sym(:cip_create_ex), Cint, (Ref{CipProblem}, Ref{Ptr{Cvoid}}), prob, href))
     end
     CipHandle(href[])
 end
@@ -135,11 +177,11 @@ function kktsolver_2x2_hip(Q, A, G, cone_dims)
         _cip_create_sparse(Q, A, G, cone_dims, CIP_ROUTE_SCHUR) : _cip_create_dense(Q, A, G, cone_dims, CIP_ROUTE_SCHUR)
     function solve2x2gen(F, F⁻ᵀ)
         packed = _pack_scaling(F, F⁻ᵀ, cone_dims)
-        _cipcheck(ccall((:cip_set_scaling_packed, libcipkkt), Cint, (Ptr{Cvoid}, Ptr{Float64}), h.ptr, packed))
-        _cipcheck(ccall((:cip_factor, libcipkkt), Cint, (Ptr{Cvoid},), h.ptr))
+        _cipcheck(ccall(_sym(:cip_set_scaling_packed), Cint, (Ptr{Cvoid}, Ptr{Float64}), h.ptr, packed))
+        _cipcheck(ccall(_sym(:cip_factor), Cint, (Ptr{Cvoid},), h.ptr))
         function solve2x2(y, w)
             Δy, Δw = zeros(n), zeros(p)
-            _cipcheck(ccall((:cip_solve2x2, libcipkkt), Cint,
+            _cipcheck(ccall(_sym(:cip_solve2x2), Cint,
                 (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
                 h.ptr, Vector{Float64}(y), Vector{Float64}(w), Δy, Δw))
             return (Δy, Δw)
@@ -153,13 +195,7 @@ end
 # and for the literal 3x3 assembly of kktsolver_sparse (src/kktsolvers.jl:254-256):
 #     conicIP(...; kktsolver = (Q, A, G, cd) -> kktsolver_hip(Q, A, G, cd; route = CIP_ROUTE_FULL3X3))
 
-# --- MathOptInterface: forwarding a kktsolver through `Optimizer` (src/MOI_wrapper.jl) --------------------------
-# `Optimizer` stores verbose/optTol/maxIters only (MOI_wrapper.jl:28-31) and calls preprocess_conicIP without a
-# kktsolver (:278-282).  The patch a maintainer applies (4 places):
-#   struct Optimizer ...                  # :28-31   add a field      kktsolver::Function
-#   Optimizer(; verbose=false, optTol=1e-6, maxIters=100, kktsolver=ConicIP.kktsolver_qr)   # :33, pass it through
-#   MOI.supports(::Optimizer, ::MOI.RawOptimizerAttribute) / MOI.set(model, MOI.RawOptimizerAttribute("kktsolver"), f)
-#                                         #          model.kktsolver = f   (so that JuMP's set_attribute works)
-#   dest.sol = preprocess_conicIP(Q, c_int, A, b, cone_dims, G, d; kktsolver = dest.kktsolver,
-#                                 verbose = dest.verbose, optTol = dest.optTol, maxIters = dest.maxIters)   # :278-282
-# after which   model = Model(() -> ConicIP.Optimizer(kktsolver = kktsolver_hip))   reaches this file from JuMP.
+"`kktsolver` for the literal 3×3 assembly of `kktsolver_sparse` (src/kktsolvers.jl:254-256) on the device."
+kktsolver_hip_full3x3(Q, A, G, cone_dims) = kktsolver_hip(Q, A, G, cone_dims; route = CIP_ROUTE_FULL3X3)
+
+end # module

@@ -39,9 +39,11 @@ E_INVALID, E_NOTFACTORED, E_SINGULAR, E_UNSUPPORTED = (_CODES[k] for k in ("CIP_
 def cpu():
     from cipkkt import _lib as L
     os.makedirs(OUT, exist_ok=True)
-    so = os.path.join(OUT, "libcipkkt_cpu.so")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(SRC):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, SRC], check=True)
+    so = os.environ.get("CIP_CPU_REF_SO")        # the -fsanitize=address,undefined build (conicip.jl_amd/build.py --asan-host)
+    if not so:
+        so = os.path.join(OUT, "libcipkkt_cpu.so")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(SRC):
+            subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, SRC], check=True)
     lib = C.CDLL(so)
     for name, (res, args) in L.SIGNATURES.items():
         if hasattr(lib, name):
