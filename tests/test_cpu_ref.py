@@ -39,7 +39,7 @@ E_INVALID, E_NOTFACTORED, E_SINGULAR, E_UNSUPPORTED = (_CODES[k] for k in ("CIP_
 def cpu():
     from cipkkt import _lib as L
     os.makedirs(OUT, exist_ok=True)
-    so = os.environ.get("CIP_CPU_REF_SO")        # the -fsanitize=address,undefined build (conicip.jl_amd/build.py --asan-host)
+    so = os.environ.get("CIP_CPU_REF_SO")        # the -fsanitize=address,undefined build (oracle/cpu_ref/build_asan.py)
     if not so:
         so = os.path.join(OUT, "libcipkkt_cpu.so")
         if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(SRC):
