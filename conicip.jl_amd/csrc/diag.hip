@@ -62,18 +62,184 @@ __device__ __forceinline__ double bperm_d(double x, int byte_addr) {
 }
 
 // Step A: LDL' of the 16x16 diagonal micro-block kb and the inverse X of its unit-lower factor, by one wave.
-// The tile is held in the f64-MFMA accumulator layout -- lane (row i = l15, group g) owns columns g, g+4, g+8,
-// g+12 -- so each of the 16 pivot steps costs a quarter of the column updates per lane; the pivot is broadcast
-// with v_readlane, the pivot column / pivot row entries move between lane groups with ds_bpermute.  X is updated
-// right-looking by the same multipliers (lane (cc = l15, g) owns rows g+4q of column cc).
-// (A row-per-lane variant -- lane i holds row i and column i of X, pivot column broadcast with v_readlane only, no LDS
-// round trip -- was built and measured in round 2: 40.5 us per kernel against 30.9: with 16 useful lanes a pivot
-// issues (15-j) x 5 fp64 instructions instead of 4 x 3, and the issue time exceeds the bpermute latency it removes.
-// A third variant moved every per-pivot operand in registers -- own-row entry by v_permlane32_swap + v_permlane16_swap,
-// the pivot ROW (instead of the pivot column: the block is symmetric) by DPP row_newbcast -- no LDS at all: 31.2 us against
-// 30.6, and with steps B/C switched off 23.7 against 20.7: the chain is ISSUE-bound (one wave, ~40 instructions of ~5
-// cycles per pivot), not latency-bound; the swaps need copies and hazard nops and cost more issue slots than the 12
-// ds_bpermute they replace.  tools/diag_bench.hip measures such variants and checks them against a host LDL'.)
+//
+// Round 3 form.  The 16 pivots are taken in four BLOCKS OF FOUR columns, and the tile is held so that a block never needs
+// a cross-lane VECTOR move while it is being factored:
+//   * lane (l15, g), register q holds tile element (row P(l15), column 4g + q), P(x) = 4 (x mod 4) + x div 4 -- the f64-MFMA
+//     accumulator layout with rows AND columns relabelled by P (the hardware pairs register q of lane group g with operand
+//     lane g + 4q = P(4g + q); relabelling both sides by the same involution keeps every MFMA consistent).  Block jb = the
+//     four registers of lane group jb: row-per-lane, 16 lanes.  X likewise: lane (l15, g) register q = X[4g + q][P(l15)].
+//   * inside block jb (EXEC = lane group jb) a pivot j is: d = v_readlane, 1/d (rcp + two Newton steps), the multipliers
+//     l = column * (1/d) (one multiply), and for each later column k of the block the SCALAR a[k][j] by v_readlane and one
+//     fma (SGPR operand) on the column, one multiply + one fma on X's row: no ds_bpermute, no select.
+//   * the block's effect on everything to its right is ONE rank-4 update each for the tile and for X,
+//         u[:, k] += sum_kk (-l_kk)[:] * a[k][j_kk]        X[r, :] += sum_kk (-l[r][j_kk]) * X[j_kk][:],
+//     two v_mfma_f64_16x16x4_f64 in place on the register tuples.  Their operands want pivot kk's vector in lane group
+//     kk: the block's lanes park their four l / unnormalised-column / X-row registers in LDS (the not-yet-written slot of
+//     this micro-panel's inverse) and every lane reads back the one of its group -- 12 narrow ds_write_b64 + 3 ds_read_b64
+//     per block instead of 18 ds_bpermute_b32 strung along the pivots.  Operand lanes of finished columns / rows read
+//     zeros, so the in-place MFMA leaves them alone (x + 0 * y).
+// v_mfma_f64_16x16x4_f64 IS the chain acc <- fma(a_kk, b_kk, acc), kk = 0, 1, 2, 3, each step rounded (tools/mfma_order.hip:
+// 512 000 random cases, no mismatch against that order, 30-40 % against any other), so every stored entry receives the
+// same fused multiply-adds on the same operands in the same order as in round 2's pivot-by-pivot form: L, d, 1/d and the
+// micro inverse are BIT-IDENTICAL to it (tools/diag_bench.hip / tools/stepa_probe.hip build that form with
+// -DDIAG_STEP_A_REF for the comparison).
+// What was measured on the way (tools/stepa_probe.hip, one wave alone on a CU, clocks per 16 pivots): round 2's form 4280
+// (267 per pivot); the same arithmetic blocked by four but still in the plain accumulator layout (three ds_bpermute pairs
+// per pivot, selects) 4110 -- of which the permutes 1400 (every ds_bpermute_b32 occupies the LDS pipe for ~17 clocks and
+// the last pair of a pivot is on its chain), the three MFMA rounds 1200 (register-tuple copies around them), the Newton
+// steps 500; the dependency chain of a pivot alone (readlane, rcp, two Newton steps, multiply, fma) is 80.
+// (Round 2 variants: row-per-lane for the whole tile 40.5 us per kernel against 30.9; every operand through
+// v_permlane*_swap / DPP instead of ds_bpermute 31.2 against 30.6.)
+__host__ __device__ constexpr int diag_perm(int x) { return 4 * (x & 3) + (x >> 2); }
+// x of lane N of the own 16-lane row (DPP row_newbcast: gfx90a and later)
+template <int N>
+__device__ __forceinline__ double row_bcast_t(double x) {
+    return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + N, 0xf, 0xf, true);      // v_mov_b64_dpp (gfx90a+: 64-bit DPP knows row_newbcast only)
+}
+// acc += x[lane N of the own row] * (-y) as ONE instruction: v_fmac_f64 is a VOP2 and takes DPP on its first source (the
+// compiler keeps v_mov_b64_dpp + v_fma_f64: two instructions on a wave that pays ~10 clocks per instruction).  The DPP
+// source must not have been written by the instruction right before (VALU write -> DPP read: 2 wait states; the
+// assembler does not check inline asm): in diag_step_a it is always a register written at least four instructions earlier.
+template <int N>
+__device__ __forceinline__ void fmac_bcast_neg_t(double &acc, double x, double y) {
+    asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(y), "n"(N));
+}
+// One block of four pivots, every lane index a TEMPLATE constant: with run-time-looking loop indices the optimiser merged the
+// four structurally identical EXEC-masked regions of diag_step_a, turned the DPP lane selects into PHIs and the selection
+// into compare-and-branch ladders (35.7 us per kernel instead of 21.8).
+template <int JB, int GJ, int GK>
+__device__ __forceinline__ void stepa_update(v4d &T, const v4d &S, const v4d &M) {     // T[gk] -= S[gj] @ (lane of row 4JB + gk) * M[gj], gk = GK .. 3
+    if constexpr (GK < 4) {
+        double t = T[GK];
+        fmac_bcast_neg_t<diag_perm(4 * JB + GK)>(t, S[GJ], M[GJ]);
+        T[GK] = t;
+        stepa_update<JB, GJ, GK + 1>(T, S, M);
+    }
+}
+template <int JB, int GJ>
+__device__ __forceinline__ void stepa_pivots(v4d &U, v4d &L, double (&dd)[4]) {
+    if constexpr (GJ < 4) {
+        // the block lives in ONE 16-lane row: a[j][j] and a[k][j] reach the row's lanes by DPP row broadcast (v_mov_b64_dpp /
+        // v_fmac_f64_dpp, VALU latency) instead of v_readlane -> SGPR -> VALU (28 clocks on every pivot's chain)
+        const double d = row_bcast_t<diag_perm(4 * JB + GJ)>(U[GJ]);
+        dd[GJ] = d;                                    // kept for the output: the in-place MFMAs turn a NaN multiplier into NaNs in
+                                                       // FINISHED columns too (0 * NaN), and the first bad pivot must be reported at its own column
+        L[GJ] = U[GJ] * fast_rcp(d);                   // multipliers l_ij = a_ij / d_j (the diagonal lane holds d/d: never stored)
+        stepa_update<JB, GJ, GJ + 1>(U, U, L);         // U[gk] -= a[k][j] * l_ij, a[k][j] (k = 4JB + gk) from the row's lane that holds row k
+        stepa_pivots<JB, GJ + 1>(U, L, dd);
+    }
+}
+template <int JB, int GJ>
+__device__ __forceinline__ void stepa_xrows(v4d &X, const v4d &L) {
+    if constexpr (GJ < 3) {
+        stepa_update<JB, GJ, GJ + 1>(X, L, X);         // X[k][:] -= l[k][j] X[j][:], l[k][j] = a[k][j] * (1/d_j) = L[gj] of the row's lane that holds row k
+        stepa_xrows<JB, GJ + 1>(X, L);
+    }
+}
+#ifdef STEPA_TIMING
+__device__ long g_stepa_t[32];
+#define STEPA_STAMP(i) do { if (threadIdx.x == 0) g_stepa_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STEPA_STAMP(i) do { } while (0)
+#endif
+template <int JB>
+__device__ __forceinline__ void stepa_round(v4d &U, v4d &X, v4d &L, double (&dd)[4], double *scr, int l15, int g) {
+    STEPA_STAMP(1 + 4 * JB);
+    if (g == JB) {
+        stepa_pivots<JB, 0>(U, L, dd);
+        if (JB < 3) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                scr[kk * 16 + l15] = L[kk];
+                scr[64 + kk * 16 + l15] = U[kk];               // column 4JB + kk as the later columns see it (before the division)
+            }
+        }
+        // the same multipliers on the block's own rows of X (under the LDS latency of the stores above)
+        stepa_xrows<JB, 0>(X, L);
+        if (JB < 3) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) scr[128 + kk * 16 + l15] = X[kk];
+        }
+    }
+    STEPA_STAMP(2 + 4 * JB);
+    if (JB < 3) {
+        // acc[q] @ lane (l15, g)  +=  sum_kk R @ lane (l15, kk) * P @ lane (g + 4q, kk).  Lanes exchange data through LDS
+        // here -- ONE round trip per block for the three operand sets: the hardware completes a wave's DS operations in
+        // order, so a read issued behind the writes sees them -- but the COMPILER must be told that other lanes' stores
+        // matter (without the wavefront-scope release / acquire pair it sank two of the three reads into the block's
+        // EXEC-masked region: 12 lane groups read stale data)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool todo = (l15 & 3) > JB;                      // hardware index l15 <-> column / X row 4 (l15 & 3) + (l15 >> 2): beyond the block?
+        const double ln = -scr[g * 16 + l15];
+        const double pu = scr[(todo ? 64 + g * 16 : 192) + l15];
+        const double xr = scr[128 + g * 16 + l15];
+        STEPA_STAMP(3 + 4 * JB);
+        U = MFMA(pu, ln, U);                                   // the tile first: the next block's first pivot waits for it
+        X = MFMA(todo ? ln : 0.0, xr, X);
+        STEPA_STAMP(4 + 4 * JB);
+    }
+}
+#ifndef DIAG_STEP_A_REF
+__device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int lane, int *info, int col0, PivotSigns sg) {
+    const int l15 = lane & 15, g = lane >> 4;
+    const int c = kb * 16;
+    const int row = diag_perm(l15);                            // the tile row / X column this lane holds
+    v4d U, X, L = (v4d){0.0, 0.0, 0.0, 0.0};
+    double dd[4] = {0.0, 0.0, 0.0, 0.0};                       // lane group jb: the four pivots d_j of its block
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        U[q] = a[(c + row) + (c + 4 * g + q) * DP];
+        X[q] = (4 * g + q == row) ? 1.0 : 0.0;
+    }
+    double *scr = xm + kb * 256;                               // [set][kk][l15], three sets: this slot is written at the very end
+    // operand lanes of the rank-4 updates: lane (l15, kk) carries the vector of pivot kk; P-side lanes whose hardware
+    // index belongs to a finished / current block ((l15 & 3) <= jb) must contribute zeros -> they read the zeroed 4th set
+    if (lane < 16) scr[192 + lane] = 0.0;
+    STEPA_STAMP(0);
+    if (!(DIAG_SKIP & 8)) {
+        stepa_round<0>(U, X, L, dd, scr, l15, g);
+        stepa_round<1>(U, X, L, dd, scr, l15, g);
+        stepa_round<2>(U, X, L, dd, scr, l15, g);
+        stepa_round<3>(U, X, L, dd, scr, l15, g);
+    }
+    STEPA_STAMP(17);
+    double dsel = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int col = 4 * g + q;
+        const double v = (col == row) ? dd[q] : L[q];          // d on the diagonal, l_ij below (above: not stored)
+        if (col <= row) a[(c + row) + (c + col) * DP] = v;
+        if (col == row) dsel = dd[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xm[kb * 256 + row * 16 + 4 * g + q] = X[q];      // xm[k = cc][jj = r] = X[r][cc]
+    {
+        // lane (l15, g = l15 & 3) holds the diagonal element of column `row` (= 4g + (l15 >> 2)); these 16 lanes are in
+        // column order, so the lowest set bit of a ballot is the FIRST bad column of the micro-block (one atomic per flag
+        // instead of one per bad lane racing for the word)
+        const bool diag_lane = g == (l15 & 3);
+        // a bad pivot: zero, non-finite, or -- the matrix is quasi-definite in this static order -- of the wrong sign
+        const int col = col0 + c + row;
+        const bool want_pos = (col >= sg.p0 && col < sg.p1) || col >= sg.N;
+        // info[0]: first bad pivot of any kind; info[2]: first zero / non-finite one (fatal even for a regularised factor,
+        // whose wrong-sign pivots the refinement of solve3x3 absorbs)
+        const bool dead = diag_lane && !(fabs(dsel) > 0.0 && fabs(dsel) < 1.7e308);
+        const bool bad = dead || (diag_lane && sg.p0 >= 0 && (dsel > 0.0) != want_pos);
+        const unsigned long long mbad = __ballot(bad), mdead = __ballot(dead);
+        if (mbad && lane == __ffsll((long long)mbad) - 1) atomicCAS(info, 0, col + 1);
+        if (mdead && lane == __ffsll((long long)mdead) - 1) atomicCAS(info + 2, 0, col + 1);
+        if (diag_lane) {
+            a[128 + (c + row) * DP] = dsel;
+            a[129 + (c + row) * DP] = fast_rcp(dsel);
+        }
+    }
+}
+#else
+// Round 2's form (pivot by pivot over the whole tile, plain accumulator layout: lane (row l15, group g) owns columns g,
+// g+4, g+8, g+12; six ds_bpermute pairs and up to eight selected updates per pivot) -- kept for the A/B tools only.
 __device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int lane, int *info, int col0, PivotSigns sg) {
     const int l15 = lane & 15, g = lane >> 4;
     const int c = kb * 16;
@@ -89,9 +255,6 @@ __device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int l
 #pragma unroll
     for (int j = 0; j < ((DIAG_SKIP & 8) ? 0 : 16); ++j) {
         const int gj = j & 3, qj = j >> 2;
-        // every cross-lane operand of the step is requested before any of them is used: ONE LDS round trip per pivot (the
-        // first version interleaved permutes, waits and predicated updates: three to four dependent round trips), and the
-        // updates are selects, not branches
         const double d = rlane(u[qj], 16 * gj + j);
         const double wi = bperm_d(u[qj], addr_r + 64 * gj);    // a[i][j], own row
         const double xj = bperm_d(x[qj], addr_r + 64 * gj);    // X[j][cc], own column
@@ -106,8 +269,8 @@ __device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int l
             if (4 * q + 3 > j) {
                 const double nu = u[q] - ti * cjv[q];
                 const double nx = x[q] - (cjv[q] * di) * xj;
-                if (4 * q > j) { u[q] = nu; x[q] = nx; }       // every lane group's column g + 4q is beyond j (known at compile time)
-                else {                                          // the one register whose columns straddle j: per-lane select
+                if (4 * q > j) { u[q] = nu; x[q] = nx; }
+                else {
                     const bool act = g + 4 * q > j;
                     u[q] = act ? nu : u[q];
                     x[q] = act ? nx : x[q];
@@ -125,11 +288,8 @@ __device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int l
         xm[kb * 256 + l15 * 16 + col] = x[q];                  // xm[k = cc][jj = r] = X[r][cc]
     }
     if (g == (l15 & 3)) {
-        // a bad pivot: zero, non-finite, or -- the matrix is quasi-definite in this static order -- of the wrong sign
         const int col = col0 + c + l15;
         const bool want_pos = (col >= sg.p0 && col < sg.p1) || col >= sg.N;
-        // info[0]: first bad pivot of any kind; info[2]: first zero / non-finite one (fatal even for a regularised factor,
-        // whose wrong-sign pivots the refinement of solve3x3 absorbs)
         const bool dead = !(fabs(dsel) > 0.0 && fabs(dsel) < 1.7e308);
         if (dead || (sg.p0 >= 0 && (dsel > 0.0) != want_pos)) atomicCAS(info, 0, col + 1);
         if (dead) atomicCAS(info + 2, 0, col + 1);
@@ -137,6 +297,7 @@ __device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int l
         a[129 + (c + l15) * DP] = fast_rcp(dsel);
     }
 }
+#endif
 
 // step B for one row tile: W = U inv(L11)' (4 MFMAs), L = W D^-1 written back into the LDS image
 __device__ __forceinline__ void diag_step_b(double *a, int it, int c, int l15, int g, const double (&xa)[4],
@@ -497,7 +658,9 @@ __global__ __launch_bounds__(256) void k_ldlt_diag_upd(double *Kb, long ld, doub
 //   the others           (UPD) the remaining tiles of the in-block update
 // The same operations on the same operands in the same order as the separate launches: bit-identical factors.
 // Every wait is for a workgroup with a lower index in the same launch (dispatched earlier); waits are bounded (~1 s).
+#ifndef PANEL_WAVES
 #define PANEL_WAVES 8                   // waves of a k_ldlt_panel workgroup: the diagonal kernel's; the other roles use the first four
+#endif
 #define PANEL_NH (PANEL_WAVES - PANEL_WAVES / 4)      // helper waves of the diagonal kernel = counts on `stage` per published micro-panel
 struct TrsmStrips {
     double *Ap; long ld;              // rows below the diagonal block, this panel's 128 columns

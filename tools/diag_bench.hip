@@ -51,6 +51,14 @@ int main() {
         double e = 0, ed = 0;
         for (int j = 0; j < N; ++j) { ed = fmax(ed, fabs(dv[j] - H[j + j * N]) / fabs(H[j + j * N])); for (int i = j + 1; i < N; ++i) e = fmax(e, fabs(G[i + j * N] - H[i + j * N])); }
         printf("max |L - L_host| %.3e, max rel |d - d_host| %.3e\n", e, ed);
+        if (getenv("DIAG_BENCH_DUMP")) {        // factor, d and the micro inverses, raw: `cmp` two builds for bit-identity
+            std::vector<double> X(8 * 256);
+            hipMemcpy(X.data(), dLi, 8 * 256 * 8, hipMemcpyDeviceToHost);
+            for (int j = 0; j < N; ++j) for (int i = 0; i < j; ++i) G[i + j * N] = 0.0;      // the strictly upper part is not output
+            FILE *f = fopen(getenv("DIAG_BENCH_DUMP"), "wb");
+            fwrite(G.data(), 8, N * N, f); fwrite(dv.data(), 8, N, f); fwrite(X.data(), 8, 8 * 256, f);
+            fclose(f);
+        }
     }
 #ifdef DIAG_TIMING
     {
