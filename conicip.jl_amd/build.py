@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "cipkkt", "libcipkkt.so")
 OBJ = os.path.join(HERE, "build")
-SOURCES = ["gemm_f64.hip", "ldlt.hip", "solve.hip", "diag.hip", "cones.hip", "sdp.hip", "sdp_large.hip", "vecops.hip", "assemble.hip", "api.hip", "driver.hip", "lockstep.hip", "batch.hip"]
+SOURCES = ["gemm_f64.hip", "ldlt.hip", "diag.hip", "cones.hip", "sdp.hip", "sdp_large.hip", "vecops.hip", "assemble.hip", "api.hip", "driver.hip", "lockstep.hip", "batch.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function"]

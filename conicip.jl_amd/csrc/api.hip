@@ -548,7 +548,7 @@ static int factor_resolve(cip_handle *h, bool wait) {
     // info_host: [0] first bad pivot of any kind (1-based column), [1] bail-out flag of the sweep kernels,
     //            [2] first zero / non-finite pivot
     if (h->info_host[3] != 0 || h->info_host[1] != 0) {
-        cip_set_error("LDL': in-launch wait gave up (panel chain %d, sweeps %d)", h->info_host[3], h->info_host[1]);
+        cip_set_error("LDL': in-launch wait of the panel chain gave up (%d)", h->info_host[3]);
         h->factored = false;
         return CIP_E_HIP;
     }
@@ -813,6 +813,30 @@ extern "C" int cip_solve4x4_dev(cip_handle *h, const double *lambda, const doubl
     const double *ry = r, *rw = r + n, *rv = r + n + p, *rs = r + n + p + m;
     double *dy = dz, *dw = dz + n, *dv = dz + n + p, *ds = dz + n + p + m;
     int rc;
+    if (h->all_r < 0) {
+        h->all_r = m > 0 ? 1 : 0;
+        for (int q = 0; q < h->cs.ncones; ++q) if (h->cs.h_cones[q].type != CIP_CONE_R) h->all_r = 0;
+        const char *e = getenv("CIP_S4_FUSED");
+        if (e && atoi(e) == 0) h->all_r = 0;
+    }
+    if (h->all_r && h->route == CIP_ROUTE_SCHUR && h->reg_rel <= 0.0) {
+        // all cones R (F = diag(f), f = the packed scaling): the element-wise launches around the sweeps fused into one kernel
+        // in front and one behind them (vecops.hip: k_s4_pre_r / k_s4_post_r), the same operations on every element
+        if (!h->factored) { cip_set_error("cip_solve4x4: no factorisation (call cip_factor first)"); return CIP_E_NOTFACTORED; }
+        CipRange rg("cip:solve3x3");
+        if ((rc = factor_resolve(h, !h->pivots_verified))) return rc;
+        if (h->reg_rel <= 0.0) {                       // (the resolve may have switched the handle to the regularised factorisation)
+            if (h->info_pending) h->spec_solves += 1;
+            h->n_solve += 1;
+            const double *f = h->cs.d_scal;
+            double *t = h->mt1, *u = h->mt3;
+            if ((rc = cip_s4_pre_r(s, m, n, p, h->Npad, f, rs, lambda, rv, ry, rw, ds, t, h->rhs, h->A_sparse ? h->T_rp : nullptr, h->T_ci, h->T_v))) return rc;
+            if (!h->A_sparse && (rc = mul_At(h, 1.0, t, 1.0, h->rhs))) return rc;
+            if ((rc = graph_run(h, &h->gx_solve, [&]() { return cip_ldlt_solve(s, h->K, h->Npad, h->ldk, h->ws, h->rhs); }))) return rc;
+            if (!h->A_sparse && (rc = mul_A(h, 1.0, h->rhs, 0.0, u))) return rc;
+            return cip_s4_post_r(s, m, n, p, f, t, h->rhs, h->A_sparse ? nullptr : u, h->A_sparse ? h->A_rp : nullptr, h->A_ci, h->A_v, dy, dw, dv, ds);
+        }
+    }
     // ds is used as t1; dv temporarily holds r.v + t1 (input z of the 3x3 solve; solve3x3 copies it before writing c)
     if (m > 0) {
         if ((rc = cip_cones_div(s, h->cs, rs, lambda, ds))) return rc;          // q

@@ -21,6 +21,7 @@ struct cip_handle {
     double *Q = nullptr;            // n x n, ld n
     double *symv_ws = nullptr;      // partial-sum tables of the symmetric mat-vec (n a multiple of 128, n >= 2048), else null
     bool A_sparse = false;
+    int all_r = -1;                 // every cone is an R cone (F diagonal): solve4x4 takes the fused element-wise path; -1: not looked at yet
     double *A = nullptr;            // m x n, ld m            (dense A only)
     double *At = nullptr;           // npad x mpad, ld npad   (dense A only; zero padded)  At[i + r*npad] = A[r,i]
     int A_nnz = 0;

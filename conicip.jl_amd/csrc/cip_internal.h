@@ -130,8 +130,6 @@ struct LdltWorkspace {        // carved out of one device allocation
     double *dinv;             // Npad   1/d
     double *dvec;             // Npad   d
     double *tmp;              // Npad   scratch vector for the solves
-    double *ybuf;             // Npad   forward-sweep result (solve.hip)
-    unsigned *sweep_ctr;      // tickets / arrival counters / flags of the two sweep kernels
     int *info;                // device int: 0 ok, >0 = 1-based column of a bad pivot (zero, non-finite, or of the wrong sign)
     PivotSigns signs;
     LdltProfile *prof;        // host object or NULL
@@ -224,6 +222,11 @@ int cip_spmv_csr(hipStream_t s, int rows, const int *rowptr, const int *colind, 
 int cip_dots(hipStream_t s, int count, const double *const *x_host, const double *const *y_host,
              const int *len_host, double *scratch_dev, void *ptrs_dev, double *out_host);
 int cip_axpby(hipStream_t s, int len, double alpha, const double *x, double beta, double *y);
+// solve4x4 around the sweeps for all-R cone sets (vecops.hip): the element-wise launches fused, same arithmetic
+int cip_s4_pre_r(hipStream_t s, int m, int n, int p, int Npad, const double *f, const double *rs, const double *lam, const double *rv,
+                 const double *ry, const double *rw, double *t1_out, double *t_out, double *rhs, const int *T_rp, const int *T_ci, const double *T_v);
+int cip_s4_post_r(hipStream_t s, int m, int n, int p, const double *f, const double *t, const double *rhs, const double *u_dense,
+                  const int *A_rp, const int *A_ci, const double *A_v, double *dy, double *dw, double *dv, double *ds);
 int cip_copy_neg(hipStream_t s, int len, const double *x, double *y, double scale);   // y = scale * x
 int cip_axpby_ps(hipStream_t s, int len, const double *alpha_host, const double *x, double beta, double *y);   // batch: alpha per problem
 int cip_zero(hipStream_t s, long len, double *y);                     // batch-aware memset(0) of doubles

@@ -15,7 +15,7 @@
 // 3/4 of the N^3/3 flops at n = 8192 are in the trailing-update GEMM (gemm_f64.hip), the rest in the K = 128 in-block tiles.
 //
 // Solves (HBM-bound, L read once per sweep): blocked substitution with the stored inverses of the diagonal blocks
-// (doubled up to 1024 wide), one gemv launch per block step and sweep (solve.hip).
+// (doubled up to 1024 wide), two gemv launches per block step and sweep.
 #include "cip_internal.h"
 #include <stdlib.h>
 #include <string.h>
@@ -140,8 +140,7 @@ size_t cip_ldlt_ws_bytes(int Npad) {
         b += al256(nbk * (size_t)(Bs / 2) * (Bs / 2) * 8 + 256);   // Tt
         b += al256((size_t)Npad * 8);                    // zbuf
     }
-    b += al256((size_t)Npad * 8) * 4;                    // dinv, dvec, tmp, ybuf
-    b += al256(4 * 2 * (2 + 2 * nblk + (size_t)Npad / 8));  // sweep counters / flags (solve.hip)
+    b += al256((size_t)Npad * 8) * 3;                    // dinv, dvec, tmp
     b += al256(64 + 8 * nblk);                           // info (16 ints) + a `ready` and a `stage` counter per 128-block (fused panel launches)
     return b;
 }
@@ -164,8 +163,6 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     ws->dinv = (double *)p;  p += al256((size_t)Npad * 8);
     ws->dvec = (double *)p;  p += al256((size_t)Npad * 8);
     ws->tmp = (double *)p;   p += al256((size_t)Npad * 8);
-    ws->ybuf = (double *)p;  p += al256((size_t)Npad * 8);
-    ws->sweep_ctr = (unsigned *)p; p += al256(4 * 2 * (2 + 2 * nblk + (size_t)Npad / 8));
     ws->info = (int *)p;     p += al256(64 + 8 * nblk);
     ws->prof = nullptr;
     ws->signs = PivotSigns{-1, 0, 0};
@@ -372,17 +369,15 @@ __global__ __launch_bounds__(256) void k_scale_vec(int n, const double *x, const
     if (i < n) y[i] = x[i] * d[i];
 }
 
-int cip_ldlt_solve_sweeps(hipStream_t s, const double *K, int Npad, long ld, const LdltWorkspace &ws, double *rhs);   // solve.hip
-// CIP_SOLVE=sweeps: one persistent kernel per sweep with flag hand-offs between workgroups (solve.hip).  Measured at
-// N = 8192: solve4x4 0.51 ms (0.56 with every wave polling) against 0.27 ms for the block-step form below; at N = 2048
-// 0.128 against 0.077 ms.  A block step costs two hand-offs on the critical path (partial sums in, block result out: poll,
-// coherent load of the vector, reduction, coherent store, flag) -- ~12 us per block, no cheaper than the two ~7.5 us
-// launches they replace, and the HBM stream beside them runs less efficiently than in the plain gemv.  Kept for experiments.
-static int g_solve_steps = -1;
-
+// Two launches per block step (the diagonal block's product, then the update of everything below / above it): 4 N / Bs - 1
+// dependent launches per solve, ~4 us of dependency latency each -- at N = 8192 the sweeps move their 0.67 GB in 31 launches
+// and 0.27 ms, 30 % of the HBM peak, and it is the launch chain, not the traffic, that is the bound.  Both attempts to put
+// the chain INSIDE a launch lost against it: round 2's one persistent kernel per sweep (per-workgroup flags and tickets:
+// 0.51 ms per solve4x4), and round 3's one launch per block step (the Bs / 4 workgroups that own the next diagonal
+// block's inputs wait for each other on a counter and compute its product while the rest of the grid streams the update:
+// bit-identical, 17 launches instead of 31 -- and 0.36 ms: the fan-in of 256 workgroups plus the coherent reload under a
+// streaming load costs ~11 us per step, more than the launch it replaces, as MI355X_MICROARCH.md's price list says).
 int cip_ldlt_solve(hipStream_t s, const double *K, int Npad, long ld, const LdltWorkspace &ws, double *rhs) {
-    if (g_solve_steps < 0) { const char *e = getenv("CIP_SOLVE"); g_solve_steps = (e && !strcmp(e, "sweeps")) ? 0 : 1; }
-    if (!g_solve_steps && !cip_tl_builder && !cip_in_batch()) return cip_ldlt_solve_sweeps(s, K, Npad, ld, ws, rhs);
     const int Bs = ws.Bs;
     const int nbk = Npad / Bs;
     const double *X = (Bs == CIP_NB) ? ws.Linv : ws.X;

@@ -286,3 +286,84 @@ int cip_copy(hipStream_t s, long len, const double *x, double *y) {
     if (!cip_in_batch() && !cip_tl_builder) { CIP_HIP_CHECK(hipMemcpyAsync(y, x, sizeof(double) * len, hipMemcpyDeviceToDevice, s)); return 0; }
     return cip_axpby(s, (int)len, 1.0, x, 0.0, y);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// solve4x4 around the triangular sweeps when EVERY cone is an R cone (F = diag(f): configs 1, 2 and 5) on the Schur route:
+// the eight element-wise launches in front of the sweeps (cone division, F', two axpby, F^-T, F^-1, the copy of x, A't for
+// a CSR A) become ONE, the nine behind them (copies, A a, F^-T, F^-1, two axpby, F, F', axpby) ONE -- each small launch is
+// ~3 us of dependency latency in a 0.27-ms call.  Every element goes through the same operations in the same order as in
+// the separate kernels (cones.hip: k_cone_div / k_apply, k_axpby, k_spmv_csr; src/ConicIP.jl:684-692 and
+// src/kktsolvers.jl:324-330): bit-identical results (tests/test_gpu_kernels.py::test_solve4x4_fused_r_path_bitwise).
+//   pre:   q = r.s / lambda ; t1 = f q ; z = t1 + r.v ; t = (z / f) / f ;  rhs = [r.y + A't ; r.w ; 0]
+//   post:  a = rhs ; u = A a ; c = t - (u / f) / f ; dv = c ; ds = t1 - f (f c)
+#pragma clang fp contract(off)
+// No contraction in these three functions (the pragma holds to the end of the file): the separate kernels round every product before the next kernel adds to it
+// (explicit fma() where k_spmv_csr's accumulation is a fused multiply-add).
+__device__ __forceinline__ double s4_t_of(const double *rs, const double *lam, const double *f, const double *rv, int j) {
+    const double fj = f[j];
+    const double t1 = (rs[j] / lam[j]) * fj;
+    return ((t1 + rv[j]) / fj) / fj;
+}
+__global__ __launch_bounds__(256) void k_s4_pre_r(int m, int n, int p, int Npad, const double *f, const double *rs, const double *lam,
+                                                   const double *rv, const double *ry, const double *rw, double *t1_out, double *t_out,
+                                                   double *rhs, const int *T_rp, const int *T_ci, const double *T_v, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO8(cb, f, rs, lam, rv, ry, rw, t1_out, t_out);
+    CIP_BO4(cb, rhs, T_rp, T_ci, T_v);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < m) {
+        const double fi = f[i];
+        const double t1 = (rs[i] / lam[i]) * fi;
+        t1_out[i] = t1;
+        t_out[i] = ((t1 + rv[i]) / fi) / fi;
+    }
+    if (i < Npad) {
+        double r = 0.0;
+        if (i < n) {
+            r = ry[i];
+            if (T_rp) {                                            // CSR of A': row i of A' . t, t recomputed per entry (same operations)
+                double s = 0;
+                for (int q = T_rp[i]; q < T_rp[i + 1]; ++q) s = fma(T_v[q], s4_t_of(rs, lam, f, rv, T_ci[q]), s);
+                r = s + r;
+            }
+        } else if (i < n + p) r = rw[i - n];
+        rhs[i] = r;
+    }
+}
+__global__ __launch_bounds__(256) void k_s4_post_r(int m, int n, int p, const double *f, const double *t, const double *rhs, const double *u_dense,
+                                                    const int *A_rp, const int *A_ci, const double *A_v, double *dy, double *dw, double *dv,
+                                                    double *ds, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO8(cb, f, t, rhs, u_dense, A_rp, A_ci, A_v, dy);
+    CIP_BO3(cb, dw, dv, ds);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dy[i] = rhs[i];
+    if (i < p) dw[i] = rhs[n + i];
+    if (i < m) {
+        double u;
+        if (A_rp) {
+            double s = 0;
+            for (int q = A_rp[i]; q < A_rp[i + 1]; ++q) s = fma(A_v[q], rhs[A_ci[q]], s);
+            u = s + 0.0;                                     // k_spmv_csr's alpha s + (beta == 0 ? 0 : ..): -0 becomes +0 there too
+        } else u = u_dense[i];
+        const double fi = f[i];
+        const double c = (t[i] + 0.0) - (u / fi) / fi;       // c = t (axpby, beta = 0), then c -= (F'F)^-1 A a
+        dv[i] = c;
+        ds[i] = ds[i] - (c * fi) * fi;                             // ds = t1 - F'(F dv)
+    }
+}
+int cip_s4_pre_r(hipStream_t s, int m, int n, int p, int Npad, const double *f, const double *rs, const double *lam, const double *rv,
+                 const double *ry, const double *rw, double *t1_out, double *t_out, double *rhs, const int *T_rp, const int *T_ci, const double *T_v) {
+    const int len = m > Npad ? m : Npad;
+    cip_launch_b(k_s4_pre_r, dim3((len + 255) / 256), dim3(256), 0, s, m, n, p, Npad, f, rs, lam, rv, ry, rw, t1_out, t_out, rhs, T_rp, T_ci, T_v);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int cip_s4_post_r(hipStream_t s, int m, int n, int p, const double *f, const double *t, const double *rhs, const double *u_dense,
+                  const int *A_rp, const int *A_ci, const double *A_v, double *dy, double *dw, double *dv, double *ds) {
+    int len = m > n ? m : n;
+    if (p > len) len = p;
+    cip_launch_b(k_s4_post_r, dim3((len + 255) / 256), dim3(256), 0, s, m, n, p, f, t, rhs, u_dense, A_rp, A_ci, A_v, dy, dw, dv, ds);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}

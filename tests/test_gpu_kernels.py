@@ -365,6 +365,57 @@ def test_solve4x4_matches_oracle():
     ks.close()
 
 
+@pytest.mark.parametrize("sparse,n,m,p", [(True, 300, 300, 0), (True, 257, 400, 9), (False, 200, 330, 7), (True, 2048, 2048, 0)])
+def test_solve4x4_fused_r_path_bitwise(sparse, n, m, p):
+    """All cones R: cip_solve4x4 runs ONE element-wise kernel in front of the triangular sweeps and one behind them
+    (vecops.hip: k_s4_pre_r / k_s4_post_r) instead of 17 small launches.  Same operations on every element in the same
+    order (no contraction across what used to be kernel boundaries): the step must equal the unfused path's bit for bit
+    (CIP_S4_FUSED=0, read when a handle's first solve4x4 runs), and the oracle's to rounding."""
+    import os
+    import cipkkt
+    from oracle.block import Block, Diagonal
+    rng = np.random.default_rng(n + m + p)
+    M = rng.standard_normal((n, n))
+    Q = M.T @ M / n + 0.05 * np.eye(n)
+    if sparse:
+        import scipy.sparse as sp
+        A = sp.random(m, n, density=0.02, random_state=3, format="csr") + (sp.identity(n, format="csr") if m == n else
+                                                                              sp.vstack([sp.identity(n), sp.csr_matrix((m - n, n))]) if m > n else 0)
+        A = sp.csr_matrix(A)
+        Ad = A.toarray()
+    else:
+        A = rng.standard_normal((m, n)) / np.sqrt(n)
+        Ad = A
+    G = rng.standard_normal((p, n)) if p else None
+    K = [("R", m // 3), ("R", m - m // 3)]
+    v, sv = rng.random(m) + 0.05, rng.random(m) + 0.05
+    r = rng.standard_normal(n + p + 2 * m)
+    outs = []
+    for fused in ("0", "1"):
+        os.environ["CIP_S4_FUSED"] = fused
+        ks = cipkkt.KKTSystem(Q, A, G, K)
+        lam = torch.zeros(m, dtype=torch.float64, device="cuda")
+        ks.set_scaling_from_iterate(dev(v), dev(sv), lam)
+        ks.factor(check=True)
+        dz = torch.zeros(n + p + 2 * m, dtype=torch.float64, device="cuda")
+        ks.solve4x4_dev(lam, dev(r), dz)
+        torch.cuda.synchronize()
+        outs.append(dz.cpu().numpy())
+        ks.close()
+    os.environ.pop("CIP_S4_FUSED")
+    np.testing.assert_array_equal(outs[0], outs[1])
+    # and it is the reference's solve4x4 (src/ConicIP.jl:684-692)
+    f = np.sqrt(sv / v)
+    lamh = f * v
+    t1 = f * (r[n + p + m:] / lamh)
+    Gd = G if p else np.zeros((0, n))
+    Kmat = np.block([[Q, Gd.T, -Ad.T], [Gd, np.zeros((p, p)), np.zeros((p, m))], [Ad, np.zeros((m, p)), np.diag(f * f)]])
+    sol = np.linalg.solve(Kmat, np.concatenate([r[:n], r[n:n + p], r[n + p:n + p + m] + t1]))
+    dv = sol[n + p:]
+    ref = np.concatenate([sol[:n + p], dv, t1 - f * (f * dv)])
+    assert np.linalg.norm(outs[1] - ref) / np.linalg.norm(ref) < 1e-9
+
+
 def test_gemv_and_dots():
     from cipkkt import MAT_A, MAT_G, MAT_Q
     rng = np.random.default_rng(2)
