@@ -358,6 +358,37 @@ __device__ __forceinline__ void diag_step_c_multi(double *a, int kb, int idx, in
         for (int q = 0; q < 4; ++q) cp[t][4 * q * DP] = acc[t][q];
 }
 
+// Round 3: the helper waves' trailing tiles LEFT-LOOKING.  Tile (it, jt) receives ALL its steps 0 .. n-1 in one visit,
+//     C -= sum_s (L[it][s] D_s) L[jt][s]',    the accumulator in registers across the steps,
+// just before it is needed (column kb + 1 and the next diagonal tile during step kb), instead of one visit per step for
+// every tile of the trailing matrix.  Per tile the same MFMAs on the same operands in the same order as the step-by-step
+// form (a store and a reload of the accumulator between steps change nothing): the factor is bit-identical.  What changes
+// is WHEN the work is done: step by step the helpers had 27 / 20 / 14 / 9 / 5 / 2 tiles to visit in steps 0 .. 5 and the
+// serial wave waited for them at the first two or three (tools/diag_bench -DDIAG_TIMING: 8230 / 6750 / 5200 clocks per
+// micro-panel against 4900 once the helpers keep up); left-looking it is 7 / 6 / 5 / 4 / 3 / 2 tiles with 1 .. 6 steps each
+// (at most one C round trip per tile, the next step's operands fetched under the current step's MFMAs), well inside the
+// serial wave's 3900 clocks at every step.
+__device__ __forceinline__ void diag_tile_left(double *a, int it, int jt, int nsteps, int l15, int g) {
+    double *cp = a + (it * 16 + l15) + (jt * 16 + g) * DP;
+    const double *pj = a + (jt * 16 + l15) + g * DP, *pi = a + (it * 16 + l15) + g * DP, *pd = a + 128 + g * DP;
+    v4d acc = (v4d){cp[0], cp[4 * DP], cp[8 * DP], cp[12 * DP]};
+    double lj[4], li[4], dv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { lj[k] = pj[4 * k * DP]; li[k] = pi[4 * k * DP]; dv[k] = pd[4 * k * DP]; }
+    for (int s = 0; s < nsteps; ++s) {
+        double nj[4], ni[4], nd[4];
+        const int o = (s + 1 < nsteps ? 16 * (s + 1) : 16 * s) * DP;      // (the last step re-reads its own operands: no branch around the loads)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { nj[k] = pj[o + 4 * k * DP]; ni[k] = pi[o + 4 * k * DP]; nd[k] = pd[o + 4 * k * DP]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = MFMA(lj[k], -(li[k] * dv[k]), acc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { lj[k] = nj[k]; li[k] = ni[k]; dv[k] = nd[k]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cp[4 * q * DP] = acc[q];
+}
+
 // X block row `it` (runtime, wave-uniform): tiles kept in registers, statically indexed
 __device__ __forceinline__ void diag_inverse_row(double *a, const double *xm, int it, int l15, int g) {
     double XT[8][4];
@@ -518,7 +549,8 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
     //   B(kb)   all waves   : L tiles of the panel rows below (round-robin over the waves)
     //   barrier
     //   wave 0              : trailing update of the NEXT diagonal micro-block, then A(kb+1)      } overlapped
-    //   the helper waves    : all other trailing tiles of step kb (any tile, operands from LDS)   }
+    //   the helper waves    : write-back of micro-panel kb, then the tiles needed next, left-looking }
+    //                         (column kb+1 and tile (kb+2, kb+2), steps 0 .. kb at once: diag_tile_left)
     //   barrier
     if (wave == 0) diag_step_a(a, xm, 0, lane, info, col0, sg);
     __syncthreads();
@@ -544,6 +576,7 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
         __syncthreads();
         DIAG_STAMP(kb, 2, tid == 0);                                  // past the B barrier
         if (wave == 0) {
+            // (kb+1, kb+1): steps 0 .. kb-1 were applied by a helper during step kb-1, step kb is this wave's
             if (!(DIAG_SKIP & 4)) diag_step_c(a, kb + 1, kb + 1, c, l15, g, d4);
             diag_step_a(a, xm, kb + 1, lane, info, col0, sg);
             DIAG_STAMP(kb, 3, tid == 0);                              // C11 + A(kb+1) done
@@ -553,7 +586,17 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
             if (!(DIAG_SKIP & 16)) diag_store_panel<PUB>(a, Kb, ld, c, hid * 64 + lane, 64 * NH);
             if (PUB) diag_publish_micro(a, xm, xm_out, dvec, dinv, kb, hid * 64 + lane, 64 * NH);
             DIAG_STAMP(kb, 6, tid == 64);                             // helper: panel stores issued
-            // the tiles of rows kb+2.. ((kb+1, kb+1) is wave 0's), dealt round-robin to the helper waves, three at a time
+#ifndef DIAG_STEP_A_REF
+            // left-looking: the tiles that are needed NEXT -- column kb+1 below its diagonal tile (the panel of step kb+1) and
+            // the diagonal tile (kb+2, kb+2) (wave 0's C11 of step kb+1) -- receive all their steps 0 .. kb now
+            const int ncol = 6 - kb;
+            const int ntl = ncol + (kb + 2 <= 7 ? 1 : 0);
+            for (int t = hid; t < ntl; t += NH) {
+                const int it = t < ncol ? kb + 2 + t : kb + 2, jt = t < ncol ? kb + 1 : kb + 2;
+                diag_tile_left(a, it, jt, kb + 1, l15, g);
+            }
+#else
+            // round 2: step kb on every tile of rows kb+2.. ((kb+1, kb+1) is wave 0's), dealt round-robin to the helper waves, three at a time
             const int ntile = (6 - kb) * (9 - kb) / 2;
             for (int idx = hid; idx < ntile; idx += 3 * NH) {
                 const int left = (ntile - idx + NH - 1) / NH;      // tiles idx, idx + NH, idx + 2 NH that exist
@@ -561,6 +604,7 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
                 else if (left == 2) diag_step_c_multi<2>(a, kb, idx, NH, c, l15, g, d4);
                 else diag_step_c_multi<1>(a, kb, idx, NH, c, l15, g, d4);
             }
+#endif
             DIAG_STAMP(kb, 7, tid == 64);                             // helper: C tiles done
             if (PUB) {                                            // the wave's stores have landed -> its count
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
