@@ -729,56 +729,56 @@ __device__ __forceinline__ unsigned strip_wait(unsigned v, unsigned target, cons
     __syncthreads();
     return r;
 }
+// Round 3: RIGHT-looking inside the wave.  The wave keeps the eight 16-column blocks T_0 .. T_7 of its rows in registers; at
+// stage kb it finishes W[:,kb] = T_kb inv(L11[kb][kb])' (4 MFMAs) and applies it to ALL later blocks at once,
+// T_r -= W[:,kb] L11[r][kb]' for r > kb: 7 - kb independent chains of 4 MFMAs that pipeline.  Round 2 built T_{kb+1} when it
+// was needed, from all earlier W blocks: a chain of 4 (kb + 1) DEPENDENT MFMAs (~100 clocks each), 28 of them after the
+// diagonal kernel's last micro-panel -- the tail of every panel launch.  Per block the same MFMAs on the same operands in
+// the same order (qq ascending): bit-identical.
 __device__ __forceinline__ void trsm_strip_pipelined(const TrsmStrips &tr, int strip, const unsigned *stage, unsigned *slot, int *info) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const long row = (long)strip * 64 + wave * 16 + l15;
     double *ap = tr.Ap + row + (long)g * tr.ld;
     double *wp = tr.W + row + (long)g * tr.ldw;
-    double wneg[8][4];
+    v4d T[8];
     unsigned v = 0;
-    v4d acc;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = ap[(long)(4 * q) * tr.ld];
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) T[r][q] = ap[(long)(r * 16 + 4 * q) * tr.ld];
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
         v = strip_wait(v, (unsigned)PANEL_NH * (kb + 1), stage, slot, info);
-        // one batch of loads per stage: the micro inverse and 1/d of kb, row block kb + 1 of L11, the wave's own next columns
-        double xo[4], dv[4], lo[7][4], an[4];
-        if (kb < 7) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) an[q] = ap[(long)((kb + 1) * 16 + 4 * q) * tr.ld];
-        }
+        // one batch of loads per stage: the micro inverse and 1/d of kb and column block kb of L11 below its diagonal tile
+        double xo[4], dv[4], lo[7][4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             xo[s] = ld_pub(tr.xm + kb * 256 + (g + 4 * s) * 16 + l15);
             dv[s] = ld_pub(tr.dinv + kb * 16 + 4 * s + g);
         }
 #pragma unroll
-        for (int qq = 0; qq < 7; ++qq)
-            if (qq <= kb && kb < 7) {
+        for (int r = 1; r < 8; ++r)
+            if (r > kb) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) lo[qq][s] = ld_pub(tr.L11 + (kb + 1) * 16 + l15 + (long)(qq * 16 + 4 * s + g) * tr.ld);
+                for (int s = 0; s < 4; ++s) lo[r - 1][s] = ld_pub(tr.L11 + r * 16 + l15 + (long)(kb * 16 + 4 * s + g) * tr.ld);
             }
         v4d w = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) w = MFMA(xo[s], acc[s], w);
+        for (int s = 0; s < 4; ++s) w = MFMA(xo[s], T[kb][s], w);
+        double wneg[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long col = kb * 16 + 4 * q;
-            wneg[kb][q] = -w[q];
+            wneg[q] = -w[q];
             wp[col * tr.ldw] = w[q];
             ap[col * tr.ld] = w[q] * dv[q];
         }
-        if (kb < 7) {
-            acc = (v4d){an[0], an[1], an[2], an[3]};
 #pragma unroll
-            for (int qq = 0; qq < 7; ++qq)
-                if (qq <= kb) {
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) acc = MFMA(lo[qq][s], wneg[qq][s], acc);
-                }
-        }
+            for (int r = 1; r < 8; ++r)
+                if (r > kb) T[r] = MFMA(lo[r - 1][s], wneg[s], T[r]);
     }
 }
 // One 16x16 tile (it >= jt) of the diagonal block's update C -= W L' (K = 128) per WAVE, operands straight from L2 into
