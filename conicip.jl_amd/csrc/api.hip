@@ -72,7 +72,7 @@ static void free_all(cip_handle *h) {
     if (h->gx_factor) { (void)hipGraphExecDestroy(h->gx_factor); h->gx_factor = nullptr; }
     if (h->gx_solve) { (void)hipGraphExecDestroy(h->gx_solve); h->gx_solve = nullptr; }
     if (h->cs.lg) { cip_sdp_large_destroy(h->cs.lg); h->cs.lg = nullptr; }
-    void *ptrs[] = {h->cs.d_sidx_small, h->cs.d_sidx, h->cs.d_sdpws, h->cs.d_sdpvec, h->cs.d_sdpflag, h->Q, h->symv_ws, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->row_cone, h->G, h->Gt,
+    void *ptrs[] = {h->cs.d_sidx_small, h->cs.d_sidx, h->cs.d_sdpws, h->cs.d_sdpvec, h->cs.d_sdpflag, h->Q, h->symv_ws, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->kdiag, h->row_cone, h->G, h->Gt,
                     h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->cs.d_partial, h->cs.d_scalar, h->K, h->Wt, h->Gm,
                     h->ws_base, h->rhs, h->mt1, h->mt2, h->mt3, h->nt1, h->pt1, h->dot_scratch, h->dot_ptrs, h->stage, h->drv, h->ref, h->c2x2};
     for (void *p : ptrs)
@@ -158,6 +158,8 @@ static int upload_problem(cip_handle *h, const cip_problem *pr) {
     }
     for (int q = 0; q < nnz; ++q)
         if (ci[q] < 0 || ci[q] >= n) { cip_set_error("CSR column index out of range"); return CIP_E_INVALID; }
+    h->A_one_per_row = true;
+    for (int r = 0; r < m; ++r) if (rp[r + 1] - rp[r] > 1) { h->A_one_per_row = false; break; }
     trp.assign(n + 1, 0); tci.assign(nnz > 0 ? nnz : 1, 0);
     tv.assign(nnz > 0 ? nnz : 1, 0.0);
     for (int q = 0; q < nnz; ++q) trp[ci[q] + 1]++;
@@ -324,6 +326,7 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
         h->A_nnz = nnz;
         DMALLOC(h->A_rp, sizeof(int) * (m + 1)); DMALLOC(h->A_ci, sizeof(int) * nnz); DMALLOC(h->A_v, sizeof(double) * nnz);
         DMALLOC(h->T_rp, sizeof(int) * (n + 1)); DMALLOC(h->T_ci, sizeof(int) * nnz); DMALLOC(h->T_v, sizeof(double) * nnz);
+        DMALLOC(h->kdiag, sizeof(double) * (n > 0 ? n : 1));
         std::vector<int> &rc_ = h->st_rowcone;
         rc_.assign(m > 0 ? m : 1, 0);
         for (size_t c = 0; c < h->h_cones.size(); ++c)
@@ -509,7 +512,7 @@ static int graph_run(cip_handle *h, hipGraphExec_t *exec, F &&enqueue) {
 // assembly + LDL' + an asynchronous read-back of the pivot flag into pinned host memory; nothing here waits for the GPU
 static int factor_enqueue(cip_handle *h) {
     int rc;
-    { CipRange rg("cip:assemble"); if ((rc = cip_assemble(h))) return rc; }
+    { CipRange rg("cip:assemble"); if ((rc = cip_assemble(h, true))) return rc; }
     if (h->timing) CIP_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
     {
         CipRange rg("cip:ldlt");
@@ -980,6 +983,7 @@ extern "C" int cip_profile_thread_get(double *out3) {
     if (cip_ldlt_profile_thread_collect(&out3[0], &out3[1], &out3[2])) { cip_set_error("thread profiling not enabled"); return CIP_E_INVALID; }
     return 0;
 }
+extern "C" int cip_set_lazy_copy(int on) { return cip_lazy_copy_set(on); }
 extern "C" int cip_set_ldlt_fused_chain(int on) { return cip_ldlt_set_fused_chain(on); }
 extern "C" int cip_set_solve_block_max(int b) { return cip_solve_block_max_set(b); }
 extern "C" int cip_set_ldlt_outer_block(int nbo) { cip_ldlt_set_outer_block(nbo); return cip_ldlt_outer_block(); }

@@ -53,12 +53,12 @@ __global__ __launch_bounds__(256) void k_copy_block_lower(double *K, long ldk, i
 // per step, a thread's eight loads in flight before its first store (one column of 512 rows per workgroup -- the first
 // 16-byte version, 262144 workgroups at n = 8192 -- ran at 2.8 TB/s: 0.19 ms of a 6.1-ms step).
 #define COPY_COLS 8
-__global__ __launch_bounds__(256) void k_copy_block_lower_v(double *K, long ldk, int r0, const double *M, long ldm, int n, double sign, CipBatch cb) {
+__global__ __launch_bounds__(256) void k_copy_block_lower_v(double *K, long ldk, int r0, const double *M, long ldm, int n, double sign, int jmax, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO2(cb, K, M);
     const int i = 2 * (blockIdx.x * 256 + threadIdx.x);
     if (i >= n) return;
-    const int jend = min(n, (((r0 + i) >> 7) + 1) * 128 - r0);      // columns up to the end of this row pair's diagonal tile
+    const int jend = min(min(n, jmax), (((r0 + i) >> 7) + 1) * 128 - r0);      // columns up to the end of this row pair's diagonal tile (and < jmax)
     for (int j0 = blockIdx.y * COPY_COLS; j0 < jend; j0 += gridDim.y * COPY_COLS) {
         v2d v[COPY_COLS];
 #pragma unroll
@@ -69,10 +69,15 @@ __global__ __launch_bounds__(256) void k_copy_block_lower_v(double *K, long ldk,
             if (j0 + u < jend) *(v2d *)(K + (r0 + i) + (long)(r0 + j0 + u) * ldk) = sign * v[u];
     }
 }
-static void launch_copy_block_lower(hipStream_t s, double *K, long ldk, int r0, const double *M, long ldm, int n, double sign) {
-    if (!(n & 1) && !(r0 & 1) && !(ldk & 1) && !(ldm & 1) && !(((uintptr_t)K | (uintptr_t)M) & 15)) {
-        const int gy = (n + COPY_COLS - 1) / COPY_COLS;
-        cip_launch_b(k_copy_block_lower_v, dim3((n + 511) / 512, gy < 32768 ? gy : 32768), dim3(256), 0, s, K, ldk, r0, M, ldm, n, sign);
+static bool copy_lower_vectorisable(const double *K, long ldk, int r0, const double *M, long ldm, int n) {
+    return !(n & 1) && !(r0 & 1) && !(ldk & 1) && !(ldm & 1) && !(((uintptr_t)K | (uintptr_t)M) & 15);
+}
+// jmax < n: only the columns [0, jmax) (the lazy copy of the Schur route)
+static void launch_copy_block_lower(hipStream_t s, double *K, long ldk, int r0, const double *M, long ldm, int n, double sign, int jmax = 1 << 30) {
+    if (copy_lower_vectorisable(K, ldk, r0, M, ldm, n)) {
+        const int nc = n < jmax ? n : jmax;
+        const int gy = (nc + COPY_COLS - 1) / COPY_COLS;
+        cip_launch_b(k_copy_block_lower_v, dim3((n + 511) / 512, gy < 32768 ? gy : 32768), dim3(256), 0, s, K, ldk, r0, M, ldm, n, sign, jmax);
     } else {
         cip_launch_b(k_copy_block_lower, dim3((n + 255) / 256, n < 32768 ? n : 32768), dim3(256), 0, s, K, ldk, r0, M, ldm, n, sign);
     }
@@ -103,6 +108,28 @@ __global__ __launch_bounds__(256) void k_schur_rows(int n, const int *trp, const
             if (j <= i) K[(base + i) + (long)(base + j) * ldk] += wa * av[b];
         }
     }
+}
+// The same for an A with at most one entry per row and R cones only -- the Schur terms are then on the diagonal -- when the
+// copy of Q is lazy: rows below `nb0` deliver K_ii = Q_ii + sum_r w_r a_ri^2 (the same fused multiply-adds in the same order
+// on the same start value as k_schur_rows on the copied Q_ii) into kdiag[i] instead of K
+__global__ __launch_bounds__(256) void k_schur_diag_lazy(int n, int nb0, const int *trp, const int *tci, const double *tv, const int *rp,
+                                                          const int *ci, const double *av, const int *row_cone, const ConeDesc *cones,
+                                                          const double *scal, const double *Q, long ldq, double *K, long ldk, double *kdiag,
+                                                          CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO8(cb, trp, tci, tv, rp, ci, av, scal, Q);
+    CIP_BO2(cb, K, kdiag);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double d = i < nb0 ? K[i + (long)i * ldk] : Q[i + (long)i * ldq];
+    for (int q = trp[i]; q < trp[i + 1]; ++q) {
+        const int r = tci[q];
+        const double wa = schur_row_weight(cones[row_cone[r]], scal, r) * tv[q];
+        for (int b = rp[r]; b < rp[r + 1]; ++b)
+            if (ci[b] == i) d += wa * av[b];
+    }
+    if (i < nb0) K[i + (long)i * ldk] = d;
+    else kdiag[i] = d;
 }
 // Gm[i, qidx] = sum over the rows r of Q cone qidx of (sqrt2/beta) (J wbar)_r A[r, i]: same ownership (thread i, column i of
 // A in ascending r; the rows of one cone are consecutive)
@@ -184,10 +211,25 @@ __global__ __launch_bounds__(256) void k_pad_identity(double *K, long ldk, int N
     if (i < Npad) K[i + (long)i * ldk] = 1.0;
 }
 
-static int assemble_schur(cip_handle *h) {
+// lazy_ok (the caller runs cip_ldlt_factor on the result right away): with a CSR A that has one entry per row, R cones only,
+// no equality block and no padding, K = Q + diag(..) -- and 3/4 (order 2048) to 9/10 (order 8192) of the copy of Q into K
+// is overwritten by the FIRST trailing update without anybody else having looked at it.  Then only the first outer block's
+// columns are copied; the first trailing update takes its C operand from Q itself with the Schur diagonal from h->kdiag
+// (EPI_LAZYC) and writes K.  Every entry of K goes through the same operations as with the full copy (bit-identical
+// factor): 115 -> 25 us per factorisation at n = 8192, 7 of the 86 ms of a config-5 pass.
+int cip_ldlt_outer_block_for(int Npad);
+static int g_lazy_copy = -1;              // CIP_LAZY_COPY / cip_set_lazy_copy: 1 (default) on, 0 off
+int cip_lazy_copy_set(int on) {
+    if (g_lazy_copy < 0) { const char *e = getenv("CIP_LAZY_COPY"); g_lazy_copy = e ? (atoi(e) != 0) : 1; }
+    const int prev = g_lazy_copy;
+    if (on == 0 || on == 1) g_lazy_copy = on;
+    return prev;
+}
+static int assemble_schur(cip_handle *h, bool lazy_ok) {
     hipStream_t s = h->stream;
     int rc;
     const int n = h->n, p = h->p;
+    h->ws.lazyC = nullptr;
     if (!h->A_sparse) {
         if ((rc = cip_cones_scale_At(s, h->cs, n, h->At, h->npad, h->Wt, h->npad))) return rc;
         GemmArgs g = {};
@@ -196,6 +238,18 @@ static int assemble_schur(cip_handle *h) {
         g.alpha = 1.0; g.lower = 1; g.Qin = h->Q; g.ldq = n; g.nvalid = n;
         if ((rc = cip_launch_gemm(s, EPI_SYRKQ, g))) return rc;
     } else {
+        const int lazy_on = g_lazy_copy < 0 ? cip_lazy_copy_set(-1) : g_lazy_copy;
+        bool all_r = h->m > 0 && h->nq == 0 && !h->cs.has_S;
+        const int nb0 = cip_ldlt_outer_block_for(h->Npad);
+        if (lazy_on && lazy_ok && all_r && h->A_one_per_row && p == 0 && h->Npad == n && n > nb0 && h->reg_rel <= 0.0 && h->kdiag &&
+            copy_lower_vectorisable(h->K, h->ldk, 0, h->Q, (long)n, n)) {
+            launch_copy_block_lower(s, h->K, h->ldk, 0, h->Q, (long)n, n, 1.0, nb0);
+            cip_launch_b(k_schur_diag_lazy, dim3((n + 255) / 256), dim3(256), 0, s, n, nb0, h->T_rp, h->T_ci, h->T_v, h->A_rp, h->A_ci, h->A_v,
+                         h->row_cone, h->cs.d_cones, h->cs.d_scal, h->Q, (long)n, h->K, h->ldk, h->kdiag);
+            CIP_HIP_CHECK(hipGetLastError());
+            h->ws.lazyC = h->Q; h->ws.lazy_ld = n; h->ws.lazy_diag = h->kdiag;
+            return 0;
+        }
         if (n > 0) {
             launch_copy_block_lower(s, h->K, h->ldk, 0, h->Q, (long)n, n, 1.0);
         }
@@ -284,8 +338,9 @@ __global__ __launch_bounds__(256) void k_regularize_rows(double *K, long ldk, in
     }
 }
 
-int cip_assemble(cip_handle *h) {
-    int rc = (h->route == CIP_ROUTE_SCHUR) ? assemble_schur(h) : assemble_full(h);
+int cip_assemble(cip_handle *h, bool lazy_ok) {
+    h->ws.lazyC = nullptr;
+    int rc = (h->route == CIP_ROUTE_SCHUR) ? assemble_schur(h, lazy_ok) : assemble_full(h);
     if (rc == 0 && h->reg_rel > 0.0) {
         // (the diagonal is modified only after every row / column maximum has been read: the second kernel reads
         //  column i strictly below the diagonal, the first one has finished before it starts)

@@ -15,6 +15,7 @@ __device__ __forceinline__ unsigned gemm_batch_prologue(GemmArgs &g, const CipBa
     g.C = (double *)((char *)g.C + off);
     if (g.Ct) g.Ct = (double *)((char *)g.Ct + off);
     if (g.Qin) g.Qin = (const double *)((const char *)g.Qin + off);
+    if (g.Cdiag) g.Cdiag = (const double *)((const char *)g.Cdiag + off);
     return blockIdx.z - pz * gz;
 }
 // the launch's own (grid.y, grid.z) batching: pointer strides in doubles
@@ -114,6 +115,12 @@ __device__ __forceinline__ void gemm_tile_64(const GemmArgs &g, double *lds, lon
             const v2d val = (v2d){acc[0][tj][q], acc[1][tj][q]};
             if (EPI == EPI_ACCUM) {
                 v2d c = *(v2d *)cp;
+                c += g.alpha * val;
+                *(v2d *)cp = c;
+            } else if (EPI == EPI_LAZYC) {    // the C operand comes from Qin (+ Cdiag on the diagonal): what a copy into C would have put there
+                v2d c = *(const v2d *)(g.Qin + row + col * g.ldq);
+                if (row == col) c.x = g.Cdiag[row];
+                if (row + 1 == col) c.y = g.Cdiag[col];
                 c += g.alpha * val;
                 *(v2d *)cp = c;
             } else if (EPI == EPI_STORE) {    // C = alpha acc, optionally also stored transposed

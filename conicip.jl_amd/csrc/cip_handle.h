@@ -21,6 +21,8 @@ struct cip_handle {
     double *Q = nullptr;            // n x n, ld n
     double *symv_ws = nullptr;      // partial-sum tables of the symmetric mat-vec (n a multiple of 128, n >= 2048), else null
     bool A_sparse = false;
+    bool A_one_per_row = false;     // CSR A with at most one entry per row (A = I, bound constraints): A'(F'F)^-1 A is diagonal for R cones
+    double *kdiag = nullptr;        // n doubles: the Schur route's diagonal of K beyond the first outer block when the copy of Q is lazy
     int all_r = -1;                 // every cone is an R cone (F diagonal): solve4x4 takes the fused element-wise path; -1: not looked at yet
     double *A = nullptr;            // m x n, ld m            (dense A only)
     double *At = nullptr;           // npad x mpad, ld npad   (dense A only; zero padded)  At[i + r*npad] = A[r,i]
@@ -86,7 +88,8 @@ struct cip_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
 };
 
-int cip_assemble(cip_handle *h);     // assemble.hip
+int cip_lazy_copy_set(int on);       // assemble.hip
+int cip_assemble(cip_handle *h, bool lazy_ok = false);     // assemble.hip; lazy_ok: the caller factors right away (see assemble_schur)
 int cip_handle_alloc(cip_handle *h, void **out, size_t bytes);      // api.hip
 int cip_create_in_arena(const struct cip_problem *pr, char *slab, size_t cap, hipStream_t stream, cip_handle **out);   // api.hip
 size_t cip_driver_bytes(const cip_handle *h);                        // driver.hip: vectors of the interior-point loop

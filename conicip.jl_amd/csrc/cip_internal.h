@@ -84,7 +84,7 @@ inline void cip_launch_b(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t
 }
 
 // ---------------------------------------------------------------- GEMM (gemm_f64.hip)
-enum { EPI_ACCUM = 0, EPI_SYRKQ = 2, EPI_STORE = 3 };
+enum { EPI_ACCUM = 0, EPI_SYRKQ = 2, EPI_STORE = 3, EPI_LAZYC = 4 };     // EPI_LAZYC: C = Cin + alpha acc with Cin = Qin (ldq), Cdiag[i] on its diagonal
 
 struct GemmArgs {
     const double *A; long lda;   // M x K, element (i,k) at A[i + k*lda]
@@ -100,6 +100,7 @@ struct GemmArgs {
     long sAy, sAz, sBy, sBz, sCy, sCz;
     int overwrite;               // EPI_ACCUM: C = alpha*acc instead of C += alpha*acc
     double *Ct; long ldct, sCty, sCtz;   // 128-tile EPI_ACCUM only, optional: the result is also stored transposed, Ct[j + i*ldct]
+    const double *Cdiag;         // EPI_LAZYC: the diagonal of Cin
     int force64;                 // plain accumulate form: quarter tiles (k_gemm_nt_64) whatever the tile count
 };
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g);
@@ -133,6 +134,10 @@ struct LdltWorkspace {        // carved out of one device allocation
     int *info;                // device int: 0 ok, >0 = 1-based column of a bad pivot (zero, non-finite, or of the wrong sign)
     PivotSigns signs;
     LdltProfile *prof;        // host object or NULL
+    // lazy copy (assemble.hip: assemble_schur): K beyond the first outer block has NOT been filled; the first trailing update
+    // reads its C operand from lazyC (the problem's Q, column-major, leading dimension lazy_ld) with lazy_diag[i] on the
+    // diagonal, and writes K.  Consumed (cleared) by the next cip_ldlt_factor.
+    const double *lazyC; long lazy_ld; const double *lazy_diag;
 };
 int cip_kernels_init(void);                // diag.hip: one-time kernel attributes (before any hipGraph capture)
 int cip_ldlt_set_fused_chain(int on);     // 1 (default): diag + previous in-block update in one launch; returns the previous setting

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_64(GemmArgs g, CipBatch cb) 
 // profiles separate it from the skinny in-block updates): block b -> 128-tile b/4, quadrant b%4.
 // 5 workgroups (20 waves) per CU; measured against the 128x128-tile kernel at 2 workgroups per CU:
 // 55.0 vs 52.4 TFLOP/s at r = 8192, K = 512 and 53.1 vs 44.0 at K = 256 (tools/gemm_bench.hip, same session).
+template <int EPI>
 __global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64(GemmArgs g, CipBatch cb) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
     bool live;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256, 4) void k_ldlt_trailing_64(GemmArgs g, CipBatc
     tile_coords((int)(blockIdx.x >> 2), 1, g.M / CIP_NB, bi, bj);
     const int sub = blockIdx.x & 3;
     if (bi == bj && sub == 2) return;            // strictly-upper quadrant of a diagonal tile: never referenced
-    gemm_tile_64<EPI_ACCUM, true>(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB);
+    gemm_tile_64<EPI, true>(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB);
 }
 
 // Batched small products (block-inverse doubling): grid.y x grid.z independent problems, C = alpha A B' (overwrite)
@@ -260,6 +261,12 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     }
     // CIP_GEMM_TILE=128: the lower-triangular update on the 128x128 kernel (kept for A/B runs of tools/gemm_bench.hip)
     static const int g_tile = [] { const char *e = getenv("CIP_GEMM_TILE"); return (e && atoi(e) == 128) ? 128 : 64; }();
+    if (epi == EPI_LAZYC) {
+        if (!g.lower || !g.Qin || !g.Cdiag || (g.ldq & 1) || (((uintptr_t)g.Qin) & 15)) { cip_set_error("gemm: bad lazy-C arguments"); return -1; }
+        cip_launch_b(k_ldlt_trailing_64<EPI_LAZYC>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
+        CIP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (epi == EPI_ACCUM && g.lower && g_tile == 64) {
         // the LDL' trailing update: every 128-tile of the lower triangle as four 64x64 quarter tiles
         // Optional XCD-aware patch order (CIP_TRAIL_PATCH=4 or 8).  PMC at r = 8192, K = 512: 1.52 GB of L2-miss
@@ -275,7 +282,7 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
             CIP_HIP_CHECK(hipGetLastError());
             return 0;
         }
-        cip_launch_b(k_ldlt_trailing_64, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
+        cip_launch_b(k_ldlt_trailing_64<EPI_ACCUM>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }

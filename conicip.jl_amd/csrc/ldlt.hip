@@ -165,6 +165,7 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     ws->tmp = (double *)p;   p += al256((size_t)Npad * 8);
     ws->info = (int *)p;     p += al256(64 + 8 * nblk);
     ws->prof = nullptr;
+    ws->lazyC = nullptr; ws->lazy_ld = 0; ws->lazy_diag = nullptr;
     ws->signs = PivotSigns{-1, 0, 0};
     ws->x_zeroed = nullptr;
 }
@@ -346,6 +347,11 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
             g.B = K + r0 + (long)C0 * ld; g.ldb = ld;
             g.C = K + r0 + (long)r0 * ld; g.ldc = ld;
             g.M = Npad - r0; g.N = Npad - r0; g.K = wblk; g.alpha = -1.0; g.lower = 1;
+            int epi = EPI_ACCUM;
+            if (C0 == 0 && ws.lazyC) {                    // the trailing matrix is still in Q: read it from there, write K
+                epi = EPI_LAZYC;
+                g.Qin = ws.lazyC + r0 + (long)r0 * ws.lazy_ld; g.ldq = ws.lazy_ld; g.Cdiag = ws.lazy_diag + r0;
+            }
             LdltProfile *prof = ws.prof ? ws.prof : (cip_tl_builder ? nullptr : g_tl_prof);
             if (prof) {
                 if ((rc = prof_event(prof, s))) return rc;
@@ -353,7 +359,7 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
                 const double live = cip_in_batch() ? (double)__builtin_popcountll(cip_tl_bz.mask) : 1.0;
                 prof->flops.push_back(live * r * (r + 1.0) * (double)wblk);   // 2 flop/MAC on the lower triangle
             }
-            if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
+            if ((rc = cip_launch_gemm(s, epi, g))) return rc;
             if (prof && (rc = prof_event(prof, s))) return rc;
         }
     }

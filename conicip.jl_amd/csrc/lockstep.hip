@@ -232,7 +232,7 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
     auto factor = [&]() -> int {
         int e2;
         h->reg_rel = 0.0;
-        if ((e2 = cip_assemble(h))) return e2;
+        if ((e2 = cip_assemble(h, true))) return e2;
         if ((e2 = cip_ldlt_factor(s, h->K, h->Npad, h->ldk, h->ws))) return e2;
         h->factored = true; h->info_pending = false;
         for (int z = 0; z < B; ++z) if ((cip_tl_bz.mask >> z) & 1ull) ++n_factor[z];

@@ -246,6 +246,10 @@ int cip_set_solve_block_max(int b);
  * micro-panel through a stage counter; 1 = diagonal kernel + previous panel's update in one launch, TRSM in its own;
  * 0 = three launches per panel.  Same factor bit for bit.  Process-wide; returns the previous setting (other values: query). */
 int cip_set_ldlt_fused_chain(int on);
+/* Schur route, CSR A with one entry per row, R cones, no equalities, order a multiple of 128 (the box-QP family): cip_factor
+ * copies only the first outer block's columns of Q into K; the first trailing update of the LDL' reads the rest from Q
+ * itself (also CIP_LAZY_COPY=0).  Same factor bit for bit.  1 (default) on, 0 off; returns the previous setting. */
+int cip_set_lazy_copy(int on);
 /* HIP-event timing of every LDL' trailing-update launch (bench.py roofline): enable, then read
  * out3 = [launches, total ms, total algorithmic flops (r(r+1)K per launch)] */
 int cip_profile_trailing(cip_handle *h, int enabled);

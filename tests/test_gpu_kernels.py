@@ -416,6 +416,39 @@ def test_solve4x4_fused_r_path_bitwise(sparse, n, m, p):
     assert np.linalg.norm(outs[1] - ref) / np.linalg.norm(ref) < 1e-9
 
 
+@pytest.mark.parametrize("n", [1024, 2048, 4096])
+def test_lazy_copy_of_Q_gives_the_same_factor_and_step(n):
+    """Box-QP family (A = I as CSR, R cones, p = 0, n a multiple of 128): cip_factor copies only the first outer block's columns
+    of Q into K and the first trailing update reads the rest of its C operand from Q (assemble.hip / EPI_LAZYC).  The factor
+    and a solve4x4 step must equal the eager copy's bit for bit."""
+    import cipkkt
+    from cipkkt import workloads as W
+    Q, c, A, b, K = W.c2_problem(n, seed=77, device="cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(n)
+    v = torch.rand(n, generator=g, dtype=torch.float64, device="cuda") + 0.05
+    s = torch.rand(n, generator=g, dtype=torch.float64, device="cuda") + 0.05
+    r = torch.randn(3 * n, generator=g, dtype=torch.float64, device="cuda")
+    outs, mats = [], []
+    for lazy in (0, 1):
+        ks = cipkkt.KKTSystem(Q, A, None, K)
+        prev = ks.lib.cip_set_lazy_copy(lazy)
+        try:
+            lam = torch.zeros(n, dtype=torch.float64, device="cuda")
+            ks.set_scaling_from_iterate(v, s, lam)
+            ks.factor(check=True)
+            dz = torch.zeros(3 * n, dtype=torch.float64, device="cuda")
+            ks.solve4x4_dev(lam, r, dz)
+            torch.cuda.synchronize()
+            outs.append(dz.cpu().numpy())
+            mats.append(np.tril(ks.kkt_matrix()))
+        finally:
+            ks.lib.cip_set_lazy_copy(prev)
+            ks.close()
+    np.testing.assert_array_equal(mats[0], mats[1])
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
 def test_gemv_and_dots():
     from cipkkt import MAT_A, MAT_G, MAT_Q
     rng = np.random.default_rng(2)
