@@ -12,6 +12,12 @@ import numpy as np
 import torch
 
 
+def release_cached_memory():
+    """Give back the device arena the library keeps between lock-step batches (cip_release_cached_memory)."""
+    from . import _lib as L
+    L.check(L.load().cip_release_cached_memory())
+
+
 def shard_indices(n_problems, rank, world):
     """Static round-robin assignment: problem i -> rank i % world."""
     return list(range(rank, n_problems, world))
@@ -234,6 +240,8 @@ def run_config5(rank, world, dist, device, steps, warmup, problems=None, count=6
     sync(); barrier(); sync()
     elapsed = time.perf_counter() - t0
     _, stats = one_pass(True)                          # untimed: the reduced statistics of one pass
+    if solve_fn is None:
+        release_cached_memory()                        # the lock-step arena (GBs) is not kept beyond the job
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

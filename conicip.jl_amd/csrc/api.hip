@@ -56,7 +56,14 @@ int cip_handle_alloc(cip_handle *h, void **out, size_t bytes) {
         if (h->arena_used + b <= h->arena_cap) { *out = h->arena + h->arena_used; h->arena_used += b; return 0; }
         h->arena_overflow = true;                  // falls back to its own allocation: the slab layout is broken
     }
-    CIP_HIP_CHECK(hipMalloc(out, bytes));
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) {
+        // the lock-step arena of an earlier batch (several GB, kept for the next one) may be what is in the way: give it back, once
+        (void)hipGetLastError();
+        (void)cip_release_cached_memory();
+        e = hipMalloc(out, bytes);
+    }
+    CIP_HIP_CHECK(e);
     return 0;
 }
 #define DMALLOC(ptr, bytes)                                                        \

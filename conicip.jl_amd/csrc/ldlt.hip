@@ -111,12 +111,12 @@ static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // thread's override (lock-step batches create their handles with 256: in a batch a block step is one launch for all
 // problems, so launches are cheap and the doubled inverses -- 1.5 GFLOP per n = 2048 factorisation on top of its 2.9 --
 // and the half-empty 1024-wide triangular blocks the solves stream are what cost).
-static int g_solve_block_max = -1;
+static std::atomic<int> g_solve_block_max{-1};
 thread_local int cip_tl_solve_block_max = 0;
 int cip_solve_block_max_set(int b) {
-    if (g_solve_block_max < 0) { const char *e = getenv("CIP_SOLVE_BLOCK"); g_solve_block_max = e ? atoi(e) : 1024; }
-    const int prev = g_solve_block_max;
-    if (b == 128 || b == 256 || b == 512 || b == 1024) g_solve_block_max = b;
+    if (g_solve_block_max.load() < 0) { const char *e = getenv("CIP_SOLVE_BLOCK"); int v = -1; g_solve_block_max.compare_exchange_strong(v, e ? atoi(e) : 1024); }
+    const int prev = g_solve_block_max.load();
+    if (b == 128 || b == 256 || b == 512 || b == 1024) g_solve_block_max.store(b);
     return prev;
 }
 int cip_solve_block(int Npad) {
@@ -224,8 +224,15 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
         // the launch takes one round -- 4 / 8 / 12 problems of order 2048: 18.7 -> 16.4, 23.3 -> 21.0, 27.9 -> 27.0 ms per pass;
         // 16 problems run in two rounds and lose against their three batched launches (31.6 -> 32.9)
         static const int lsmax = [] { const char *e = getenv("CIP_LOCKSTEP_PANEL_MAX"); return e ? atoi(e) : 12; }();
-        static const int lscus = [] { const char *e = getenv("CIP_LOCKSTEP_PANEL_CUS"); return e ? atoi(e) : 400; }();
-        const bool small_group = cip_in_batch() && g_fuse_diag == 3 && cip_tl_bz.B <= lsmax && (long)cip_tl_bz.B * (1 + Npad / 64) <= lscus;
+        // every problem's diagonal kernel, producers and strips (one 160-KB workgroup per CU) must be resident at once: the
+        // limit is the device's CU count (CIP_LOCKSTEP_PANEL_CUS overrides)
+        static const int lscus = [] {
+            if (const char *e = getenv("CIP_LOCKSTEP_PANEL_CUS")) return atoi(e);
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            return cus;
+        }();
+        const bool small_group = cip_in_batch() && g_fuse_diag == 3 && cip_tl_bz.B <= lsmax && (long)cip_tl_bz.B * (10 + Npad / 64) <= lscus;
         const bool fuse = g_fuse_diag && (!cip_in_batch() || small_group);
         if (fuse && g_fuse_diag == 3) {
             const bool upd = t > 0 && rest_of_block_args(K, Npad, ld, Wb, C0, wblk, t - 1, gu);

@@ -65,15 +65,17 @@ struct ArenaCache {
     // last probe: shape signature -> slab bytes
     std::vector<long> sig; size_t slab = 0;
 } g_cache;
-int arena_acquire(size_t bytes, char **out) {
+// *cap: the allocation's true size (a recycled arena may be larger than asked for; it goes back into the cache with that size)
+int arena_acquire(size_t bytes, char **out, size_t *cap) {
     int dev = 0;
     CIP_HIP_CHECK(hipGetDevice(&dev));
     {
         std::lock_guard<std::mutex> lk(g_cache.mu);
-        if (g_cache.ptr && g_cache.device == dev && g_cache.bytes >= bytes) { *out = g_cache.ptr; g_cache.ptr = nullptr; return 0; }
+        if (g_cache.ptr && g_cache.device == dev && g_cache.bytes >= bytes) { *out = g_cache.ptr; *cap = g_cache.bytes; g_cache.ptr = nullptr; g_cache.bytes = 0; return 0; }
         if (g_cache.ptr) { (void)hipFree(g_cache.ptr); g_cache.ptr = nullptr; g_cache.bytes = 0; }
     }
     CIP_HIP_CHECK(hipMalloc((void **)out, bytes));
+    *cap = bytes;
     return 0;
 }
 void arena_release(char *ptr, size_t bytes) {
@@ -168,7 +170,7 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
     G.stride = gran * 256;
     const size_t gather_bytes = sizeof(double) * (size_t)B * CIP_GATHER;
     G.arena_bytes = G.stride * (size_t)B + gather_bytes;
-    if ((rc = arena_acquire(G.arena_bytes, &G.arena))) return rc;
+    if ((rc = arena_acquire(G.arena_bytes, &G.arena, &G.arena_bytes))) return rc;
     G.gather_dev = (double *)(G.arena + G.stride * (size_t)B);
     CIP_HIP_CHECK(hipHostMalloc((void **)&G.gather_host, gather_bytes, hipHostMallocDefault));
     G.h.assign(B, nullptr);

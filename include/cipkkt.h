@@ -206,7 +206,9 @@ int cip_conicip_problems(int count, const cip_problem *probs, const double *cons
                          double *const *v, cip_result *res, int in_flight);
 /* the same, in LOCK-STEP: the problems must have identical shape (n, m, p, cone list, route, dense-or-CSR A) and no S
  * cone of matrix order >= 133; they advance through the loop together, every step ONE launch with the problem index in the grid (groups of up
- * to 64).  Results are bit-identical to cip_conicip on each problem.  Returns CIP_E_UNSUPPORTED (nothing written) when
+ * to 64).  Results are bit-identical to cip_conicip on each problem run with the same solve block (lock-step handles use
+ * min(cip_set_solve_block_max, 256): a standalone handle of order >= 1024 sums its triangular solves in wider blocks unless
+ * cip_set_solve_block_max(256) is called first -- the difference is rounding).  Returns CIP_E_UNSUPPORTED (nothing written) when
  * the batch does not qualify -- fall back to cip_conicip_problems.  A problem whose factorisation meets a bad pivot leaves
  * the group and is solved by the one-problem loop afterwards. */
 int cip_conicip_lockstep(int count, const cip_problem *probs, const double *const *c, const double *const *bvec,
