@@ -209,7 +209,8 @@ __device__ __forceinline__ double lg_rsqrt(double x) {
 // the dot products and the rotation.  Ends after the first sweep whose largest rotation had cos^2 < 1e-16 (the next
 // sweep would find nothing above the 1e-30 threshold: quadratic convergence), or after a sweep without any rotation.
 // G_in V = U diag(sigma): column i ends as sigma_i u_i, all of svd(Lz' Ls) that nestod_sdc uses (src/ConicIP.jl:204-208).
-__global__ __launch_bounds__(LG_T) void k_lg_jacobi(double *G, int rp, int b, unsigned *ctr, int *err) {
+template <int NT>
+__global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsigned *ctr, int *err) {
     extern __shared__ double sh[];
     __shared__ int s_rot;
     __shared__ double s_nrm[32];
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(LG_T) void k_lg_jacobi(double *G, int rp, int b, un
     const int nbk = rp / b, m = nbk, nwg = nbk / 2;
     const int ld = lg_pitch(rp);
     const int nc = 2 * b;                                  // columns in LDS
-    const int tpp = LG_T / b;                              // lanes per column pair (32 or 64); rp == 8 * tpp
+    const int tpp = NT / b;                              // lanes per column pair (32 or 64); rp == 8 * tpp
     const int part = tid % tpp, pair = tid / tpp;
     unsigned phase = 0;
     unsigned *bar = ctr, *sweepflag = ctr + 8;
@@ -242,18 +243,32 @@ __global__ __launch_bounds__(LG_T) void k_lg_jacobi(double *G, int rp, int b, un
         }
         return (c * c > 1e-16 * (a * bb)) ? 2 : 1;
     };
+    // a block pair is 2 b rp = 16384 doubles whatever (b, rp): 16 per thread.  All 16 coherent loads of a thread are issued
+    // before the first LDS store (one at a time, store after load, each global round trip was exposed: 16 x ~1.5 us per
+    // outer round -- half of a sweep's time)
     auto load = [&](int bp, int bq) {                      // coherent loads: other workgroups wrote these blocks
-        for (int e = tid; e < nc * rp; e += LG_T) {
-            const int i = e % rp, c = e / rp;
-            sh[i + c * ld] = lg_ld(G + i + (long)(c < b ? bp * b + c : bq * b + (c - b)) * rp);
+        double t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + u * NT, i = e % rp, c = e / rp;
+            t[u] = lg_ld(G + i + (long)(c < b ? bp * b + c : bq * b + (c - b)) * rp);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + u * NT;
+            sh[e % rp + (e / rp) * ld] = t[u];
         }
         if (tid == 0) s_rot = 0;
         __syncthreads();
     };
     auto store = [&](int bp, int bq) {
-        for (int e = tid; e < nc * rp; e += LG_T) {
-            const int i = e % rp, c = e / rp;
-            lg_st(G + i + (long)(c < b ? bp * b + c : bq * b + (c - b)) * rp, sh[i + c * ld]);
+        double t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int e = tid + u * NT; t[u] = sh[e % rp + (e / rp) * ld]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + u * NT, i = e % rp, c = e / rp;
+            lg_st(G + i + (long)(c < b ? bp * b + c : bq * b + (c - b)) * rp, t[u]);
         }
     };
     for (int sweep = 0; sweep < 40; ++sweep) {
@@ -738,11 +753,25 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
     hipLaunchKernelGGL(k_lg_tfac, lg_grid(n2), dim3(256), 0, s, w->Ks, w->ws.dvec, w->Ts, rp);
     if ((rc = lg_gemm(s, w->G, 0, w->Tz, 0, w->Ts, 0, rp, 1))) return rc;           // G = Lz' Ls          (:204)
     {
-        const int b = rp <= 256 ? 32 : 16;
+        // column blocks of 16: rp / 32 workgroups (8 at order 256, 16 at 512), each with 2 b columns in LDS and rp / 8 lanes per
+        // column pair.  At order 256 the blocks were 32 wide in round 2 -- 4 workgroups of 1024 threads: a rotation round is bound
+        // by instruction issue on its CU (16 waves), so half the pairs per CU is nearly half the time per round, and twice the
+        // outer rounds (grid barrier + block exchange each) cost less than that buys (CIP_LG_JACOBI_B=32 restores it)
+        static const int bforce = [] { const char *e = getenv("CIP_LG_JACOBI_B"); return e ? atoi(e) : 0; }();
+        const int b = (rp <= 256 && (bforce == 32 || bforce == 8)) ? bforce : 16;
+        const int nt = b * (rp / 8);                               // 512 (order 256, b = 16), 256 (b = 8) or 1024
         const size_t shm = (size_t)2 * b * lg_pitch(rp) * sizeof(double);
-        if ((rc = lg_set_attr((const void *)k_lg_jacobi, shm))) return rc;
         CIP_HIP_CHECK(hipMemsetAsync(w->ctr, 0, 1024, s));
-        hipLaunchKernelGGL(k_lg_jacobi, dim3(rp / b / 2), dim3(LG_T), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
+        if (nt == 256) {
+            if ((rc = lg_set_attr((const void *)k_lg_jacobi<256>, shm))) return rc;
+            hipLaunchKernelGGL(k_lg_jacobi<256>, dim3(rp / b / 2), dim3(256), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
+        } else if (nt == 512) {
+            if ((rc = lg_set_attr((const void *)k_lg_jacobi<512>, shm))) return rc;
+            hipLaunchKernelGGL(k_lg_jacobi<512>, dim3(rp / b / 2), dim3(512), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
+        } else {
+            if ((rc = lg_set_attr((const void *)k_lg_jacobi<1024>, shm))) return rc;
+            hipLaunchKernelGGL(k_lg_jacobi<1024>, dim3(rp / b / 2), dim3(1024), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
+        }
     }
     if (getenv("CIP_LG_DEBUG")) {
         unsigned hc[64];
@@ -750,7 +779,7 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
         CIP_HIP_CHECK(hipStreamSynchronize(s));
         int sweeps = 0;
         for (int q = 8; q < 48; ++q) if (hc[q]) ++sweeps;
-        fprintf(stderr, "[lg] jacobi: %d sweeps with a rotation above cos^2 = 1e-16, %u barriers\n", sweeps, hc[0] / (unsigned)(rp / (rp <= 256 ? 32 : 16) / 2));
+        fprintf(stderr, "[lg] jacobi: %d sweeps with a rotation above cos^2 = 1e-16, %u barriers\n", sweeps, hc[0] / (unsigned)(rp / 16 / 2));
     }
     double *lam = w->vec;
     hipLaunchKernelGGL(k_lg_colnorm, dim3((rp + 3) / 4), dim3(256), 0, s, w->G, lam, rp);
