@@ -1,6 +1,7 @@
 """Same-session A/B of library builds on the headline step (n = 8192): assemble + factor time and KKT solves/s, each
 variant in its own process (CIPKKT_LIB), alternating, `rounds` times.
-usage: python tools/ab_factor.py name=path.so [name=path.so ...] [--rounds 3] [--n 8192]"""
+usage: python tools/ab_factor.py name=path.so|default|env:VAR=VALUE [...] [--rounds 3] [--n 8192]
+(env:VAR=VALUE runs the in-tree build with that environment variable set)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = [a for a in sys.argv[1:] if "=" in a]
@@ -11,7 +12,10 @@ for r in range(rounds):
     for a in args:
         name, path = a.split("=", 1)
         env = dict(os.environ)
-        if path != "default":
+        if path.startswith("env:"):
+            k, v = path[4:].split("=", 1)
+            env[k] = v
+        elif path != "default":
             env["CIPKKT_LIB"] = os.path.abspath(path)
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-c5", "--n", n, "--steps", "20", "--warmup", "3"],
                              capture_output=True, text=True, env=env)
