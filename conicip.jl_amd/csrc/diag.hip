@@ -32,6 +32,14 @@ __device__ long g_diag_t[8 * 8];                 // [kb][slot]: s_memtime stamps
 #else
 #define DIAG_STAMP(kb, slot, cond) do { } while (0)
 #endif
+#ifdef PANEL_TIMING
+// development (tools/panel_stamps.py): s_memrealtime (100 MHz, one clock for the chip) at the phases of a k_ldlt_panel<true> launch
+__device__ long g_panel_t[32];
+#define PANEL_STAMP(slot, cond) do { if (cond) g_panel_t[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int cip_debug_panel_stamps(long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_panel_t), sizeof(long) * 32); }
+#else
+#define PANEL_STAMP(slot, cond) do { } while (0)
+#endif
 #define XM_OFF (CIP_NB * DP)             // 8 x 256 doubles: xm[kb][k*16 + jj] = Xm_kb[jj][k]
 #define DIAG2_LDS_BYTES ((CIP_NB * DP + 8 * 256) * 8)
 
@@ -510,6 +518,7 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
     const bool idle = wave != 0 && (wave & 3) == 0;
     const int hid = wave - 1 - (wave >> 2);                    // helper index 0 .. NH - 1
     __builtin_amdgcn_s_setprio(3);
+    PANEL_STAMP(0, WAIT && PUB && tid == 0);
     if (WAIT) {
         if (tid == 0) {
             const long t0 = __builtin_amdgcn_s_memtime();
@@ -518,6 +527,7 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
                 if (__builtin_amdgcn_s_memtime() - t0 > 2000000000L) { atomicCAS(info + 3, 0, -9); break; }   // ~1 s of shader clock: never hang the GPU
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            PANEL_STAMP(4, PUB);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -552,8 +562,10 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
     //   the helper waves    : write-back of micro-panel kb, then the tiles needed next, left-looking }
     //                         (column kb+1 and tile (kb+2, kb+2), steps 0 .. kb at once: diag_tile_left)
     //   barrier
+    PANEL_STAMP(2, WAIT && PUB && tid == 0);                            // the block is in LDS
     if (wave == 0) diag_step_a(a, xm, 0, lane, info, col0, sg);
     __syncthreads();
+    PANEL_STAMP(6, WAIT && PUB && tid == 0);                            // A(0) done, B(0) starts
     for (int kb = 0; kb < 7; ++kb) {
         const int c = kb * 16;
         double xa[4], di4[4], d4[4];
@@ -613,12 +625,14 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
         }
         __syncthreads();
     }
+    PANEL_STAMP(7, WAIT && PUB && tid == 0);                            // last pivot done
     if (PUB) {
         diag_store_panel<true>(a, Kb, ld, 112, tid, 64 * NW);
         diag_publish_micro(a, xm, xm_out, dvec, dinv, 7, tid, 64 * NW);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) atomicAdd(stage, (unsigned)NH);
+        PANEL_STAMP(8, WAIT && tid == 0);
         return;
     }
 
@@ -814,6 +828,8 @@ __device__ __forceinline__ void diag_block_producer(const GemmArgs &g, int tile,
     for (int q = 0; q < 4; ++q) st_pub(cp + (long)(4 * q) * g.ldc, cpre[q] + g.alpha * acc[q]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) atomicAdd(ready, 1u);
+    PANEL_STAMP(10, lane == 0 && tile == 0);
+    PANEL_STAMP(11, lane == 0 && tile == 35);
 }
 #define PANEL_PRODUCERS 9               // 36 tiles, one per wave, four waves per workgroup: one wave per SIMD (two would share its MFMA pipe)
 template <bool UPD>
@@ -840,6 +856,7 @@ __global__ __launch_bounds__(64 * PANEL_WAVES) void k_ldlt_panel(double *Kb, lon
     __builtin_amdgcn_s_setprio(3);
     const int first = UPD ? 1 + PANEL_PRODUCERS : 1;
     if (UPD && b <= PANEL_PRODUCERS) {
+        PANEL_STAMP(9, threadIdx.x == 0 && b == 1);
         if (threadIdx.x < 256) diag_block_producer(g, (b - 1) * 4 + (int)(threadIdx.x >> 6), ready);
         return;
     }
@@ -853,13 +870,19 @@ __global__ __launch_bounds__(64 * PANEL_WAVES) void k_ldlt_panel(double *Kb, lon
             gemm_tile_64_k128<false>(g, sm, (long)(2 + strip) * SB, SB);
             __syncthreads();
         }
+        PANEL_STAMP(12, UPD && threadIdx.x == 0 && strip == 0);              // strip 0: its two update tiles done
         trsm_strip_pipelined(tr, strip, stage, (unsigned *)sm, info);
+        PANEL_STAMP(13, UPD && threadIdx.x == 0 && strip == 0);
+        PANEL_STAMP(14, UPD && threadIdx.x == 0 && strip == tr.strips - 1);
         return;
     }
     if (UPD) {
+        // column-major from tile column 2 on, the tiles on and below the diagonal only (C's first row is its first column's:
+        // tile (i, j) with i < j lies in the upper triangle, which nobody reads)
         const int tm = g.M / SB;
-        const int t = 2 * tm + (b - first - tr.strips);           // column-major, from tile column 2 on
-        gemm_tile_64_k128<false>(g, sm, (long)(t % tm) * SB, (long)(t / tm) * SB);
+        int t = b - first - tr.strips, j = 2;
+        while (t >= tm - j) { t -= tm - j; ++j; }
+        gemm_tile_64_k128<false>(g, sm, (long)(j + t) * SB, (long)j * SB);
     }
 }
 
@@ -1040,7 +1063,7 @@ int cip_launch_panel(hipStream_t s, double *Kb, long ld, double *xm_out, double 
     if (g) {
         const int tm = g->M / SB, tn = g->N / SB;
         if (tm != tr.strips + 2 || tn < 2) { cip_set_error("panel launch: update / TRSM shapes disagree"); return -1; }
-        const long grid = 1 + PANEL_PRODUCERS + tr.strips + (long)tm * (tn - 2);
+        const long grid = 1 + PANEL_PRODUCERS + tr.strips + ((long)tm * (tn - 2) - ((long)tn * (tn - 1) / 2 - 1));   // lower tiles of columns 2 .. tn-1
         cip_launch_b(k_ldlt_panel<true>, dim3((unsigned)grid), dim3(64 * PANEL_WAVES), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg,
                      ready, stage, *g, tr);
     } else {

@@ -44,11 +44,29 @@ int cip_ldlt_outer_block_for(int Npad) {
     fuse_env();
     return (Npad >= 4096 && g_fuse_diag) ? 768 : 512;    // not a function of the batch: lock-step groups reproduce the one-problem loop bit for bit
 }
+#define CIP_NBO_MAX 1024
+#define CIP_TAIL_MAX 4608               // widest last block (CIP_LDLT_TAIL is clamped to it): Wbuf has room for it from order 4096 on
+static size_t wbuf_cols(int Npad) { return Npad >= 4096 ? (Npad < CIP_TAIL_MAX ? Npad : CIP_TAIL_MAX) : CIP_NBO_MAX; }
+// The LAST outer block takes everything that is left once that is no more than CIP_LDLT_TAIL columns (round 3; automatic
+// widths only, orders from 4096 on).  At the bottom of the matrix a trailing update is a handful of tiles per CU behind a
+// K = 768 loop (r = 1280 and r = 512 at n = 8192: 36 us each, 6 TFLOP/s) while the panel launches leave most of the chip idle:
+// in a wide last block the same flops are in-block update tiles (K = 128, lower triangle only) that run BESIDE the diagonal
+// kernels.  Same-session A/B at n = 8192, tail 0 / 1280 / 2048 / 2816 / 3584 / 4352: 180.5 / 181.8 / 183.1 / 185.4 / 184.7 /
+// 182.5 KKT solves/s (beyond 2816 the block's first panel launches are bound by their ~900 tiles: 57 / 52 / 51 us).
+// A function of the order and the column only, like the width itself.
+static int ldlt_tail_cols(void) {
+    static const int v = [] { const char *e = getenv("CIP_LDLT_TAIL"); const int t = e ? atoi(e) : 2816; return t > CIP_TAIL_MAX ? CIP_TAIL_MAX : t; }();
+    return v;
+}
+static int outer_block_width(int Npad, int C0) {
+    const int NBO = cip_ldlt_outer_block_for(Npad), left = Npad - C0;
+    if (g_nbo == 0 && NBO == 768 && left <= ldlt_tail_cols()) return left;
+    return left < NBO ? left : NBO;
+}
 int cip_ldlt_outer_block(void) { return g_nbo; }
 void cip_ldlt_set_outer_block(int nbo) {
     if (nbo == 0 || (nbo >= CIP_NB && nbo % CIP_NB == 0 && nbo <= 1024)) g_nbo = nbo;
 }
-#define CIP_NBO_MAX 1024
 
 // ---- optional instrumentation: HIP events around every trailing-update launch (bench.py roofline)
 #include <vector>
@@ -130,7 +148,7 @@ int cip_solve_block(int Npad) {
 size_t cip_ldlt_ws_bytes(int Npad) {
     const size_t nblk = Npad / CIP_NB;
     size_t b = 0;
-    b += al256((size_t)Npad * CIP_NBO_MAX * 8);          // Wbuf
+    b += al256((size_t)Npad * wbuf_cols(Npad) * 8);       // Wbuf
     b += al256(nblk * CIP_NB * CIP_NB * 8) * 2;          // Linv, LinvT
     b += al256(nblk * 2048 * 8);                         // Xm
     {
@@ -148,7 +166,7 @@ size_t cip_ldlt_ws_bytes(int Npad) {
 void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     const size_t nblk = Npad / CIP_NB;
     char *p = (char *)base;
-    ws->Wbuf = (double *)p;  p += al256((size_t)Npad * CIP_NBO_MAX * 8);
+    ws->Wbuf = (double *)p;  p += al256((size_t)Npad * wbuf_cols(Npad) * 8);
     ws->Linv = (double *)p;  p += al256(nblk * CIP_NB * CIP_NB * 8);
     ws->LinvT = (double *)p; p += al256(nblk * CIP_NB * CIP_NB * 8);
     ws->Xm = (double *)p;    p += al256(nblk * 2048 * 8);
@@ -339,13 +357,12 @@ static int build_solve_blocks(hipStream_t s, double *K, int Npad, long ld, const
 
 int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws) {
     if (Npad % CIP_NB) { cip_set_error("ldlt: N must be a multiple of 128"); return -1; }
-    const int NBO = cip_ldlt_outer_block_for(Npad);
     int rc;
     // [0] bad pivot, [1] sweep bail-out, [2] dead pivot, [3] fused-launch wait timed out; from word 16: `ready` counters
     if ((rc = zero_fill(s, ws.info, 64 + 8 * (size_t)(Npad / CIP_NB)))) return rc;
     // serial right-looking schedule: panels of the outer block, then ONE trailing update
-    for (int C0 = 0; C0 < Npad; C0 += NBO) {
-        const int wblk = (Npad - C0 < NBO) ? (Npad - C0) : NBO;
+    for (int C0 = 0, wblk = 0; C0 < Npad; C0 += wblk) {
+        wblk = outer_block_width(Npad, C0);
         if ((rc = factor_outer_panels(s, K, Npad, ld, ws, ws.Wbuf, C0, wblk))) return rc;
         const int r0 = C0 + wblk;
         if (r0 < Npad) {

@@ -1,0 +1,23 @@
+"""Phase stamps of the LAST k_ldlt_panel<true> launch of a factorisation (library built with -DPANEL_TIMING:
+tools/build_variant.sh ptim diag.hip -DPANEL_TIMING; CIPKKT_LIB=...).  Times in us relative to workgroup 0's entry.
+usage: CIPKKT_LIB=conicip.jl_amd/build/variants/libcipkkt_ptim.so python tools/panel_stamps.py [n] [stop_after_panels]"""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "conicip.jl_amd"))
+import cipkkt
+from cipkkt import workloads as W, _lib
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+Q, c, A, b, K = W.c2_problem(n, seed=1234, device="cuda")
+ks = cipkkt.KKTSystem(Q, A, None, K)
+v = torch.ones(n, dtype=torch.float64, device="cuda"); s = torch.ones(n, dtype=torch.float64, device="cuda")
+ks.set_scaling_from_iterate(v, s)
+lib = _lib.load()
+names = {0: "wg0 entry", 4: "ready seen", 2: "block in LDS", 6: "A(0) done", 7: "last pivot", 8: "wg0 end", 9: "producer wg1 entry",
+         10: "producer (0,0) counted", 11: "producer (7,7) counted", 12: "strip 0 update tiles done", 13: "strip 0 TRSM done",
+         14: "last strip TRSM done"}
+for rep in range(3):
+    ks.factor(); torch.cuda.synchronize()
+    t = (ctypes.c_long * 32)()
+    assert lib.cip_debug_panel_stamps(t) == 0
+    t0 = t[0]
+    print("rep", rep, " | ".join("%s %.2f" % (names[i], (t[i] - t0) / 100.0) for i in (0, 9, 10, 11, 4, 2, 6, 7, 8, 12, 13, 14) if t[i]))
