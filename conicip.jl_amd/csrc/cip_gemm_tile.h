@@ -211,3 +211,98 @@ __device__ __forceinline__ void gemm_tile_64_k128(const GemmArgs &g, double *lds
             }
         }
 }
+
+// ---- the same K = 128 tile for a GROUP of four waves that shares its workgroup with another group (diag.hip: k_ldlt_panel,
+// where a TRSM strip or a second tile job lives in the other four waves of the workgroup): no s_barrier -- the hardware
+// barrier counts every live wave of the workgroup -- but a generation-counted LDS word the group's four waves meet on.
+// LDS traffic of one wave is in order, so "my ds_writes have landed (lgkmcnt(0)), then my ds_add" is a release and the
+// spin's ds_read followed by dependent ds_reads an acquire; the asm memory clobbers keep the compiler from moving LDS
+// accesses across.  64 KB of LDS per group: the operands pass through two 32-KB buffers a QUARTER of K at a time (quarter
+// q + 1 is written while quarter q feeds the MFMAs; the wait that publishes it also says everybody is done with the buffer
+// quarter q + 2 goes into): four meetings per tile.  Same k order from a zero accumulator, same C + alpha acc: bit-identical
+// to gemm_tile_64_k128.
+struct GrpBar { unsigned *ctr; unsigned gen; };
+__device__ __forceinline__ void grp_barrier(GrpBar &b) {
+    b.gen += 4u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(b.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(b.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < b.gen) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+// QUEUE: the group works through a tile queue (an agent-scope counter): the index of its NEXT tile is drawn behind this
+// tile's operand loads (loads return in order: the draw must not sit in front of them) and handed to the other three waves
+// through `slot` at the tile's last meeting; returned to every thread.
+template <bool QUEUE>
+__device__ __forceinline__ unsigned gemm_tile_64_k128_grp(const GemmArgs &g, double *lds, long i0, long j0, int gt, GrpBar &bar,
+                                                          unsigned *tileq, unsigned *slot) {
+    const int lane = gt & 63;
+    const int wave = gt >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int k_ld = gt >> 5, rp = gt & 31;
+    const double *Ap = g.A + i0 + 2 * rp;
+    const double *Bp = g.B + j0 + 2 * rp;
+    const long rowo = i0 + wm * 32 + 2 * l15;
+    v2d cpre[2][4];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cpre[tj][q] = *(const v2d *)(g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * q) + tj) * g.ldc);
+    v2d ra[16], rb[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const long k = q * 8 + k_ld;
+        ra[q] = *(const v2d *)(Ap + k * g.lda);
+        rb[q] = *(const v2d *)(Bp + k * g.ldb);
+    }
+    unsigned nxt = 0u;
+    if (QUEUE && gt == 0) nxt = __hip_atomic_fetch_add(tileq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        double *la = lds + (qt & 1) * (64 * SB), *lb = la + 32 * SB;       // buffer qt & 1: [32 k][64 rows] per operand
+        if (qt == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                *(v2d *)(la + (q * 8 + k_ld) * SB + 2 * rp) = ra[q];
+                *(v2d *)(lb + (q * 8 + k_ld) * SB + 2 * rp) = rb[q];
+            }
+        }
+        if (QUEUE && qt == 3 && gt == 0) *(volatile unsigned *)slot = nxt;
+        grp_barrier(bar);
+        if (qt < 3) {
+            double *na = lds + ((qt + 1) & 1) * (64 * SB), *nb = na + 32 * SB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                *(v2d *)(na + (q * 8 + k_ld) * SB + 2 * rp) = ra[4 * (qt + 1) + q];
+                *(v2d *)(nb + (q * 8 + k_ld) * SB + 2 * rp) = rb[4 * (qt + 1) + q];
+            }
+        }
+        const double *pa = la + wm * 32 + 2 * l15, *pb = lb + wn * 32 + 2 * l15;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int kk = ks * 4 + l4;
+            const v2d fi = *(const v2d *)(pa + kk * SB);
+            const v2d fj = *(const v2d *)(pb + kk * SB);
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.x, fi.x, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.x, fi.y, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.y, fi.x, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj.y, fi.y, acc[1][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double *cp = g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * q) + tj) * g.ldc;
+            v2d c = cpre[tj][q];
+            c += g.alpha * (v2d){acc[0][tj][q], acc[1][tj][q]};
+            *(v2d *)cp = c;
+        }
+    if (QUEUE) nxt = *(volatile unsigned *)slot;
+    return nxt;
+}

@@ -35,8 +35,10 @@ __device__ long g_diag_t[8 * 8];                 // [kb][slot]: s_memtime stamps
 #ifdef PANEL_TIMING
 // development (tools/panel_stamps.py): s_memrealtime (100 MHz, one clock for the chip) at the phases of a k_ldlt_panel<true> launch
 __device__ long g_panel_t[32];
-#define PANEL_STAMP(slot, cond) do { if (cond) g_panel_t[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ int g_panel_col = -1;                 // -1: every launch stamps (the last one stays); else the launch of the panel at this column
+#define PANEL_STAMP(slot, cond) do { if ((cond) && (g_panel_col < 0 || g_panel_col == col0)) g_panel_t[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int cip_debug_panel_stamps(long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_panel_t), sizeof(long) * 32); }
+extern "C" int cip_debug_panel_col(int col) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_panel_col), &col, sizeof(int)); }
 #else
 #define PANEL_STAMP(slot, cond) do { } while (0)
 #endif
@@ -754,8 +756,23 @@ __device__ __forceinline__ unsigned strip_wait(unsigned v, unsigned target, cons
 // was needed, from all earlier W blocks: a chain of 4 (kb + 1) DEPENDENT MFMAs (~100 clocks each), 28 of them after the
 // diagonal kernel's last micro-panel -- the tail of every panel launch.  Per block the same MFMAs on the same operands in
 // the same order (qq ascending): bit-identical.
+// the wait of a strip whose four waves share the workgroup with a tile group (k_ldlt_panel<true>): no barrier, every wave
+// polls for itself (one blocking agent-scope load per round trip: four pollers per strip do not load the L2 channel)
+__device__ __forceinline__ unsigned strip_wait_wave(unsigned v, unsigned target, const unsigned *stage, int *info) {
+    if (v >= target) return v;
+    unsigned x = 0u;
+    if ((threadIdx.x & 63) == 0) {
+        const long t0 = __builtin_amdgcn_s_memtime();
+        while ((x = __hip_atomic_load(stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memtime() - t0 > 2000000000L) { atomicCAS(info + 3, 0, -9); x = 0xffffffffu; break; }   // never hang the GPU
+        }
+    }
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)x);
+}
+template <bool WAVEWAIT>
 __device__ __forceinline__ void trsm_strip_pipelined(const TrsmStrips &tr, int strip, const unsigned *stage, unsigned *slot, int *info) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const long row = (long)strip * 64 + wave * 16 + l15;
     double *ap = tr.Ap + row + (long)g * tr.ld;
@@ -768,7 +785,8 @@ __device__ __forceinline__ void trsm_strip_pipelined(const TrsmStrips &tr, int s
         for (int q = 0; q < 4; ++q) T[r][q] = ap[(long)(r * 16 + 4 * q) * tr.ld];
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
-        v = strip_wait(v, (unsigned)PANEL_NH * (kb + 1), stage, slot, info);
+        v = WAVEWAIT ? strip_wait_wave(v, (unsigned)PANEL_NH * (kb + 1), stage, info)
+                     : strip_wait(v, (unsigned)PANEL_NH * (kb + 1), stage, slot, info);
         // one batch of loads per stage: the micro inverse and 1/d of kb and column block kb of L11 below its diagonal tile
         double xo[4], dv[4], lo[7][4];
 #pragma unroll
@@ -828,19 +846,50 @@ __device__ __forceinline__ void diag_block_producer(const GemmArgs &g, int tile,
     for (int q = 0; q < 4; ++q) st_pub(cp + (long)(4 * q) * g.ldc, cpre[q] + g.alpha * acc[q]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) atomicAdd(ready, 1u);
-    PANEL_STAMP(10, lane == 0 && tile == 0);
-    PANEL_STAMP(11, lane == 0 && tile == 35);
 }
 #define PANEL_PRODUCERS 9               // 36 tiles, one per wave, four waves per workgroup: one wave per SIMD (two would share its MFMA pipe)
+// Round 3, the update tiles as a QUEUE.  The launch's LDS size is the diagonal kernel's (160 KB), so every workgroup has a
+// CU to itself -- and at the top of the matrix 126 strips held 126 CUs for the whole launch although they mostly wait, while
+// the 1000 update tiles of the block's second panel queued for the other 120 (56 / 47 / 39-us launches where the chain needs
+// 28).  Now every workgroup behind the producers is TWO groups of four waves (64 KB of LDS and an LDS meeting word each,
+// gemm_tile_64_k128_grp): group 0 of the first `strips` workgroups is the strip (its two update tiles, then the TRSM,
+// every wave polling `stage` for itself), every other group -- the strips' second halves, both halves of the `workers`
+// workgroups behind them, and the strips' own waves once their TRSM is done -- draws 64x64 tiles from `tileq` until it runs
+// dry.  Nobody waits for a tile job, a tile job waits for nobody: forward progress as before.  Each tile is computed by
+// one group in the order of gemm_tile_64_k128: the factor's bits do not depend on who drew what.
+#define PANEL_GRP_DOUBLES 8192          // 64 KB per group; the control words (two meeting counters, two queue slots, a flag) behind both
+#define PANEL_NONE 0xffffffffu
+__device__ __forceinline__ void panel_tile_jobs(const GemmArgs &g, double *lds, int gt, GrpBar &bar, unsigned *tileq, unsigned *slot,
+                                                unsigned first_tile, unsigned nstatic) {
+    // column-major from tile column 2 on, the tiles on and below the diagonal only (C's first row is its first column's:
+    // tile (i, j) with i < j lies in the upper triangle, which nobody reads).  Column-major on purpose: the tiles in flight
+    // at any time are neighbours in a column -- contiguous 512-byte pieces of the same 64 columns of C, spread over the
+    // memory channels; a row-major order (tried with one queue per XCD, so that the eight tiles of a tile row would share
+    // their W rows in one L2) puts them 64 KB x 64 apart on the same channels and ran 35-70 % slower.
+    const int tm = g.M / SB, tn = g.N / SB;
+    const unsigned ntiles = (unsigned)(tm * (tn - 2) - (tn * (tn - 1) / 2 - 1));
+    unsigned t = first_tile;                                      // a worker's first job needs no draw; the queue hands out nstatic, nstatic + 1, ..
+    if (t == PANEL_NONE) {                                        // late starters (the strips' groups) draw their first one too
+        if (gt == 0) *(volatile unsigned *)slot = __hip_atomic_fetch_add(tileq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        grp_barrier(bar);
+        t = nstatic + *(volatile unsigned *)slot;
+    }
+    while (t < ntiles) {
+        int r = (int)t, j = 2;
+        while (r >= tm - j) { r -= tm - j; ++j; }
+        t = nstatic + gemm_tile_64_k128_grp<true>(g, lds, (long)(j + r) * SB, (long)j * SB, gt, bar, tileq, slot);
+    }
+}
 template <bool UPD>
 __global__ __launch_bounds__(64 * PANEL_WAVES) void k_ldlt_panel(double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
                                                                   int *info, int col0, PivotSigns sg, unsigned *ready, unsigned *stage,
-                                                                  GemmArgs g, TrsmStrips tr, CipBatch cb) {
+                                                                  unsigned *tileq, GemmArgs g, TrsmStrips tr, CipBatch cb) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     // small lock-step groups (ldlt.hip: factor_outer_panels, up to 12 problems): problem z's workgroups follow those of the
     // problems before it in dispatch order, so every wait is still for a workgroup dispatched earlier
     CIP_BATCH_GUARD(cb);
     CIP_BO7(cb, Kb, xm_out, dvec, dinv, info, ready, stage);
+    CIP_BO1(cb, tileq);
     {
         const long off = (long)blockIdx.z * cb.stride;
         g.A = (const double *)((const char *)g.A + off); g.B = (const double *)((const char *)g.B + off); g.C = (double *)((char *)g.C + off);
@@ -853,37 +902,54 @@ __global__ __launch_bounds__(64 * PANEL_WAVES) void k_ldlt_panel(double *Kb, lon
         diag_body<UPD, true, PANEL_WAVES>(sm, Kb, ld, xm_out, dvec, dinv, info, col0, sg, ready, stage, 36u);
         return;
     }
-    __builtin_amdgcn_s_setprio(3);
-    const int first = UPD ? 1 + PANEL_PRODUCERS : 1;
-    if (UPD && b <= PANEL_PRODUCERS) {
+    if (!UPD) {                                         // first panel of an outer block: strips only, four-wave jobs
+        __builtin_amdgcn_s_setprio(3);
+        if (threadIdx.x >= 256) return;
+        trsm_strip_pipelined<false>(tr, b - 1, stage, (unsigned *)sm, info);
+        return;
+    }
+    if (b <= PANEL_PRODUCERS) {
+        __builtin_amdgcn_s_setprio(3);
         PANEL_STAMP(9, threadIdx.x == 0 && b == 1);
         if (threadIdx.x < 256) diag_block_producer(g, (b - 1) * 4 + (int)(threadIdx.x >> 6), ready);
         return;
     }
-    if (threadIdx.x >= 256) return;                 // strips and update tiles are four-wave jobs (barriers count live waves only)
-    if (b - first < tr.strips) {
+    const int first = 1 + PANEL_PRODUCERS;
+    const int grp = (int)(threadIdx.x >> 8), gt = (int)(threadIdx.x & 255);
+    unsigned *ctl = (unsigned *)(sm + 2 * PANEL_GRP_DOUBLES);
+    if (threadIdx.x < 5) ctl[threadIdx.x] = 0u;
+    __syncthreads();                                    // the one hardware barrier of these workgroups: all eight waves are still here
+    GrpBar bar = {ctl + grp, 0u};
+    double *lds = sm + grp * PANEL_GRP_DOUBLES;
+    // the two halves of worker workgroup w start at once on tiles 2 w and 2 w + 1; everything else is drawn from the queue
+    const int w = b - first - tr.strips, nworkers = (int)gridDim.x - first - tr.strips;
+    const unsigned first_tile = w >= 0 ? (unsigned)(2 * w + grp) : PANEL_NONE;
+    if (w < 0) {
+        // a strip workgroup: the strip's rows of this panel's columns first receive the previous panel's update -- tiles
+        // (2 + strip, 0) and (2 + strip, 1), one per group, side by side (the head of the launch's critical path); then group 0
+        // is the strip and group 1 a tile group
         const int strip = b - first;
-        if (UPD) {
-            // the strip's rows of this panel's columns first receive the previous panel's update (tiles (2 + strip, 0), (2 + strip, 1))
-            gemm_tile_64_k128<false>(g, sm, (long)(2 + strip) * SB, 0);
-            __syncthreads();
-            gemm_tile_64_k128<false>(g, sm, (long)(2 + strip) * SB, SB);
-            __syncthreads();
+        __builtin_amdgcn_s_setprio(3);
+        gemm_tile_64_k128_grp<false>(g, lds, (long)(2 + strip) * SB, (long)grp * SB, gt, bar, nullptr, nullptr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // a TRSM wave's rows were written by all eight waves
+        grp_barrier(bar);
+        if (gt == 0) __hip_atomic_fetch_add(ctl + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (grp == 0) {
+            while (__hip_atomic_load(ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2u) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            PANEL_STAMP(12, threadIdx.x == 0 && strip == 0);          // strip 0: its two update tiles done
+            trsm_strip_pipelined<true>(tr, strip, stage, nullptr, info);
+            PANEL_STAMP(13, threadIdx.x == 0 && strip == 0);
+            PANEL_STAMP(14, threadIdx.x == 0 && strip == tr.strips - 1);
         }
-        PANEL_STAMP(12, UPD && threadIdx.x == 0 && strip == 0);              // strip 0: its two update tiles done
-        trsm_strip_pipelined(tr, strip, stage, (unsigned *)sm, info);
-        PANEL_STAMP(13, UPD && threadIdx.x == 0 && strip == 0);
-        PANEL_STAMP(14, UPD && threadIdx.x == 0 && strip == tr.strips - 1);
-        return;
+        __builtin_amdgcn_s_setprio(0);
     }
-    if (UPD) {
-        // column-major from tile column 2 on, the tiles on and below the diagonal only (C's first row is its first column's:
-        // tile (i, j) with i < j lies in the upper triangle, which nobody reads)
-        const int tm = g.M / SB;
-        int t = b - first - tr.strips, j = 2;
-        while (t >= tm - j) { t -= tm - j; ++j; }
-        gemm_tile_64_k128<false>(g, sm, (long)(j + t) * SB, (long)j * SB);
-    }
+    PANEL_STAMP(15, w == 0 && threadIdx.x == 0);                          // worker 0: starts on tiles
+    PANEL_STAMP(17, w < 0 && b == first && threadIdx.x == 256);            // strip 0's second half: starts on tiles
+    panel_tile_jobs(g, lds, gt, bar, tileq, ctl + 2 + grp, first_tile, (unsigned)(2 * nworkers));
+    PANEL_STAMP(16, w == 0 && threadIdx.x == 0);                          // worker 0: queue dry
+    PANEL_STAMP(18, w < 0 && b == first && threadIdx.x == 256);
+    PANEL_STAMP(19, w == nworkers - 1 && threadIdx.x == 0);               // last worker: queue dry
 }
 
 // X = inv(L) for every 128x128 diagonal block of a factored matrix, one workgroup per block (they are
@@ -1057,18 +1123,30 @@ int cip_launch_diag_upd(hipStream_t s, double *Kb, long ld, double *xm_out, doub
 // given (as cip_launch_diag_upd), and the TRSM of the `rows` rows below the block; `ready` / `stage`: zeroed device words
 // of this launch's own
 int cip_launch_panel(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
-                     PivotSigns sg, unsigned *ready, unsigned *stage, const GemmArgs *g, int rows, double *W, long ldw) {
+                     PivotSigns sg, unsigned *ready, unsigned *stage, unsigned *tileq, const GemmArgs *g, int rows, double *W, long ldw) {
     if (cip_kernels_init()) return -3;
     TrsmStrips tr = {Kb + CIP_NB, ld, Kb, xm_out, dinv, W, ldw, rows / 64};
     if (g) {
         const int tm = g->M / SB, tn = g->N / SB;
         if (tm != tr.strips + 2 || tn < 2) { cip_set_error("panel launch: update / TRSM shapes disagree"); return -1; }
-        const long grid = 1 + PANEL_PRODUCERS + tr.strips + ((long)tm * (tn - 2) - ((long)tn * (tn - 1) / 2 - 1));   // lower tiles of columns 2 .. tn-1
+        // tile workers: a workgroup (two tile groups) for every CU the diagonal kernel, the producers and the strips leave
+        // free (per problem of a lock-step group), no more than the tiles the strips' groups do not take as their first ones
+        static const int ncu = [] {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            return cus;
+        }();
+        const long ntiles = (long)tm * (tn - 2) - ((long)tn * (tn - 1) / 2 - 1);   // lower tiles of columns 2 .. tn-1
+        long workers = ncu / (cip_in_batch() ? cip_tl_bz.B : 1) - 1 - PANEL_PRODUCERS - tr.strips;
+        if (workers > (ntiles + 1) / 2) workers = (ntiles + 1) / 2;
+        if (workers < 1 && ntiles > 0 && tr.strips == 0) workers = 1;
+        if (workers < 0) workers = 0;
+        const long grid = 1 + PANEL_PRODUCERS + tr.strips + workers;
         cip_launch_b(k_ldlt_panel<true>, dim3((unsigned)grid), dim3(64 * PANEL_WAVES), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg,
-                     ready, stage, *g, tr);
+                     ready, stage, tileq, *g, tr);
     } else {
         cip_launch_b(k_ldlt_panel<false>, dim3((unsigned)(1 + tr.strips)), dim3(64 * PANEL_WAVES), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv,
-                     info, col0, sg, ready, stage, GemmArgs{}, tr);
+                     info, col0, sg, ready, stage, tileq, GemmArgs{}, tr);
     }
     CIP_HIP_CHECK(hipGetLastError());
     return 0;

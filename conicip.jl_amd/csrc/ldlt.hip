@@ -45,7 +45,7 @@ int cip_ldlt_outer_block_for(int Npad) {
     return (Npad >= 4096 && g_fuse_diag) ? 768 : 512;    // not a function of the batch: lock-step groups reproduce the one-problem loop bit for bit
 }
 #define CIP_NBO_MAX 1024
-#define CIP_TAIL_MAX 4608               // widest last block (CIP_LDLT_TAIL is clamped to it): Wbuf has room for it from order 4096 on
+#define CIP_TAIL_MAX 3072               // widest last block (CIP_LDLT_TAIL is clamped to it): Wbuf has room for it from order 4096 on
 static size_t wbuf_cols(int Npad) { return Npad >= 4096 ? (Npad < CIP_TAIL_MAX ? Npad : CIP_TAIL_MAX) : CIP_NBO_MAX; }
 // The LAST outer block takes everything that is left once that is no more than CIP_LDLT_TAIL columns (round 3; automatic
 // widths only, orders from 4096 on).  At the bottom of the matrix a trailing update is a handful of tiles per CU behind a
@@ -159,7 +159,7 @@ size_t cip_ldlt_ws_bytes(int Npad) {
         b += al256((size_t)Npad * 8);                    // zbuf
     }
     b += al256((size_t)Npad * 8) * 3;                    // dinv, dvec, tmp
-    b += al256(64 + 8 * nblk);                           // info (16 ints) + a `ready` and a `stage` counter per 128-block (fused panel launches)
+    b += al256(64 + 12 * nblk);                          // info (16 ints) + a `ready`, a `stage` and a tile-queue counter per 128-block (fused panel launches)
     return b;
 }
 
@@ -181,7 +181,7 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     ws->dinv = (double *)p;  p += al256((size_t)Npad * 8);
     ws->dvec = (double *)p;  p += al256((size_t)Npad * 8);
     ws->tmp = (double *)p;   p += al256((size_t)Npad * 8);
-    ws->info = (int *)p;     p += al256(64 + 8 * nblk);
+    ws->info = (int *)p;     p += al256(64 + 12 * nblk);
     ws->prof = nullptr;
     ws->lazyC = nullptr; ws->lazy_ld = 0; ws->lazy_diag = nullptr;
     ws->signs = PivotSigns{-1, 0, 0};
@@ -196,7 +196,7 @@ int cip_launch_diag_upd(hipStream_t s, double *Kb, long ld, double *xm_out, doub
 int cip_launch_diag_inverse(hipStream_t s, const double *K, long ld, int nblk, const double *xm_all, double *Linv,
                             double *LinvT, int Bs);
 int cip_launch_panel(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
-                     PivotSigns sg, unsigned *ready, unsigned *stage, const GemmArgs *g, int rows, double *W, long ldw);
+                     PivotSigns sg, unsigned *ready, unsigned *stage, unsigned *tileq, const GemmArgs *g, int rows, double *W, long ldw);
 int cip_launch_trsm_subst(hipStream_t s, double *Ap, long ld, int rows, const double *L11, const double *xm,
                           const double *dinv, double *W, long ldw);
 
@@ -256,7 +256,7 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
             const bool upd = t > 0 && rest_of_block_args(K, Npad, ld, Wb, C0, wblk, t - 1, gu);
             unsigned *ctr = (unsigned *)(ws.info + 16);
             if ((rc = cip_launch_panel(s, K + c0 + (long)c0 * ld, ld, ws.Xm + (size_t)jb * 2048, ws.dvec + c0, ws.dinv + c0, ws.info, c0,
-                                       ws.signs, ctr + jb, ctr + Npad / CIP_NB + jb, upd ? &gu : nullptr, r,
+                                       ws.signs, ctr + jb, ctr + Npad / CIP_NB + jb, ctr + 2 * (Npad / CIP_NB) + jb, upd ? &gu : nullptr, r,
                                        Wb + (c0 + CIP_NB) + (long)(t * CIP_NB) * Npad, Npad)))
                 return rc;
             continue;
@@ -359,7 +359,7 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
     if (Npad % CIP_NB) { cip_set_error("ldlt: N must be a multiple of 128"); return -1; }
     int rc;
     // [0] bad pivot, [1] sweep bail-out, [2] dead pivot, [3] fused-launch wait timed out; from word 16: `ready` counters
-    if ((rc = zero_fill(s, ws.info, 64 + 8 * (size_t)(Npad / CIP_NB)))) return rc;
+    if ((rc = zero_fill(s, ws.info, 64 + 12 * (size_t)(Npad / CIP_NB)))) return rc;
     // serial right-looking schedule: panels of the outer block, then ONE trailing update
     for (int C0 = 0, wblk = 0; C0 < Npad; C0 += wblk) {
         wblk = outer_block_width(Npad, C0);
