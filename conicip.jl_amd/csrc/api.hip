@@ -991,6 +991,7 @@ extern "C" int cip_profile_thread_get(double *out3) {
     return 0;
 }
 extern "C" int cip_set_lazy_copy(int on) { return cip_lazy_copy_set(on); }
+extern "C" int cip_set_sdp_lanczos(int on) { return cip_sdp_large_lanczos(on); }
 extern "C" int cip_set_ldlt_fused_chain(int on) { return cip_ldlt_set_fused_chain(on); }
 extern "C" int cip_set_solve_block_max(int b) { return cip_solve_block_max_set(b); }
 extern "C" int cip_set_ldlt_outer_block(int nbo) { cip_ldlt_set_outer_block(nbo); return cip_ldlt_outer_block(); }

@@ -33,6 +33,15 @@
 #define LG_SQRT2 1.4142135623730951
 #define LG_SQRT1_2 0.7071067811865476
 
+__device__ int g_lz_hist[40];           // k_lg_lanczos1: histogram of step counts (bins of 8)
+#ifdef LZ_TIMING
+__device__ long g_lz_t[8];              // development: clocks per phase, summed over all calls (thread 0)
+#define LZ_T0() long lz_t = __builtin_amdgcn_s_memtime()
+#define LZ_T(i) do { if (threadIdx.x == 0) { const long t_ = __builtin_amdgcn_s_memtime(); g_lz_t[i] += t_ - lz_t; lz_t = t_; } } while (0)
+#else
+#define LZ_T0() do { } while (0)
+#define LZ_T(i) do { } while (0)
+#endif
 struct LargeWs {
     int rp = 0;                    // padded order (256 or 512)
     int chunk = 64;                // columns of A per batched congruence
@@ -522,6 +531,7 @@ int cip_sdp_large_create(int rmax_large, int nlarge, LargeWs **out) {
     w->batchX = (double *)p; p += (size_t)w->chunk * m2;
     w->batchT = (double *)p; p += (size_t)w->chunk * m2;
     w->ctr = (unsigned *)p; p += al256(1024);
+    CIP_HIP_CHECK(hipMemset(w->ctr, 0, 1024));
     w->ldl_z = p; p += al256(cip_ldlt_ws_bytes(rp));
     w->ldl_s = p;
     cip_ldlt_ws_carve(w->ldl_z, rp, &w->wz);
@@ -532,6 +542,21 @@ int cip_sdp_large_create(int rmax_large, int nlarge, LargeWs **out) {
 }
 void cip_sdp_large_destroy(LargeWs *w) {
     if (!w) return;
+    if (const char *e = getenv("CIP_LG_LANCZOS_STATS")) {
+        if (atoi(e)) {
+            int st[40];
+            if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_lz_hist), sizeof(st)) == hipSuccess) {
+                fprintf(stderr, "lanczos max-step, steps per call (bins of 8):");
+                for (int q = 0; q <= 32; ++q) if (st[q]) fprintf(stderr, " [%d-%d]: %d", 8 * q, 8 * q + 7, st[q]);
+                fprintf(stderr, "\n");
+            }
+#ifdef LZ_TIMING
+            long tt[8];
+            if (hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_lz_t), sizeof(tt)) == hipSuccess)
+                fprintf(stderr, "lanczos clocks: load+v1 %ld | A v %ld | alpha %ld | dots %ld | update %ld | beta %ld | multisection %ld | rest of check %ld\n", tt[0], tt[1], tt[2], tt[3], tt[4], tt[5], tt[7], tt[6]);
+#endif
+        }
+    }
     if (w->base) (void)hipFree(w->base);
     delete w;
 }
@@ -716,6 +741,339 @@ __global__ __launch_bounds__(512) void k_lg_tridiag1(const double *M, int ldm, c
     }
 }
 
+// ---- The max-step needs ONE eigenvalue -- the largest (or smallest) -- of its symmetric r x r matrix, not the tridiagonal
+// form: Lanczos with full reorthogonalisation, the matrix in registers as in k_lg_tridiag1 (same load, same p = A v), and the
+// verdict of maxstep_sdc (src/ConicIP.jl:272-303) in the same launch (round 3; replaces k_lg_tridiag1 + k_lg_sturm for
+// r <= 256: 1.15 + 0.28 ms per max-step, six max-steps per iteration, half of config 4's time).
+//   v_1 fixed (every component non-zero inside the r x r block, zero in the padding: the padded rows never enter);
+//   step j:  w = A v_j, alpha_j = w'v_j, w orthogonalised against v_1..v_j twice (classical Gram-Schmidt, "twice is
+//   enough": it also removes alpha_j v_j and beta_{j-1} v_{j-1}), beta_j = |w|, v_{j+1} = w / beta_j;
+//   at j = 8, 12, .., 32, 40, .., 64, 80, ..: theta = the wanted extreme eigenvalue of T_j by multisection on the Sturm
+//   count (512 shifts per round, down to the last bit), s = its eigenvector by one inverse iteration with the shift at the
+//   OUTER end of the final bracket (T - sigma I is then definite: the LDL' sweep needs no pivoting), and the classical
+//   bound: A has an eigenvalue within beta_j |s_j| of theta.  Stop at beta_j |s_j| <= 1e-11 |T|; at j = r the recurrence is
+//   a complete tridiagonalisation and theta is exact -- the fallback is the loop's own end.
+// theta <= lambda_max always (Ritz values lie inside the spectrum); that the largest Ritz value converges to lambda_max
+// and not to a smaller eigenvalue rests on v_1 not being orthogonal to the extreme eigenvector, as in every Krylov eigensolver.
+// On the max-step matrices of config 4's family the stop comes after 9-90 steps, 30 on average; the eigenvalue then agrees
+// with LAPACK's to 1e-15 (the bound is quadratic in the residual when the eigenvalue is isolated).  Deterministic: fixed
+// start, fixed order of every sum.
+#define LZ_LDSV 64                      // Lanczos vectors kept in LDS; the later ones in a global scratch (L2)
+#define LZ_LDS_DOUBLES (256 + 8 * 256 + 256 * 6 + 64 + LZ_LDSV * 256)
+// 1/x to ~1 ulp (hardware estimate + one Newton step): the Sturm counts only look at signs, the inverse iteration only
+// feeds a convergence test
+__device__ __forceinline__ double lz_rcp(double x) {
+    const double r0 = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r0, 1.0), r0, r0);
+}
+// sum over the 16 lanes of a DPP row, in every lane (xor 1, 2 as quad permutations, then the two mirrors)
+template <int CTRL>
+__device__ __forceinline__ double lz_dpp_add(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return x + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lz_sum16(double x) {
+    x = lz_dpp_add<0xB1>(x); x = lz_dpp_add<0x4E>(x); x = lz_dpp_add<0x141>(x); return lz_dpp_add<0x140>(x);
+}
+// sum over the wave's four 16-lane rows, in every lane (v_permlane16_swap / v_permlane32_swap of two copies)
+__device__ __forceinline__ double lz_sum_rows(double x) {
+    {
+        const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+        x = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    }
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ double lz_sum256(double x, double *red, int slot) {      // sum over threads 0..255 (4 waves), all 512 threads call
+    const int tid = threadIdx.x;
+    x = lz_sum_rows(lz_sum16(x));
+    if (tid < 256 && (tid & 63) == 0) red[slot * 4 + (tid >> 6)] = x;
+    __syncthreads();
+    return (red[slot * 4] + red[slot * 4 + 1]) + (red[slot * 4 + 2] + red[slot * 4 + 3]);
+}
+__global__ __launch_bounds__(512) void k_lg_lanczos1(const double *M, int ldm, const double *dscale, int r, int want_max, double scale,
+                                                      const int *info, double *partial, int item, double *Vg, int *stat) {
+    extern __shared__ double sh[];
+    double *rowp = sh, *colp = sh + 256;                      // p = A v: row sums [i], column sums per wave [wave][j]
+    double *vs = colp + 8 * 256, *wsv = vs + 256, *al = wsv + 256, *be = al + 256, *hb = be + 256, *zz = hb + 256;
+    double *red = zz + 256, *Vl = red + 64;
+    __shared__ int s_first;
+    __shared__ double s_res[4];
+    const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
+    const double INF = __builtin_inf();
+    if (info && info[0]) {                                     // X not positive definite -> Inf (:277-280)
+        if (tid == 0) { partial[item] = INF; if (stat) stat[0] = 0; }
+        return;
+    }
+    LZ_T0();
+    double a[8][16];                                           // blocks bj <= 2 ai + 1 only (k_lg_tridiag1's layout)
+#pragma unroll
+    for (int ai = 0; ai < 8; ++ai)
+#pragma unroll
+        for (int bj = 0; bj < 16; ++bj) {
+            if (bj <= 2 * ai + 1) {
+                a[ai][bj] = 0.0;
+                const int i = 32 * ai + tr, j = 16 * bj + tc;
+                if (i < r && j < r) {
+                    // M[j + i ldm] is the coalesced one of the pair (tc runs along a column); an unscaled M is mat(x): symmetric
+                    double x = M[j + (long)i * ldm];
+                    if (dscale) x = 0.5 * (M[i + (long)j * ldm] + x) * (rsqrt(dscale[i]) * rsqrt(dscale[j]));
+                    a[ai][bj] = x;
+                }
+            }
+        }
+    // LDS copy of v_k: element i at k 256 + (i ^ 8 (k & 7)) -- the eight vectors a wave reads together in the dot products
+    // (eight lanes each, eight consecutive elements) then sit in different banks; a whole vector read by 256 threads is a permutation
+    auto vput = [&](int k, int i, double x) { if (k < LZ_LDSV) Vl[k * 256 + (i ^ ((k & 7) << 3))] = x; else __builtin_nontemporal_store(x, Vg + (size_t)(k - LZ_LDSV) * 256 + i); };
+    // v_1
+    double vi = 0.0;
+    if (tid < r) vi = cos(0.7 * tid + 0.3) + 1.0 / (1.0 + tid);
+    {
+        const double n2 = lz_sum256(tid < 256 ? vi * vi : 0.0, red, 0);
+        vi *= 1.0 / sqrt(n2);
+    }
+    if (tid < 256) { vs[tid] = vi; vput(0, tid, vi); }
+    __syncthreads();
+    LZ_T(0);
+    int m = 0;
+    double th_lo = 0.0, th_hi = 0.0, ascale = 0.0, prev_lo = 0.0;
+    bool done = false, have_prev = false;
+    for (int j = 0; j < r && !done; ++j) {
+        // ---- w = A v_j: row parts (all stored blocks) summed over the 16 lanes of a row of the thread grid, column parts (blocks
+        // strictly below the 32 x 32 diagonal blocks) over the wave's four grid rows, then over the eight waves through LDS
+        {
+            double t16[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t16[q] = vs[16 * q + tc];
+#pragma unroll
+            for (int ai = 0; ai < 8; ++ai) {
+                double pr = 0.0;
+#pragma unroll
+                for (int bj = 0; bj <= 2 * ai + 1; ++bj) pr = fma(a[ai][bj], t16[bj], pr);
+                pr = lz_sum16(pr);
+                if (tc == 0) rowp[32 * ai + tr] = pr;
+            }
+            double t8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t8[q] = vs[32 * q + tr];
+#pragma unroll
+            for (int bj = 0; bj < 16; ++bj) {
+                double pc = 0.0;
+#pragma unroll
+                for (int ai = bj / 2 + 1; ai < 8; ++ai) pc = fma(a[ai][bj], t8[ai], pc);
+                pc = lz_sum_rows(pc);
+                if ((tid & 63) < 16) colp[(tid >> 6) * 256 + 16 * bj + tc] = pc;
+            }
+        }
+        __syncthreads();
+        double wi = 0.0;
+        if (tid < 256) {
+            double s1 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s1 += colp[q * 256 + tid];
+            wi = rowp[tid] + s1;
+        }
+        LZ_T(1);
+        // ---- the recurrence's own terms first: w -= beta_{j-1} v_{j-1}, alpha_j = v_j'w, w -= alpha_j v_j.  (Taking them out
+        // in the Gram-Schmidt sweep with everything else needs its second pass at EVERY step: they are the large components,
+        // and with a basis orthogonal to delta the sweep then puts delta |alpha| / beta of them back along the old vectors.)
+        if (tid < 256 && j > 0) {
+            const int k = j - 1;
+            const double vp = k < LZ_LDSV ? Vl[k * 256 + (tid ^ ((k & 7) << 3))] : __builtin_nontemporal_load(Vg + (size_t)(k - LZ_LDSV) * 256 + tid);
+            wi = fma(-be[k], vp, wi);
+        }
+        double alpha = lz_sum256(tid < 256 ? wi * vs[tid] : 0.0, red, 2);
+        if (tid < 256) { wi = fma(-alpha, vs[tid], wi); wsv[tid] = wi; }
+        __syncthreads();
+        LZ_T(2);
+        // ---- then w orthogonal to v_0 .. v_j by classical Gram-Schmidt: what it finds is rounding noise while the basis is
+        // orthogonal; a second sweep when the first one took out a sizeable part of w ("twice is enough")
+        double nrm2 = 0.0;
+        for (int pass = 0; pass < 2; ++pass) {
+            {                                                  // h_k = v_k'w: eight threads per vector
+                const int k = tid >> 3, l8 = tid & 7;
+                double h = 0.0;
+                if (k <= j) {
+                    const double *vk = Vl + k * 256;
+                    const int sw = (k & 7) << 3;
+#pragma unroll 8
+                    for (int q = 0; q < 32; ++q) { const int i = 8 * q + l8; h = fma(vk[i ^ sw], wsv[i], h); }
+                }
+                h += __shfl_xor(h, 1); h += __shfl_xor(h, 2); h += __shfl_xor(h, 4);
+                if (k <= j && l8 == 0) hb[k] = h;
+            }
+            for (int k0 = LZ_LDSV; k0 <= j; k0 += 64) {         // the vectors beyond the LDS copy
+                const int k = k0 + (tid >> 3), l8 = tid & 7;
+                double h = 0.0;
+                if (k <= j) {
+                    const double *vk = Vg + (size_t)(k - LZ_LDSV) * 256;
+#pragma unroll 8
+                    for (int q = 0; q < 32; ++q) { const int i = 8 * q + l8; h = fma(__builtin_nontemporal_load(vk + i), wsv[i], h); }
+                }
+                h += __shfl_xor(h, 1); h += __shfl_xor(h, 2); h += __shfl_xor(h, 4);
+                if (k <= j && l8 == 0) hb[k] = h;
+            }
+            __syncthreads();
+            LZ_T(3);
+            alpha += hb[j];
+            double h2 = 0.0;                                   // |h|^2: what this sweep takes out of w
+            if (tid < 256) {
+                double acc0 = 0.0, acc1 = 0.0;
+                const int jl = j < LZ_LDSV ? j : LZ_LDSV - 1;
+                int k = 0;
+                for (; k + 1 <= jl; k += 2) {
+                    const double h0 = hb[k], h1 = hb[k + 1];
+                    acc0 = fma(h0, Vl[k * 256 + (tid ^ ((k & 7) << 3))], acc0);
+                    acc1 = fma(h1, Vl[(k + 1) * 256 + (tid ^ (((k + 1) & 7) << 3))], acc1);
+                    h2 = fma(h0, h0, fma(h1, h1, h2));
+                }
+                if (k <= jl) { const double h0 = hb[k]; acc0 = fma(h0, Vl[k * 256 + (tid ^ ((k & 7) << 3))], acc0); h2 = fma(h0, h0, h2); }
+#pragma unroll 8
+                for (int kk = LZ_LDSV; kk <= j; ++kk) {
+                    const double h0 = hb[kk];
+                    acc1 = fma(h0, __builtin_nontemporal_load(Vg + (size_t)(kk - LZ_LDSV) * 256 + tid), acc1);
+                    h2 = fma(h0, h0, h2);
+                }
+                wi -= acc0 + acc1;
+                wsv[tid] = wi;
+            }
+            nrm2 = lz_sum256(tid < 256 ? wi * wi : 0.0, red, pass);        // (its barrier also publishes wsv)
+            LZ_T(4);
+            // (Daniel, Gragg, Kaufman, Stewart.)  h2 is the same in every thread below 256; thread 0 decides
+            if (pass == 0) {
+                if (tid == 0) s_first = (nrm2 >= 0.5 * (nrm2 + h2)) ? 1 : 0;
+                __syncthreads();
+                const int skip = s_first;
+                __syncthreads();
+                if (skip) break;
+            }
+        }
+        const double beta = sqrt(nrm2);
+        if (tid == 0) { al[j] = alpha; be[j] = beta; }
+        m = j + 1;
+        LZ_T(5);
+        // ---- convergence test
+        ascale = fmax(ascale, fabs(alpha) + beta);
+        const bool check = m == r || !(beta > 1e-13 * ascale) || (m >= 24 && ((m <= 64 && (m & 7) == 0) || (m & 15) == 0));
+        if (check) {
+            __syncthreads();                                   // al / be of this step
+            double lo = INF, hi = -INF;
+            for (int i = tid; i < m; i += 512) {
+                const double rad = (i > 0 ? fabs(be[i - 1]) : 0.0) + (i + 1 < m ? fabs(be[i]) : 0.0);
+                lo = fmin(lo, al[i] - rad);
+                hi = fmax(hi, al[i] + rad);
+            }
+            for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
+            if ((tid & 63) == 0) { red[16 + (tid >> 6)] = lo; red[24 + (tid >> 6)] = hi; }
+            __syncthreads();
+            lo = red[16]; hi = red[24];
+            for (int q = 1; q < 8; ++q) { lo = fmin(lo, red[16 + q]); hi = fmax(hi, red[24 + q]); }
+            const double span = fmax(fabs(lo), fabs(hi));
+            const double isp = 1.0 / fmax(span, 1e-300);
+            hi += 1e-15 * span + 1e-300;
+            lo -= 1e-15 * span + 1e-300;
+            // the extreme Ritz value only moves outwards as T grows (interlacing): the last test's inner bracket end still bounds it
+            // on the inside, and it usually moves very little -- the first round's shifts crowd towards that end (geometrically,
+            // eight per octave), the others are uniform
+            // scaled copies for the Sturm counts: a_i / |T| in zz, (b_i / |T|)^2 in wsv (both free here)
+            for (int i = tid; i < m; i += 512) { zz[i] = al[i] * isp; const double bsc = be[i] * isp; wsv[i] = bsc * bsc; }
+            __syncthreads();
+            bool geo = false;
+            if (have_prev) { if (want_max) { if (prev_lo > lo) { lo = prev_lo; geo = true; } } else if (prev_lo < hi) { hi = prev_lo; geo = true; } }
+            for (int round = 0; round < 9; ++round) {
+                if (!(hi - lo > 1e-15 * fmax(fabs(lo), fabs(hi)))) break;      // a few ulps: the midpoint is good to 5e-16
+                // shift number t (1 .. 512) at distance u_t (hi - lo) from the inner end: u_t = t / 513, or 2^((t - 513) / 8) in a
+                // warm-started first round (eight per octave, crowding towards the inner end)
+                const bool g0 = geo && round == 0;
+                const double wdt = hi - lo;
+                auto u_of = [&](int t) -> double {
+                    if (!g0) return (double)t * (1.0 / 513.0);
+                    const double c8[8] = {1.0, 1.0905077326652577, 1.189207115002721, 1.2968395546510096, 1.4142135623730951,
+                                          1.5422108254079407, 1.681792830507429, 1.8340080864093424};       // 2^(q / 8)
+                    const int e = t - 513;
+                    return ldexp(c8[e & 7], e >> 3);
+                };
+                auto shift_at = [&](int t) -> double {         // t = 0 .. 513: inner end .. outer end
+                    if (t <= 0) return want_max ? lo : hi;
+                    if (t >= 513) return want_max ? hi : lo;
+                    return want_max ? lo + u_of(t) * wdt : hi - u_of(t) * wdt;
+                };
+                const double xs = want_max ? lo + u_of(tid + 1) * wdt : hi - u_of(tid + 1) * wdt;
+                // Sturm count without divisions: p_i = (a_i - x) p_{i-1} - b_{i-1}^2 p_{i-2} on entries scaled by 1 / |T| (factors
+                // of modulus <= 2; the pair is rescaled every eight steps); an eigenvalue below x for every i where p_i and
+                // p_{i-1} differ in sign -- the q_i = p_i / p_{i-1} < 0 of the quotient form (a zero takes its predecessor's sign)
+                int cnt = 0;
+                const double xsc = xs * isp;
+                double p0 = 1.0, p1 = zz[0] - xsc;
+                if (p1 < 0.0) ++cnt;
+#pragma unroll 4
+                for (int i = 1; i < m; ++i) {
+                    const double p2 = fma(zz[i] - xsc, p1, -wsv[i - 1] * p0);
+                    // q_i = p2 / p1 < 0  <=>  signs differ (a zero p1 counts as positive, as the 1e-300 of the quotient form)
+                    if ((p2 < 0.0) != (p1 < 0.0 || (p1 == 0.0 && p0 < 0.0))) ++cnt;
+                    p0 = p1; p1 = p2;
+                    if ((i & 7) == 7) {
+                        const double mg = fmax(fabs(p0), fabs(p1));
+                        const double sc = mg > 1e100 ? 1e-100 : (mg < 1e-100 ? 1e100 : 1.0);
+                        p0 *= sc; p1 *= sc;
+                    }
+                }
+                // outside the spectrum of T (on the wanted side)?  the first such shift, counted from the inner end
+                const bool hit = want_max ? (cnt >= m) : (cnt == 0);
+                if (tid == 0) s_first = 512;
+                __syncthreads();
+                if (hit) atomicMin(&s_first, tid);
+                __syncthreads();
+                const int f = s_first;
+                __syncthreads();
+                const double inner = shift_at(f), outer = shift_at(f + 1);      // theta lies between shifts f and f + 1
+                if (want_max) { lo = inner; hi = outer; } else { hi = inner; lo = outer; }
+            }
+            th_lo = lo; th_hi = hi;
+            prev_lo = want_max ? lo : hi; have_prev = true;
+            LZ_T(7);
+            if (tid == 0) {
+                // the Ritz vector's last component: (T - theta I) s = 0 solved from the BOTTOM with s_m = 1 --
+                //   s_{i-1} = ((theta - a_i) s_i - b_i s_{i+1}) / b_{i-1}
+                // -- the growing direction of the recurrence when the Ritz pair has converged (its weight sits in the early
+                // Lanczos vectors), hence the stable one; before convergence the estimate is rough and the answer is "go on" anyway
+                const double th = 0.5 * (lo + hi);
+                double s1 = 1.0, s2 = 0.0, n2 = 1.0;               // s_i, s_{i+1}
+                int rescaled = 0;
+                for (int i = m - 1; i >= 1; --i) {
+                    double bb = be[i - 1];
+                    if (fabs(bb) < 1e-300) bb = 1e-300;
+                    const double s0 = ((th - al[i]) * s1 - (i + 1 < m ? be[i] : 0.0) * s2) * lz_rcp(bb);
+                    s2 = s1; s1 = s0;
+                    n2 += s0 * s0;
+                    if (n2 > 1e200) { s1 *= 1e-100; s2 *= 1e-100; n2 *= 1e-200; rescaled += 1; }
+                }
+                // |s_m| / |s| = 10^(-100 rescaled) / sqrt(n2)
+                s_res[0] = rescaled ? 0.0 : beta / sqrt(n2);
+                s_res[1] = span;
+            }
+            __syncthreads();
+            done = (s_res[0] <= 1e-11 * s_res[1]) || !(beta > 1e-14 * s_res[1]) || m == r;
+        }
+        LZ_T(6);
+        if (!done) {
+            const double vn = wi / beta;
+            if (tid < 256) { vs[tid] = vn; vput(j + 1, tid, vn); }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        const double ev = 0.5 * (th_lo + th_hi);
+        if (want_max) { const double mx = ev * scale; partial[item] = (mx < 0.0) ? INF : 1.0 / mx; }
+        else partial[item] = (ev > 0.0) ? 0.0 : -1.0 + ev;
+        if (stat) stat[0] = m;
+        atomicAdd(g_lz_hist + (m >> 3 < 32 ? m >> 3 : 32), 1);       // histogram of step counts (CIP_LG_LANCZOS_STATS=1 prints it at destroy)
+    }
+}
+
 static int lg_tridiag(hipStream_t s, LargeWs *w, const double *M, const double *dscale, int r) {
     int rc;
     // CIP_LG_TRIDIAG1=0: the cooperative kernel at every order (A/B runs)
@@ -804,6 +1162,15 @@ int cip_sdp_large_refresh(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li,
     return 0;
 }
 
+// 1 (default; CIP_LG_LANCZOS=0 changes it): the max-step's extreme eigenvalue by k_lg_lanczos1 at orders <= 256; 0: full
+// tridiagonalisation + Sturm multisection at every order (A/B runs, tests).  on < 0 only reads; returns the previous setting
+#include <atomic>
+int cip_sdp_large_lanczos(int on) {
+    static std::atomic<int> mode{[] { const char *e = getenv("CIP_LG_LANCZOS"); return (e && atoi(e) == 0) ? 0 : 1; }()};
+    const int prev = mode.load();
+    if (on == 0 || on == 1) mode.store(on);
+    return prev;
+}
 // maxstep_sdc for one large cone: partial[cd.item]
 int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *d, double scale,
                           double *partial) {
@@ -811,8 +1178,17 @@ int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const d
     const long n2 = (long)rp * rp;
     int rc;
     double *dg = w->vec + 1 * rp, *of = w->vec + 2 * rp;
+    // CIP_LG_LANCZOS=0: the full tridiagonalisation + Sturm multisection at every order (A/B runs, tests)
+    const bool lz = cip_sdp_large_lanczos(-1) && r <= 256;
+    if (lz && (rc = lg_set_attr((const void *)k_lg_lanczos1, LZ_LDS_DOUBLES * sizeof(double)))) return rc;
     if (!d) {                                                                       // maxstep_sdc(x, nothing) :295-303
         hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, x + cd.off, 1L, 0L, w->M3, r, rp, 0.0);
+        if (lz) {
+            hipLaunchKernelGGL(k_lg_lanczos1, dim3(1), dim3(512), LZ_LDS_DOUBLES * sizeof(double), s, w->M3, rp, (const double *)nullptr, r, 0,
+                               1.0, (const int *)nullptr, partial, cd.item, w->M1, (int *)(w->ctr + 200));
+            CIP_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
         if ((rc = lg_tridiag(s, w, w->M3, nullptr, r))) return rc;
         hipLaunchKernelGGL(k_lg_sturm, dim3(1), dim3(LG_T), 0, s, dg, of, r, 0, 1.0, (const int *)nullptr, partial, cd.item);
         CIP_HIP_CHECK(hipGetLastError());
@@ -824,7 +1200,13 @@ int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const d
     const double *Xi = (w->wz.Bs == CIP_NB) ? w->wz.Linv : w->wz.X;                // inv(L_unit)
     if ((rc = lg_gemm(s, w->M2, 0, Xi, 0, w->M1, 0, rp, 1))) return rc;             // inv(L) D        (D symmetric)
     if ((rc = lg_gemm(s, w->M3, 0, w->M2, 0, Xi, 0, rp, 1))) return rc;             // inv(L) D inv(L)'
-    if ((rc = lg_tridiag(s, w, w->M3, w->wz.dvec, r))) return rc;                   // ... scaled by d^-1/2 on both sides
+    if (lz) {                                                                       // ... scaled by d^-1/2 on both sides
+        hipLaunchKernelGGL(k_lg_lanczos1, dim3(1), dim3(512), LZ_LDS_DOUBLES * sizeof(double), s, w->M3, rp, (const double *)w->wz.dvec, r, 1,
+                           scale, (const int *)w->wz.info, partial, cd.item, w->M1, (int *)(w->ctr + 200));
+        CIP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    if ((rc = lg_tridiag(s, w, w->M3, w->wz.dvec, r))) return rc;
     hipLaunchKernelGGL(k_lg_sturm, dim3(1), dim3(LG_T), 0, s, dg, of, r, 1, scale, (const int *)w->wz.info, partial, cd.item);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;

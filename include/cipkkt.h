@@ -252,6 +252,10 @@ int cip_set_ldlt_fused_chain(int on);
  * copies only the first outer block's columns of Q into K; the first trailing update of the LDL' reads the rest from Q
  * itself (also CIP_LAZY_COPY=0).  Same factor bit for bit.  1 (default) on, 0 off; returns the previous setting. */
 int cip_set_lazy_copy(int on);
+/* S cones of order 133..256: the max-step's extreme eigenvalue (the reference's eigmin / eigmax, src/ConicIP.jl:272-303) by
+   Lanczos with full reorthogonalisation (1, default) or by a full tridiagonalisation + Sturm multisection (0); < 0 only
+   reads.  Returns the previous setting.  Same eigenvalue to ~1e-11 relative either way; for A/B runs and tests. */
+int cip_set_sdp_lanczos(int on);
 /* HIP-event timing of every LDL' trailing-update launch (bench.py roofline): enable, then read
  * out3 = [launches, total ms, total algorithmic flops (r(r+1)K per launch)] */
 int cip_profile_trailing(cip_handle *h, int enabled);

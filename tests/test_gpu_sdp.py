@@ -169,3 +169,55 @@ def test_mixed_rqs_problem():
     assert sol.status == ref.status == "Optimal"
     assert sol.Iter == ref.Iter
     np.testing.assert_allclose(sol.y, ref.y, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("r", [133, 200, 256])
+def test_lanczos_maxstep_against_lapack_on_hard_spectra(r):
+    """Round 3: at orders 133..256 the max-step takes its ONE eigenvalue from Lanczos with full reorthogonalisation
+    (sdp_large.hip: k_lg_lanczos1) instead of a full tridiagonalisation.  Spectra chosen against it: a tight cluster at the
+    wanted end, a dense edge (semicircle: the slowest case, close to a complete tridiagonalisation), an exactly repeated extreme
+    eigenvalue, one isolated outlier, a multiple of the identity (breakdown at the first step), a rank-one perturbation of it;
+    both variants of maxstep_sdc (src/ConicIP.jl:272-303) against LAPACK at 1e-10, and against the library's own
+    tridiagonalisation + Sturm path (cip_set_sdp_lanczos(0))."""
+    import cipkkt
+    from cipkkt import _lib
+    lib = _lib.load()
+    k = r * (r + 1) // 2
+    ks = cipkkt.KKTSystem(np.eye(2), np.zeros((k, 2)), None, [("S", k)])
+    rng = np.random.default_rng(r)
+    Qm, _ = np.linalg.qr(rng.standard_normal((r, r)))
+    def sym(lam):
+        M = (Qm * lam) @ Qm.T
+        return 0.5 * (M + M.T)
+    spectra = {
+        "cluster at the top": np.concatenate([1.0 + 0.3 * rng.random(r - 4), 2.0 + 1e-9 * np.arange(4)]),
+        "cluster at the bottom": np.concatenate([1.0 + 0.3 * rng.random(r - 4), 0.05 + 1e-10 * np.arange(4)]),
+        "semicircle": None,
+        "repeated extreme": np.concatenate([np.linspace(0.5, 1.5, r - 3), [2.5, 2.5, 2.5]]),
+        "outlier": np.concatenate([np.linspace(0.9, 1.1, r - 1), [40.0]]),
+        "identity": np.full(r, 3.0),
+        "identity + rank one": None,
+    }
+    for name, lam in spectra.items():
+        if name == "semicircle":
+            G = rng.standard_normal((r, r)); D = (G + G.T) / np.sqrt(2 * r)
+        elif name == "identity + rank one":
+            u = rng.standard_normal(r); D = 3.0 * np.eye(r) - 2.0 * np.outer(u, u) / (u @ u)
+        else:
+            D = sym(lam)
+        X = sym(0.5 + rng.random(r))                                   # the point: positive definite
+        x, d = dev(oc.vecm(X)), dev(oc.vecm(D))
+        ref_d, ref_n = oc.maxstep_sdc(oc.vecm(X), oc.vecm(D)), oc.maxstep_sdc(oc.vecm(D - 2.0 * np.eye(r)), None)
+        dn = dev(oc.vecm(D - 2.0 * np.eye(r)))
+        prev = lib.cip_set_sdp_lanczos(1)
+        got_d, got_n = ks.maxstep(x, d), ks.maxstep(dn, None)
+        lib.cip_set_sdp_lanczos(0)
+        tri_d, tri_n = ks.maxstep(x, d), ks.maxstep(dn, None)
+        lib.cip_set_sdp_lanczos(prev)
+        for got, tri, ref, what in ((got_d, tri_d, ref_d, "maxstep(x, d)"), (got_n, tri_n, ref_n, "maxstep(x, nothing)")):
+            if np.isinf(ref):
+                assert np.isinf(got) and np.isinf(tri), (name, what)
+            else:
+                assert got == pytest.approx(ref, rel=1e-10, abs=1e-12), (name, what, got, ref)
+                assert got == pytest.approx(tri, rel=1e-10, abs=1e-12), (name, what, got, tri)
+    ks.close()
