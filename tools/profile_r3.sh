@@ -29,6 +29,13 @@ python3 $R/tools/pmc_traffic.py $OUT/final_pmc_fetch.csv $OUT/final_pmc_write.cs
 for v in 4 8; do python3 $R/tools/pmc_traffic.py $OUT/patch${v}_pmc_FETCH_SIZE.csv $OUT/patch${v}_pmc_WRITE_SIZE.csv patch$v >> $OUT/trail_patch_ab.txt 2>&1; done
 # per-launch durations of the panel chain and the trailing updates along one factorisation
 bash $R/tools/panel_trace.sh r3=default > $OUT/panel_trace.txt 2>&1
+# phase stamps of one panel launch (library built with -DPANEL_TIMING: tools/build_variant.sh ptim diag.hip -DPANEL_TIMING): a quiet
+# launch at the bottom of the matrix and the tile-bound second launch of the factorisation; the whole step's kernel timeline
+if [ -f $R/conicip.jl_amd/build/variants/libcipkkt_ptim.so ]; then
+  ( echo "n = 2048, last panel launch with an update:"; CIPKKT_LIB=$R/conicip.jl_amd/build/variants/libcipkkt_ptim.so python3 $R/tools/panel_stamps.py 2048 2>&1 | tail -2
+    echo "n = 8192, the launch of the panel at column 128 (964 update tiles):"; CIPKKT_LIB=$R/conicip.jl_amd/build/variants/libcipkkt_ptim.so python3 $R/tools/panel_stamps.py 8192 128 2>&1 | tail -2 ) > $OUT/panel_stamps.txt
+fi
+bash $R/tools/step_trace.sh r3=default > $OUT/step_trace.txt 2>&1
 # the diagonal kernel: round 2's step A / helper schedule against round 3's (bit-identity + time per kernel + phase clocks)
 bash $R/tools/diag_ab.sh $OUT/diag_ab > $OUT/diag_ab.txt 2>&1
 # solve4x4: fused element-wise kernels around the sweeps against the separate launches
@@ -36,6 +43,7 @@ bash $R/tools/diag_ab.sh $OUT/diag_ab > $OUT/diag_ab.txt 2>&1
 # config 4 (SDP, matrix order 256) and config 3 (SOCP, 512 x Q(8)): per-kernel time
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4 -o c4 -- python3 $R/tools/c4_time.py 256 > $OUT/c4_time.txt 2>/dev/null
 cp $OUT/c4/c4_kernel_stats.csv $OUT/c4_kernel_stats.csv
+( CIP_LG_LANCZOS_STATS=1 python3 $R/tools/c4_run.py 256; echo "CIP_LG_LANCZOS=0:"; CIP_LG_LANCZOS=0 python3 $R/tools/c4_run.py 256 ) > $OUT/c4_lanczos_ab.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3 -o c3 -- python3 $R/tools/bench_configs.py c3 > $OUT/c3_time.txt 2>/dev/null
 cp $OUT/c3/c3_kernel_stats.csv $OUT/c3_kernel_stats.csv
 # config 5 on one GPU (the multi-GPU workload of bench.py): lock-step (default), the RCCL path with one rank, shard sizes
