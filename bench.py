@@ -51,9 +51,9 @@ import torch
 
 TRAILING_KERNELS = ("k_ldlt_trailing_64",)
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X vendor fp64 matrix peak (dense); see DESIGN.md §5
-# what the chip can issue at the clock it holds under this kernel: 256 CUs x 4 SIMDs x 2048 flop / 64 cycles x 2.15 GHz
-# (GRBM_GUI_ACTIVE / 8 / duration of profiles/r3/final_pmc_mfma.csv: 2.152 GHz, 2.17 in round 2; tools/mfma_peak.hip measures 77.6 at 2.37 GHz unloaded)
-FP64_MFMA_CLOCK_LIMITED_TFLOPS = 256 * 4 * 32 * 2.15e9 / 1e12
+# what the chip can issue at the clock it holds under this kernel: 256 CUs x 4 SIMDs x 2048 flop / 64 cycles x 2.12 GHz
+# (GRBM_GUI_ACTIVE / 8 / duration of profiles/r3/final_pmc_mfma.csv: 2.117 GHz, 2.17 in round 2; tools/mfma_peak.hip measures 77.6 at 2.37 GHz unloaded)
+FP64_MFMA_CLOCK_LIMITED_TFLOPS = 256 * 4 * 32 * 2.12e9 / 1e12
 HBM_PEAK_GBS = 8000.0
 PMC_ROUNDS = ("r3", "r2", "r1")
 

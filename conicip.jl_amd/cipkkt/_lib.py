@@ -74,6 +74,7 @@ SIGNATURES = {
     "cip_cone_prod_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cip_cone_div_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cip_maxstep_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, c_double_p]),
+    "cip_maxstep_pair_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, c_double_p]),
     "cip_cone_identity_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cip_gemv_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_double, C.c_void_p]),
     "cip_dots_dev": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_int_p,

@@ -254,8 +254,7 @@ def conicIP(Q, c, A, b, cone_dims, G=None, d=None, *,
     r0s.zero_()
     solve4x4(e, r0, z)
     if m > 0:
-        a_v = ks.maxstep(zv, None)
-        a_s = ks.maxstep(zs, None)
+        a_v, a_s = ks.maxstep_pair(zv, None, zs, None)
         ks.axpby(-a_v, e, 1.0, zv)
         ks.axpby(-a_s, e, 1.0, zs)
 
@@ -363,7 +362,8 @@ def conicIP(Q, c, A, b, cone_dims, G=None, d=None, *,
         solve4x4(lam, r0, daff)
         _, _, dav, das = parts(daff)
         if m > 0:
-            a_aff = min(ks.maxstep(zv, dav), 1.0, ks.maxstep(zs, das))
+            a_aff_v, a_aff_s = ks.maxstep_pair(zv, dav, zs, das)
+            a_aff = min(a_aff_v, 1.0, a_aff_s)
             x1x2, x1y2, y1x2, y1y2 = ks.dots([(zv, zs), (zv, das), (dav, zs), (dav, das)])
             rho = (x1x2 - a_aff * x1y2 - a_aff * y1x2 + a_aff * a_aff * y1y2) / mubar    # fts :162-163,:886
             sigma = max(0.0, min(1.0, rho)) ** 3
@@ -407,8 +407,8 @@ def conicIP(Q, c, A, b, cone_dims, G=None, d=None, *,
 
         # ------------------------------------------------------------ step (:927-932)
         if m > 0:
-            a_v = min(ks.maxstep(zv, dzv, 1.0 / (1.0 - DTB)), 1.0)
-            a_s = min(ks.maxstep(zs, dzs, 1.0 / (1.0 - DTB)), 1.0)
+            a_v, a_s = ks.maxstep_pair(zv, dzv, zs, dzs, 1.0 / (1.0 - DTB))
+            a_v, a_s = min(a_v, 1.0), min(a_s, 1.0)
             alpha = min(a_v, a_s)
         else:
             alpha = 1.0

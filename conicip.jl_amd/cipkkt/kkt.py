@@ -254,6 +254,12 @@ class KKTSystem:
         L.check(self.lib.cip_maxstep_dev(self.h, _ptr(x), _ptr(d), float(scale), C.byref(out)))
         return out.value
 
+    def maxstep_pair(self, x1, d1, x2, d2, scale=1.0):
+        """(maxstep(x1, d1 * scale), maxstep(x2, d2 * scale)) with one wait (src/ConicIP.jl:708-709, :881-882, :927-928)."""
+        out = (C.c_double * 2)()
+        L.check(self.lib.cip_maxstep_pair_dev(self.h, _ptr(x1), _ptr(d1), _ptr(x2), _ptr(d2), float(scale), out))
+        return out[0], out[1]
+
     def cone_identity(self, e):
         L.check(self.lib.cip_cone_identity_dev(self.h, _ptr(e)))
 

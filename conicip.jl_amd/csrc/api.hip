@@ -266,7 +266,7 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
     DMALLOC(h->cs.d_cones, sizeof(ConeDesc) * h->h_cones.size());
     DMALLOC(h->cs.d_items, sizeof(WorkItem) * h->h_items.size());
     DMALLOC(h->cs.d_scal, sizeof(double) * soff);
-    DMALLOC(h->cs.d_partial, sizeof(double) * (nslots + 1));
+    DMALLOC(h->cs.d_partial, sizeof(double) * 2 * (nslots + 1));      // two sets: the pair of max-steps (cip_cones_maxstep2)
     DMALLOC(h->cs.d_scalar, sizeof(double) * 8);
     h->cs.ns = (int)sidx.size(); h->cs.rmax = rmax; h->cs.kmax = kmax;
     h->cs.ns_small = 0; h->cs.nlarge = 0; h->cs.lg = nullptr; h->cs.d_sidx_small = nullptr;
@@ -880,6 +880,11 @@ extern "C" int cip_cone_div_dev(cip_handle *h, const double *x, const double *y,
 extern "C" int cip_maxstep_dev(cip_handle *h, const double *x, const double *d, double scale, double *alpha_host) {
     if (!h || !alpha_host) return CIP_E_INVALID;
     return cip_cones_maxstep(h->stream, h->cs, x, d, scale, alpha_host);
+}
+extern "C" int cip_maxstep_pair_dev(cip_handle *h, const double *x1, const double *d1, const double *x2, const double *d2, double scale,
+                                    double *alpha_host2) {
+    if (!h || !alpha_host2) return CIP_E_INVALID;
+    return cip_cones_maxstep2(h->stream, h->cs, x1, d1, x2, d2, scale, alpha_host2);
 }
 extern "C" int cip_cone_identity_dev(cip_handle *h, double *e) {
     if (!h) return CIP_E_INVALID;

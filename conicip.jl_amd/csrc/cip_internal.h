@@ -205,7 +205,10 @@ int cip_sdp_large_apply(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, i
 int cip_sdp_large_prod(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *y, double *out);
 int cip_sdp_large_lanczos(int on);                  // sdp_large.hip: Lanczos max-step on (1) / off (0), < 0 reads; returns the previous setting
 int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *d, double scale,
-                          double *partial);
+                          double *partial, int side = 0);
+bool cip_sdp_large_pairable(const LargeWs *w);            // the v- and s-side max-steps of a pair can run side by side
+int cip_sdp_large_fork(hipStream_t s, LargeWs *w, hipStream_t *s2);
+int cip_sdp_large_join(hipStream_t s, LargeWs *w);
 int cip_sdp_large_scale_At(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, int n, const double *At, long ldat, double *Wt,
                            long ldwt);
 int cip_cones_nt_scaling(hipStream_t s, const ConeSet &cs, const double *v, const double *sv, double *lambda);
@@ -215,6 +218,12 @@ int cip_cones_apply(hipStream_t s, const ConeSet &cs, int mode, const double *x,
 int cip_cones_prod(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out);
 int cip_cones_div(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out);
 int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const double *d, double scale, double *alpha_host);
+// the pair of the interior-point loop (src/ConicIP.jl:708-709, :881-882, :927-928): alpha_host2 = {maxstep(x1, d1), maxstep(x2, d2)},
+// one wait; large S cones: the two sides on two streams
+int cip_cones_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const double *d1, const double *x2, const double *d2,
+                       double scale, double *alpha_host2);
+int cip_sdp_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const double *d1, double *p1, const double *x2,
+                     const double *d2, double *p2, double scale);
 int cip_cones_identity(hipStream_t s, const ConeSet &cs, double *e);
 // Wt[i, r] = (F^-T a_i)_r for every row i of At (n rows, ld ldat): Wt = At * F^-1
 int cip_cones_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, long ldat, double *Wt, long ldwt);

@@ -446,6 +446,27 @@ int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const d
     CIP_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
 }
+int cip_cones_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const double *d1, const double *x2, const double *d2,
+                       double scale, double *alpha_host2) {
+    if (cs.nitems == 0 || cip_in_batch() || !cs.has_S) {           // nothing to overlap: two plain calls
+        const int B = cip_tl_bz.B > 1 ? cip_tl_bz.B : 1;
+        int rc = cip_cones_maxstep(s, cs, x1, d1, scale, alpha_host2);
+        if (rc) return rc;
+        return cip_cones_maxstep(s, cs, x2, d2, scale, alpha_host2 + B);
+    }
+    double *p1 = cs.d_partial, *p2 = cs.d_partial + cs.nslots + 1;
+    cip_launch_b(k_maxstep, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x1, d1, scale, p1);
+    cip_launch_b(k_maxstep, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x2, d2, scale, p2);
+    CIP_HIP_CHECK(hipGetLastError());
+    int rc = cip_sdp_maxstep2(s, cs, x1, d1, p1, x2, d2, p2, scale);
+    if (rc) return rc;
+    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)p1, cs.nslots, cs.d_scalar, (double *)nullptr);
+    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)p2, cs.nslots, cs.d_scalar + 1, (double *)nullptr);
+    CIP_HIP_CHECK(hipGetLastError());
+    CIP_HIP_CHECK(hipMemcpyAsync(alpha_host2, cs.d_scalar, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    CIP_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
 int cip_cones_identity(hipStream_t s, const ConeSet &cs, double *e) {
     if (cs.nitems == 0) return 0;
     cip_launch_b(k_cone_identity, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, e);

@@ -109,9 +109,9 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
     if ((rc = cip_factor_resolve(h, 1)) != 0) { if (rc == CIP_E_SINGULAR) return finish(CIP_STATUS_ERROR); return rc; }
     CK(cip_solve4x4_dev(h, e, r0.base, z.base)); ++n_solve;
     if (m > 0) {
-        double a_v, a_s;
-        CK(cip_maxstep_dev(h, z.v, nullptr, 1.0, &a_v));
-        CK(cip_maxstep_dev(h, z.s, nullptr, 1.0, &a_s));
+        double a2[2];
+        CK(cip_maxstep_pair_dev(h, z.v, nullptr, z.s, nullptr, 1.0, a2));
+        const double a_v = a2[0], a_s = a2[1];
         CK(D.axpby(m, -a_v, e, 1.0, z.v));
         CK(D.axpby(m, -a_s, e, 1.0, z.s));
     }
@@ -157,9 +157,9 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
         CK(cip_solve4x4_dev(h, lam, r0.base, daff.base)); ++n_solve;
         double a_aff = 1.0, sigma = 0.0;
         if (m > 0) {
-            double a1, a2;
-            CK(cip_maxstep_dev(h, z.v, daff.v, 1.0, &a1));
-            CK(cip_maxstep_dev(h, z.s, daff.s, 1.0, &a2));
+            double ap[2];
+            CK(cip_maxstep_pair_dev(h, z.v, daff.v, z.s, daff.s, 1.0, ap));
+            const double a1 = ap[0], a2 = ap[1];
             a_aff = std::fmin(std::fmin(a1, 1.0), a2);
             const double *qx[4] = {z.v, z.v, daff.v, daff.v};
             const double *qy[4] = {z.s, daff.s, z.s, daff.s};
@@ -209,9 +209,9 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
         // ------------------------------------------------------------ step (:927-932)
         double alpha = 1.0;
         if (m > 0) {
-            double a_v, a_s;
-            CK(cip_maxstep_dev(h, z.v, dz.v, 1.0 / (1.0 - o.DTB), &a_v));
-            CK(cip_maxstep_dev(h, z.s, dz.s, 1.0 / (1.0 - o.DTB), &a_s));
+            double ap[2];
+            CK(cip_maxstep_pair_dev(h, z.v, dz.v, z.s, dz.s, 1.0 / (1.0 - o.DTB), ap));
+            const double a_v = ap[0], a_s = ap[1];
             alpha = std::fmin(std::fmin(a_v, 1.0), std::fmin(a_s, 1.0));
         }
         CK(D.axpby(D.NT, -alpha, dz.base, 1.0, z.base));

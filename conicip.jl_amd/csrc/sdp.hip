@@ -937,6 +937,26 @@ int cip_sdp_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const dou
     }
     return 0;
 }
+// both sides of a pair: the small cones one side after the other (they share their scratch), the large ones side by side
+int cip_sdp_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const double *d1, double *p1, const double *x2,
+                     const double *d2, double *p2, double scale) {
+    int rc;
+    if (cs.nlarge == 0 || !cip_sdp_large_pairable(cs.lg)) {
+        if ((rc = cip_sdp_maxstep(s, cs, x1, d1, scale, p1))) return rc;
+        return cip_sdp_maxstep(s, cs, x2, d2, scale, p2);
+    }
+    ConeSet small = cs;                                            // (a view: same buffers, no large cones)
+    small.nlarge = 0;
+    if ((rc = cip_sdp_maxstep(s, small, x1, d1, scale, p1))) return rc;
+    if ((rc = cip_sdp_maxstep(s, small, x2, d2, scale, p2))) return rc;
+    hipStream_t s2;
+    if ((rc = cip_sdp_large_fork(s, cs.lg, &s2))) return rc;
+    for (int li = 0; li < cs.nlarge; ++li)
+        if ((rc = cip_sdp_large_maxstep(s, cs.lg, cs.h_cones[cs.large_cone[li]], x1, d1, scale, p1, 0))) return rc;
+    for (int li = 0; li < cs.nlarge; ++li)
+        if ((rc = cip_sdp_large_maxstep(s2, cs.lg, cs.h_cones[cs.large_cone[li]], x2, d2, scale, p2, 1))) return rc;
+    return cip_sdp_large_join(s, cs.lg);
+}
 int cip_sdp_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, long ldat, double *Wt, long ldwt) {
     if (cs.ns_small > 0) {
         const int gx = n < cs.sdp_slots / cs.ns ? n : cs.sdp_slots / cs.ns;

@@ -53,6 +53,8 @@ struct LargeWs {
     unsigned *ctr;                 // barrier counters / sweep flags (256 words)
     void *ldl_z = nullptr, *ldl_s = nullptr;
     LdltWorkspace wz, ws;
+    hipStream_t s2 = nullptr;      // the s-side max-step of a pair runs here, beside the v-side one on the handle's stream
+    hipEvent_t efork = nullptr, ejoin = nullptr;
 };
 
 __device__ __forceinline__ int lg_vidx(int i, int j, int r) { return i * r - i * (i - 1) / 2 + (j - i); }   // i <= j
@@ -542,6 +544,9 @@ int cip_sdp_large_create(int rmax_large, int nlarge, LargeWs **out) {
 }
 void cip_sdp_large_destroy(LargeWs *w) {
     if (!w) return;
+    if (w->s2) (void)hipStreamDestroy(w->s2);
+    if (w->efork) (void)hipEventDestroy(w->efork);
+    if (w->ejoin) (void)hipEventDestroy(w->ejoin);
     if (const char *e = getenv("CIP_LG_LANCZOS_STATS")) {
         if (atoi(e)) {
             int st[40];
@@ -1171,43 +1176,66 @@ int cip_sdp_large_lanczos(int on) {
     if (on == 0 || on == 1) mode.store(on);
     return prev;
 }
+// The two max-steps of a pair (v side, s side: src/ConicIP.jl:708-709, :881-882, :927-928) are independent: side 1 works in the
+// NT scaling's s-side buffers (Ks, its LDL' workspace, Tz / Ts / G as M1 / M2 / M3 -- all idle between scalings) on a second
+// stream.  Orders <= 256 only (the cooperative tridiagonalisation above that shares `vec` and `ctr`).
+bool cip_sdp_large_pairable(const LargeWs *w) { return w && w->rp <= 256 && cip_sdp_large_lanczos(-1); }
+int cip_sdp_large_fork(hipStream_t s, LargeWs *w, hipStream_t *s2) {
+    if (!w->s2) {
+        CIP_HIP_CHECK(hipStreamCreateWithFlags(&w->s2, hipStreamNonBlocking));
+        CIP_HIP_CHECK(hipEventCreateWithFlags(&w->efork, hipEventDisableTiming));
+        CIP_HIP_CHECK(hipEventCreateWithFlags(&w->ejoin, hipEventDisableTiming));
+    }
+    CIP_HIP_CHECK(hipEventRecord(w->efork, s));
+    CIP_HIP_CHECK(hipStreamWaitEvent(w->s2, w->efork, 0));
+    *s2 = w->s2;
+    return 0;
+}
+int cip_sdp_large_join(hipStream_t s, LargeWs *w) {
+    CIP_HIP_CHECK(hipEventRecord(w->ejoin, w->s2));
+    CIP_HIP_CHECK(hipStreamWaitEvent(s, w->ejoin, 0));
+    return 0;
+}
 // maxstep_sdc for one large cone: partial[cd.item]
 int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *d, double scale,
-                          double *partial) {
+                          double *partial, int side) {
     const int r = cd.r, rp = w->rp;
     const long n2 = (long)rp * rp;
     int rc;
     double *dg = w->vec + 1 * rp, *of = w->vec + 2 * rp;
+    double *const Kx = side ? w->Ks : w->Kz, *const M1 = side ? w->Tz : w->M1, *const M2 = side ? w->Ts : w->M2, *const M3 = side ? w->G : w->M3;
+    LdltWorkspace &wx = side ? w->ws : w->wz;
+    int *const stat = (int *)(w->ctr + 200 + side);
     // CIP_LG_LANCZOS=0: the full tridiagonalisation + Sturm multisection at every order (A/B runs, tests)
     const bool lz = cip_sdp_large_lanczos(-1) && r <= 256;
     if (lz && (rc = lg_set_attr((const void *)k_lg_lanczos1, LZ_LDS_DOUBLES * sizeof(double)))) return rc;
     if (!d) {                                                                       // maxstep_sdc(x, nothing) :295-303
-        hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, x + cd.off, 1L, 0L, w->M3, r, rp, 0.0);
+        hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, x + cd.off, 1L, 0L, M3, r, rp, 0.0);
         if (lz) {
-            hipLaunchKernelGGL(k_lg_lanczos1, dim3(1), dim3(512), LZ_LDS_DOUBLES * sizeof(double), s, w->M3, rp, (const double *)nullptr, r, 0,
-                               1.0, (const int *)nullptr, partial, cd.item, w->M1, (int *)(w->ctr + 200));
+            hipLaunchKernelGGL(k_lg_lanczos1, dim3(1), dim3(512), LZ_LDS_DOUBLES * sizeof(double), s, M3, rp, (const double *)nullptr, r, 0,
+                               1.0, (const int *)nullptr, partial, cd.item, M1, stat);
             CIP_HIP_CHECK(hipGetLastError());
             return 0;
         }
-        if ((rc = lg_tridiag(s, w, w->M3, nullptr, r))) return rc;
+        if ((rc = lg_tridiag(s, w, M3, nullptr, r))) return rc;
         hipLaunchKernelGGL(k_lg_sturm, dim3(1), dim3(LG_T), 0, s, dg, of, r, 0, 1.0, (const int *)nullptr, partial, cd.item);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, x + cd.off, 1L, 0L, w->Kz, r, rp, 1.0);
-    if ((rc = cip_ldlt_factor(s, w->Kz, rp, rp, w->wz))) return rc;                 // X = L D L'
-    hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, d + cd.off, 1L, 0L, w->M1, r, rp, 0.0);
-    const double *Xi = (w->wz.Bs == CIP_NB) ? w->wz.Linv : w->wz.X;                // inv(L_unit)
-    if ((rc = lg_gemm(s, w->M2, 0, Xi, 0, w->M1, 0, rp, 1))) return rc;             // inv(L) D        (D symmetric)
-    if ((rc = lg_gemm(s, w->M3, 0, w->M2, 0, Xi, 0, rp, 1))) return rc;             // inv(L) D inv(L)'
+    hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, x + cd.off, 1L, 0L, Kx, r, rp, 1.0);
+    if ((rc = cip_ldlt_factor(s, Kx, rp, rp, wx))) return rc;                 // X = L D L'
+    hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, d + cd.off, 1L, 0L, M1, r, rp, 0.0);
+    const double *Xi = (wx.Bs == CIP_NB) ? wx.Linv : wx.X;                // inv(L_unit)
+    if ((rc = lg_gemm(s, M2, 0, Xi, 0, M1, 0, rp, 1))) return rc;             // inv(L) D        (D symmetric)
+    if ((rc = lg_gemm(s, M3, 0, M2, 0, Xi, 0, rp, 1))) return rc;             // inv(L) D inv(L)'
     if (lz) {                                                                       // ... scaled by d^-1/2 on both sides
-        hipLaunchKernelGGL(k_lg_lanczos1, dim3(1), dim3(512), LZ_LDS_DOUBLES * sizeof(double), s, w->M3, rp, (const double *)w->wz.dvec, r, 1,
-                           scale, (const int *)w->wz.info, partial, cd.item, w->M1, (int *)(w->ctr + 200));
+        hipLaunchKernelGGL(k_lg_lanczos1, dim3(1), dim3(512), LZ_LDS_DOUBLES * sizeof(double), s, M3, rp, (const double *)wx.dvec, r, 1,
+                           scale, (const int *)wx.info, partial, cd.item, M1, stat);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    if ((rc = lg_tridiag(s, w, w->M3, w->wz.dvec, r))) return rc;
-    hipLaunchKernelGGL(k_lg_sturm, dim3(1), dim3(LG_T), 0, s, dg, of, r, 1, scale, (const int *)w->wz.info, partial, cd.item);
+    if ((rc = lg_tridiag(s, w, M3, wx.dvec, r))) return rc;
+    hipLaunchKernelGGL(k_lg_sturm, dim3(1), dim3(LG_T), 0, s, dg, of, r, 1, scale, (const int *)wx.info, partial, cd.item);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -153,6 +153,11 @@ int cip_apply_F_dev(cip_handle *h, int mode, const double *x, double *out);     
 int cip_cone_prod_dev(cip_handle *h, const double *x, const double *y, double *out);     /* src/ConicIP.jl:637-665 */
 int cip_cone_div_dev(cip_handle *h, const double *x, const double *y, double *out);      /* src/ConicIP.jl:607-635: solve y o out = x */
 int cip_maxstep_dev(cip_handle *h, const double *x, const double *d, double scale, double *alpha_host); /* src/ConicIP.jl:571-587; d == NULL -> the `nothing` variant; steps along d*scale */
+/* the pair the interior-point loop always asks for together (src/ConicIP.jl:708-709, :881-882, :927-928): alpha_host2[0] =
+ * maxstep(x1, d1 * scale), alpha_host2[1] = maxstep(x2, d2 * scale), one wait; with S cones of order 133..256 the two sides run
+ * side by side on two streams.  Same values as two cip_maxstep_dev calls. */
+int cip_maxstep_pair_dev(cip_handle *h, const double *x1, const double *d1, const double *x2, const double *d2, double scale,
+                         double *alpha_host2);
 int cip_cone_identity_dev(cip_handle *h, double *e);                                     /* src/ConicIP.jl:559-565 */
 
 /* ---- vector helpers for a device-resident driver loop (device pointers) */
