@@ -221,3 +221,21 @@ def test_lanczos_maxstep_against_lapack_on_hard_spectra(r):
                 assert got == pytest.approx(ref, rel=1e-10, abs=1e-12), (name, what, got, ref)
                 assert got == pytest.approx(tri, rel=1e-10, abs=1e-12), (name, what, got, tri)
     ks.close()
+
+
+@pytest.mark.parametrize("cone_dims", [[("R", 700)], [("Q", 40), ("R", 9), ("S", 6)], [("S", 200 * 201 // 2)],
+                                       [("R", 5), ("S", 150 * 151 // 2), ("S", 10)]])
+def test_maxstep_pair_equals_two_calls(cone_dims):
+    """cip_maxstep_pair_dev -- the pair the loop asks for together (src/ConicIP.jl:708-709, :881-882, :927-928); with a large S
+    cone its two sides run on two streams in the NT scaling's idle buffers -- returns exactly what two cip_maxstep_dev calls do."""
+    import cipkkt
+    m = sum(k for _, k in cone_dims)
+    ks = cipkkt.KKTSystem(np.eye(2), np.zeros((m, 2)), None, cone_dims)
+    rng = np.random.default_rng(m)
+    for rep in range(3):
+        v, s = dev(interior(cone_dims, rng)), dev(interior(cone_dims, rng))
+        dv, ds = dev(rng.standard_normal(m)), dev(rng.standard_normal(m))
+        for scale in (1.0, 1.0 / 0.99):
+            assert ks.maxstep_pair(v, dv, s, ds, scale) == (ks.maxstep(v, dv, scale), ks.maxstep(s, ds, scale))
+        assert ks.maxstep_pair(dv, None, ds, None) == (ks.maxstep(dv, None), ks.maxstep(ds, None))
+    ks.close()
