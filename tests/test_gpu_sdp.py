@@ -177,6 +177,7 @@ def test_lanczos_maxstep_against_lapack_on_hard_spectra(r):
     (sdp_large.hip: k_lg_lanczos1) instead of a full tridiagonalisation.  Spectra chosen against it: a tight cluster at the
     wanted end, a dense edge (semicircle: the slowest case, close to a complete tridiagonalisation), an exactly repeated extreme
     eigenvalue, one isolated outlier, a multiple of the identity (breakdown at the first step), a rank-one perturbation of it;
+    a negative definite and a zero direction (no bound: Inf);
     both variants of maxstep_sdc (src/ConicIP.jl:272-303) against LAPACK at 1e-10, and against the library's own
     tridiagonalisation + Sturm path (cip_set_sdp_lanczos(0))."""
     import cipkkt
@@ -197,6 +198,8 @@ def test_lanczos_maxstep_against_lapack_on_hard_spectra(r):
         "outlier": np.concatenate([np.linspace(0.9, 1.1, r - 1), [40.0]]),
         "identity": np.full(r, 3.0),
         "identity + rank one": None,
+        "negative definite": -(0.5 + rng.random(r)),                   # no step bound: Inf (src/ConicIP.jl:288-290)
+        "zero": np.zeros(r),
     }
     for name, lam in spectra.items():
         if name == "semicircle":
