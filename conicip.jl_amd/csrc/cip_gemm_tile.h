@@ -244,10 +244,6 @@ __device__ __forceinline__ unsigned gemm_tile_64_k128_grp(const GemmArgs &g, dou
     const double *Bp = g.B + j0 + 2 * rp;
     const long rowo = i0 + wm * 32 + 2 * l15;
     v2d cpre[2][4];
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cpre[tj][q] = *(const v2d *)(g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * q) + tj) * g.ldc);
     v2d ra[16], rb[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -274,6 +270,13 @@ __device__ __forceinline__ unsigned gemm_tile_64_k128_grp(const GemmArgs &g, dou
         }
         if (QUEUE && qt == 3 && gt == 0) *(volatile unsigned *)slot = nxt;
         grp_barrier(bar);
+        if (qt == 1) {
+            // the C tile: fetched once half of the staging registers are free again, two quarters of MFMAs ahead of its use
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cpre[tj][q] = *(const v2d *)(g.C + rowo + (j0 + wn * 32 + 2 * (l4 + 4 * q) + tj) * g.ldc);
+        }
         if (qt < 3) {
             double *na = lds + ((qt + 1) & 1) * (64 * SB), *nb = na + 32 * SB;
 #pragma unroll
