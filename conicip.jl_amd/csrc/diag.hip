@@ -536,22 +536,29 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
         // 16-byte loads that bypass the non-coherent caches (buffer load with the sc1 policy bit = agent scope)
         typedef int v4i_t __attribute__((ext_vector_type(4)));
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)Kb, 0, 0x7fffffff, 0x00020000);
-        if (NW == 4 || tid < 256) {
-            v4i_t t[32];
+        {
+            // every wave of the workgroup takes part (eight waves: 16 loads per thread instead of 32 on four), and the pairs
+            // that lie wholly above the diagonal are not fetched at all
+            constexpr int LT = (NW == 4) ? 256 : 512, PER = 8192 / LT;
+            if (tid < LT) {
+                v4i_t t[PER];
 #pragma unroll
-            for (int q = 0; q < 32; ++q) {
-                const int e = q * 256 + tid;                         // pair index: rows 2*(e&63), +1 ; column e>>6
-                const long off = (2 * (e & 63) + (long)(e >> 6) * ld) * 8;
-                t[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);
-            }
+                for (int q = 0; q < PER; ++q) {
+                    const int e = q * LT + tid;                      // pair index: rows 2*(e&63), +1 ; column e>>6
+                    const int i = 2 * (e & 63), j = e >> 6;
+                    const long off = (i + (long)j * ld) * 8;
+                    t[q] = (v4i_t){0, 0, 0, 0};
+                    if (i + 1 >= j) t[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);
+                }
 #pragma unroll
-            for (int q = 0; q < 32; ++q) {
-                const int e = q * 256 + tid;
-                const int i = 2 * (e & 63), j = e >> 6;
-                v2d v = __builtin_bit_cast(v2d, t[q]);
-                if (i < j) v.x = 0.0;                                // strictly upper part -> 0
-                if (i + 1 < j) v.y = 0.0;
-                *(v2d *)(a + i + j * DP) = v;
+                for (int q = 0; q < PER; ++q) {
+                    const int e = q * LT + tid;
+                    const int i = 2 * (e & 63), j = e >> 6;
+                    v2d v = __builtin_bit_cast(v2d, t[q]);
+                    if (i < j) v.x = 0.0;                            // strictly upper part -> 0
+                    if (i + 1 < j) v.y = 0.0;
+                    *(v2d *)(a + i + j * DP) = v;
+                }
             }
         }
     } else if (!(DIAG_SKIP & 16) && (NW == 4 || tid < 256)) diag_load_block(a, Kb, ld, tid);
