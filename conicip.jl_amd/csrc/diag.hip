@@ -724,12 +724,13 @@ __global__ __launch_bounds__(256) void k_ldlt_diag_upd(double *Kb, long ld, doub
 //                        once stage >= PANEL_NH (kb + 1):  W[:,kb] = T_kb inv(L11[kb][kb])',  T_{kb+1} = A21[:,kb+1] - sum W[:,q] L11[kb+1][q]'
 //   the others           (UPD) the remaining tiles of the in-block update
 // The same operations on the same operands in the same order as the separate launches: bit-identical factors.
-// Who waits for whom inside the launch: the strips wait for workgroup 0 (lower index: dispatched earlier); workgroup 0 waits for
-// the producers 1..9 -- HIGHER indices, dispatched right behind it: forward progress relies on the launch's first ten
-// workgroups becoming resident together, which holds when the chain has the chip to itself (one launch at a time on the
-// handle's stream) and, in small lock-step groups, while every problem's long-lived workgroups fit on the chip at once
-// (ldlt.hip: factor_outer_panels checks that against the device's CU count).  Every wait is bounded (~1 s of shader clock)
-// and then raises info[3] instead of hanging.
+// Who waits for whom inside the launch: the strips wait for workgroup 0 (lower index: dispatched earlier, so resident or
+// done); workgroup 0 waits for the producers 1..9 -- HIGHER indices, dispatched right behind it.  Workgroups are dispatched
+// in index order (x, then z = the problem of a lock-step group): the only thing that can stand between a workgroup 0 and its
+// producers is a chip full of EARLIER workgroups, all of which can finish without them (the first problem's group is always
+// complete on the chip), so every wait ends; with the chain alone on the handle's stream the ten are resident at once and
+// the wait is the producers' own time.  Lock-step groups of up to ~4 rounds of the chip take this launch too (ldlt.hip:
+// factor_outer_panels).  Every wait is bounded (~1 s of shader clock) and then raises info[3] instead of hanging.
 #ifndef PANEL_WAVES
 #define PANEL_WAVES 8                   // waves of a k_ldlt_panel workgroup: the diagonal kernel's; the other roles use the first four
 #endif

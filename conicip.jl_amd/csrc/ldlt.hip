@@ -236,19 +236,20 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
         // diagonal kernel's launch also carries the previous panel's in-block update (diag.hip: k_ldlt_diag_upd).
         GemmArgs gu;
         fuse_env();
-        // fused only when the chain has the chip to itself: a lock-step batch is throughput-bound and wants its tiles' occupancy
-        // ... except small lock-step groups, which take the one-launch-per-panel form too (grid.z = problems): while every
-        // problem's long-lived workgroups (diagonal kernel + strips: 1 + Npad / 64 at the first panel) fit on the chip at once
-        // the launch takes one round -- 4 / 8 / 12 problems of order 2048: 18.7 -> 16.4, 23.3 -> 21.0, 27.9 -> 27.0 ms per pass;
-        // 16 problems run in two rounds and lose against their three batched launches (31.6 -> 32.9)
-        static const int lsmax = [] { const char *e = getenv("CIP_LOCKSTEP_PANEL_MAX"); return e ? atoi(e) : 12; }();
-        // every problem's diagonal kernel, producers and strips (one 160-KB workgroup per CU) must be resident at once: the
-        // limit is the device's CU count (CIP_LOCKSTEP_PANEL_CUS overrides)
+        // fused when the chain has the chip to itself -- and in lock-step groups (grid.z = problems) while the group's
+        // long-lived workgroups (diagonal kernel, producers, strips: 10 + Npad / 64 per problem at the first panel) are no more
+        // than about four rounds of the chip: order 2048, 8 / 16 / 24 problems 19.9 -> 17.8, 28.0 -> 26.5, 37.6 -> 37.1 ms per
+        // pass against the three batched launches per panel, 32 problems equal, 64 problems 83 -> 86 (a big batch is
+        // throughput-bound and wants the tiles' occupancy).  Residency is a matter of speed, not of progress: a strip waits
+        // for its own problem's workgroup 0 only, which was dispatched before it; a workgroup 0 waits for its producers, which
+        // follow it in dispatch order and find a CU as soon as any earlier problem's workgroups retire -- and the first
+        // problem's always can.
+        static const int lsmax = [] { const char *e = getenv("CIP_LOCKSTEP_PANEL_MAX"); return e ? atoi(e) : 32; }();
         static const int lscus = [] {
             if (const char *e = getenv("CIP_LOCKSTEP_PANEL_CUS")) return atoi(e);
             int dev = 0, cus = 256;
             if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            return cus;
+            return 4 * cus;
         }();
         const bool small_group = cip_in_batch() && g_fuse_diag == 3 && cip_tl_bz.B <= lsmax && (long)cip_tl_bz.B * (10 + Npad / 64) <= lscus;
         const bool fuse = g_fuse_diag && (!cip_in_batch() || small_group);
