@@ -448,7 +448,7 @@ int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const d
 }
 int cip_cones_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const double *d1, const double *x2, const double *d2,
                        double scale, double *alpha_host2) {
-    if (cs.nitems == 0 || cip_in_batch() || !cs.has_S) {           // nothing to overlap: two plain calls
+    if (cs.nitems == 0 || cip_in_batch()) {                        // (a lock-step group gathers per problem: two plain calls)
         const int B = cip_tl_bz.B > 1 ? cip_tl_bz.B : 1;
         int rc = cip_cones_maxstep(s, cs, x1, d1, scale, alpha_host2);
         if (rc) return rc;
@@ -458,8 +458,7 @@ int cip_cones_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const
     cip_launch_b(k_maxstep, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x1, d1, scale, p1);
     cip_launch_b(k_maxstep, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x2, d2, scale, p2);
     CIP_HIP_CHECK(hipGetLastError());
-    int rc = cip_sdp_maxstep2(s, cs, x1, d1, p1, x2, d2, p2, scale);
-    if (rc) return rc;
+    if (cs.has_S) { const int rc = cip_sdp_maxstep2(s, cs, x1, d1, p1, x2, d2, p2, scale); if (rc) return rc; }
     cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)p1, cs.nslots, cs.d_scalar, (double *)nullptr);
     cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)p2, cs.nslots, cs.d_scalar + 1, (double *)nullptr);
     CIP_HIP_CHECK(hipGetLastError());
