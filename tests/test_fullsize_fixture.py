@@ -28,6 +28,9 @@ def test_fixture_is_complete():
     assert all(b < a for a, b in zip(mus[1:], mus[2:]))          # mu decreases once the loop is under way
     c3 = d["c3_socp_seed11"]
     assert c3["status"] == "Optimal" and c3["kktsolver"] == "kktsolver_qr" and len(c3["trace"]) == c3["Iter"]
+    c4 = d["c4_sdp_r256_seed5"]
+    assert (c4["status"], c4["r"], c4["n"], c4["p"]) == ("Optimal", 256, 1024, 16) and c4["kktsolver"] == "kktsolver_schur_exact"
+    assert len(c4["trace"]) == c4["Iter"] and len(c4["v"]) == 64
     c5 = d["c5_n2048_seed4000"]["problems"]
     assert sorted(map(int, c5)) == list(range(64)) and all(p["status"] == "Optimal" for p in c5.values())
 

@@ -136,12 +136,20 @@ def test_c4_sdp_vs_oracle(r, n, p):
 
 
 def test_c4_sdp_r256_full_size():
-    """The literal reading of config 4: matrix order 256, ("S", 32896), n = 1024, p = 16."""
+    """The literal reading of config 4: matrix order 256, ("S", 32896), n = 1024, p = 16: the oracle's trajectory (fixture:
+    the exact block elimination of the 3x3 system, oracle.kktsolvers.kktsolver_schur_exact -- kktsolver_qr's dense F would be
+    32896 x 32896) with both loops, and the optimality conditions of the returned point."""
     import cipkkt
     prob = W.c4_sdp(r=256, n=1024, p=16, seed=5)
     sol = cipkkt.conicIP(*prob, optTol=1e-6)
     assert sol.status == "Optimal"
     check_optimality(*prob, sol, 2e-5)
+    fx = FULLSIZE["c4_sdp_r256_seed5"]
+    # n_solve: the oracle's plugin counts its solves the same way; the iterates agree to 1e-6 (the S-cone scaling is unique up
+    # to an orthogonal factor only, its invariants are what the loop sees)
+    assert_same_trajectory(sol, fx, "c4 r=256, native loop")
+    py = cipkkt.conicIP(*prob, optTol=1e-6, driver="python")
+    assert_same_trajectory(py, fx, "c4 r=256, per-operation loop")
 
 
 def test_c5_all_64_problems():
