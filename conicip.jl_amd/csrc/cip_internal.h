@@ -105,6 +105,16 @@ struct GemmArgs {
 };
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g);
 
+// ---------------------------------------------------------------- small results back to the host (vecops.hip)
+// The loop's scalars (max-step minima, dot products, the lock-step gather) are a few doubles the host must SEE before it can go
+// on: a D2H copy into pageable memory is a staging kernel in front of the wait (eleven of them per iteration in the kernel trace).
+// Instead: the reduction kernel stores straight into host-mapped pinned memory (one per host thread), the host records an event
+// behind it and spins on it (0.0561 -> 0.0552 s to converge at n = 8192; spinning itself measures the same as a blocking
+// hipStreamSynchronize on this stack: CIP_SPIN_WAIT=0).
+struct CipHostScratch { double *host; double *dev; };       // 512 doubles; host == what the GPU wrote once cip_wait(s) has returned
+int cip_host_scratch(CipHostScratch *out);
+int cip_wait(hipStream_t s);
+
 // ---------------------------------------------------------------- LDL' (ldlt.hip)
 struct LdltProfile;           // optional per-launch event timing of the trailing-update kernel (ldlt.hip)
 LdltProfile *cip_ldlt_profile_create(void);

@@ -433,17 +433,20 @@ int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const d
     CIP_HIP_CHECK(hipGetLastError());
     if (cs.has_S) { int rc = cip_sdp_maxstep(s, cs, x, d, scale, cs.d_partial); if (rc) return rc; }
     const CipBatchCtx &bc = cip_tl_bz;
-    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)cs.d_partial, cs.nslots, cs.d_scalar,
+    CipHostScratch hs;
+    int rc;
+    if ((rc = cip_host_scratch(&hs))) return rc;
+    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)cs.d_partial, cs.nslots, bc.B > 1 ? cs.d_scalar : hs.dev,
                  bc.B > 1 ? bc.gather_dev : (double *)nullptr);
     CIP_HIP_CHECK(hipGetLastError());
     if (bc.B > 1) {                          // alpha_host: B values
         CIP_HIP_CHECK(hipMemcpyAsync(bc.gather_host, bc.gather_dev, sizeof(double) * bc.B * CIP_GATHER, hipMemcpyDeviceToHost, s));
-        CIP_HIP_CHECK(hipStreamSynchronize(s));
+        if ((rc = cip_wait(s))) return rc;
         for (int z = 0; z < bc.B; ++z) alpha_host[z] = bc.gather_host[z * CIP_GATHER];
         return 0;
     }
-    CIP_HIP_CHECK(hipMemcpyAsync(alpha_host, cs.d_scalar, sizeof(double), hipMemcpyDeviceToHost, s));
-    CIP_HIP_CHECK(hipStreamSynchronize(s));
+    if ((rc = cip_wait(s))) return rc;       // the minimum went straight into the host-mapped scratch
+    alpha_host[0] = hs.host[0];
     return 0;
 }
 int cip_cones_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const double *d1, const double *x2, const double *d2,
@@ -459,11 +462,14 @@ int cip_cones_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const
     cip_launch_b(k_maxstep, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x2, d2, scale, p2);
     CIP_HIP_CHECK(hipGetLastError());
     if (cs.has_S) { const int rc = cip_sdp_maxstep2(s, cs, x1, d1, p1, x2, d2, p2, scale); if (rc) return rc; }
-    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)p1, cs.nslots, cs.d_scalar, (double *)nullptr);
-    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)p2, cs.nslots, cs.d_scalar + 1, (double *)nullptr);
+    CipHostScratch hs;
+    int rc;
+    if ((rc = cip_host_scratch(&hs))) return rc;
+    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)p1, cs.nslots, hs.dev, (double *)nullptr);
+    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)p2, cs.nslots, hs.dev + 1, (double *)nullptr);
     CIP_HIP_CHECK(hipGetLastError());
-    CIP_HIP_CHECK(hipMemcpyAsync(alpha_host2, cs.d_scalar, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-    CIP_HIP_CHECK(hipStreamSynchronize(s));
+    if ((rc = cip_wait(s))) return rc;       // both minima went straight into the host-mapped scratch
+    alpha_host2[0] = hs.host[0]; alpha_host2[1] = hs.host[1];
     return 0;
 }
 int cip_cones_identity(hipStream_t s, const ConeSet &cs, double *e) {

@@ -251,7 +251,7 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
     auto eject_bad_pivots = [&](bool read_back, unsigned long long fmask) -> int {
         if (read_back) {
             CIP_HIP_CHECK(hipMemcpyAsync(G.gather_host, G.gather_dev, gather_bytes, hipMemcpyDeviceToHost, s));
-            CIP_HIP_CHECK(hipStreamSynchronize(s));
+            { const int rcw = cip_wait(s); if (rcw) return rcw; }
         }
         for (int z = 0; z < B; ++z) {
             if (!((fmask >> z) & 1ull)) continue;

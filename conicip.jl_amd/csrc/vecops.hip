@@ -214,19 +214,62 @@ int cip_dots(hipStream_t s, int count, const double *const *x_host, const double
     double *out = scratch_dev + DOT_MAX * DOT_NB;
     const CipBatchCtx &bc = cip_tl_bz;
     cip_launch_b(k_dots1, dim3(DOT_NB, count), dim3(256), 0, s, (const DotPtrs *)ptrs_dev, partial);
-    cip_launch_b(k_dots2, dim3(count), dim3(64), 0, s, (const double *)partial, out, bc.B > 1 ? bc.gather_dev : (double *)nullptr);
+    CipHostScratch hs;
+    int rc;
+    if ((rc = cip_host_scratch(&hs))) return rc;
+    const bool direct = bc.B <= 1 && count <= 512;                 // one problem: the sums go straight to the host
+    cip_launch_b(k_dots2, dim3(count), dim3(64), 0, s, (const double *)partial, direct ? hs.dev : out, bc.B > 1 ? bc.gather_dev : (double *)nullptr);
     CIP_HIP_CHECK(hipGetLastError());
     if (bc.B > 1) {
         // out_host: B x count, problem-major; masked-off problems keep whatever the gather buffer held (callers ignore them)
         CIP_HIP_CHECK(hipMemcpyAsync(bc.gather_host, bc.gather_dev, sizeof(double) * bc.B * CIP_GATHER, hipMemcpyDeviceToHost, s));
-        CIP_HIP_CHECK(hipStreamSynchronize(s));
+        if ((rc = cip_wait(s))) return rc;
         for (int z = 0; z < bc.B; ++z)
             for (int i = 0; i < count; ++i) out_host[z * count + i] = bc.gather_host[z * CIP_GATHER + i];
         return 0;
     }
-    CIP_HIP_CHECK(hipMemcpyAsync(out_host, out, sizeof(double) * count, hipMemcpyDeviceToHost, s));
-    CIP_HIP_CHECK(hipStreamSynchronize(s));
+    if (!direct) CIP_HIP_CHECK(hipMemcpyAsync(out_host, out, sizeof(double) * count, hipMemcpyDeviceToHost, s));
+    if ((rc = cip_wait(s))) return rc;
+    if (direct) for (int i = 0; i < count; ++i) out_host[i] = hs.host[i];
     return 0;
+}
+
+// ---- small results back to the host (cip_internal.h)
+#include <stdlib.h>
+struct HostScratchTL {
+    double *host = nullptr, *dev = nullptr;
+    hipEvent_t ev = nullptr;
+    ~HostScratchTL() { if (ev) (void)hipEventDestroy(ev); if (host) (void)hipHostFree(host); }
+};
+static thread_local HostScratchTL g_tl_scratch;
+static int scratch_init(void) {
+    HostScratchTL &t = g_tl_scratch;
+    if (t.host) return 0;
+    void *p = nullptr, *d = nullptr;
+    CIP_HIP_CHECK(hipHostMalloc(&p, 512 * sizeof(double), hipHostMallocMapped));
+    CIP_HIP_CHECK(hipHostGetDevicePointer(&d, p, 0));
+    CIP_HIP_CHECK(hipEventCreateWithFlags(&t.ev, hipEventDisableTiming));
+    t.host = (double *)p; t.dev = (double *)d;
+    return 0;
+}
+int cip_host_scratch(CipHostScratch *out) {
+    const int rc = scratch_init();
+    if (rc) return rc;
+    out->host = g_tl_scratch.host; out->dev = g_tl_scratch.dev;
+    return 0;
+}
+int cip_wait(hipStream_t s) {
+    static const int spin = [] { const char *e = getenv("CIP_SPIN_WAIT"); return (e && atoi(e) == 0) ? 0 : 1; }();
+    if (!spin) { CIP_HIP_CHECK(hipStreamSynchronize(s)); return 0; }
+    const int rc = scratch_init();
+    if (rc) return rc;
+    CIP_HIP_CHECK(hipEventRecord(g_tl_scratch.ev, s));
+    for (;;) {
+        const hipError_t e = hipEventQuery(g_tl_scratch.ev);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) { CIP_HIP_CHECK(e); }
+        __builtin_ia32_pause();
+    }
 }
 
 __global__ __launch_bounds__(256) void k_axpby(int len, double alpha, const double *x, double beta, double *y, CipBatch cb) {
