@@ -243,3 +243,19 @@ def test_maxstep_pair_equals_two_calls(cone_dims):
             assert ks.maxstep_pair(v, dv, s, ds, scale) == (ks.maxstep(v, dv, scale), ks.maxstep(s, ds, scale))
         assert ks.maxstep_pair(dv, None, ds, None) == (ks.maxstep(dv, None), ks.maxstep(ds, None))
     ks.close()
+
+
+@pytest.mark.parametrize("r,n,p,seed", [(133, 64, 4, 919850), (192, 40, 4, 790518), (256, 24, 0, 639913)])
+def test_large_s_cone_programs_walk_the_oracles_trajectory(r, n, p, seed):
+    """Config 4's family on the large-cone path (orders 133..256: Lanczos max-step, the two max-steps of a pair side by side)
+    against the oracle with the exact block elimination: same status, same iteration count, iterates at 1e-8
+    (tools/fuzz_sdp.py draws more of them)."""
+    import cipkkt
+    from cipkkt import workloads as W
+    from oracle import kktsolvers as ok
+    prob = W.c4_sdp(r=r, n=n, p=p, seed=seed)
+    ref = oracle_conicIP(*prob, optTol=1e-6, kktsolver=ok.kktsolver_schur_exact)
+    got = cipkkt.conicIP(*prob, optTol=1e-6)
+    assert got.status == ref.status == "Optimal" and got.Iter == ref.Iter
+    np.testing.assert_allclose(got.y, ref.y, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(got.v, ref.v, rtol=1e-7, atol=1e-8)
