@@ -2,6 +2,8 @@
 # A/B of the diagonal kernel's step A on the GPU box: round 2's pivot-by-pivot form (-DDIAG_STEP_A_REF) against the
 # rank-4 blocked form -- time per launch and bit-identity of L, d and the micro inverses on three matrix classes.
 # usage (on the GPU box, from the repo root): bash tools/diag_ab.sh [outdir]
+# the three binaries are built in the build container (they travel with the snapshot):
+#   cd tools && for v in new:'' ref:-DDIAG_STEP_A_REF tim:-DDIAG_TIMING; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -w -I../include ${v#*:} -o diag_bench_${v%%:*} diag_bench.hip; done
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd); OUT=${1:-$R/gpurun_out/diag_ab}; mkdir -p $OUT
 for m in 0 1 2; do
