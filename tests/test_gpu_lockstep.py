@@ -186,10 +186,13 @@ def test_s_cones_in_lockstep():
     _assert_identical(lock, one)
 
 
-def test_config5_reduced_lockstep_matches_threads():
-    """BASELINE config 5 at reduced count: 8 x n = 2048 dense QPs generated in HBM; lock-step == thread pool, bit for bit"""
+@pytest.mark.parametrize("count", [8, 24])
+def test_config5_reduced_lockstep_matches_threads(count):
+    """BASELINE config 5 at reduced count: 8 / 24 x n = 2048 dense QPs generated in HBM (the per-rank shards at 8 GPUs, and a
+    group whose one-launch-per-panel chain is four rounds of the chip: 24 x 42 long-lived workgroups on 256 CUs);
+    lock-step == thread pool, bit for bit"""
     from cipkkt.workloads import c5_batch
-    prs = c5_batch(count=8, n=2048, seed=4000, device=torch.device("cuda:0"))
+    prs = c5_batch(count=count, n=2048, seed=4000, device=torch.device("cuda:0"))
     one = _solve(prs, "threads", in_flight=4)
     lock = _solve(prs, "lockstep")
     _assert_identical(lock, one)
