@@ -883,9 +883,19 @@ __device__ __forceinline__ void panel_tile_jobs(const GemmArgs &g, double *lds, 
         t = nstatic + *(volatile unsigned *)slot;
     }
     while (t < ntiles) {
-        int r = (int)t, j = 2;
-        while (r >= tm - j) { r -= tm - j; ++j; }
-        t = nstatic + gemm_tile_64_k128_grp<true>(g, lds, (long)(j + r) * SB, (long)j * SB, gt, bar, tileq, slot);
+        // index -> tile.  Column pairs (j, j + 1), j = 2, 4, ..: inside a pair the rows i > j, each as (i, j), (i, j + 1) -- two
+        // consecutive indices share their 64 KB of W rows, and the two groups of a worker workgroup start on such a couple
+        // (2 w, 2 w + 1): one fetch through the fabric instead of two in the first round, when everybody loads at once; behind
+        // all pairs the diagonal tiles (j, j), which have no partner (their right neighbour lies above the diagonal)
+        const int npair = (tn - 2) / 2;
+        int r = (int)t, ti = 0, tj = 0, p = 0;
+        for (; p < npair; ++p) {
+            const int j = 2 + 2 * p, n = 2 * (tm - j - 1);
+            if (r < n) { ti = j + 1 + (r >> 1); tj = j + (r & 1); break; }
+            r -= n;
+        }
+        if (p == npair) { tj = 2 + 2 * r; ti = tj; }               // r-th diagonal tile of an even column
+        t = nstatic + gemm_tile_64_k128_grp<true>(g, lds, (long)ti * SB, (long)tj * SB, gt, bar, tileq, slot);
     }
 }
 template <bool UPD>
