@@ -523,6 +523,10 @@ static int factor_enqueue(cip_handle *h) {
     if (h->timing) CIP_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
     {
         CipRange rg("cip:ldlt");
+        if (h->gx_factor && h->gx_factor_lazyC != h->ws.lazyC) {     // recorded under another lazy-copy state: record again
+            (void)hipGraphExecDestroy(h->gx_factor); h->gx_factor = nullptr;
+        }
+        h->gx_factor_lazyC = h->ws.lazyC;
         if ((rc = graph_run(h, &h->gx_factor, [&]() { return cip_ldlt_factor(h->stream, h->K, h->Npad, h->ldk, h->ws); }))) return rc;
     }
     h->n_factor += 1;
@@ -589,6 +593,7 @@ static int factor_resolve(cip_handle *h, bool wait) {
         info = h->info_host[2];
     }
     h->factored = false;
+    h->pivots_verified = false;      // keep waiting for the flag after a factorisation that failed
     cip_set_error("LDL': zero, non-finite or wrong-sign pivot at column %d%s", info,
                   h->reg_rel > 0.0 ? " (regularised factorisation)" : "");
     return CIP_E_SINGULAR;
@@ -616,6 +621,7 @@ extern "C" int cip_set_regularization(cip_handle *h, double rel, int automatic) 
     if (!h || !(rel >= 0.0)) { cip_set_error("cip_set_regularization: bad argument"); return CIP_E_INVALID; }
     h->reg_rel = rel;
     h->auto_reg = automatic != 0;
+    h->pivots_verified = false;      // a different matrix is factored from now on: the next *_dev solve waits for its flag again
     return 0;
 }
 extern "C" int cip_get_regularization(cip_handle *h, double *rel, int *times_switched_on) {
@@ -829,7 +835,11 @@ extern "C" int cip_solve4x4_dev(cip_handle *h, const double *lambda, const doubl
         const char *e = getenv("CIP_S4_FUSED");
         if (e && atoi(e) == 0) h->all_r = 0;
     }
-    if (h->all_r && h->route == CIP_ROUTE_SCHUR && h->reg_rel <= 0.0) {
+    // the fused kernels read r across threads (CSR gathers) while writing dz: an in-place call (dz overlapping r) takes the
+    // element-wise generic path, which tolerates it
+    const size_t len4 = (size_t)n + p + 2 * (size_t)m;
+    const bool aliased = dz < r + len4 && r < dz + len4;
+    if (h->all_r && !aliased && h->route == CIP_ROUTE_SCHUR && h->reg_rel <= 0.0) {
         // all cones R (F = diag(f), f = the packed scaling): the element-wise launches around the sweeps fused into one kernel
         // in front and one behind them (vecops.hip: k_s4_pre_r / k_s4_post_r), the same operations on every element
         if (!h->factored) { cip_set_error("cip_solve4x4: no factorisation (call cip_factor first)"); return CIP_E_NOTFACTORED; }

@@ -80,6 +80,10 @@ struct cip_handle {
 
     // ---- hipGraphs of the two launch-bound inner loops of small systems (opt-in, CIP_GRAPH=1; api.hip: graph_run)
     hipGraphExec_t gx_factor = nullptr, gx_solve = nullptr;
+    // what the recorded factorisation baked in besides the handle's fixed pointers: where the first trailing update reads
+    // its C operand (ws.lazyC: Q while the copy is lazy, else null).  A replay under another state would read stale data
+    // (ADVICE r3): factor_enqueue drops the graph and records a new one when it differs.
+    const double *gx_factor_lazyC = nullptr;
     int graph_state = 0;            // 0 undecided, 1 in use, -1 off (null stream, large system, capture failed, CIP_GRAPH=0)
 
     // ---- stats

@@ -951,11 +951,13 @@ int cip_sdp_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const d
     if ((rc = cip_sdp_maxstep(s, small, x2, d2, scale, p2))) return rc;
     hipStream_t s2;
     if ((rc = cip_sdp_large_fork(s, cs.lg, &s2))) return rc;
-    for (int li = 0; li < cs.nlarge; ++li)
-        if ((rc = cip_sdp_large_maxstep(s, cs.lg, cs.h_cones[cs.large_cone[li]], x1, d1, scale, p1, 0))) return rc;
-    for (int li = 0; li < cs.nlarge; ++li)
-        if ((rc = cip_sdp_large_maxstep(s2, cs.lg, cs.h_cones[cs.large_cone[li]], x2, d2, scale, p2, 1))) return rc;
-    return cip_sdp_large_join(s, cs.lg);
+    // (a failure between fork and join still joins: the forked stream must not be left running ahead of s)
+    for (int li = 0; li < cs.nlarge && rc == 0; ++li)
+        rc = cip_sdp_large_maxstep(s, cs.lg, cs.h_cones[cs.large_cone[li]], x1, d1, scale, p1, 0);
+    for (int li = 0; li < cs.nlarge && rc == 0; ++li)
+        rc = cip_sdp_large_maxstep(s2, cs.lg, cs.h_cones[cs.large_cone[li]], x2, d2, scale, p2, 1);
+    const int rj = cip_sdp_large_join(s, cs.lg);
+    return rc ? rc : rj;
 }
 int cip_sdp_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, long ldat, double *Wt, long ldwt) {
     if (cs.ns_small > 0) {

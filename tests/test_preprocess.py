@@ -82,14 +82,35 @@ def test_oracle_preprocess_infeasible():
     check_infeasible(o_pre)
 
 
-def test_product_imcols_matches_oracle():
+def test_product_imcols_properties():
+    """The product's `imcols` against what `src/preprocessor.jl:10-30` promises, not against the oracle's copy of the
+    same LAPACK call: the rows kept are independent, as many as the rank numpy computes on its own (SVD), every dropped
+    row lies in their span, and the consistency verdict is that of a least-squares residual."""
     from cipkkt.preprocess import imcols
     check_imcols(imcols)
     rng = np.random.default_rng(5)
-    A = rng.standard_normal((7, 5)) @ rng.standard_normal((5, 12))          # rank 5
-    b = A @ rng.standard_normal(12)
-    (r1, ok1), (r2, ok2) = imcols(A, b), o_imcols(A, b)
-    assert ok1 and ok2 and len(r1) == len(r2) == 5
+    for (mr, rk, nc) in [(7, 5, 12), (12, 3, 6), (9, 9, 9), (20, 4, 40), (6, 1, 3)]:
+        A = rng.standard_normal((mr, rk)) @ rng.standard_normal((rk, nc))
+        x0 = rng.standard_normal(nc)
+        rows, ok = imcols(A, A @ x0)
+        r = np.linalg.matrix_rank(A)
+        assert ok and len(rows) == r == rk and rows == sorted(set(rows))
+        sv = np.linalg.svd(A[rows], compute_uv=False)
+        assert sv[-1] > 1e-8 * sv[0]                                   # kept rows independent
+        others = [i for i in range(mr) if i not in rows]
+        if others:                                                     # dropped rows are combinations of the kept ones
+            coef = np.linalg.lstsq(A[rows].T, A[others].T, rcond=None)[0]
+            assert np.abs(A[rows].T @ coef - A[others].T).max() < 1e-9 * np.abs(A).max()
+        # inconsistent right-hand side: move b off the range of A (only possible when A has dependent rows)
+        if r < mr:
+            u = np.linalg.svd(A)[0][:, r]                              # a direction orthogonal to range(A)
+            assert imcols(A, A @ x0 + u) == ([], False)
+        # scaling of the data does not change the verdict (the reference normalises by ||A||, :14)
+        assert imcols(1e6 * A, 1e6 * (A @ x0))[0] == rows
+    # sparse input takes the same path
+    As = sp.csr_matrix(np.vstack([np.eye(4), np.eye(4)[:2]]))
+    rows, ok = imcols(As, np.array([1.0, 2, 3, 4, 1, 2]))
+    assert ok and len(rows) == 4 and np.linalg.matrix_rank(As.toarray()[rows]) == 4
 
 
 @pytest.mark.gpu
