@@ -113,6 +113,7 @@ SIGNATURES = {
     "cip_set_lazy_copy": (C.c_int, [C.c_int]),
     "cip_set_sdp_lanczos": (C.c_int, [C.c_int]),
     "cip_set_ldlt_fused_chain": (C.c_int, [C.c_int]),
+    "cip_set_ldlt_side_prep": (C.c_int, [C.c_int]),
     "cip_profile_trailing": (C.c_int, [C.c_void_p, C.c_int]),
     "cip_profile_get": (C.c_int, [C.c_void_p, c_double_p]),
 }

@@ -127,6 +127,41 @@ def c3_socp(n=4096, ncones=512, kq=8, p=512, seed=11):
     return np.eye(n), randn_np(seed + 2, n), A, b, [("Q", kq)] * ncones, G, np.zeros(p)
 
 
+def soc_single(n=500, seed=42, dense=False):
+    """The reference's "single large SOC" benchmark problem (benchmark/profile.jl:43-52; benchmark/report.md:57-59: 6
+    iterations on its draw): Q = I, c ~ N(0,1), A = [0; I] (sparse unless `dense`), b = [-1; 0], one ("Q", n+1) cone, i.e.
+    minimise 1/2 |y|^2 - c'y over the unit ball -- solution c / max(1, |c|)."""
+    import scipy.sparse as sp
+    A = sp.vstack([sp.csr_matrix((1, n)), sp.identity(n, format="csr")], format="csr")
+    b = np.zeros(n + 1)
+    b[0] = -1.0
+    return (sp.identity(n, format="csr") if not dense else np.eye(n)), randn_np(seed, n), (A.toarray() if dense else A), b, \
+        [("Q", n + 1)]
+
+
+def soc_many_small(n=500, k=250, seed=42, density=0.1):
+    """The reference's "many small SOCs" benchmark problem (benchmark/profile.jl:54-69; report.md:60-62: 9 iterations on
+    its draw): k cones ("Q", 3), A = sprandn(3k, n, 0.1), head rows b = -1, Q = I."""
+    import scipy.sparse as sp
+    m = 3 * k
+    mask = uniform_np(seed, m * n).reshape(m, n) < density
+    A = sp.csr_matrix(np.where(mask, randn_np(seed + 7, m, n), 0.0))
+    b = np.zeros(m)
+    b[::3] = -1.0
+    return sp.identity(n, format="csr"), randn_np(seed + 1, n), A, b, [("Q", 3)] * k
+
+
+def soc_large_dense(n=4096, seed=21):
+    """One ("Q", n+1) cone behind a DENSE A: head row zero with b = -1 (the bound), tail rows N(0,1)/sqrt(n), b = 0 --
+    |A_tail y| <= 1, strictly feasible at y = 0; Q = I.  The large-SOC case of SURVEY 8(f3) (src/kktsolvers.jl:60-131,
+    :192-240 treat such blocks specially): on the device the Q cone is two O(mn) passes beside the m n^2 SYRK."""
+    A = randn_np(seed, n + 1, n) / np.sqrt(n)
+    A[0, :] = 0.0
+    b = np.zeros(n + 1)
+    b[0] = -1.0
+    return np.eye(n), randn_np(seed + 2, n), A, b, [("Q", n + 1)]
+
+
 def vecm_identity(r):
     """vecm(I_r) (src/ConicIP.jl:128-151): ones at the diagonal positions of the row-major upper triangle."""
     e = np.zeros(r * (r + 1) // 2)

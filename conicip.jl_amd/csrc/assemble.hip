@@ -98,15 +98,33 @@ __global__ __launch_bounds__(256) void k_schur_rows(int n, const int *trp, const
                                                      const ConeDesc *cones, const double *scal, double *K, long ldk, int base, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO8(cb, trp, tci, tv, rp, ci, av, scal, K);
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // Round 4: one WAVE per variable i (it was one thread: n = 500 with a 10 %-dense A -- the reference's "many small SOCs"
+    // benchmark, benchmark/profile.jl:54-69 -- put 3750 dependent read-modify-writes on each of 500 threads, 2.3 ms beside a
+    // 0.19-ms factorisation).  The rows r of column i are still taken one after the other, ascending; the entries of row r
+    // (distinct columns j) go to the lanes.  Entry (i, j) therefore receives the same additions in the same order as
+    // before: bit-identical, no atomics.  Two rows may hit the same (i, j) from different lanes: the wave's accesses to K go
+    // to L2 (agent scope) and one row's stores are waited for before the next row's loads.
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
+    double *Ki = K + (base + i) + (long)base * ldk;
     for (int q = trp[i]; q < trp[i + 1]; ++q) {
         const int r = tci[q];
         const double wa = schur_row_weight(cones[row_cone[r]], scal, r) * tv[q];
-        for (int b = rp[r]; b < rp[r + 1]; ++b) {
+        const int b1 = rp[r + 1];
+        bool wrote = false;
+        for (int b = rp[r] + lane; b < b1; b += 64) {
             const int j = ci[b];
-            if (j <= i) K[(base + i) + (long)(base + j) * ldk] += wa * av[b];
+            if (j <= i) {
+                double *kp = Ki + (long)j * ldk;
+                double x = __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x += wa * av[b];
+                __hip_atomic_store(kp, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wrote = true;
+            }
         }
+        (void)wrote;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 // The same for an A with at most one entry per row and R cones only -- the Schur terms are then on the diagonal -- when the
@@ -176,7 +194,8 @@ __global__ __launch_bounds__(256) void k_fill_ftf(const ConeDesc *cones, const W
         }
     } else if (cd.type == CIP_CONE_Q) {
         // F'F = F^2 = beta^2 (2 wbar wbar' - J); a pack of small cones: the workgroup walks through its cones
-        const int ncone = it.width ? it.len : 1;
+        if (!it.width) return;                            // a large cone: k_fill_ftf_qbig
+        const int ncone = it.len;
         for (int q = 0; q < ncone; ++q) {
             const ConeDesc qc = cones[it.cone + q];
             const int k = qc.dim;
@@ -192,6 +211,29 @@ __global__ __launch_bounds__(256) void k_fill_ftf(const ConeDesc *cones, const W
                 if (i == j) v -= (i == 0) ? 1.0 : -1.0;
                 K[(qc.off + i) + (long)(qc.off + j) * ldk] = -b2 * v;
             }
+        }
+    }
+}
+// -F'F of a Q cone of dimension > 64: the k (k + 1) / 2 entries of its lower triangle by column, many workgroups (round 4: one
+// workgroup walked all k^2 of them, 19 ms at k = 4097)
+__global__ __launch_bounds__(256) void k_fill_ftf_qbig(const ConeDesc *cones, const WorkItem *items, const double *scal,
+                                                        double *K, long ldk, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO2(cb, scal, K);
+    const WorkItem it = items[blockIdx.x];
+    const ConeDesc qc = cones[it.cone];
+    if (qc.type != CIP_CONE_Q || it.width) return;
+    const int k = qc.dim;
+    const double beta = scal[qc.soff];
+    const double *w = scal + qc.soff + 1;
+    const double b2 = beta * beta, w0 = w[0];
+    for (int j = blockIdx.y; j < k; j += gridDim.y) {
+        const double wj = (j == 0) ? (w0 * w0 / beta - 1.0) : (w0 * w[j] / beta);
+        for (int i = j + threadIdx.x; i < k; i += 256) {
+            const double wi = (i == 0) ? (w0 * w0 / beta - 1.0) : (w0 * w[i] / beta);
+            double v = 2.0 * wi * wj;
+            if (i == j) v -= (i == 0) ? 1.0 : -1.0;
+            K[(qc.off + i) + (long)(qc.off + j) * ldk] = -b2 * v;
         }
     }
 }
@@ -254,7 +296,7 @@ static int assemble_schur(cip_handle *h, bool lazy_ok) {
             launch_copy_block_lower(s, h->K, h->ldk, 0, h->Q, (long)n, n, 1.0);
         }
         if (h->m > 0) {
-            cip_launch_b(k_schur_rows, dim3((n + 255) / 256), dim3(256), 0, s, n, h->T_rp, h->T_ci, h->T_v, h->A_rp, h->A_ci,
+            cip_launch_b(k_schur_rows, dim3((n + 3) / 4), dim3(256), 0, s, n, h->T_rp, h->T_ci, h->T_v, h->A_rp, h->A_ci,
                                h->A_v, h->row_cone, h->cs.d_cones, h->cs.d_scal, h->K, h->ldk, 0);
             if (h->nq > 0) {
                 if ((rc = cip_zero(s, (long)h->npad * h->nqpad, h->Gm))) return rc;
@@ -287,6 +329,8 @@ static int assemble_full(cip_handle *h) {
     if (h->cs.nitems > 0)
         cip_launch_b(k_fill_ftf, dim3(h->cs.nitems), dim3(256), 0, s, h->cs.d_cones, h->cs.d_items, h->cs.d_scal,
                            h->K, h->ldk);
+    if (h->cs.nbigq > 0)
+        cip_launch_b(k_fill_ftf_qbig, dim3(h->cs.nitems, 128), dim3(256), 0, s, h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->K, h->ldk);
     if (h->cs.has_S) { int rc = cip_sdp_fill_ftf(s, h->cs, h->K, h->ldk); if (rc) return rc; }
     if (m > 0 && n > 0) {
         if (!h->A_sparse)
@@ -340,6 +384,8 @@ __global__ __launch_bounds__(256) void k_regularize_rows(double *K, long ldk, in
 
 int cip_assemble(cip_handle *h, bool lazy_ok) {
     h->ws.lazyC = nullptr;
+    // K is about to be overwritten: the side stream may still be reading the previous factor (a factorisation without solves)
+    { const int rj = cip_ldlt_side_join(h->stream, h->ws, -1); if (rj) return rj; }
     int rc = (h->route == CIP_ROUTE_SCHUR) ? assemble_schur(h, lazy_ok) : assemble_full(h);
     if (rc == 0 && h->reg_rel > 0.0) {
         // (the diagonal is modified only after every row / column maximum has been read: the second kernel reads

@@ -48,6 +48,7 @@ struct cip_handle {
     double *Wt = nullptr;           // npad x mpad   At * F^-1           (dense-A Schur route)
     double *Gm = nullptr;           // npad x nqpad  rank-1 columns of the Q cones (sparse-A Schur route)
     void *ws_base = nullptr; LdltWorkspace ws = {};
+    struct LdltSide *ldlt_side = nullptr;   // side stream + events of the overlapped solve preparation (ldlt.hip), created on first use
     bool assembled = false, factored = false;
     // static regularisation K + delta diag(+1 .. -1 ..), delta = reg_rel * max|K_ii|: 0 until a factorisation meets a
     // bad pivot (auto_reg), then kept for the lifetime of the handle; the loops' iterative refinement absorbs it

@@ -148,8 +148,15 @@ struct LdltWorkspace {        // carved out of one device allocation
     // reads its C operand from lazyC (the problem's Q, column-major, leading dimension lazy_ld) with lazy_diag[i] on the
     // diagonal, and writes K.  Consumed (cleared) by the next cip_ldlt_factor.
     const double *lazyC; long lazy_ld; const double *lazy_diag;
+    // solve preparation beside the panel chain of the last (wide) outer block (ldlt.hip: cip_ldlt_factor): where the owner
+    // keeps the side stream / events, created on first use (NULL: always behind the factorisation, on its own stream)
+    struct LdltSide **side;
 };
+struct LdltSide;
+void cip_ldlt_side_destroy(struct LdltSide *sd);
+int cip_ldlt_side_join(hipStream_t s, const struct LdltWorkspace &ws, int J);   // ldlt.hip: wait for the side stream's solve preparation (J < 0: all of it)
 int cip_kernels_init(void);                // diag.hip: one-time kernel attributes (before any hipGraph capture)
+int cip_ldlt_set_side_prep(int on);       // 1 (default): solve preparation beside the last outer block's panel chain; returns the previous setting
 int cip_ldlt_set_fused_chain(int on);     // 1 (default): diag + previous in-block update in one launch; returns the previous setting
 int cip_solve_block(int Npad);
 int cip_solve_block_max_set(int b);              // 128 | 256 | 512 | 1024 (0: query); returns the previous limit
@@ -188,6 +195,7 @@ struct ConeSet {
     double *d_partial;        // nslots doubles (reductions)
     double *d_scalar;         // 8 doubles
     int has_S;
+    int nbigq;                // Q cones of dimension > 64 (one work item each): the assembly gives them their own multi-workgroup kernels
     // S cones (sdp.hip)
     int ns, rmax, kmax;       // number of S cones, largest matrix order / vectorised length
     int *d_sidx;              // device: cone index of every S cone
@@ -227,7 +235,7 @@ int cip_sdp_scaling_changed(hipStream_t s, const ConeSet &cs);     // sdp.hip: t
 int cip_cones_apply(hipStream_t s, const ConeSet &cs, int mode, const double *x, double *out);
 int cip_cones_prod(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out);
 int cip_cones_div(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out);
-int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const double *d, double scale, double *alpha_host);
+int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const double *d, double scale, double *alpha_host, int defer_slot = -1);
 // the pair of the interior-point loop (src/ConicIP.jl:708-709, :881-882, :927-928): alpha_host2 = {maxstep(x1, d1), maxstep(x2, d2)},
 // one wait; large S cones: the two sides on two streams
 int cip_cones_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const double *d1, const double *x2, const double *d2,

@@ -191,21 +191,28 @@ __global__ __launch_bounds__(256) void k_apply(const ConeDesc *cones, const Work
 }
 
 // Wt[i, off + e] = (F^-T a_i)_e,  a_i = At[i, off:off+k]   (thread per row i of At, coalesced along i)
+#define SCALE_AT_SPLIT 16
 __global__ __launch_bounds__(256) void k_scale_At(const ConeDesc *cones, const WorkItem *items, const double *scal,
                                                    int n, const double *At, long ldat, double *Wt, long ldwt, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO3(cb, scal, At, Wt);
     const WorkItem it = items[blockIdx.y];
     const ConeDesc cd = cones[it.cone];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // grid.x = row blocks x SCALE_AT_SPLIT: an R chunk's (up to 2048) columns are dealt to SCALE_AT_SPLIT workgroups per row
+    // block (round 4: one thread walked all of them -- one R cone of 4097 rows behind n = 4096 was 48 workgroups and 0.7 ms)
+    const int nxb = gridDim.x / SCALE_AT_SPLIT, sub = blockIdx.x / nxb;
+    const int i = (blockIdx.x % nxb) * 256 + threadIdx.x;
     if (i >= n) return;
     if (cd.type == CIP_CONE_R) {
-        for (int e = it.start; e < it.start + it.len; ++e) {
+        const int per = (it.len + SCALE_AT_SPLIT - 1) / SCALE_AT_SPLIT;
+        const int e0 = it.start + sub * per, e1 = min(it.start + it.len, e0 + per);
+        for (int e = e0; e < e1; ++e) {
             const long c = cd.off + e;
             Wt[i + c * ldwt] = At[i + c * ldat] / scal[cd.soff + e];
         }
     } else if (cd.type == CIP_CONE_Q) {
-        const int ncone = it.width ? it.len : 1;          // a pack of small cones: this thread's row through each of them
+        if (!it.width || sub) return;                     // a large cone: k_scale_At_qbig; a pack: the first of the split only
+        const int ncone = it.len;                         // a pack of small cones: this thread's row through each of them
         for (int q = 0; q < ncone; ++q) {
             const ConeDesc qc = cones[it.cone + q];
             const int k = qc.dim;
@@ -220,6 +227,46 @@ __global__ __launch_bounds__(256) void k_scale_At(const ConeDesc *cones, const W
             wp[0] = (w[0] * t - ap[0]) * ib;
             for (int e = 1; e < k; ++e) wp[(long)e * ldwt] = (ap[(long)e * ldat] - w[e] * t) * ib;
         }
+    }
+}
+
+// The same for a Q cone of dimension > 64 (round 4; SURVEY 8(f3): the reference lifts / densifies such blocks,
+// src/kktsolvers.jl:60-131).  F^-T a = (a - J w t) / beta... with t = (w0 a_0 - sum_e w_e a_e) / beta is two O(k) passes per row
+// of A'; one thread per row walked them alone (k = 4097, n = 4096: 16 workgroups, 1.8 ms beside a 2.3-ms SYRK).  Here a
+// workgroup takes 16 rows and spreads the cone's entries over 16 thread columns (e = c, c + 16, ..): 16 partial dot products
+// per row, summed in a fixed order through LDS, then the element-wise pass on the same split -- n / 16 workgroups, the
+// second pass re-reads what the first brought into L2.  Deterministic (no atomics); O(k n) beside the SYRK's O(k n^2).
+__global__ __launch_bounds__(256) void k_scale_At_qbig(const ConeDesc *cones, const WorkItem *items, const double *scal,
+                                                        int n, const double *At, long ldat, double *Wt, long ldwt, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO3(cb, scal, At, Wt);
+    const WorkItem it = items[blockIdx.y];
+    const ConeDesc cd = cones[it.cone];
+    if (cd.type != CIP_CONE_Q || it.width) return;
+    __shared__ double part[16][17];
+    const int r = threadIdx.x & 15, c = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + r;
+    const bool live = i < n;
+    const int k = cd.dim;
+    const double beta = scal[cd.soff], ib = 1.0 / beta;
+    const double *w = scal + cd.soff + 1;
+    const double *ap = At + (live ? i : 0) + (long)cd.off * ldat;
+    double acc = 0.0;
+    for (int e = c; e < k; e += 16) {
+        const double a = ap[(long)e * ldat];
+        acc += (e == 0 ? w[0] : -w[e]) * a;
+    }
+    part[r][c] = acc;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += part[r][q];
+    t *= ib;
+    if (!live) return;
+    double *wp = Wt + i + (long)cd.off * ldwt;
+    for (int e = c; e < k; e += 16) {
+        const double a = ap[(long)e * ldat];
+        wp[(long)e * ldwt] = (e == 0 ? (w[0] * t - a) : (a - w[e] * t)) * ib;
     }
 }
 
@@ -346,7 +393,7 @@ __global__ __launch_bounds__(256) void k_maxstep(const ConeDesc *cones, const Wo
     }
 }
 
-__global__ __launch_bounds__(256) void k_min_reduce(const double *partial, int n, double *out, double *gather, CipBatch cb) {
+__global__ __launch_bounds__(256) void k_min_reduce(const double *partial, int n, double *out, double *gather, int gslot, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO2(cb, partial, out);
     __shared__ double sh[12];
@@ -361,7 +408,7 @@ __global__ __launch_bounds__(256) void k_min_reduce(const double *partial, int n
     const int bad = __syncthreads_or(nan_seen);
     if (threadIdx.x == 0) {
         out[0] = bad ? __builtin_nan("") : m2;
-        if (gather) gather[blockIdx.z * CIP_GATHER] = out[0];        // lock-step batch: one read-back for all problems
+        if (gather) gather[blockIdx.z * CIP_GATHER + gslot] = out[0];        // lock-step batch: one read-back for all problems
     }
 }
 
@@ -427,7 +474,10 @@ int cip_cones_div(hipStream_t s, const ConeSet &cs, const double *x, const doubl
     if (cs.has_S) return cip_sdp_div(s, cs, x, y, out);
     return 0;
 }
-int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const double *d, double scale, double *alpha_host) {
+// defer_slot >= 0 (lock-step batches only): the minima go to slot `defer_slot` of every problem's row of the gather buffer and
+// the call returns without a read-back -- they ride on the NEXT read-back of that buffer (lockstep.hip pairs the v- and
+// s-side max-steps and the dot products that follow them: one host round trip instead of three); alpha_host is not touched
+int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const double *d, double scale, double *alpha_host, int defer_slot) {
     if (cs.nitems == 0) { for (int z = 0; z < (cip_tl_bz.B > 1 ? cip_tl_bz.B : 1); ++z) alpha_host[z] = __builtin_inf(); return 0; }
     cip_launch_b(k_maxstep, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x, d, scale, cs.d_partial);
     CIP_HIP_CHECK(hipGetLastError());
@@ -436,9 +486,11 @@ int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const d
     CipHostScratch hs;
     int rc;
     if ((rc = cip_host_scratch(&hs))) return rc;
+    const bool defer = bc.B > 1 && defer_slot >= 0;
     cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)cs.d_partial, cs.nslots, bc.B > 1 ? cs.d_scalar : hs.dev,
-                 bc.B > 1 ? bc.gather_dev : (double *)nullptr);
+                 bc.B > 1 ? bc.gather_dev : (double *)nullptr, defer ? defer_slot : 0);
     CIP_HIP_CHECK(hipGetLastError());
+    if (defer) return 0;
     if (bc.B > 1) {                          // alpha_host: B values
         CIP_HIP_CHECK(hipMemcpyAsync(bc.gather_host, bc.gather_dev, sizeof(double) * bc.B * CIP_GATHER, hipMemcpyDeviceToHost, s));
         if ((rc = cip_wait(s))) return rc;
@@ -465,8 +517,8 @@ int cip_cones_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const
     CipHostScratch hs;
     int rc;
     if ((rc = cip_host_scratch(&hs))) return rc;
-    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)p1, cs.nslots, hs.dev, (double *)nullptr);
-    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)p2, cs.nslots, hs.dev + 1, (double *)nullptr);
+    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)p1, cs.nslots, hs.dev, (double *)nullptr, 0);
+    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)p2, cs.nslots, hs.dev + 1, (double *)nullptr, 0);
     CIP_HIP_CHECK(hipGetLastError());
     if ((rc = cip_wait(s))) return rc;       // both minima went straight into the host-mapped scratch
     alpha_host2[0] = hs.host[0]; alpha_host2[1] = hs.host[1];
@@ -480,8 +532,11 @@ int cip_cones_identity(hipStream_t s, const ConeSet &cs, double *e) {
 }
 int cip_cones_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, long ldat, double *Wt, long ldwt) {
     if (cs.nitems == 0 || n == 0) return 0;
-    cip_launch_b(k_scale_At, dim3((n + 255) / 256, cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items,
+    cip_launch_b(k_scale_At, dim3(((n + 255) / 256) * SCALE_AT_SPLIT, cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items,
                        cs.d_scal, n, At, ldat, Wt, ldwt);
+    if (cs.nbigq > 0)
+        cip_launch_b(k_scale_At_qbig, dim3((n + 15) / 16, cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items,
+                           cs.d_scal, n, At, ldat, Wt, ldwt);
     CIP_HIP_CHECK(hipGetLastError());
     if (cs.has_S) return cip_sdp_scale_At(s, cs, n, At, ldat, Wt, ldwt);
     return 0;

@@ -484,6 +484,53 @@ __device__ __forceinline__ void diag_store_panel(const double *a, double *Kb, lo
         }
     }
 }
+// Round 4: L' AS THE FACTOR IS WRITTEN.  The forward sweep of the solves reads L' from the upper triangle (coalesced column
+// dots); until round 3 a pass over the whole factor behind the factorisation put it there (k_mirror_lower: 91 us at n = 8192,
+// 4 ms of a 64-problem config-5 pass).  Now whoever stores a piece of L stores its transpose too, as 32-byte pieces of 128-byte
+// runs: the diagonal kernel for the block's own columns (below), the TRSM strips for theirs (wave_store_T).  Plain stores:
+// nobody reads the upper triangle before the solves.
+// columns [c, c+16) of the LDS image, rows below the diagonal: K[j, i] = L[i][j] for i > j; `t` of `nt` threads
+__device__ __forceinline__ void diag_store_panel_T(const double *a, double *Kb, long ld, int c, int t, int nt) {
+#ifdef CIP_NO_TSTORE
+    return;                                                  // A/B partner (with CIP_LDLT_MIRROR=1): tools/build_variant.sh notstore diag.hip -DCIP_NO_TSTORE
+#endif
+    for (int e = t; e < CIP_NB * 4; e += nt) {
+        const int i = e >> 2, j0 = c + 4 * (e & 3);             // row i of L, columns j0 .. j0+3 -> K[j0 .. j0+3, i]
+        if (i <= j0) continue;
+        double *dst = Kb + j0 + (long)i * ld;
+        const double v0 = a[i + j0 * DP], v1 = a[i + (j0 + 1) * DP], v2 = a[i + (j0 + 2) * DP], v3 = a[i + (j0 + 3) * DP];
+        if (i > j0 + 3) {
+            *(v2d *)dst = (v2d){v0, v1};
+            *(v2d *)(dst + 2) = (v2d){v2, v3};
+        } else {                                                // the row crosses the diagonal inside this piece
+            dst[0] = v0;
+            if (i > j0 + 1) dst[1] = v1;
+            if (i > j0 + 2) dst[2] = v2;
+        }
+    }
+}
+// A wave's 16 x 16 tile in the accumulator layout -- lane (l15, g), register q = element (row l15, column 4q + g) -- stored
+// TRANSPOSED: dst[c + r * ld] = tile[r][c].  Through a 16 x 17 LDS scratch of the wave's own: lane (r = lane / 4, cq = lane % 4)
+// then holds columns 4 cq .. 4 cq + 3 of row r, 32 contiguous bytes of the 128-byte run of that row.
+__device__ __forceinline__ void wave_store_T(double *scr, const double (&v)[4], double *dst, long ld, int lane) {
+#ifdef CIP_NO_TSTORE
+    return;
+#endif
+    const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) scr[l15 * 17 + 4 * q + g] = v[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int r = lane >> 2, cq = lane & 3;
+    const double *sp = scr + r * 17 + 4 * cq;
+    const double t0 = sp[0], t1 = sp[1], t2 = sp[2], t3 = sp[3];
+    double *d = dst + 4 * cq + (long)r * ld;
+    *(v2d *)d = (v2d){t0, t1};
+    *(v2d *)(d + 2) = (v2d){t2, t3};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // (the scratch is rewritten by the next call)
+    __builtin_amdgcn_wave_barrier();
+}
 // micro-panel kb's inverse, d and 1/d -> global, write-through (PUB launches publish them per micro-panel)
 __device__ __forceinline__ void diag_publish_micro(const double *a, const double *xm, double *xm_out, double *dvec, double *dinv,
                                                    int kb, int t, int nt) {
@@ -631,6 +678,9 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) atomicAdd(stage, 1u);
             }
+            // L' of the micro-panel: behind the count (nobody waits for these stores; placed in front of it they held every
+            // helper at the count's vmcnt(0) for a store round trip and the panel launches ran 1.3 us longer)
+            if (!(DIAG_SKIP & 16)) diag_store_panel_T(a, Kb, ld, c, hid * 64 + lane, 64 * NH);
         }
         __syncthreads();
     }
@@ -642,11 +692,12 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
         __syncthreads();
         if (tid == 0) atomicAdd(stage, (unsigned)NH);
         PANEL_STAMP(8, WAIT && tid == 0);
+        diag_store_panel_T(a, Kb, ld, 112, tid, 64 * NW);
         return;
     }
 
     // ---- last micro-panel, d and the micro inverses out; the strictly upper part of K is left untouched
-    if (!(DIAG_SKIP & 16)) diag_store_panel(a, Kb, ld, 112, tid, 64 * NW);
+    if (!(DIAG_SKIP & 16)) { diag_store_panel(a, Kb, ld, 112, tid, 64 * NW); diag_store_panel_T(a, Kb, ld, 112, tid, 64 * NW); }
     if (tid < CIP_NB) {
         dvec[tid] = a[128 + tid * DP];
         dinv[tid] = a[129 + tid * DP];
@@ -778,11 +829,15 @@ __device__ __forceinline__ unsigned strip_wait_wave(unsigned v, unsigned target,
     }
     return (unsigned)__builtin_amdgcn_readfirstlane((int)x);
 }
+// tscr: 4 x 272 doubles of LDS (one transposition scratch per wave) for the L' stores
 template <bool WAVEWAIT>
-__device__ __forceinline__ void trsm_strip_pipelined(const TrsmStrips &tr, int strip, const unsigned *stage, unsigned *slot, int *info) {
+__device__ __forceinline__ void trsm_strip_pipelined(const TrsmStrips &tr, int strip, const unsigned *stage, unsigned *slot, int *info, double *tscr) {
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const long row = (long)strip * 64 + wave * 16 + l15;
+    double *scr = tscr + wave * 272;
+    // L' of this wave's rows: K[c0 + k, c0 + 128 + row0 + r], row0 = 64 strip + 16 wave (L11 = the diagonal block at (c0, c0))
+    double *ut = const_cast<double *>(tr.L11) + (long)(CIP_NB + strip * 64 + wave * 16) * tr.ld;
     double *ap = tr.Ap + row + (long)g * tr.ld;
     double *wp = tr.W + row + (long)g * tr.ldw;
     v4d T[8];
@@ -811,19 +866,21 @@ __device__ __forceinline__ void trsm_strip_pipelined(const TrsmStrips &tr, int s
         v4d w = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < 4; ++s) w = MFMA(xo[s], T[kb][s], w);
-        double wneg[4];
+        double wneg[4], lq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long col = kb * 16 + 4 * q;
             wneg[q] = -w[q];
+            lq[q] = w[q] * dv[q];
             wp[col * tr.ldw] = w[q];
-            ap[col * tr.ld] = w[q] * dv[q];
+            ap[col * tr.ld] = lq[q];
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int r = 1; r < 8; ++r)
                 if (r > kb) T[r] = MFMA(lo[r - 1][s], wneg[s], T[r]);
+        wave_store_T(scr, lq, ut + kb * 16, tr.ld, lane);          // behind the MFMAs' issue: off the chain
     }
 }
 // One 16x16 tile (it >= jt) of the diagonal block's update C -= W L' (K = 128) per WAVE, operands straight from L2 into
@@ -923,7 +980,7 @@ __global__ __launch_bounds__(64 * PANEL_WAVES) void k_ldlt_panel(double *Kb, lon
     if (!UPD) {                                         // first panel of an outer block: strips only, four-wave jobs
         __builtin_amdgcn_s_setprio(3);
         if (threadIdx.x >= 256) return;
-        trsm_strip_pipelined<false>(tr, b - 1, stage, (unsigned *)sm, info);
+        trsm_strip_pipelined<false>(tr, b - 1, stage, (unsigned *)sm, info, sm + 64);
         return;
     }
     if (b <= PANEL_PRODUCERS) {
@@ -956,7 +1013,7 @@ __global__ __launch_bounds__(64 * PANEL_WAVES) void k_ldlt_panel(double *Kb, lon
             while (__hip_atomic_load(ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2u) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
             PANEL_STAMP(12, threadIdx.x == 0 && strip == 0);          // strip 0: its two update tiles done
-            trsm_strip_pipelined<true>(tr, strip, stage, nullptr, info);
+            trsm_strip_pipelined<true>(tr, strip, stage, nullptr, info, lds);
             PANEL_STAMP(13, threadIdx.x == 0 && strip == 0);
             PANEL_STAMP(14, threadIdx.x == 0 && strip == tr.strips - 1);
         }
@@ -1067,6 +1124,7 @@ __global__ __launch_bounds__(256) void k_trsm_subst(double *__restrict__ Ap, lon
     }
     __syncthreads();
     double wneg[8][4];
+    double lreg[8][4];
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
         v4d acc = (v4d){areg[kb][0], areg[kb][1], areg[kb][2], areg[kb][3]};
@@ -1083,9 +1141,19 @@ __global__ __launch_bounds__(256) void k_trsm_subst(double *__restrict__ Ap, lon
         for (int q = 0; q < 4; ++q) {
             const long col = kb * 16 + 4 * q;
             wneg[kb][q] = -w[q];
+            lreg[kb][q] = w[q] * ds[col + g];
             wp[col * ldw] = w[q];
-            ap[col * ld] = w[q] * ds[col + g];
+            ap[col * ld] = lreg[kb][q];
         }
+    }
+    // L' of the strip (round 4: no mirror pass behind the factorisation), transposed through the L11 tile buffer once every
+    // wave is done with it.  L11 = &K[c0, c0], Ap = &K[c0 + 128, c0]: the strip's rows are columns c0 + 128 + row of L'.
+    __syncthreads();
+    {
+        double *scr = lt + wave * 272;
+        double *ut = const_cast<double *>(L11) + (long)(CIP_NB + blockIdx.x * 64 + wave * 16) * ld;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) wave_store_T(scr, lreg[kb], ut + kb * 16, ld, lane);
     }
 }
 

@@ -186,6 +186,7 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     ws->lazyC = nullptr; ws->lazy_ld = 0; ws->lazy_diag = nullptr;
     ws->signs = PivotSigns{-1, 0, 0};
     ws->x_zeroed = nullptr;
+    ws->side = nullptr;
 }
 
 // diag.hip
@@ -224,10 +225,10 @@ int cip_ldlt_set_fused_chain(int on) { fuse_env(); const int prev = g_fuse_diag;
 
 // one inner-panel sweep of an outer block: [strip update] -> diagonal kernel -> TRSM, for each 128 columns
 static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws, double *Wb, int C0,
-                               int wblk) {
+                               int wblk, int t0 = 0, int t1 = -1) {
     int rc;
-    const int T = wblk / CIP_NB;
-    for (int t = 0; t < T; ++t) {
+    const int T = t1 < 0 ? wblk / CIP_NB : t1;               // panels [t0, T) of the block (all of them by default)
+    for (int t = t0; t < T; ++t) {
         const int c0 = C0 + t * CIP_NB;
         const int jb = c0 / CIP_NB;
         const int r = Npad - c0 - CIP_NB;
@@ -298,11 +299,11 @@ static int zero_fill(hipStream_t s, void *p, size_t bytes) {
 
 // upper triangle <- (strictly lower triangle)': gives the forward sweep the same coalesced
 // "column-dot" access as the backward sweep (U[k, i] = L[i, k])
-__global__ __launch_bounds__(256) void k_mirror_lower(double *K, long ld, CipBatch cb) {
+__global__ __launch_bounds__(256) void k_mirror_lower(double *K, long ld, int bj0, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO1(cb, K);
     __shared__ double t[32][33];
-    const int bi = blockIdx.x, bj = blockIdx.y;      // 32x32 tile (row tile bi, column tile bj), bi >= bj
+    const int bi = blockIdx.x + bj0, bj = blockIdx.y + bj0;      // 32x32 tile (row tile bi, column tile bj), bi >= bj; bj0: first column tile of the range
     if (bi < bj) return;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int q = 0; q < 32; q += 8) t[ty + q][tx] = K[(long)(bi * 32 + tx) + (long)(bj * 32 + ty + q) * ld];
@@ -316,22 +317,42 @@ __global__ __launch_bounds__(256) void k_mirror_lower(double *K, long ld, CipBat
 //   inv([L11 0; L21 L22]) = [X11 0; -X22 L21 X11  X22],
 // two batched MFMA GEMMs per level (Tt = X11' L21', then X21 = -X22 Tt' together with its transpose), so that a
 // triangular solve is Npad/Bs block steps (8 at n = 8192) instead of Npad/128 (64).
-static int build_solve_blocks(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws) {
+// the strictly upper blocks of X (lower of XT) are never written by the preparation: zeroed once per workspace, on the
+// factorisation's own stream before anything else (the ranges below may run on two streams)
+static int ensure_x_zeroed(hipStream_t s, int Npad, const LdltWorkspace &ws) {
     const int Bs = ws.Bs;
-    const int nbk = Npad / Bs;
+    if (Bs == CIP_NB || (ws.x_zeroed && *ws.x_zeroed)) return 0;
     int rc;
-    cip_launch_b(k_mirror_lower, dim3(Npad / 32, Npad / 32), dim3(256), 0, s, K, ld);
-    if (Bs == CIP_NB)                                                   // X == Linv, XT == LinvT
-        return cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.Linv, ws.LinvT, CIP_NB);
-    if (!ws.x_zeroed || !*ws.x_zeroed) {
-        // the strictly upper blocks of X (lower of XT) are never written afterwards: zero them once per workspace
-        if ((rc = zero_fill(s, ws.X, sizeof(double) * (size_t)nbk * Bs * Bs))) return rc;
-        if ((rc = zero_fill(s, ws.XT, sizeof(double) * (size_t)nbk * Bs * Bs))) return rc;
-        if (ws.x_zeroed && (!cip_in_batch() || cip_tl_bz.mask == (cip_tl_bz.B >= 64 ? ~0ull : ((1ull << cip_tl_bz.B) - 1)))) *ws.x_zeroed = 1;
+    const int nall = Npad / Bs;
+    if ((rc = zero_fill(s, ws.X, sizeof(double) * (size_t)nall * Bs * Bs))) return rc;
+    if ((rc = zero_fill(s, ws.XT, sizeof(double) * (size_t)nall * Bs * Bs))) return rc;
+    if (ws.x_zeroed && (!cip_in_batch() || cip_tl_bz.mask == (cip_tl_bz.B >= 64 ? ~0ull : ((1ull << cip_tl_bz.B) - 1)))) *ws.x_zeroed = 1;
+    return 0;
+}
+// [J0, J1): the range of Bs-wide diagonal blocks to prepare (their columns are final), all of them by default.  The mirror
+// covers the same columns (every row below them).  Ranges are independent of each other (own slices of X / XT / Tt).
+static int build_solve_blocks(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws, int J0 = 0, int J1 = -1) {
+    const int Bs = ws.Bs;
+    if (J1 < 0) J1 = Npad / Bs;
+    const int nbk = J1 - J0;
+    if (nbk <= 0) return 0;
+    int rc;
+    // (no mirror pass: L' is written with the factor, diag.hip: diag_store_panel_T / wave_store_T; CIP_LDLT_MIRROR=1 runs the
+    //  old pass on top of it -- it rewrites the same values -- for A/B timing)
+    static const int mirror_pass = [] { const char *e = getenv("CIP_LDLT_MIRROR"); return e ? atoi(e) : 0; }();
+    if (mirror_pass) {
+        const int bj0 = J0 * (Bs / 32), nct = nbk * (Bs / 32);
+        cip_launch_b(k_mirror_lower, dim3(Npad / 32 - bj0, nct), dim3(256), 0, s, K, ld, bj0);
     }
-    // the inverses of the 128-blocks, written straight into the diagonal of X / XT
-    if ((rc = cip_launch_diag_inverse(s, K, ld, Npad / CIP_NB, ws.Xm, ws.X, ws.XT, Bs))) return rc;
+    const int per = Bs / CIP_NB;
+    const double *xm0 = ws.Xm + (size_t)J0 * per * 2048;
+    const double *Kd = K + (long)J0 * Bs * (ld + 1);
+    if (Bs == CIP_NB)                                                   // X == Linv, XT == LinvT
+        return cip_launch_diag_inverse(s, Kd, ld, nbk, xm0, ws.Linv + (size_t)J0 * CIP_NB * CIP_NB, ws.LinvT + (size_t)J0 * CIP_NB * CIP_NB, CIP_NB);
     const long bs2 = (long)Bs * Bs, tt2 = (long)(Bs / 2) * (Bs / 2);
+    double *X0 = ws.X + (size_t)J0 * bs2, *XT0 = ws.XT + (size_t)J0 * bs2, *Tt0 = ws.Tt + (size_t)J0 * tt2;
+    // the inverses of the 128-blocks, written straight into the diagonal of X / XT
+    if ((rc = cip_launch_diag_inverse(s, Kd, ld, nbk * per, xm0, X0, XT0, Bs))) return rc;
     for (int h = CIP_NB; h < Bs; h *= 2) {
         const int P = Bs / (2 * h);                          // pairs per block
         const long pX = 2L * h * (Bs + 1);                   // pair stride inside a block of X / XT
@@ -340,18 +361,86 @@ static int build_solve_blocks(hipStream_t s, double *K, int Npad, long ld, const
         g.M = g.N = g.K = h; g.lower = 0; g.overwrite = 1; g.by = nbk; g.bz = P;
         // Tt = XT11 * L21'
         g.alpha = 1.0;
-        g.A = ws.XT; g.lda = Bs; g.sAy = bs2; g.sAz = pX;
-        g.B = K + h; g.ldb = ld; g.sBy = (long)Bs * (ld + 1); g.sBz = pK;
-        g.C = ws.Tt; g.ldc = h; g.sCy = tt2; g.sCz = (long)h * h;
+        g.A = XT0; g.lda = Bs; g.sAy = bs2; g.sAz = pX;
+        g.B = Kd + h; g.ldb = ld; g.sBy = (long)Bs * (ld + 1); g.sBz = pK;
+        g.C = Tt0; g.ldc = h; g.sCy = tt2; g.sCz = (long)h * h;
         if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
         // X21 = -X22 * Tt'  and, from the same accumulators, XT12 = X21' (stored transposed by the epilogue)
         g.alpha = -1.0;
-        g.A = ws.X + h + (long)h * Bs; g.lda = Bs; g.sAy = bs2; g.sAz = pX;
-        g.B = ws.Tt; g.ldb = h; g.sBy = tt2; g.sBz = (long)h * h;
-        g.C = ws.X + h; g.ldc = Bs; g.sCy = bs2; g.sCz = pX;
-        g.Ct = ws.XT + (long)h * Bs; g.ldct = Bs; g.sCty = bs2; g.sCtz = pX;
+        g.A = X0 + h + (long)h * Bs; g.lda = Bs; g.sAy = bs2; g.sAz = pX;
+        g.B = Tt0; g.ldb = h; g.sBy = tt2; g.sBz = (long)h * h;
+        g.C = X0 + h; g.ldc = Bs; g.sCy = bs2; g.sCz = pX;
+        g.Ct = XT0 + (long)h * Bs; g.ldct = Bs; g.sCty = bs2; g.sCtz = pX;
         if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
         g.Ct = nullptr;
+    }
+    return 0;
+}
+
+// ---- solve preparation BESIDE the panel chain (round 4).  The block inverses and the mirror image of columns that are
+// final do not depend on the rest of the factorisation, and at the bottom of the matrix the panel launches are a latency-
+// bound chain on a mostly idle chip.  When the last outer block is wide (>= 2 solve blocks begin or end in it) the
+// preparation of every solve block whose columns are final is enqueued on a SIDE stream: everything to the left of the
+// wide block when its panel chain starts, then one solve block each time the chain passes a multiple of Bs; only the last
+// solve block is prepared behind the factorisation.  One event per fork (the main stream records, the side stream waits),
+// one join at the end.  Off: CIP_SIDE_PREP=0, lock-step batches, graph capture.
+struct LdltSide {
+    hipStream_t s2 = nullptr;
+    hipEvent_t fork[16] = {};         // recorded on the factorisation's stream: the columns of group g are final
+    hipEvent_t done[16] = {};         // recorded on the side stream: group g's solve blocks are prepared
+    int j0[16] = {};                  // first solve block of group g
+    int nfork = 0;                    // groups of the last factorisation
+    int waited = 0;                   // groups the factorisation's stream has waited for (cip_ldlt_side_join)
+};
+void cip_ldlt_side_destroy(LdltSide *sd) {
+    if (!sd) return;
+    if (sd->s2) (void)hipStreamSynchronize(sd->s2);          // its kernels read the handle's memory, which is freed next
+    for (hipEvent_t e : sd->fork) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : sd->done) if (e) (void)hipEventDestroy(e);
+    if (sd->s2) (void)hipStreamDestroy(sd->s2);
+    delete sd;
+}
+static std::atomic<int> g_side_prep{-1};
+static int side_prep_mode(void) {
+    if (g_side_prep.load() < 0) { const char *e = getenv("CIP_SIDE_PREP"); int v = -1; g_side_prep.compare_exchange_strong(v, e ? (atoi(e) != 0) : 1); }
+    return g_side_prep.load();
+}
+int cip_ldlt_set_side_prep(int on) { const int prev = side_prep_mode(); if (on == 0 || on == 1) g_side_prep.store(on); return prev; }
+static LdltSide *side_get(const LdltWorkspace &ws) {
+    if (!ws.side) return nullptr;
+    if (*ws.side) return *ws.side;
+    LdltSide *sd = new LdltSide();
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);             // lo = numerically greatest = LOWEST priority: the chain goes first
+    bool ok = hipStreamCreateWithPriority(&sd->s2, hipStreamNonBlocking, lo) == hipSuccess;
+    for (hipEvent_t &e : sd->fork) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    for (hipEvent_t &e : sd->done) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); cip_ldlt_side_destroy(sd); return nullptr; }
+    *ws.side = sd;
+    return sd;
+}
+static int side_fork(LdltSide *sd, hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws, int J0, int J1) {
+    if (J1 <= J0) return 0;
+    if (sd->nfork >= 16) return build_solve_blocks(s, K, Npad, ld, ws, J0, J1);
+    const int g = sd->nfork++;
+    sd->j0[g] = J0;
+    CIP_HIP_CHECK(hipEventRecord(sd->fork[g], s));
+    CIP_HIP_CHECK(hipStreamWaitEvent(sd->s2, sd->fork[g], 0));
+    const int rc = build_solve_blocks(sd->s2, K, Npad, ld, ws, J0, J1);
+    CIP_HIP_CHECK(hipEventRecord(sd->done[g], sd->s2));
+    return rc;
+}
+// The factorisation's stream waits for the side stream's groups that hold solve blocks <= J (J < 0: all of them).  The
+// factorisation itself does NOT join: the last group -- the solve blocks whose columns the last panels produce -- is
+// prepared while the first solve's element-wise kernel and the first block steps of its forward sweep run (they need the
+// first blocks only); cip_ldlt_solve joins group by group as its sweep reaches their blocks, and whoever overwrites K or
+// the block inverses next (the next assembly, cip_factor's timing read-out) joins everything.
+int cip_ldlt_side_join(hipStream_t s, const LdltWorkspace &ws, int J) {
+    LdltSide *sd = ws.side ? *ws.side : nullptr;
+    if (!sd) return 0;
+    while (sd->waited < sd->nfork && (J < 0 || sd->j0[sd->waited] <= J)) {
+        CIP_HIP_CHECK(hipStreamWaitEvent(s, sd->done[sd->waited], 0));
+        sd->waited += 1;
     }
     return 0;
 }
@@ -361,9 +450,39 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
     int rc;
     // [0] bad pivot, [1] sweep bail-out, [2] dead pivot, [3] fused-launch wait timed out; from word 16: `ready` counters
     if ((rc = zero_fill(s, ws.info, 64 + 12 * (size_t)(Npad / CIP_NB)))) return rc;
+    if ((rc = ensure_x_zeroed(s, Npad, ws))) return rc;
+    const int Bs = ws.Bs;
+    LdltSide *sd = nullptr;
+    int Jdone = 0;                                           // solve blocks [0, Jdone) are prepared or being prepared on the side stream
     // serial right-looking schedule: panels of the outer block, then ONE trailing update
     for (int C0 = 0, wblk = 0; C0 < Npad; C0 += wblk) {
         wblk = outer_block_width(Npad, C0);
+        const bool last = C0 + wblk >= Npad;
+        // side preparation only in a wide last block: at least one solve-block boundary strictly inside it or at its start,
+        // and more than one solve block in the matrix
+        if (last && side_prep_mode() && !cip_in_batch() && !cip_tl_builder && Bs > CIP_NB && Npad / Bs >= 2 &&
+            wblk >= 2 * cip_ldlt_outer_block_for(Npad) && wblk > Bs && (sd = side_get(ws))) {
+            if ((rc = cip_ldlt_side_join(s, ws, -1))) return rc;      // (a factorisation nobody solved with)
+            sd->nfork = 0; sd->waited = 0;
+            fuse_env();
+            // panel by panel; from `side_from` columns before the end on, fork whenever the columns of another solve block
+            // are final (the first fork takes everything to its left).  The wide block's FIRST panel launches carry ~900
+            // update tiles each and fill the chip: side work beside them costs the chain what it saves (same-session A/B,
+            // forking from the block's start: 187.5 against 188.7 KKT solves/s); the last ones are a chain on an idle chip.
+            static const int side_from = [] { const char *e = getenv("CIP_SIDE_PREP_FROM"); return e ? atoi(e) : 2048; }();
+            for (int c = C0; c < Npad; ) {
+                if (c % Bs == 0 && Npad - c <= side_from && c / Bs > Jdone) {
+                    if ((rc = side_fork(sd, s, K, Npad, ld, ws, Jdone, c / Bs))) return rc;
+                    Jdone = c / Bs;
+                }
+                int cend = (c / Bs + 1) * Bs;               // next solve-block boundary
+                if (cend > Npad) cend = Npad;
+                // the panels [c, cend) of the wide block: factor_outer_panels on a sub-range keeps the block's W buffer layout
+                if ((rc = factor_outer_panels(s, K, Npad, ld, ws, ws.Wbuf, C0, wblk, (c - C0) / CIP_NB, (cend - C0) / CIP_NB))) return rc;
+                c = cend;
+            }
+            continue;                                        // (the last block has no trailing update)
+        }
         if ((rc = factor_outer_panels(s, K, Npad, ld, ws, ws.Wbuf, C0, wblk))) return rc;
         const int r0 = C0 + wblk;
         if (r0 < Npad) {
@@ -388,7 +507,8 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
             if (prof && (rc = prof_event(prof, s))) return rc;
         }
     }
-    return build_solve_blocks(s, K, Npad, ld, ws);
+    if (sd && sd->nfork > 0) return side_fork(sd, s, K, Npad, ld, ws, Jdone, Npad / Bs);      // joined by the solves (cip_ldlt_side_join)
+    return build_solve_blocks(s, K, Npad, ld, ws, Jdone, Npad / Bs);
 }
 
 // ---------------------------------------------------------------------------
@@ -418,6 +538,7 @@ int cip_ldlt_solve(hipStream_t s, const double *K, int Npad, long ld, const Ldlt
     double *y = ws.tmp, *z = ws.zbuf;
     for (int J = 0; J < nbk; ++J) {
         const long C0 = (long)J * Bs;
+        if ((rc = cip_ldlt_side_join(s, ws, J))) return rc;          // (a no-op once every group has been waited for)
         if ((rc = cip_gemv_t(s, Bs, Bs, 1.0, XT + J * bs2, Bs, rhs + C0, 0.0, y + C0))) return rc;
         const int below = Npad - (int)C0 - Bs;
         if (below > 0 &&

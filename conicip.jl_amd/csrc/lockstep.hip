@@ -43,6 +43,7 @@ struct BatchScope {           // activates the batch context for the calling thr
 // the four pivot-flag words of a factorisation into slots 32..35 of the problem's row of the gather buffer (slots 0..31
 // carry the dot products: the flags come back with the same device-to-host copy)
 #define INFO_SLOT 32
+#define STEP_SLOT 40            // deferred max-step minima (cones.hip: cip_cones_maxstep with a defer slot)
 __global__ void k_gather_info(const int *info, double *gather, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO1(cb, info);
@@ -285,8 +286,9 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
         CK(cip_solve4x4_dev(h, e, r0.base, zv.base));
         for (int z = 0; z < B; ++z) if ((active >> z) & 1ull) ++n_solve[z];
         if (m > 0) {
-            CK(cip_cones_maxstep(s, h->cs, zv.v, nullptr, 1.0, av.data()));
+            CK(cip_cones_maxstep(s, h->cs, zv.v, nullptr, 1.0, nullptr, STEP_SLOT));
             CK(cip_cones_maxstep(s, h->cs, zv.s, nullptr, 1.0, as.data()));
+            for (int z = 0; z < B; ++z) av[z] = G.gather_host[(size_t)z * CIP_GATHER + STEP_SLOT];
             for (int z = 0; z < B; ++z) { av[z] = -av[z]; as[z] = -as[z]; }
             CK(cip_axpby_ps(s, m, av.data(), e, 1.0, zv.v));
             CK(cip_axpby_ps(s, m, as.data(), e, 1.0, zv.s));
@@ -334,12 +336,18 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
         for (int z = 0; z < B; ++z) if ((active >> z) & 1ull) ++n_solve[z];
         for (int z = 0; z < B; ++z) sigma[z] = 0.0;
         if (m > 0) {
-            CK(cip_cones_maxstep(s, h->cs, zv.v, daff.v, 1.0, av.data()));
-            CK(cip_cones_maxstep(s, h->cs, zv.s, daff.s, 1.0, as.data()));
+            // one host round trip for the three results (round 4; it was three): the two max-steps leave their minima in slots
+            // STEP_SLOT, STEP_SLOT + 1 of the gather buffer, which comes back with the dot products
+            CK(cip_cones_maxstep(s, h->cs, zv.v, daff.v, 1.0, nullptr, STEP_SLOT));
+            CK(cip_cones_maxstep(s, h->cs, zv.s, daff.s, 1.0, nullptr, STEP_SLOT + 1));
             const double *qx[4] = {zv.v, zv.v, daff.v, daff.v};
             const double *qy[4] = {zv.s, daff.s, zv.s, daff.s};
             const int ql[4] = {m, m, m, m};
             CK(cip_dots(s, 4, qx, qy, ql, h->dot_scratch, h->dot_ptrs, q4.data()));
+            for (int z = 0; z < B; ++z) {
+                av[z] = G.gather_host[(size_t)z * CIP_GATHER + STEP_SLOT];
+                as[z] = G.gather_host[(size_t)z * CIP_GATHER + STEP_SLOT + 1];
+            }
             for (int z = 0; z < B; ++z) {
                 if (!((active >> z) & 1ull)) continue;
                 const double a_aff = std::fmin(std::fmin(av[z], 1.0), as[z]);
@@ -398,8 +406,10 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
         // ------------------------------------------------------------ step (:927-932)
         for (int z = 0; z < B; ++z) alpha[z] = 1.0;
         if (m > 0) {
-            CK(cip_cones_maxstep(s, h->cs, zv.v, dz.v, 1.0 / (1.0 - o.DTB), av.data()));
+            // (one round trip for the pair: the v side rides on the s side's read-back)
+            CK(cip_cones_maxstep(s, h->cs, zv.v, dz.v, 1.0 / (1.0 - o.DTB), nullptr, STEP_SLOT));
             CK(cip_cones_maxstep(s, h->cs, zv.s, dz.s, 1.0 / (1.0 - o.DTB), as.data()));
+            for (int z = 0; z < B; ++z) av[z] = G.gather_host[(size_t)z * CIP_GATHER + STEP_SLOT];
             for (int z = 0; z < B; ++z) alpha[z] = std::fmin(std::fmin(av[z], 1.0), std::fmin(as[z], 1.0));
         }
         for (int z = 0; z < B; ++z) tmpB[z] = -alpha[z];

@@ -253,6 +253,10 @@ int cip_set_solve_block_max(int b);
  * micro-panel through a stage counter; 1 = diagonal kernel + previous panel's update in one launch, TRSM in its own;
  * 0 = three launches per panel.  Same factor bit for bit.  Process-wide; returns the previous setting (other values: query). */
 int cip_set_ldlt_fused_chain(int on);
+/* solve preparation (block inverses for the triangular sweeps, mirror image of L) of every solve block whose columns are final,
+ * on a side stream beside the last panels of the factorisation instead of behind it (also CIP_SIDE_PREP; CIP_SIDE_PREP_FROM =
+ * columns before the end from which it forks, default 2048).  1 (default) on, 0 off.  Same bits.  Returns the previous setting. */
+int cip_set_ldlt_side_prep(int on);
 /* Schur route, CSR A with one entry per row, R cones, no equalities, order a multiple of 128 (the box-QP family): cip_factor
  * copies only the first outer block's columns of Q into K; the first trailing update of the LDL' reads the rest from Q
  * itself (also CIP_LAZY_COPY=0).  Same factor bit for bit.  1 (default) on, 0 off; returns the previous setting. */

@@ -111,6 +111,42 @@ def test_c2_headline_n8192():
     ks.close()
 
 
+def test_c2_headline_full3x3_n8192():
+    """Config 2 at full size through the LITERAL 3x3 assembly (src/kktsolvers.jl:254-257: [Q G' -A'; G 0 0; A 0 F'F], here
+    symmetrised and in the pivot order (3,1,2), order N = n + m = 16384): it is the same linear system as the Schur
+    route's, so the oracle's trajectory fixture of `test_c2_headline_n8192` applies unchanged -- status / Iter / n_factor /
+    n_solve equal, mu and alpha at 1e-6 per iteration, the iterate at 1e-6 -- and one solve3x3 at a late scaling has a backward
+    error < 1e-12 against the problem's own operators (round-3 review, NS-1)."""
+    import cipkkt
+    n = 8192
+    Q, c, A, b, K = W.c2_problem(n, seed=1234, device="cuda")
+    ks = cipkkt.KKTSystem(Q, A, None, K, route="full3x3")
+    assert ks.N == 2 * n
+    its = []
+    sol = cipkkt.conicIP(Q, c, A, b, K, optTol=1e-6, system=ks, keep_iterates=its, driver="python")
+    fx = FULLSIZE["c2_n8192_seed1234"]
+    assert_same_trajectory(sol, fx, "c2 n=8192, literal 3x3 route (N = 16384), per-operation loop")
+    nat = cipkkt.conicIP(Q, c, A, b, K, optTol=1e-6, system=ks)
+    assert_same_trajectory(nat, fx, "c2 n=8192, literal 3x3 route (N = 16384), native loop")
+    assert np.array_equal(nat.y, sol.y)
+    Qh = Q.cpu().numpy()
+    check_optimality(Qh, c, A, b, K, np.zeros((0, n)), np.zeros(0), sol, 1e-5)
+    z = its[-2]
+    v, s = z[n:2 * n].clone(), z[2 * n:3 * n].clone()
+    ks.set_scaling_from_iterate(v, s)
+    ks.factor()
+    rng = np.random.default_rng(0)
+    x, zz = rng.standard_normal(n), rng.standard_normal(n)
+    a, _, cc = ks.solve3x3(x, np.zeros(0), zz)
+    d2 = (s / v).cpu().numpy()
+    r1 = Qh @ a - cc - x
+    r2 = a + d2 * cc - zz
+    normK = max(np.abs(Qh).sum(axis=1).max() + 1, d2.max() + 1)
+    berr = np.sqrt(r1 @ r1 + r2 @ r2) / (normK * np.sqrt(a @ a + cc @ cc) + np.sqrt(x @ x + zz @ zz))
+    assert berr < 1e-12, berr
+    ks.close()
+
+
 def test_c3_socp_full_size_portable_inputs():
     import cipkkt
     prob = W.c3_socp()

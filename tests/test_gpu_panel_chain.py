@@ -182,3 +182,44 @@ def test_first_solve_after_factor_waits_for_the_pivot_flag():
     scale = 1 + max(np.linalg.norm(v) for v in (ah, bh, ch))
     assert max(np.linalg.norm(r1), np.linalg.norm(r2), np.linalg.norm(r3)) < 1e-8 * scale
     ks.close()
+
+
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_side_stream_solve_preparation_bitwise(n):
+    """Round 4: block inverses + mirror image of the solve blocks whose columns are final run on a side stream beside the last
+    panels of the factorisation (ldlt.hip: cip_ldlt_factor).  The factor and every solve must be bit-identical to the serial
+    preparation -- over repeated factorisations with solves in between (the next assembly overwrites K: the join matters)."""
+    import cipkkt
+    from cipkkt import workloads as W
+    Q, c, A, b, K = W.c2_problem(n, seed=77, device="cuda")
+    ks = cipkkt.KKTSystem(Q, A, None, K)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    outs = {}
+    prev = ks.lib.cip_set_ldlt_side_prep(0)
+    try:
+        for mode in (0, 1, 0, 1):
+            ks.lib.cip_set_ldlt_side_prep(mode)
+            res = []
+            for it in range(4):
+                v = torch.rand(n, dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(10 + it)) + 0.1
+                s = torch.rand(n, dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(20 + it)) + 0.1
+                ks.set_scaling_from_iterate(v, s)
+                ks.factor()
+                x = torch.randn(n, dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(30 + it))
+                z = torch.randn(n, dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(40 + it))
+                a_, c_ = torch.zeros_like(x), torch.zeros_like(z)
+                y0 = torch.zeros(0, dtype=torch.float64, device="cuda")
+                ks.solve3x3_dev(x, y0, z, a_, y0, c_)
+                ks.solve3x3_dev(z, y0, x, c_, y0, z.clone())       # a second solve on the same factor
+                torch.cuda.synchronize()
+                res.append((a_.clone(), c_.clone()))
+            if mode in outs:
+                for (a0, c0), (a1, c1) in zip(outs[mode], res):
+                    assert torch.equal(a0, a1) and torch.equal(c0, c1)
+            outs[mode] = res
+        for (a0, c0), (a1, c1) in zip(outs[0], outs[1]):
+            assert torch.equal(a0, a1) and torch.equal(c0, c1), "side-stream preparation changed a solve"
+    finally:
+        ks.lib.cip_set_ldlt_side_prep(prev)
+        ks.close()
