@@ -112,6 +112,16 @@ unsigned long long full_mask(int B) { return B >= 64 ? ~0ull : ((1ull << B) - 1u
 
 }   // namespace
 
+// Solve-block limit of a lock-step group's handles: 256 whatever the group size (a block step is one launch for all problems,
+// and the doubled block inverses -- 1.5 GFLOP per n = 2048 factorisation at 1024 -- are what cost).  Round 4 measured the small
+// groups too (8 problems of order 2048, the per-rank shard of config 5 on 8 GPUs): 256 / 512 / 1024 -> 16.5 / 16.5 / 17.3 ms per
+// pass.  CIP_LOCKSTEP_SOLVE_BLOCK overrides; never above the process-wide limit.
+extern "C" int cip_lockstep_solve_block_for(int B) {
+    const char *e = getenv("CIP_LOCKSTEP_SOLVE_BLOCK");
+    (void)B;
+    const int want = e ? atoi(e) : 256, glob = cip_solve_block_max_set(0);
+    return want < glob ? want : glob;
+}
 // One lock-step group (B <= CIP_BATCH_MAX problems of the same shape).  Returns 0 and fills res / y / w / v of every
 // problem, or an error code (nothing meaningful written).
 static int lockstep_group(int B, const cip_problem *probs, const double *const *c, const double *const *b,
@@ -135,13 +145,9 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
     // solve-block limit of the group's handles (see ldlt.hip: cip_solve_block)
     struct SolveBlockScope {
         int saved;
-        SolveBlockScope() : saved(cip_tl_solve_block_max) {
-            const char *e = getenv("CIP_LOCKSTEP_SOLVE_BLOCK");
-            const int want = e ? atoi(e) : 256, glob = cip_solve_block_max_set(0);
-            cip_tl_solve_block_max = want < glob ? want : glob;
-        }
+        explicit SolveBlockScope(int B_) : saved(cip_tl_solve_block_max) { cip_tl_solve_block_max = cip_lockstep_solve_block_for(B_); }
         ~SolveBlockScope() { cip_tl_solve_block_max = saved; }
-    } solve_block_scope;
+    } solve_block_scope(B);
     // ---- slab size: create problem 0 once with ordinary allocations and count what it asked for
     size_t slab = 0;
     // CSR: the slab depends on the number of non-zeros -- part of the signature when the row pointers are host memory

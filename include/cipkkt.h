@@ -248,6 +248,10 @@ int cip_set_ldlt_outer_block(int nbo);    /* 0 = automatic (768 from order 4096 
 /* tuning knob: widest block of the triangular solves' block-step form (128, 256, 512 or 1024; 0 = query).  Applies to
  * handles created afterwards; returns the previous value.  Lock-step batches use min(this, 256) for their handles. */
 int cip_set_solve_block_max(int b);
+/* the solve-block limit cip_conicip_lockstep gives the handles of a group of B problems (256, never more than
+ * cip_set_solve_block_max's value; CIP_LOCKSTEP_SOLVE_BLOCK overrides): a one-problem run with this limit
+ * reproduces the group's iterates bit for bit */
+int cip_lockstep_solve_block_for(int B);
 /* panel chain of the serial schedule (also CIP_FUSE_DIAG): 3 (default) = one launch per 128-column panel -- diagonal kernel,
  * the previous panel's in-block update and this panel's TRSM, the TRSM following the diagonal kernel micro-panel by
  * micro-panel through a stage counter; 1 = diagonal kernel + previous panel's update in one launch, TRSM in its own;

@@ -15,12 +15,13 @@ pytestmark = pytest.mark.gpu
 
 
 def _solve(prs, mode, in_flight=4):
-    """the thread-pool reference runs with the solve-block limit the lock-step groups use for their handles (256): the
-    block size changes the summation order of the triangular solves, and the comparison below is bit for bit"""
+    """the thread-pool reference runs with the solve-block limit the lock-step group uses for its handles (256 unless
+    CIP_LOCKSTEP_SOLVE_BLOCK says otherwise; groups are formed of at most 64 problems): the block size changes the summation order of the
+    triangular solves, and the comparison below is bit for bit"""
     from cipkkt import _lib as L
     from cipkkt.batch import _solve_problems_native
     lib = L.load()
-    prev = lib.cip_set_solve_block_max(256) if mode == "threads" else None
+    prev = lib.cip_set_solve_block_max(lib.cip_lockstep_solve_block_for(min(len(prs), 64))) if mode == "threads" else None
     try:
         return _solve_problems_native(prs, torch.device("cuda:0"), in_flight, mode)
     finally:
