@@ -112,7 +112,7 @@ def make_problem(Q, A, G, cone_dims, route, device):
     pr.Q, pr.ldq = dense(Q, n, n), n
     a_sparse = False
     csr_host = False
-    if m > 0 and _is_sparse(A) and not any(t == "S" for t, _ in cone_dims):
+    if m > 0 and _is_sparse(A):          # (S cones too, round 4: the library expands their rows on the device)
         csr = A.tocsr()
         csr.sort_indices()
         # the CSR arrays stay on the host (CIP_FLAG_CSR_HOST): the library builds the CSR of A' there and uploads both

@@ -81,7 +81,7 @@ static void free_all(cip_handle *h) {
     if (h->gx_solve) { (void)hipGraphExecDestroy(h->gx_solve); h->gx_solve = nullptr; }
     if (h->cs.lg) { cip_sdp_large_destroy(h->cs.lg); h->cs.lg = nullptr; }
     void *ptrs[] = {h->cs.d_sidx_small, h->cs.d_sidx, h->cs.d_sdpws, h->cs.d_sdpvec, h->cs.d_sdpflag, h->Q, h->symv_ws, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->kdiag, h->row_cone, h->G, h->Gt,
-                    h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->cs.d_partial, h->cs.d_scalar, h->K, h->Wt, h->Gm,
+                    h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->cs.d_partial, h->cs.d_scalar, h->K, h->Wt, h->Gm, h->AtS, h->WtS,
                     h->ws_base, h->rhs, h->mt1, h->mt2, h->mt3, h->nt1, h->pt1, h->dot_scratch, h->dot_ptrs, h->stage, h->drv, h->ref, h->c2x2};
     for (void *p : ptrs)
         if (p && !in_arena(h, p)) (void)hipFree(p);
@@ -186,6 +186,7 @@ static int upload_problem(cip_handle *h, const cip_problem *pr) {
         CIP_HIP_CHECK(hipMemcpyAsync(h->T_v, tv.data(), sizeof(double) * nnz, hipMemcpyHostToDevice, s));
     }
     h->staging_live = true;
+    if (h->AtS) return cip_scatter_AtS(h);                  // assemble.hip: the S cones' rows of A' as a dense block
     return 0;
 }
 
@@ -215,7 +216,7 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
     int rmax = 0, kmax = 0;
     for (int c = 0; c < pr->ncones; ++c) {
         ConeDesc cd = {};
-        cd.type = pr->cone_type[c]; cd.dim = pr->cone_dim[c]; cd.off = off; cd.soff = (int)soff; cd.r = 0; cd.qidx = -1;
+        cd.type = pr->cone_type[c]; cd.dim = pr->cone_dim[c]; cd.off = off; cd.soff = (int)soff; cd.r = 0; cd.qidx = -1; cd.aoff = off;
         if (cd.dim <= 0) { cip_set_error("cone %d has dimension %d", c, cd.dim); return CIP_E_INVALID; }
         if (cd.type == CIP_CONE_R) { soff += cd.dim; }
         else if (cd.type == CIP_CONE_Q) { soff += 1 + cd.dim; cd.qidx = nq++; }
@@ -261,7 +262,14 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
         }
     }
     if (off != m) { cip_set_error("cone_dims cover %d rows but A has %d", off, m); return CIP_E_INVALID; }
-    if (has_S && pr->A == NULL && m > 0) { cip_set_error("S cones need a dense A"); return CIP_E_UNSUPPORTED; }
+    if (has_S && pr->A == NULL && m > 0) {
+        // CSR A with S cones (round 4; the reference builds its Schur system from a sparse A whatever the cones,
+        // src/kktsolvers.jl:289-293): the S cones' rows are expanded, once, into a dense transposed block of their own
+        // (upload_problem) for the congruences of the Schur scaling; everything else stays CSR
+        int ao = 0;
+        for (ConeDesc &cd : h->h_cones) if (cd.type == CIP_CONE_S) { cd.aoff = ao; ao += cd.dim; }
+        h->mS = ao; h->mSpad = rup(ao, CIP_KT);
+    }
     h->nq = nq; h->nqpad = rup(nq > 0 ? nq : 1, CIP_KT);
     h->cs.nbigq = 0;
     for (const ConeDesc &cd : h->h_cones) if (cd.type == CIP_CONE_Q && cd.dim > 64) h->cs.nbigq += 1;
@@ -343,6 +351,12 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
             for (int e = 0; e < h->h_cones[c].dim; ++e) rc_[h->h_cones[c].off + e] = (int)c;
         DMALLOC(h->row_cone, sizeof(int) * m);
         if (m > 0) CIP_HIP_CHECK(hipMemcpyAsync(h->row_cone, rc_.data(), sizeof(int) * m, hipMemcpyHostToDevice, s));
+        if (h->mS > 0 && h->route == CIP_ROUTE_SCHUR) {
+            DMALLOC(h->AtS, sizeof(double) * (size_t)h->npad * h->mSpad);
+            DMALLOC(h->WtS, sizeof(double) * (size_t)h->npad * h->mSpad);
+            CIP_HIP_CHECK(hipMemsetAsync(h->AtS, 0, sizeof(double) * (size_t)h->npad * h->mSpad, s));
+            CIP_HIP_CHECK(hipMemsetAsync(h->WtS, 0, sizeof(double) * (size_t)h->npad * h->mSpad, s));
+        }
         if (h->route == CIP_ROUTE_SCHUR) DMALLOC(h->Gm, sizeof(double) * (size_t)h->npad * h->nqpad);
     }
     if ((rc = upload_problem(h, pr))) return rc;

@@ -90,6 +90,7 @@ static void launch_copy_block_lower(hipStream_t s, double *K, long ldk, int r0, 
 // row of A).
 __device__ __forceinline__ double schur_row_weight(const ConeDesc &cd, const double *scal, int r) {
     if (cd.type == CIP_CONE_R) { const double d = scal[cd.soff + (r - cd.off)]; return 1.0 / (d * d); }
+    if (cd.type == CIP_CONE_S) return 0.0;                  // (never used: the callers skip S rows, whose (F'F)^-1 is not diagonal)
     const double beta = scal[cd.soff];
     return ((r == cd.off) ? -1.0 : 1.0) / (beta * beta);
 }
@@ -110,7 +111,9 @@ __global__ __launch_bounds__(256) void k_schur_rows(int n, const int *trp, const
     double *Ki = K + (base + i) + (long)base * ldk;
     for (int q = trp[i]; q < trp[i + 1]; ++q) {
         const int r = tci[q];
-        const double wa = schur_row_weight(cones[row_cone[r]], scal, r) * tv[q];
+        const ConeDesc rc = cones[row_cone[r]];
+        if (rc.type == CIP_CONE_S) continue;                // S rows: dense congruences + a GEMM (assemble_schur)
+        const double wa = schur_row_weight(rc, scal, r) * tv[q];
         const int b1 = rp[r + 1];
         bool wrote = false;
         for (int b = rp[r] + lane; b < b1; b += 64) {
@@ -176,6 +179,28 @@ __global__ __launch_bounds__(256) void k_schur_qcols(int n, const int *trp, cons
         acc += (jw * 1.4142135623730951 / beta) * tv[q];
     }
     if (cur >= 0) Gm[i + (long)cur * ldgm] = acc;
+}
+
+// CSR A with S cones: AtS[i, aoff_c + (r - off_c)] = A[r, i] for the rows r of every S cone c (thread i walks column i of A)
+__global__ __launch_bounds__(256) void k_scatter_AtS(int n, const int *trp, const int *tci, const double *tv, const int *row_cone,
+                                                      const ConeDesc *cones, double *AtS, long ld, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO4(cb, trp, tci, tv, AtS);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int q = trp[i]; q < trp[i + 1]; ++q) {
+        const int r = tci[q];
+        const ConeDesc cd = cones[row_cone[r]];
+        if (cd.type == CIP_CONE_S) AtS[i + (long)(cd.aoff + (r - cd.off)) * ld] = tv[q];
+    }
+}
+int cip_scatter_AtS(cip_handle *h) {
+    if (!h->AtS || h->n == 0) return 0;
+    CIP_HIP_CHECK(hipMemsetAsync(h->AtS, 0, sizeof(double) * (size_t)h->npad * h->mSpad, h->stream));      // (cip_update_problem: new values)
+    hipLaunchKernelGGL(k_scatter_AtS, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->n, h->T_rp, h->T_ci, h->T_v, h->row_cone,
+                       h->cs.d_cones, h->AtS, (long)h->npad, CipBatch{0, 1ull});
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 // ---------------------------------------------------------------- full 3x3 route: -F'F block
@@ -308,6 +333,14 @@ static int assemble_schur(cip_handle *h, bool lazy_ok) {
     if (h->Npad > n) {
         cip_launch_b(k_fill_rest, dim3((h->Npad + 255) / 256, (h->Npad - n) < 32768 ? (h->Npad - n) : 32768), dim3(256), 0, s, h->K, h->ldk, n, p,
                            h->Npad, h->G, (long)p);
+    }
+    if (h->A_sparse && h->AtS) {
+        // the S cones' part of A'(F'F)^-1 A: W = A_S' F^-1 by congruences on the dense block of their rows, then K += W W'
+        if ((rc = cip_sdp_scale_At(s, h->cs, n, h->AtS, (long)h->npad, h->WtS, (long)h->npad))) return rc;
+        GemmArgs g = {};
+        g.A = h->WtS; g.lda = h->npad; g.B = h->WtS; g.ldb = h->npad;
+        g.C = h->K; g.ldc = h->ldk; g.M = h->npad; g.N = h->npad; g.K = h->mSpad; g.alpha = 1.0; g.lower = 1;
+        if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
     }
     if (h->A_sparse && h->nq > 0 && h->m > 0) {
         // after k_fill_rest: the rank-nq update touches whole 128-tiles (adds exact zeros outside [0,n)^2)

@@ -30,6 +30,8 @@ struct cip_handle {
     int *A_rp = nullptr, *A_ci = nullptr; double *A_v = nullptr;   // CSR of A  (m rows)
     int *T_rp = nullptr, *T_ci = nullptr; double *T_v = nullptr;   // CSR of A' (n rows)
     int *row_cone = nullptr;        // m ints: cone index of every row of A
+    // CSR A with S cones (round 4): the rows of the S cones as a dense transposed block, and its scaled image (Schur route)
+    double *AtS = nullptr, *WtS = nullptr; int mS = 0, mSpad = 0;     // npad x mSpad each, ld npad; cone c's rows at columns [aoff, aoff + dim)
     double *G = nullptr;            // p x n, ld p
     double *Gt = nullptr;           // n x p, ld n
 
@@ -94,6 +96,7 @@ struct cip_handle {
 };
 
 int cip_lazy_copy_set(int on);       // assemble.hip
+int cip_scatter_AtS(cip_handle *h);   // assemble.hip: CSR A with S cones: their rows of A' as a dense block (h->AtS)
 int cip_assemble(cip_handle *h, bool lazy_ok = false);     // assemble.hip; lazy_ok: the caller factors right away (see assemble_schur)
 int cip_handle_alloc(cip_handle *h, void **out, size_t bytes);      // api.hip
 int cip_create_in_arena(const struct cip_problem *pr, char *slab, size_t cap, hipStream_t stream, cip_handle **out);   // api.hip

@@ -178,6 +178,8 @@ struct ConeDesc {             // one per cone
     int r;                    // S cone: matrix order
     int qidx;                 // Q cone: running index among Q cones (else -1)
     int item;                 // this cone's (first) slot in the partial-result array
+    int aoff;                 // S cone: first column of its rows in the A' / A'F^-1 operands of the Schur scaling (= off for a dense A; CSR A:
+                              // offset inside the dense block of the S cones' rows, api.hip)
 };
 struct WorkItem {             // unit of work (one 256-thread workgroup) of the per-cone kernels
     int cone;                 // index into ConeDesc[] (first cone of a pack)
@@ -238,6 +240,7 @@ int cip_cones_div(hipStream_t s, const ConeSet &cs, const double *x, const doubl
 int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const double *d, double scale, double *alpha_host, int defer_slot = -1);
 // the pair of the interior-point loop (src/ConicIP.jl:708-709, :881-882, :927-928): alpha_host2 = {maxstep(x1, d1), maxstep(x2, d2)},
 // one wait; large S cones: the two sides on two streams
+int cip_sdp_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, long ldat, double *Wt, long ldwt);   // sdp.hip: the S cones' columns only
 int cip_cones_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const double *d1, const double *x2, const double *d2,
                        double scale, double *alpha_host2);
 int cip_sdp_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const double *d1, double *p1, const double *x2,

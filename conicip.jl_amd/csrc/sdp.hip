@@ -715,7 +715,7 @@ __global__ __launch_bounds__(SD_TMAX) void k_sdp_scale_At(const ConeDesc *cones,
     const double *R = scal + cd.soff;
     const int slot = blockIdx.y * gridDim.x + blockIdx.x;
     for (int i = blockIdx.x; i < n; i += gridDim.x)
-        sd_congruence(R, R + (size_t)r * r, CIP_OP_FINVT, At + i + (long)cd.off * ldat, ldat, Wt + i + (long)cd.off * ldwt,
+        sd_congruence(R, R + (size_t)r * r, CIP_OP_FINVT, At + i + (long)cd.aoff * ldat, ldat, Wt + i + (long)cd.aoff * ldwt,
                       ldwt, r, sd_ws(wsb, slot, r, 0), sd_ws(wsb, slot, r, 1), sd_ws(wsb, slot, r, 2));
 }
 

@@ -1250,11 +1250,11 @@ int cip_sdp_large_scale_At(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li
     for (int i0 = 0; i0 < n; i0 += w->chunk) {
         const int nb = (n - i0 < w->chunk) ? (n - i0) : w->chunk;
         dim3 gm((unsigned)((n2 + 255) / 256), nb);
-        hipLaunchKernelGGL(k_lg_mat, gm, dim3(256), 0, s, At + i0 + (long)cd.off * ldat, ldat, 1L, w->batchX, r, rp, 0.0);
+        hipLaunchKernelGGL(k_lg_mat, gm, dim3(256), 0, s, At + i0 + (long)cd.aoff * ldat, ldat, 1L, w->batchX, r, rp, 0.0);
         if ((rc = lg_gemm(s, w->batchT, n2, Rip, 0, w->batchX, n2, rp, nb))) return rc;     // Rinv X      (X symmetric)
         if ((rc = lg_gemm(s, w->batchX, n2, w->batchT, n2, Rip, 0, rp, nb))) return rc;     // (Rinv X) Rinv'
         dim3 gv((unsigned)(((long)r * r + 255) / 256), nb);
-        hipLaunchKernelGGL(k_lg_vecm, gv, dim3(256), 0, s, w->batchX, Wt + i0 + (long)cd.off * ldwt, ldwt, 1L, r, rp);
+        hipLaunchKernelGGL(k_lg_vecm, gv, dim3(256), 0, s, w->batchX, Wt + i0 + (long)cd.aoff * ldwt, ldwt, 1L, r, rp);
     }
     CIP_HIP_CHECK(hipGetLastError());
     return 0;

@@ -95,12 +95,13 @@ end
 """
     kktsolver_hip(Q, A, G, cone_dims; route = CIP_ROUTE_SCHUR)
 
-Drop-in `kktsolver` for `conicIP` running the Newton step on an AMD MI355X.  A `SparseMatrixCSC` A without "S"
-cones goes to the device as CSR (O(nnz) Schur assembly: the README box-QP, A = I); anything else is uploaded dense.
+Drop-in `kktsolver` for `conicIP` running the Newton step on an AMD MI355X.  A `SparseMatrixCSC` A goes to the
+device as CSR whatever the cones (O(nnz) Schur assembly for "R" / "Q" rows: the README box-QP, A = I; the rows of "S"
+cones are expanded into a dense block on the device); a dense A is uploaded dense.
 """
 function kktsolver_hip(Q, A, G, cone_dims; route = CIP_ROUTE_SCHUR)
     n, m, p = size(Q, 1), size(A, 1), size(G, 1)
-    h = if A isa SparseMatrixCSC && !any(c -> c[1] == "S", cone_dims)
+    h = if A isa SparseMatrixCSC
         _cip_create_sparse(Q, A, G, cone_dims, route)
     else
         _cip_create_dense(Q, A, G, cone_dims, route)
@@ -173,7 +174,7 @@ end
 # (cip_solve2x2 solves [Q + Aᵀ(FᵀF)⁻¹A  Gᵀ; G 0][Δy; Δw] = [y; w] on the factor of the Schur route).
 function kktsolver_2x2_hip(Q, A, G, cone_dims)
     n, p = size(Q, 1), size(G, 1)
-    h = (A isa SparseMatrixCSC && !any(c -> c[1] == "S", cone_dims)) ?
+    h = (A isa SparseMatrixCSC) ?
         _cip_create_sparse(Q, A, G, cone_dims, CIP_ROUTE_SCHUR) : _cip_create_dense(Q, A, G, cone_dims, CIP_ROUTE_SCHUR)
     function solve2x2gen(F, F⁻ᵀ)
         packed = _pack_scaling(F, F⁻ᵀ, cone_dims)

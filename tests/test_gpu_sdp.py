@@ -259,3 +259,73 @@ def test_large_s_cone_programs_walk_the_oracles_trajectory(r, n, p, seed):
     assert got.status == ref.status == "Optimal" and got.Iter == ref.Iter
     np.testing.assert_allclose(got.y, ref.y, rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(got.v, ref.v, rtol=1e-7, atol=1e-8)
+
+
+# ---- CSR A together with S cones on the device (round 4: no host-side densification)
+def test_reference_sparse_psd_projection_without_densification():
+    """test/runtests.jl:527-552: project onto the PSD cone with A = sparse identity (6 x 6), one ("S", 6) cone -- through
+    the CSR entry of the C ABI (cip_problem.A_rowptr ...): the library expands the S cone's rows on the device.  Same
+    iteration count as the oracle (the reference pins Iter == 6 for its data; here: equal to the oracle's) and the analytic
+    answer diag(1, 1, 1, 0, 0, 0) of the reference's own problem."""
+    import cipkkt
+    import scipy.sparse as sp
+    from oracle.conicip import conicIP as oracle_conicIP
+    import problems as P
+    Q, c, A, b, K = P.psd_projection()[:5]
+    want = P.psd_projection()[7]
+    As = sp.csr_matrix(A)
+    ref = oracle_conicIP(Q, c, np.asarray(As.todense()), b, K, optTol=1e-7)
+    for route in ("schur", "full3x3"):
+        ks = cipkkt.KKTSystem(Q, As, None, K, route=route)
+        assert ks.A_sparse, "CSR A with an S cone must reach the library as CSR"
+        got = cipkkt.conicIP(Q, c, As, b, K, optTol=1e-7, system=ks, kktsolver=route)
+        assert got.status == ref.status == "Optimal" and got.Iter == ref.Iter
+        np.testing.assert_allclose(got.y, ref.y, rtol=1e-6, atol=1e-7)
+        assert np.abs(got.y - want).max() < 1e-3                  # `tol` of test/runtests.jl:13
+        ks.close()
+
+
+@pytest.mark.parametrize("route", ["schur", "full3x3"])
+def test_csr_A_with_mixed_R_Q_S_cones_equals_dense_A(route):
+    """A random program with R, Q and two S cones (one of them interleaved between the others): the CSR upload -- O(nnz)
+    Schur rows for R / Q, congruences on the expanded S rows + one GEMM -- walks the trajectory of the dense upload and of
+    the oracle; the assembled Schur matrix agrees with the dense path's to 1e-12."""
+    import cipkkt
+    import scipy.sparse as sp
+    from oracle.conicip import conicIP as oracle_conicIP
+    from oracle import cones as oc
+    rng = np.random.default_rng(42)
+    n, p = 30, 3
+    K = [("R", 12), ("S", 10), ("Q", 5), ("S", 21), ("R", 4)]
+    m = sum(k for _, k in K)
+    A = np.where(rng.random((m, n)) < 0.3, rng.standard_normal((m, n)), 0.0)
+    xs = []
+    for t, k in K:                                              # b = A y0 - s0 with s0 strictly inside the cone, y0 = 1
+        if t == "R":
+            xs.append(rng.random(k) + 0.5)
+        elif t == "Q":
+            x = rng.standard_normal(k); x[0] = np.linalg.norm(x[1:]) + 1.0; xs.append(x)
+        else:
+            r = int(round((np.sqrt(1 + 8 * k) - 1) / 2)); M = rng.standard_normal((r, r)); xs.append(oc.vecm(M @ M.T / r + np.eye(r)))
+    s0 = np.concatenate(xs)
+    b = A @ np.ones(n) - s0
+    G = rng.standard_normal((p, n)); d = G @ np.ones(n)
+    Mq = rng.standard_normal((n, n)); Q = Mq.T @ Mq / n + 0.1 * np.eye(n); c = rng.standard_normal(n)
+    ref = oracle_conicIP(Q, c, A, b, K, G, d, optTol=1e-7)
+    dense = cipkkt.conicIP(Q, c, A, b, K, G, d, optTol=1e-7, kktsolver=route)
+    csr = cipkkt.conicIP(Q, c, sp.csr_matrix(A), b, K, G, d, optTol=1e-7, kktsolver=route)
+    assert ref.status == dense.status == csr.status == "Optimal"
+    assert ref.Iter == dense.Iter == csr.Iter
+    np.testing.assert_allclose(csr.y, dense.y, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(csr.y, ref.y, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(csr.v, ref.v, rtol=1e-5, atol=1e-6)
+    if route == "schur":
+        kd = cipkkt.KKTSystem(Q, A, G, K); kc = cipkkt.KKTSystem(Q, sp.csr_matrix(A), G, K)
+        import torch
+        v, s = torch.as_tensor(s0 * 1.3, device="cuda"), torch.as_tensor(s0, device="cuda")
+        for ks in (kd, kc):
+            ks.set_scaling_from_iterate(v, s); ks.assemble_only()
+        Kd, Kc = kd.kkt_matrix(), kc.kkt_matrix()
+        N = n + p
+        np.testing.assert_allclose(np.tril(Kc[:N, :N]), np.tril(Kd[:N, :N]), rtol=1e-12, atol=1e-12 * np.abs(Kd).max())
+        kd.close(); kc.close()
