@@ -55,7 +55,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X vendor fp64 matrix peak (dense); see 
 # (GRBM_GUI_ACTIVE / 8 / duration of profiles/r3/final_pmc_mfma.csv: 2.117 GHz, 2.17 in round 2; tools/mfma_peak.hip measures 77.6 at 2.37 GHz unloaded)
 FP64_MFMA_CLOCK_LIMITED_TFLOPS = 256 * 4 * 32 * 2.12e9 / 1e12
 HBM_PEAK_GBS = 8000.0
-PMC_ROUNDS = ("r3", "r2", "r1")
+PMC_ROUNDS = ("r4", "r3", "r2", "r1")
 
 
 def pmc_dir():
@@ -132,7 +132,7 @@ def cpu_baseline(Q_host, n, solves_per_factor, budget_s=100.0):
         rngp = np.random.default_rng(0)
         npb = 4096 if n >= 4096 else max(256, n)
         Mp = rngp.standard_normal((npb, npb))
-        Sp = Mp @ Mp.T / npb + np.eye(npb)
+        Sp = np.asfortranarray(Mp @ Mp.T / npb + np.eye(npb))      # column-major, as LAPACK wants it (a C-ordered input is transposed first)
         best_g, best_p = (1e30, cores), (1e30, cores)
         for nt in sorted({c for c in (8, 16, 32, 64, 128, logical) if c <= logical}):
             with threadpool_limits(limits=nt):
@@ -142,7 +142,7 @@ def cpu_baseline(Q_host, n, solves_per_factor, budget_s=100.0):
                     t0 = time.perf_counter()
                     Mp @ Mp
                     dg = min(dg, time.perf_counter() - t0)
-                    Sc = Sp.copy()
+                    Sc = Sp.copy(order="F")
                     t0 = time.perf_counter()
                     sla.cho_factor(Sc, lower=True, overwrite_a=True, check_finite=False)
                     dp = min(dp, time.perf_counter() - t0)

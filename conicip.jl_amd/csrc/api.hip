@@ -80,7 +80,7 @@ static void free_all(cip_handle *h) {
     if (h->ldlt_side) { cip_ldlt_side_destroy(h->ldlt_side); h->ldlt_side = nullptr; }
     if (h->gx_solve) { (void)hipGraphExecDestroy(h->gx_solve); h->gx_solve = nullptr; }
     if (h->cs.lg) { cip_sdp_large_destroy(h->cs.lg); h->cs.lg = nullptr; }
-    void *ptrs[] = {h->cs.d_sidx_small, h->cs.d_sidx, h->cs.d_sdpws, h->cs.d_sdpvec, h->cs.d_sdpflag, h->Q, h->symv_ws, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->kdiag, h->row_cone, h->G, h->Gt,
+    void *ptrs[] = {h->cs.d_bigq, h->cs.d_ritems, h->cs.d_sidx_small, h->cs.d_sidx, h->cs.d_sdpws, h->cs.d_sdpvec, h->cs.d_sdpflag, h->Q, h->symv_ws, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->kdiag, h->row_cone, h->G, h->Gt,
                     h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->cs.d_partial, h->cs.d_scalar, h->K, h->Wt, h->Gm, h->AtS, h->WtS,
                     h->ws_base, h->rhs, h->mt1, h->mt2, h->mt3, h->nt1, h->pt1, h->dot_scratch, h->dot_ptrs, h->stage, h->drv, h->ref, h->c2x2};
     for (void *p : ptrs)
@@ -223,7 +223,7 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
         else if (cd.type == CIP_CONE_S) {
             const int r = (int)llround((sqrt(1.0 + 8.0 * cd.dim) - 1.0) / 2.0);     // ord() src/ConicIP.jl:85
             if (r * (r + 1) / 2 != cd.dim) { cip_set_error("S cone %d: %d is not a triangular number", c, cd.dim); return CIP_E_INVALID; }
-            if (r > 512) { cip_set_error("S cone %d: matrix order %d > 512 is not supported by the workgroup-per-cone kernels", c, r); return CIP_E_UNSUPPORTED; }
+            if (r > 1024) { cip_set_error("S cone %d: matrix order %d > 1024 is not supported", c, r); return CIP_E_UNSUPPORTED; }
             cd.r = r; soff += 2 * (size_t)r * r; has_S = true;
             sidx.push_back(c);
             if (r > rmax) rmax = r;
@@ -271,8 +271,25 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
         h->mS = ao; h->mSpad = rup(ao, CIP_KT);
     }
     h->nq = nq; h->nqpad = rup(nq > 0 ? nq : 1, CIP_KT);
-    h->cs.nbigq = 0;
-    for (const ConeDesc &cd : h->h_cones) if (cd.type == CIP_CONE_Q && cd.dim > 64) h->cs.nbigq += 1;
+    h->cs.nbigq = 0; h->cs.d_bigq = nullptr;
+    h->st_bigq.clear();
+    for (size_t it = 0; it < h->h_items.size(); ++it) {
+        const ConeDesc &cd = h->h_cones[h->h_items[it].cone];
+        if (cd.type == CIP_CONE_Q && h->h_items[it].width == 0) h->st_bigq.push_back((int)it);
+    }
+    h->cs.nbigq = (int)h->st_bigq.size();
+    h->st_ritems.clear();
+    for (size_t it = 0; it < h->h_items.size(); ++it)
+        if (h->h_cones[h->h_items[it].cone].type == CIP_CONE_R) h->st_ritems.push_back((int)it);
+    h->cs.nritems = (int)h->st_ritems.size(); h->cs.d_ritems = nullptr;
+    if (h->cs.nritems > 0) {
+        DMALLOC(h->cs.d_ritems, sizeof(int) * h->st_ritems.size());
+        CIP_HIP_CHECK(hipMemcpyAsync(h->cs.d_ritems, h->st_ritems.data(), sizeof(int) * h->st_ritems.size(), hipMemcpyHostToDevice, s));
+    }
+    if (h->cs.nbigq > 0) {
+        DMALLOC(h->cs.d_bigq, sizeof(int) * h->st_bigq.size());
+        CIP_HIP_CHECK(hipMemcpyAsync(h->cs.d_bigq, h->st_bigq.data(), sizeof(int) * h->st_bigq.size(), hipMemcpyHostToDevice, s));
+    }
     h->cs.ncones = pr->ncones; h->cs.nitems = (int)h->h_items.size(); h->cs.nslots = nslots; h->cs.m = m; h->cs.scal_len = soff; h->cs.has_S = has_S;
     DMALLOC(h->cs.d_cones, sizeof(ConeDesc) * h->h_cones.size());
     DMALLOC(h->cs.d_items, sizeof(WorkItem) * h->h_items.size());

@@ -241,13 +241,12 @@ __global__ __launch_bounds__(256) void k_fill_ftf(const ConeDesc *cones, const W
 }
 // -F'F of a Q cone of dimension > 64: the k (k + 1) / 2 entries of its lower triangle by column, many workgroups (round 4: one
 // workgroup walked all k^2 of them, 19 ms at k = 4097)
-__global__ __launch_bounds__(256) void k_fill_ftf_qbig(const ConeDesc *cones, const WorkItem *items, const double *scal,
+__global__ __launch_bounds__(256) void k_fill_ftf_qbig(const ConeDesc *cones, const WorkItem *items, const int *bigq, const double *scal,
                                                         double *K, long ldk, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO2(cb, scal, K);
-    const WorkItem it = items[blockIdx.x];
+    const WorkItem it = items[bigq[blockIdx.x]];
     const ConeDesc qc = cones[it.cone];
-    if (qc.type != CIP_CONE_Q || it.width) return;
     const int k = qc.dim;
     const double beta = scal[qc.soff];
     const double *w = scal + qc.soff + 1;
@@ -363,7 +362,7 @@ static int assemble_full(cip_handle *h) {
         cip_launch_b(k_fill_ftf, dim3(h->cs.nitems), dim3(256), 0, s, h->cs.d_cones, h->cs.d_items, h->cs.d_scal,
                            h->K, h->ldk);
     if (h->cs.nbigq > 0)
-        cip_launch_b(k_fill_ftf_qbig, dim3(h->cs.nitems, 128), dim3(256), 0, s, h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->K, h->ldk);
+        cip_launch_b(k_fill_ftf_qbig, dim3(h->cs.nbigq, 128), dim3(256), 0, s, h->cs.d_cones, h->cs.d_items, (const int *)h->cs.d_bigq, h->cs.d_scal, h->K, h->ldk);
     if (h->cs.has_S) { int rc = cip_sdp_fill_ftf(s, h->cs, h->K, h->ldk); if (rc) return rc; }
     if (m > 0 && n > 0) {
         if (!h->A_sparse)

@@ -191,6 +191,9 @@ __global__ __launch_bounds__(256) void k_apply(const ConeDesc *cones, const Work
 }
 
 // Wt[i, off + e] = (F^-T a_i)_e,  a_i = At[i, off:off+k]   (thread per row i of At, coalesced along i)
+// The packs of small Q cones; the R chunks and the large Q cones have kernels of their own below (grids over THEIR items only:
+// an empty workgroup costs ~50 ns of dispatch, and config 3's 512 x Q(8) ran 130 -> 330 us when 15 of 16 workgroups of a
+// common grid exited at once)
 #define SCALE_AT_SPLIT 16
 __global__ __launch_bounds__(256) void k_scale_At(const ConeDesc *cones, const WorkItem *items, const double *scal,
                                                    int n, const double *At, long ldat, double *Wt, long ldwt, CipBatch cb) {
@@ -198,35 +201,41 @@ __global__ __launch_bounds__(256) void k_scale_At(const ConeDesc *cones, const W
     CIP_BO3(cb, scal, At, Wt);
     const WorkItem it = items[blockIdx.y];
     const ConeDesc cd = cones[it.cone];
-    // grid.x = row blocks x SCALE_AT_SPLIT: an R chunk's (up to 2048) columns are dealt to SCALE_AT_SPLIT workgroups per row
-    // block (round 4: one thread walked all of them -- one R cone of 4097 rows behind n = 4096 was 48 workgroups and 0.7 ms)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || cd.type != CIP_CONE_Q || !it.width) return;
+    const int ncone = it.len;                             // a pack of small cones: this thread's row through each of them
+    for (int q = 0; q < ncone; ++q) {
+        const ConeDesc qc = cones[it.cone + q];
+        const int k = qc.dim;
+        const double beta = scal[qc.soff];
+        const double *w = scal + qc.soff + 1;
+        const double *ap = At + i + (long)qc.off * ldat;
+        double *wp = Wt + i + (long)qc.off * ldwt;
+        double t = w[0] * ap[0];
+        for (int e = 1; e < k; ++e) t -= w[e] * ap[(long)e * ldat];
+        t /= beta;
+        const double ib = 1.0 / beta;
+        wp[0] = (w[0] * t - ap[0]) * ib;
+        for (int e = 1; e < k; ++e) wp[(long)e * ldwt] = (ap[(long)e * ldat] - w[e] * t) * ib;
+    }
+}
+// R chunks (up to 2048 rows of A each): grid.x = row blocks x SCALE_AT_SPLIT, a chunk's columns dealt to SCALE_AT_SPLIT
+// workgroups per row block (round 4: one thread walked all of them -- one R cone of 4097 rows behind n = 4096 was 48
+// workgroups and 0.7 ms); grid.y = the R items
+__global__ __launch_bounds__(256) void k_scale_At_r(const ConeDesc *cones, const WorkItem *items, const int *ritems, const double *scal,
+                                                     int n, const double *At, long ldat, double *Wt, long ldwt, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO3(cb, scal, At, Wt);
+    const WorkItem it = items[ritems[blockIdx.y]];
+    const ConeDesc cd = cones[it.cone];
     const int nxb = gridDim.x / SCALE_AT_SPLIT, sub = blockIdx.x / nxb;
     const int i = (blockIdx.x % nxb) * 256 + threadIdx.x;
     if (i >= n) return;
-    if (cd.type == CIP_CONE_R) {
-        const int per = (it.len + SCALE_AT_SPLIT - 1) / SCALE_AT_SPLIT;
-        const int e0 = it.start + sub * per, e1 = min(it.start + it.len, e0 + per);
-        for (int e = e0; e < e1; ++e) {
-            const long c = cd.off + e;
-            Wt[i + c * ldwt] = At[i + c * ldat] / scal[cd.soff + e];
-        }
-    } else if (cd.type == CIP_CONE_Q) {
-        if (!it.width || sub) return;                     // a large cone: k_scale_At_qbig; a pack: the first of the split only
-        const int ncone = it.len;                         // a pack of small cones: this thread's row through each of them
-        for (int q = 0; q < ncone; ++q) {
-            const ConeDesc qc = cones[it.cone + q];
-            const int k = qc.dim;
-            const double beta = scal[qc.soff];
-            const double *w = scal + qc.soff + 1;
-            const double *ap = At + i + (long)qc.off * ldat;
-            double *wp = Wt + i + (long)qc.off * ldwt;
-            double t = w[0] * ap[0];
-            for (int e = 1; e < k; ++e) t -= w[e] * ap[(long)e * ldat];
-            t /= beta;
-            const double ib = 1.0 / beta;
-            wp[0] = (w[0] * t - ap[0]) * ib;
-            for (int e = 1; e < k; ++e) wp[(long)e * ldwt] = (ap[(long)e * ldat] - w[e] * t) * ib;
-        }
+    const int per = (it.len + SCALE_AT_SPLIT - 1) / SCALE_AT_SPLIT;
+    const int e0 = it.start + sub * per, e1 = min(it.start + it.len, e0 + per);
+    for (int e = e0; e < e1; ++e) {
+        const long c = cd.off + e;
+        Wt[i + c * ldwt] = At[i + c * ldat] / scal[cd.soff + e];
     }
 }
 
@@ -236,13 +245,12 @@ __global__ __launch_bounds__(256) void k_scale_At(const ConeDesc *cones, const W
 // workgroup takes 16 rows and spreads the cone's entries over 16 thread columns (e = c, c + 16, ..): 16 partial dot products
 // per row, summed in a fixed order through LDS, then the element-wise pass on the same split -- n / 16 workgroups, the
 // second pass re-reads what the first brought into L2.  Deterministic (no atomics); O(k n) beside the SYRK's O(k n^2).
-__global__ __launch_bounds__(256) void k_scale_At_qbig(const ConeDesc *cones, const WorkItem *items, const double *scal,
+__global__ __launch_bounds__(256) void k_scale_At_qbig(const ConeDesc *cones, const WorkItem *items, const int *bigq, const double *scal,
                                                         int n, const double *At, long ldat, double *Wt, long ldwt, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO3(cb, scal, At, Wt);
-    const WorkItem it = items[blockIdx.y];
+    const WorkItem it = items[bigq[blockIdx.y]];              // grid.y = the large Q cones (an empty workgroup costs ~50 ns of dispatch)
     const ConeDesc cd = cones[it.cone];
-    if (cd.type != CIP_CONE_Q || it.width) return;
     __shared__ double part[16][17];
     const int r = threadIdx.x & 15, c = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + r;
@@ -532,10 +540,13 @@ int cip_cones_identity(hipStream_t s, const ConeSet &cs, double *e) {
 }
 int cip_cones_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, long ldat, double *Wt, long ldwt) {
     if (cs.nitems == 0 || n == 0) return 0;
-    cip_launch_b(k_scale_At, dim3(((n + 255) / 256) * SCALE_AT_SPLIT, cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items,
-                       cs.d_scal, n, At, ldat, Wt, ldwt);
+    if (cs.nitems - cs.nritems - cs.nbigq - cs.ns > 0)              // (items that are packs of small Q cones)
+        cip_launch_b(k_scale_At, dim3((n + 255) / 256, cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, cs.d_scal, n, At, ldat, Wt, ldwt);
+    if (cs.nritems > 0)
+        cip_launch_b(k_scale_At_r, dim3(((n + 255) / 256) * SCALE_AT_SPLIT, cs.nritems), dim3(256), 0, s, cs.d_cones, cs.d_items,
+                           (const int *)cs.d_ritems, cs.d_scal, n, At, ldat, Wt, ldwt);
     if (cs.nbigq > 0)
-        cip_launch_b(k_scale_At_qbig, dim3((n + 15) / 16, cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items,
+        cip_launch_b(k_scale_At_qbig, dim3((n + 15) / 16, cs.nbigq), dim3(256), 0, s, cs.d_cones, cs.d_items, (const int *)cs.d_bigq,
                            cs.d_scal, n, At, ldat, Wt, ldwt);
     CIP_HIP_CHECK(hipGetLastError());
     if (cs.has_S) return cip_sdp_scale_At(s, cs, n, At, ldat, Wt, ldwt);

@@ -471,7 +471,9 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
             // forking from the block's start: 187.5 against 188.7 KKT solves/s); the last ones are a chain on an idle chip.
             static const int side_from = [] { const char *e = getenv("CIP_SIDE_PREP_FROM"); return e ? atoi(e) : 2048; }();
             for (int c = C0; c < Npad; ) {
-                if (c % Bs == 0 && Npad - c <= side_from && c / Bs > Jdone) {
+                // (forks no finer than 1024 columns: with a 512-wide solve block -- order 4608, config 3 -- a fork per block was five
+                //  groups of tiny launches per factorisation, 0.2 ms of side work more than the serial preparation)
+                if (c % (Bs > 1024 ? Bs : 1024) == 0 && Npad - c <= side_from && c / Bs > Jdone) {
                     if ((rc = side_fork(sd, s, K, Npad, ld, ws, Jdone, c / Bs))) return rc;
                     Jdone = c / Bs;
                 }

@@ -220,7 +220,8 @@ __device__ __forceinline__ double lg_rsqrt(double x) {
 // the dot products and the rotation.  Ends after the first sweep whose largest rotation had cos^2 < 1e-16 (the next
 // sweep would find nothing above the 1e-30 threshold: quadratic convergence), or after a sweep without any rotation.
 // G_in V = U diag(sigma): column i ends as sigma_i u_i, all of svd(Lz' Ls) that nestod_sdc uses (src/ConicIP.jl:204-208).
-template <int NT>
+// EPL: elements of a column per lane (rp == EPL * tpp): 8 up to order 512; 16 at order 1024 (round 4), where 64 lanes hold a column
+template <int NT, int EPL = 8>
 __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsigned *ctr, int *err) {
     extern __shared__ double sh[];
     __shared__ int s_rot;
@@ -229,18 +230,18 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsi
     const int nbk = rp / b, m = nbk, nwg = nbk / 2;
     const int ld = lg_pitch(rp);
     const int nc = 2 * b;                                  // columns in LDS
-    const int tpp = NT / b;                              // lanes per column pair (32 or 64); rp == 8 * tpp
+    const int tpp = NT / b;                              // lanes per column pair (32 or 64); rp == EPL * tpp
     const int part = tid % tpp, pair = tid / tpp;
     unsigned phase = 0;
     unsigned *bar = ctr, *sweepflag = ctr + 8;
     // rotation of LDS columns p, q; returns 0 / 1 (rotated, small) / 2 (rotated, cos^2 >= 1e-16)
     auto rotate = [&](int p, int q) -> int {
         double *gp = sh + p * ld, *gq = sh + q * ld;
-        double xv[8], yv[8], a = 0.0, bb = 0.0, c = 0.0;
+        double xv[EPL], yv[EPL], a = 0.0, bb = 0.0, c = 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { xv[u] = gp[part + u * tpp]; yv[u] = gq[part + u * tpp]; }
+        for (int u = 0; u < EPL; ++u) { xv[u] = gp[part + u * tpp]; yv[u] = gq[part + u * tpp]; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { a += xv[u] * xv[u]; bb += yv[u] * yv[u]; c += xv[u] * yv[u]; }
+        for (int u = 0; u < EPL; ++u) { a += xv[u] * xv[u]; bb += yv[u] * yv[u]; c += xv[u] * yv[u]; }
         for (int o = tpp >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o); bb += __shfl_xor(bb, o); c += __shfl_xor(c, o); }
         if (!(c * c > 1e-30 * (a * bb) && c != 0.0)) return 0;
         const double zeta = (bb - a) * 0.5 * lg_rcp(c);
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsi
         const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * lg_rcp(fabs(zeta) + h2 * lg_rsqrt(h2));
         const double cs = lg_rsqrt(1.0 + tt * tt), sn = cs * tt;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < EPL; ++u) {
             gp[part + u * tpp] = cs * xv[u] - sn * yv[u];
             gq[part + u * tpp] = sn * xv[u] + cs * yv[u];
         }
@@ -258,14 +259,14 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsi
     // before the first LDS store (one at a time, store after load, each global round trip was exposed: 16 x ~1.5 us per
     // outer round -- half of a sweep's time)
     auto load = [&](int bp, int bq) {                      // coherent loads: other workgroups wrote these blocks
-        double t[16];
+        double t[2 * EPL];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 2 * EPL; ++u) {
             const int e = tid + u * NT, i = e % rp, c = e / rp;
             t[u] = lg_ld(G + i + (long)(c < b ? bp * b + c : bq * b + (c - b)) * rp);
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 2 * EPL; ++u) {
             const int e = tid + u * NT;
             sh[e % rp + (e / rp) * ld] = t[u];
         }
@@ -273,11 +274,11 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsi
         __syncthreads();
     };
     auto store = [&](int bp, int bq) {
-        double t[16];
+        double t[2 * EPL];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int e = tid + u * NT; t[u] = sh[e % rp + (e / rp) * ld]; }
+        for (int u = 0; u < 2 * EPL; ++u) { const int e = tid + u * NT; t[u] = sh[e % rp + (e / rp) * ld]; }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 2 * EPL; ++u) {
             const int e = tid + u * NT, i = e % rp, c = e / rp;
             lg_st(G + i + (long)(c < b ? bp * b + c : bq * b + (c - b)) * rp, t[u]);
         }
@@ -313,14 +314,14 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsi
                 // squared norm `a` and the partners' (s_nrm, in LDS) follow the rotations (a' = a - t c, b' = b + t c)
                 // instead of being re-summed -- a round is then one dot product, 8 LDS loads and 8 stores per lane
                 double *gp = sh + pair * ld;
-                double xv[8], a = 0.0;
+                double xv[EPL], a = 0.0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { xv[u] = gp[part + u * tpp]; a += xv[u] * xv[u]; }
+                for (int u = 0; u < EPL; ++u) { xv[u] = gp[part + u * tpp]; a += xv[u] * xv[u]; }
                 {
                     double *gq0 = sh + (b + pair) * ld;
                     double bq2 = 0.0;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { const double y = gq0[part + u * tpp]; bq2 += y * y; }
+                    for (int u = 0; u < EPL; ++u) { const double y = gq0[part + u * tpp]; bq2 += y * y; }
                     for (int o = tpp >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o); bq2 += __shfl_xor(bq2, o); }
                     if (part == 0) s_nrm[pair] = bq2;
                 }
@@ -328,9 +329,9 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsi
                 for (int it = 0; it < b; ++it) {
                     const int qi = (pair + it) % b;
                     double *gq = sh + (b + qi) * ld;
-                    double yv[8], c = 0.0;
+                    double yv[EPL], c = 0.0;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { yv[u] = gq[part + u * tpp]; c += xv[u] * yv[u]; }
+                    for (int u = 0; u < EPL; ++u) { yv[u] = gq[part + u * tpp]; c += xv[u] * yv[u]; }
                     for (int o = tpp >> 1; o > 0; o >>= 1) c += __shfl_xor(c, o);
                     const double bb = s_nrm[qi];
                     if (c * c > 1e-30 * (a * bb) && c != 0.0) {
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsi
                         const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * lg_rcp(fabs(zeta) + h2 * lg_rsqrt(h2));
                         const double cs = lg_rsqrt(1.0 + tt * tt), sn = cs * tt;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
+                        for (int u = 0; u < EPL; ++u) {
                             const double x = xv[u];
                             xv[u] = cs * x - sn * yv[u];
                             gq[part + u * tpp] = sn * x + cs * yv[u];
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsi
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) gp[part + u * tpp] = xv[u];
+                for (int u = 0; u < EPL; ++u) gp[part + u * tpp] = xv[u];
                 __syncthreads();
             }
             rotated = s_rot > rotated ? s_rot : rotated;
@@ -373,14 +374,14 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsi
 // column (by its owner), so that after the barrier every workgroup can form the updated next column -- the Householder
 // vector of the following step -- by itself:  a[:, k+1] - v w_0 - w v_0.
 __global__ __launch_bounds__(LG_T) void k_lg_tridiag(const double *M, int ldm, const double *dscale, int r, double *dg, double *of,
-                                                      double *xbuf /* 2 x ldm */, double *pbuf /* 2 x ldm */, unsigned *ctr, int *err) {
+                                                      double *xbuf /* 2 x ldm */, double *pbuf /* 2 x ldm */, unsigned *ctr, int *err, int slab) {
     extern __shared__ double sh[];
     const int tid = threadIdx.x;
     const int nwg = gridDim.x, w = blockIdx.x;
-    const int c0 = w * LG_SLAB, ncol = (r - c0 < LG_SLAB) ? (r - c0) : LG_SLAB;
+    const int c0 = w * slab, ncol = (r - c0 < slab) ? (r - c0) : slab;
     const int ld = r | 1;
     double *a = sh;                                  // slab: a[i + c * ld]
-    double *v = sh + (size_t)LG_SLAB * ld, *wv = v + r, *vn = wv + r, *red = vn + r;
+    double *v = sh + (size_t)slab * ld, *wv = v + r, *vn = wv + r, *red = vn + r;
     unsigned phase = 0;
     for (int e = tid; e < ncol * r; e += LG_T) {
         const int i = e % r, c = e / r, j = c0 + c;
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(LG_T) void k_lg_tridiag(const double *M, int ldm, c
     __syncthreads();
     // column `col` below its diagonal, as it stands in the owner's slab -> xb
     auto publish = [&](int col, double *xb) {
-        if (col / LG_SLAB == w) {
+        if (col / slab == w) {
             const int cc = col - c0, mm = r - col - 1;
             for (int i = tid; i < mm; i += LG_T) lg_st(xb + i, a[(col + 1 + i) + cc * ld]);
         }
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(LG_T) void k_lg_tridiag(const double *M, int ldm, c
     __syncthreads();
     for (int k = 0; k + 1 < r; ++k) {
         const int m = r - k - 1;
-        const int owner = k / LG_SLAB, kc = k - owner * LG_SLAB;
+        const int owner = k / slab, kc = k - owner * slab;
         double *xb = xbuf + (size_t)((k + 1) & 1) * ldm, *pb = pbuf + (size_t)(k & 1) * ldm;
         if (w == owner && tid == 0) dg[k] = a[k + kc * ld];
         double part = 0.0;
@@ -452,14 +453,14 @@ __global__ __launch_bounds__(LG_T) void k_lg_tridiag(const double *M, int ldm, c
         __syncthreads();
         double *t = v; v = vn; vn = t;
     }
-    if ((r - 1) / LG_SLAB == w && tid == 0) { dg[r - 1] = a[(r - 1) + ((r - 1) - c0) * ld]; of[r - 1] = 0.0; }
+    if ((r - 1) / slab == w && tid == 0) { dg[r - 1] = a[(r - 1) + ((r - 1) - c0) * ld]; of[r - 1] = 0.0; }
 }
 
 // extreme eigenvalue of the tridiagonal (dg, of) by multisection on the Sturm count (one workgroup), then the max-step
 // verdict of maxstep_sdc (src/ConicIP.jl:272-303): partial[item] <- Inf / 1/(scale lambda_max) / the `nothing` variant
 __global__ __launch_bounds__(LG_T) void k_lg_sturm(const double *dgg, const double *ofg, int r, int want_max, double scale,
                                                     const int *info, double *partial, int item) {
-    __shared__ double dg[512], of[512], red[64];
+    __shared__ double dg[1024], of[1024], red[64];
     __shared__ int first;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double INF = __builtin_inf();
@@ -515,12 +516,13 @@ __global__ __launch_bounds__(LG_T) void k_lg_sturm(const double *dgg, const doub
 
 // ------------------------------------------------------------------------------------------ host side
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
-int cip_sdp_large_padded(int r) { return r <= 256 ? 256 : 512; }
+int cip_sdp_large_padded(int r) { return r <= 256 ? 256 : (r <= 512 ? 512 : 1024); }
 
 int cip_sdp_large_create(int rmax_large, int nlarge, LargeWs **out) {
     LargeWs *w = new LargeWs();
     const int rp = cip_sdp_large_padded(rmax_large);
     w->rp = rp;
+    if (rp > 512) w->chunk = 16;                               // (two batches of chunk matrices of 8 MB each)
     const size_t m2 = al256((size_t)rp * rp * 8);
     size_t bytes = 8 * m2 + 4 * (size_t)nlarge * m2 + al256(12 * (size_t)rp * 8) + 2 * (size_t)w->chunk * m2 + al256(1024) +
                    2 * al256(cip_ldlt_ws_bytes(rp));
@@ -1090,13 +1092,15 @@ static int lg_tridiag(hipStream_t s, LargeWs *w, const double *M, const double *
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    const int nwg = (r + LG_SLAB - 1) / LG_SLAB;
-    const size_t shm = ((size_t)LG_SLAB * (r | 1) + 3 * (size_t)r + 64) * sizeof(double);
+    // a workgroup keeps a slab of 32 columns in LDS for the whole reduction; above order ~600 that no longer fits: 16 columns
+    const int slab = ((size_t)LG_SLAB * (r | 1) + 3 * (size_t)r + 64) * sizeof(double) <= 160 * 1024 ? LG_SLAB : LG_SLAB / 2;
+    const int nwg = (r + slab - 1) / slab;
+    const size_t shm = ((size_t)slab * (r | 1) + 3 * (size_t)r + 64) * sizeof(double);
     if ((rc = lg_set_attr((const void *)k_lg_tridiag, shm))) return rc;
     CIP_HIP_CHECK(hipMemsetAsync(w->ctr, 0, 1024, s));
     double *dg = w->vec + 1 * w->rp, *of = w->vec + 2 * w->rp, *xbuf = w->vec + 3 * w->rp, *pbuf = w->vec + 5 * w->rp;   // 2 x rp each
     hipLaunchKernelGGL(k_lg_tridiag, dim3(nwg), dim3(LG_T), shm, s, M, w->rp, dscale, r, dg, of, xbuf, pbuf, w->ctr,
-                       (int *)(w->ctr + 128));
+                       (int *)(w->ctr + 128), slab);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1121,11 +1125,14 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
         // by instruction issue on its CU (16 waves), so half the pairs per CU is nearly half the time per round, and twice the
         // outer rounds (grid barrier + block exchange each) cost less than that buys (CIP_LG_JACOBI_B=32 restores it)
         static const int bforce = [] { const char *e = getenv("CIP_LG_JACOBI_B"); return e ? atoi(e) : 0; }();
-        const int b = (rp <= 256 && (bforce == 32 || bforce == 8)) ? bforce : 16;
-        const int nt = b * (rp / 8);                               // 512 (order 256, b = 16), 256 (b = 8) or 1024
+        const int b = rp > 512 ? 8 : ((rp <= 256 && (bforce == 32 || bforce == 8)) ? bforce : 16);
+        const int nt = rp > 512 ? b * 64 : b * (rp / 8);           // 512 (order 256, b = 16), 256 (b = 8), 1024 (order 512) or 512 (order 1024: 64 lanes x 16 elements per column)
         const size_t shm = (size_t)2 * b * lg_pitch(rp) * sizeof(double);
         CIP_HIP_CHECK(hipMemsetAsync(w->ctr, 0, 1024, s));
-        if (nt == 256) {
+        if (rp > 512) {
+            if ((rc = lg_set_attr((const void *)k_lg_jacobi<512, 16>, shm))) return rc;
+            hipLaunchKernelGGL((k_lg_jacobi<512, 16>), dim3(rp / b / 2), dim3(512), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
+        } else if (nt == 256) {
             if ((rc = lg_set_attr((const void *)k_lg_jacobi<256>, shm))) return rc;
             hipLaunchKernelGGL(k_lg_jacobi<256>, dim3(rp / b / 2), dim3(256), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
         } else if (nt == 512) {

@@ -39,8 +39,10 @@ def interior(cone_dims, rng):
 
 @pytest.mark.parametrize("cone_dims", [[("S", 6)], [("S", 21)], [("S", 15), ("S", 3)],
                                        [("R", 5), ("Q", 4), ("S", 10)], [("S", 465)], [("S", 2080)], [("S", 5050), ("S", 6)],
-                                       [("S", 8256)], [("S", 11325)], [("S", 20100), ("S", 10)], [("S", 32896)], [("S", 45150)]],
-                         ids=["r3", "r6", "r5+r2", "mixed", "r30", "r64", "r100+r3", "r128", "r150", "r200+r4", "r256", "r300"])
+                                       [("S", 8256)], [("S", 11325)], [("S", 20100), ("S", 10)], [("S", 32896)], [("S", 45150)],
+                                       [("S", 205120)], [("S", 500500), ("S", 6)]],
+                         ids=["r3", "r6", "r5+r2", "mixed", "r30", "r64", "r100+r3", "r128", "r150", "r200+r4", "r256", "r300",
+                              "r640", "r1000+r3"])
 def test_sdp_cone_ops(cone_dims):
     import cipkkt
     from cipkkt import OP_F, OP_FT, OP_FINV, OP_FINVT
@@ -245,11 +247,12 @@ def test_maxstep_pair_equals_two_calls(cone_dims):
     ks.close()
 
 
-@pytest.mark.parametrize("r,n,p,seed", [(133, 64, 4, 919850), (192, 40, 4, 790518), (256, 24, 0, 639913)])
+@pytest.mark.parametrize("r,n,p,seed", [(133, 64, 4, 919850), (192, 40, 4, 790518), (256, 24, 0, 639913), (640, 12, 0, 31337)])
 def test_large_s_cone_programs_walk_the_oracles_trajectory(r, n, p, seed):
-    """Config 4's family on the large-cone path (orders 133..256: Lanczos max-step, the two max-steps of a pair side by side)
-    against the oracle with the exact block elimination: same status, same iteration count, iterates at 1e-8
-    (tools/fuzz_sdp.py draws more of them)."""
+    """Config 4's family on the large-cone path (orders 133..256: Lanczos max-step, the two max-steps of a pair side by side;
+    round 4: order 640 on the order-1024 workspaces -- 64 Jacobi workgroups with 16 elements per lane, tridiagonalisation in
+    16-column slabs; the reference has no order limit, src/ConicIP.jl:196-210) against the oracle with the exact block
+    elimination: same status, same iteration count, iterates at 1e-8 (tools/fuzz_sdp.py draws more of them)."""
     import cipkkt
     from cipkkt import workloads as W
     from oracle import kktsolvers as ok
