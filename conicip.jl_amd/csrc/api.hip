@@ -81,7 +81,7 @@ static void free_all(cip_handle *h) {
     if (h->gx_solve) { (void)hipGraphExecDestroy(h->gx_solve); h->gx_solve = nullptr; }
     if (h->cs.lg) { cip_sdp_large_destroy(h->cs.lg); h->cs.lg = nullptr; }
     void *ptrs[] = {h->cs.d_bigq, h->cs.d_ritems, h->cs.d_sidx_small, h->cs.d_sidx, h->cs.d_sdpws, h->cs.d_sdpvec, h->cs.d_sdpflag, h->Q, h->symv_ws, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->kdiag, h->row_cone, h->G, h->Gt,
-                    h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->cs.d_partial, h->cs.d_scalar, h->K, h->Wt, h->Gm, h->AtS, h->WtS,
+                    h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->cs.d_partial, h->cs.d_scalar, h->K, h->Wt, h->syrk_ws, h->Gm, h->AtS, h->WtS,
                     h->ws_base, h->rhs, h->mt1, h->mt2, h->mt3, h->nt1, h->pt1, h->dot_scratch, h->dot_ptrs, h->stage, h->drv, h->ref, h->c2x2};
     for (void *p : ptrs)
         if (p && !in_arena(h, p)) (void)hipFree(p);
@@ -352,6 +352,8 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
         if (h->route == CIP_ROUTE_SCHUR) {
             DMALLOC(h->Wt, sizeof(double) * (size_t)h->npad * h->mpad);
             CIP_HIP_CHECK(hipMemsetAsync(h->Wt, 0, sizeof(double) * (size_t)h->npad * h->mpad, s));
+            h->syrk_n = cip_syrk_split(h->npad, h->mpad, &h->syrk_len);
+            if (h->syrk_n > 1) DMALLOC(h->syrk_ws, sizeof(double) * (size_t)h->syrk_n * h->npad * h->npad);
         }
     } else {
         int nnz = 0;

@@ -302,6 +302,7 @@ static int assemble_schur(cip_handle *h, bool lazy_ok) {
         g.A = h->Wt; g.lda = h->npad; g.B = h->Wt; g.ldb = h->npad;
         g.C = h->K; g.ldc = h->ldk; g.M = h->npad; g.N = h->npad; g.K = h->mpad;
         g.alpha = 1.0; g.lower = 1; g.Qin = h->Q; g.ldq = n; g.nvalid = n;
+        g.ksplit_ws = h->syrk_ws; g.ksplit_n = h->syrk_n; g.ksplit_len = h->syrk_len;
         if ((rc = cip_launch_gemm(s, EPI_SYRKQ, g))) return rc;
     } else {
         const int lazy_on = g_lazy_copy < 0 ? cip_lazy_copy_set(-1) : g_lazy_copy;

@@ -48,6 +48,7 @@ struct cip_handle {
     // ---- KKT matrix + factor (level 2 output)
     double *K = nullptr; long ldk = 0;
     double *Wt = nullptr;           // npad x mpad   At * F^-1           (dense-A Schur route)
+    double *syrk_ws = nullptr; int syrk_n = 1, syrk_len = 0;   // split-K images of the Schur formation (few output tiles, long K: config 4)
     double *Gm = nullptr;           // npad x nqpad  rank-1 columns of the Q cones (sparse-A Schur route)
     void *ws_base = nullptr; LdltWorkspace ws = {};
     struct LdltSide *ldlt_side = nullptr;   // side stream + events of the overlapped solve preparation (ldlt.hip), created on first use

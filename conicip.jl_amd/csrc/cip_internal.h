@@ -102,7 +102,12 @@ struct GemmArgs {
     double *Ct; long ldct, sCty, sCtz;   // 128-tile EPI_ACCUM only, optional: the result is also stored transposed, Ct[j + i*ldct]
     const double *Cdiag;         // EPI_LAZYC: the diagonal of Cin
     int force64;                 // plain accumulate form: quarter tiles (k_gemm_nt_64) whatever the tile count
+    // EPI_SYRKQ with few output tiles and a long K (round 4): the k range is cut into `ksplit_n` slices of `ksplit_len` columns, every
+    // slice's product goes to its own M x M image in `ksplit_ws`, a second launch adds them up in slice order together with Qin
+    double *ksplit_ws; int ksplit_n, ksplit_len;
 };
+// how cip_launch_gemm(EPI_SYRKQ) would split an (M x M, K) Schur formation: number of slices (1: no split) and their length
+int cip_syrk_split(int M, int K, int *len);
 int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g);
 
 // ---------------------------------------------------------------- small results back to the host (vecops.hip)

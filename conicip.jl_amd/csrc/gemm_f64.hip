@@ -212,6 +212,58 @@ __global__ __launch_bounds__(256, 4) void k_syrkq_64(GemmArgs g, CipBatch cb) {
     gemm_tile_64<EPI_SYRKQ>(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB);
 }
 
+// The same with few output tiles and a long K -- config 4: S = 1024 x 1024 from K = m = 32896, 136 quarter tiles on a chip with
+// room for 1280 workgroups, 23 TFLOP/s.  Split-K: grid.y slices of the k range, each slice's product stored to its own image
+// (EPI_STORE), then k_syrk_reduce adds the images in slice order to Qin: deterministic, no atomics.
+__global__ __launch_bounds__(256, 4) void k_syrk_splitk_64(GemmArgs g, CipBatch cb) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
+    bool live;
+    (void)gemm_batch_prologue(g, cb, live);
+    if (!live) return;
+    int bi, bj;
+    tile_coords((int)(blockIdx.x >> 2), 1, g.M / CIP_NB, bi, bj);
+    const int sub = blockIdx.x & 3;
+    if (bi == bj && sub == 2) return;
+    const long k0 = (long)blockIdx.y * g.ksplit_len;
+    g.A += k0 * g.lda; g.B += k0 * g.ldb;
+    g.K = (g.K - k0 < g.ksplit_len) ? (int)(g.K - k0) : g.ksplit_len;
+    g.C = (double *)((char *)g.ksplit_ws + (long)(blockIdx.z / (g.bz > 0 ? g.bz : 1)) * cb.stride) + (long)blockIdx.y * g.M * g.M;
+    g.ldc = g.M; g.Ct = nullptr;
+    gemm_tile_64<EPI_STORE>(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB);
+}
+// C[i, j] = Qin[i, j] + sum_b image_b[i, j] for i >= j (by 64-tiles), i, j < nvalid; one thread per row pair of a 64 x 64 tile column
+__global__ __launch_bounds__(256) void k_syrk_reduce(GemmArgs g, CipBatch cb) {
+    bool live;
+    (void)gemm_batch_prologue(g, cb, live);
+    if (!live) return;
+    const double *ws = (const double *)((const char *)g.ksplit_ws + (long)(blockIdx.z / (g.bz > 0 ? g.bz : 1)) * cb.stride);
+    int bi, bj;
+    tile_coords((int)blockIdx.x, 1, g.M / SB, bi, bj);                 // 64-tiles of the lower triangle
+    const int r2 = threadIdx.x & 31, c0 = threadIdx.x >> 5;             // row pair, first column (8 columns per pass)
+    const long row = (long)bi * SB + 2 * r2;
+    const long img = (long)g.M * g.M;
+    for (int c = c0; c < SB; c += 8) {
+        const long col = (long)bj * SB + c;
+        if (col >= g.nvalid || row >= g.nvalid) continue;
+        v2d acc = (v2d){0.0, 0.0};
+        for (int b = 0; b < g.ksplit_n; ++b) acc += *(const v2d *)(ws + b * img + row + col * g.M);
+        const double *qp = g.Qin + row + col * g.ldq;
+        double *cp = g.C + row + col * g.ldc;
+        if (row + 1 < g.nvalid) *(v2d *)cp = (v2d){qp[0], qp[1]} + g.alpha * acc;
+        else *cp = qp[0] + g.alpha * acc.x;
+    }
+}
+int cip_syrk_split(int M, int K, int *len) {
+    static const int on = [] { const char *e = getenv("CIP_SYRK_SPLITK"); return e ? atoi(e) : 1; }();
+    const long tm = M / CIP_NB, wgs = 4 * (tm * (tm + 1) / 2);
+    int n = 1;
+    if (on && wgs < 640 && K >= 4096) { n = (int)((1280 + wgs - 1) / wgs); if (n > 16) n = 16; }
+    int l = ((K + n - 1) / n + CIP_KT - 1) / CIP_KT * CIP_KT;
+    n = (K + l - 1) / l;
+    if (len) *len = l;
+    return n;
+}
+
 // XCD-aware order (optional, CIP_TRAIL_PATCH): workgroups are dealt round-robin to the 8 XCDs, so XCD x is handed whole
 // p x p patches of quarter tiles (patches x, x+8, ...): the 2p half-panels of a patch are then fetched into that
 // XCD's L2 once for p^2 tiles instead of once per tile.
@@ -283,6 +335,15 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
             return 0;
         }
         cip_launch_b(k_ldlt_trailing_64<EPI_ACCUM>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
+        CIP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    if (epi == EPI_SYRKQ && g.lower && g_tile == 64 && g.ksplit_ws && g.ksplit_n > 1) {
+        GemmArgs gs = g;
+        gs.alpha = 1.0;                                          // (the images hold the plain products; alpha is applied by the reduction)
+        cip_launch_b(k_syrk_splitk_64, dim3((unsigned)(4 * tiles), (unsigned)g.ksplit_n), dim3(256), 0, s, gs);
+        const long t64 = (long)(g.M / SB) * (g.M / SB + 1) / 2;
+        cip_launch_b(k_syrk_reduce, dim3((unsigned)t64), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
