@@ -234,6 +234,50 @@ def cpu_baseline(Q_host, n, solves_per_factor, budget_s=100.0):
                                 "t_potrf, to be read against host_dgemm_gflops" % (solves_per_factor, n))
 
 
+def live_pmc_traffic(args):
+    """HBM-side bytes per trailing-update launch MEASURED IN THIS RUN: two child processes under `rocprofv3 --pmc` (FETCH_SIZE,
+    then WRITE_SIZE: separate passes, counters only -- no tracing beside them, MI355X_MICROARCH.md), each running this script on
+    the same workload for three steps without the CPU leg.  Started BEFORE this process touches the GPU (children, never an
+    exec).  Returns (bytes per launch, launches) or (None, reason); the caller then falls back to the committed passes."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    tot = {}
+    nl = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="cip_pmc_", dir="/tmp")
+            env = dict(os.environ, CIP_BENCH_PMC_CHILD="1", TMPDIR="/tmp")
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-converge", "--no-c5", "--no-live-pmc",
+                   "--n", str(args.n), "--route", args.route]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                shutil.rmtree(d, ignore_errors=True)
+                return None, "rocprofv3 --pmc %s child failed (rc %d)" % (ctr, r.returncode)
+            t, k = 0.0, 0
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row["Counter_Name"] == ctr and row["Kernel_Name"].replace("void ", "").startswith(TRAILING_KERNELS):
+                        t += float(row["Counter_Value"]); k += 1
+            shutil.rmtree(d, ignore_errors=True)
+            if k == 0:
+                return None, "no trailing-update dispatch in the %s pass" % ctr
+            tot[ctr], nl[ctr] = t, k
+        if nl["FETCH_SIZE"] != nl["WRITE_SIZE"]:
+            return None, "the two passes saw different launch counts"
+        # gfx950: FETCH_SIZE counts half the bytes of wide streaming reads -> doubled (MI355X_MICROARCH.md, section HBM); both in KiB
+        return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / nl["FETCH_SIZE"], nl["FETCH_SIZE"]
+    except Exception as e:                                   # never let the measurement of a side figure take the bench down
+        return None, "live PMC pass failed: %r" % (e,)
+
+
 def pmc_traffic_per_launch():
     """Average HBM bytes per trailing-update launch from the committed PMC passes (gfx950: FETCH_SIZE counts half
     the bytes of wide streaming reads -> doubled, MI355X_MICROARCH.md section HBM).  None when absent."""
@@ -329,6 +373,9 @@ def main():
     ap.add_argument("--batch-mode", default="lockstep", choices=["lockstep", "threads"],
                     help="c5: lock-step batch (one launch per step for all problems of the rank) or host threads + streams")
     ap.add_argument("--no-c5", action="store_true", help="c2: skip the single-GPU config-5 figure")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="c2: do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes before the GPU is "
+                         "touched); replay the committed passes instead")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -341,6 +388,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    live_traffic = (None, "not requested")
+    if (world == 1 and args.gpus == 1 and (args.workload in (None, "c2")) and not args.no_live_pmc and not args.no_cpu_baseline
+            and not os.environ.get("CIP_BENCH_PMC_CHILD") and torch.cuda.device_count() > 0):
+        # (only in the full default run -- the A/B and profiling invocations pass --no-cpu-baseline -- and before this process
+        #  initialises the GPU: torch.cuda.device_count() does not)
+        live_traffic = live_pmc_traffic(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the KKT path has no CPU fallback)")
     if torch.cuda.device_count() <= local_rank:
@@ -368,6 +421,7 @@ def main():
         return dict(value=stats["n_factor"] * steps / el, unit="KKT solves/s", ms_per_pass=el / steps * 1e3,
                     problems_per_s=64 * steps / el, n_optimal=stats["n_optimal"], n_problems=stats["n_problems"],
                     iters=stats["iters"], n_factor=stats["n_factor"], n_solve=stats["n_solve"],
+                    rank_busy_ms_min=stats.get("rank_busy_ms_min"), rank_busy_ms_max=stats.get("rank_busy_ms_max"),
                     batch_mode=args.batch_mode, in_flight_per_gpu=args.in_flight if args.batch_mode == "threads" else None,
                     note="64 dense QPs n=m=2048 (seeds 4000+i), problem i -> rank i mod N, level-1 upload included, "
                          "%s; KKT solves = factorisations" % ("cip_conicip_lockstep (one launch per step for the rank's whole shard)"
@@ -560,9 +614,13 @@ def main():
                          "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                          "clock_limited_peak": FP64_MFMA_CLOCK_LIMITED_TFLOPS,
                          "frac_of_clock_limited_peak": ach / FP64_MFMA_CLOCK_LIMITED_TFLOPS,
-                         "traffic": pmc_traffic_per_launch(),
-                         "traffic_source": (os.path.relpath(pdir, ROOT) + "/final_pmc_{fetch,write}.csv: REPLAYED from the committed "
-                                            "rocprofv3 --pmc passes of this same command, not measured in this run") if pdir else None,
+                         "traffic": live_traffic[0] if live_traffic[0] is not None else pmc_traffic_per_launch(),
+                         "traffic_source": (("MEASURED in this run: two child passes of this script under rocprofv3 --pmc (FETCH_SIZE, "
+                                             "WRITE_SIZE; %d trailing-update launches each) before the timed process touched the GPU"
+                                             % live_traffic[1]) if live_traffic[0] is not None else
+                                            ((os.path.relpath(pdir, ROOT) + "/final_pmc_{fetch,write}.csv: REPLAYED from the committed "
+                                              "rocprofv3 --pmc passes of this same command, not measured in this run (live pass: %s)"
+                                              % (live_traffic[1],)) if pdir else None)),
                          "traffic_note": "HBM-side bytes per trailing-update launch = (2*FETCH_SIZE + WRITE_SIZE) KiB of "
                                          "k_ldlt_trailing_64, averaged over its launches (separate --pmc passes; null if absent)",
                          "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(1.0, prof["launches"]),

@@ -237,13 +237,19 @@ def run_config5(rank, world, dist, device, steps, warmup, problems=None, count=6
     t0 = time.perf_counter()
     for _ in range(steps):
         one_pass(False)
-    sync(); barrier(); sync()
+    sync()
+    busy = time.perf_counter() - t0                    # this rank's own time for its shard (before it waits for the others)
+    barrier(); sync()
     elapsed = time.perf_counter() - t0
     _, stats = one_pass(True)                          # untimed: the reduced statistics of one pass
     if solve_fn is None:
         release_cached_memory()                        # the lock-step arena (GBs) is not kept beyond the job
+    busy_min = busy_max = busy
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
+        dev = device if device is not None else "cpu"
+        t = torch.tensor([elapsed, busy, -busy], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, busy_max, busy_min = float(t[0].item()), float(t[1].item()), -float(t[2].item())
+    # load imbalance over the ranks (problems need different iteration counts): per-pass busy time of the fastest / slowest rank
+    stats = dict(stats, rank_busy_ms_min=1e3 * busy_min / max(steps, 1), rank_busy_ms_max=1e3 * busy_max / max(steps, 1))
     return stats, elapsed
