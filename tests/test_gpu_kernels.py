@@ -449,6 +449,62 @@ def test_lazy_copy_of_Q_gives_the_same_factor_and_step(n):
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
+def test_factor_graph_follows_the_lazy_copy_state_and_the_regularisation(monkeypatch):
+    """with CIP_GRAPH=1 the recorded factorisation bakes in whether the first trailing update reads its C
+    operand from Q (lazy copy) or from K; a replay under the other state would read stale data.  One handle, graph replay on:
+    lazy -> eager -> lazy -> regularised (the eager assembly + a shifted diagonal) -- after every switch the factor and a
+    solve4x4 step must equal those of a fresh handle WITHOUT graphs in the same state, bit for bit."""
+    import cipkkt
+    from cipkkt import workloads as W
+    n = 1024
+    Q, c, A, b, K = W.c2_problem(n, seed=78, device="cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    v = torch.rand(n, generator=g, dtype=torch.float64, device="cuda") + 0.05
+    s = torch.rand(n, generator=g, dtype=torch.float64, device="cuda") + 0.05
+    r = torch.randn(3 * n, generator=g, dtype=torch.float64, device="cuda")
+
+    def step(ks):
+        lam = torch.zeros(n, dtype=torch.float64, device="cuda")
+        ks.set_scaling_from_iterate(v, s, lam)
+        ks.factor(check=True)
+        dz = torch.zeros(3 * n, dtype=torch.float64, device="cuda")
+        ks.solve4x4_dev(lam, r, dz)
+        torch.cuda.synchronize()
+        return np.tril(ks.kkt_matrix()), dz.cpu().numpy()
+
+    def reference(lazy, reg):
+        monkeypatch.delenv("CIP_GRAPH", raising=False)
+        ks = cipkkt.KKTSystem(Q, A, None, K)
+        prev = ks.lib.cip_set_lazy_copy(lazy)
+        try:
+            if reg:
+                cipkkt._lib.check(ks.lib.cip_set_regularization(ks.h, 1e-12, 1))
+            return step(ks)
+        finally:
+            ks.lib.cip_set_lazy_copy(prev)
+            ks.close()
+
+    refs = {(lz, rg): reference(lz, rg) for lz, rg in ((1, 0), (0, 0), (0, 1))}
+    monkeypatch.setenv("CIP_GRAPH", "1")
+    ks = cipkkt.KKTSystem(Q, A, None, K)
+    prev = ks.lib.cip_set_lazy_copy(1)
+    try:
+        for lz, rg in ((1, 0), (0, 0), (1, 0), (1, 0), (0, 0)):
+            ks.lib.cip_set_lazy_copy(lz)
+            Kf, dz = step(ks)
+            np.testing.assert_array_equal(Kf, refs[(lz, rg)][0], err_msg="factor, lazy=%d" % lz)
+            np.testing.assert_array_equal(dz, refs[(lz, rg)][1], err_msg="step, lazy=%d" % lz)
+        cipkkt._lib.check(ks.lib.cip_set_regularization(ks.h, 1e-12, 1))      # regularised: the assembly copies eagerly whatever the knob
+        ks.lib.cip_set_lazy_copy(1)
+        Kf, dz = step(ks)
+        np.testing.assert_array_equal(Kf, refs[(0, 1)][0], err_msg="regularised factor under graph replay")
+        np.testing.assert_array_equal(dz, refs[(0, 1)][1])
+    finally:
+        ks.lib.cip_set_lazy_copy(prev)
+        ks.close()
+
+
 def test_gemv_and_dots():
     from cipkkt import MAT_A, MAT_G, MAT_Q
     rng = np.random.default_rng(2)
