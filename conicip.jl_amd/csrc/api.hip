@@ -323,8 +323,8 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
         CIP_HIP_CHECK(hipMemcpyAsync(h->cs.d_sidx, h->st_sidx.data(), sizeof(int) * sidx.size(), hipMemcpyHostToDevice, s));
         DMALLOC(h->cs.d_sdpws, sizeof(double) * (size_t)h->cs.sdp_slots * 6 * rmax * rmax);
         DMALLOC(h->cs.d_sdpvec, sizeof(double) * (size_t)h->cs.sdp_slots * 2 * kmax);
-        DMALLOC(h->cs.d_sdpflag, sizeof(int) * 4);
-        CIP_HIP_CHECK(hipMemsetAsync(h->cs.d_sdpflag, 0, sizeof(int) * 4, s));
+        DMALLOC(h->cs.d_sdpflag, sizeof(int) * 16);               // [0]: an iterate left the cone; [4 + li]: gate of large cone li's general division
+        CIP_HIP_CHECK(hipMemsetAsync(h->cs.d_sdpflag, 0, sizeof(int) * 16, s));
     }
     if (!h->h_cones.empty())
         CIP_HIP_CHECK(hipMemcpyAsync(h->cs.d_cones, h->h_cones.data(), sizeof(ConeDesc) * h->h_cones.size(), hipMemcpyHostToDevice, s));

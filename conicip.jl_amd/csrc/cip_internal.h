@@ -230,6 +230,7 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
 int cip_sdp_large_refresh(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, const double *scal);
 int cip_sdp_large_apply(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, int mode, const double *x, double *out);
 int cip_sdp_large_prod(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *y, double *out);
+int cip_sdp_large_div(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *y, double *out, int *flag);
 int cip_sdp_large_lanczos(int on);                  // sdp_large.hip: Lanczos max-step on (1) / off (0), < 0 reads; returns the previous setting
 int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *d, double scale,
                           double *partial, int side = 0);

@@ -758,11 +758,19 @@ __global__ __launch_bounds__(SD_TMAX) void k_sdp_prod(const ConeDesc *cones, con
 }
 
 // out: Y O + O Y = X  (dsdc! = vecm(lyap(Y, -X)) src/ConicIP.jl:347-353)
+// gate (large cones, sdp_large.hip: cip_sdp_large_div): the chip-wide element-wise kernels have already written the quotient
+// unless *gate is up (the divisor is not diagonal); the word is taken down again here
 __global__ __launch_bounds__(SD_TMAX) void k_sdp_div(const ConeDesc *cones, const int *sidx, const double *x, const double *y,
-                                                   double *out, double *wsb, int cap, CipBatch cb) {
+                                                   double *out, double *wsb, int cap, int *gate, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO4(cb, x, y, out, wsb);
     extern __shared__ double sh[];
+    if (gate) {
+        const int up = *gate;
+        __syncthreads();
+        if (threadIdx.x == 0) *gate = 0;
+        if (!up) return;
+    }
     const ConeDesc cd = cones[sidx[blockIdx.x]];
     const int r = cd.r;
     double *X = sd_ws(wsb, blockIdx.x, r, 0), *Y = sd_ws(wsb, blockIdx.x, r, 1), *V = sd_ws(wsb, blockIdx.x, r, 2),
@@ -915,8 +923,27 @@ int cip_sdp_prod(hipStream_t s, const ConeSet &cs, const double *x, const double
 }
 int cip_sdp_div(hipStream_t s, const ConeSet &cs, const double *x, const double *y, double *out) {
     if (sd_set_lds_attr((const void *)k_sdp_div, cs.rmax, 2)) return -3;
-    cip_launch_b(k_sdp_div, dim3(cs.ns), dim3(sd_threads(cs.rmax)), sd_shmem(cs.rmax, 2), s, cs.d_cones, cs.d_sidx, x, y, out, cs.d_sdpws,
-                       sd_cap(cs.rmax, 2));
+    if (cs.nlarge == 0 || cip_in_batch()) {
+        cip_launch_b(k_sdp_div, dim3(cs.ns), dim3(sd_threads(cs.rmax)), sd_shmem(cs.rmax, 2), s, cs.d_cones, cs.d_sidx, x, y, out, cs.d_sdpws,
+                           sd_cap(cs.rmax, 2), (int *)nullptr);
+        CIP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    if (cs.ns_small > 0)
+        cip_launch_b(k_sdp_div, dim3(cs.ns_small), dim3(sd_threads(cs.rmax)), sd_shmem(cs.rmax, 2), s, cs.d_cones, cs.d_sidx_small, x, y, out,
+                           cs.d_sdpws, sd_cap(cs.rmax, 2), (int *)nullptr);
+    for (int li = 0; li < cs.nlarge; ++li) {
+        // a large cone: element-wise and chip-wide when the divisor is diagonal (it is, in the interior-point loop); the general
+        // one-workgroup kernel behind it only runs when the check raised the gate
+        const int c = cs.large_cone[li];
+        int pos = 0;
+        for (int q = 0; q < c; ++q) pos += cs.h_cones[q].type == CIP_CONE_S;
+        int *gate = cs.d_sdpflag + 4 + li;
+        const int rc = cip_sdp_large_div(s, cs.lg, cs.h_cones[c], x, y, out, gate);
+        if (rc) return rc;
+        cip_launch_b(k_sdp_div, dim3(1), dim3(sd_threads(cs.rmax)), sd_shmem(cs.rmax, 2), s, cs.d_cones, (const int *)(cs.d_sidx + pos), x, y, out,
+                           cs.d_sdpws, sd_cap(cs.rmax, 2), gate);
+    }
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }

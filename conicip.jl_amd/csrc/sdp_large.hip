@@ -1284,6 +1284,36 @@ int cip_sdp_large_apply(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, i
     return 0;
 }
 
+// Jordan division by a DIAGONAL element (dsdc!, src/ConicIP.jl:347-353, with Y = diag(y): every division of the interior-point loop
+// is by lambda = vecm(diag(Lambda)), :686): O_ij = X_ij / (y_i + y_j), element-wise on the vecm layout (the sqrt(2) of the off-diagonal
+// entries cancels) -- chip-wide, one workgroup per matrix row, instead of one workgroup walking mat / divide / vecm over r^2
+// entries (225 us at order 256).  k_lg_div_check raises flag[0] when y has a non-zero off-diagonal entry; k_lg_div_diag writes the
+// quotient when it has none; the general kernel (sdp.hip: k_sdp_div) runs behind them and returns at once unless the flag is up.
+__device__ __forceinline__ long lg_rowoff(int i, int r) { return (long)i * r - (long)i * (i - 1) / 2; }       // vecm offset of (i, i)
+__global__ __launch_bounds__(256) void k_lg_div_check(const double *y, int r, int *flag) {
+    const int i = blockIdx.x;
+    const double *row = y + lg_rowoff(i, r);
+    int bad = 0;
+    for (int j = 1 + threadIdx.x; j < r - i; j += 256) bad |= (row[j] != 0.0);
+    if (threadIdx.x == 0 && !(row[0] == row[0])) bad = 1;                  // NaN on the diagonal: let the general path propagate it
+    if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(flag, 1);
+}
+__global__ __launch_bounds__(256) void k_lg_div_diag(const double *x, const double *y, double *out, int r, const int *flag) {
+    if (*flag) return;
+    const int i = blockIdx.x;
+    const long o = lg_rowoff(i, r);
+    const double yi = y[o];
+    for (int j = threadIdx.x; j < r - i; j += 256) out[o + j] = x[o + j] / (yi + y[lg_rowoff(i + j, r)]);
+}
+// returns with flag[0] = 1 when the general path must run for this cone (the caller launches it; it resets the flag)
+int cip_sdp_large_div(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *y, double *out, int *flag) {
+    (void)w;
+    hipLaunchKernelGGL(k_lg_div_check, dim3(cd.r), dim3(256), 0, s, y + cd.off, cd.r, flag);
+    hipLaunchKernelGGL(k_lg_div_diag, dim3(cd.r), dim3(256), 0, s, x + cd.off, y + cd.off, out + cd.off, cd.r, (const int *)flag);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // out = x o y = vecm(XY + YX)  (xsdc!, src/ConicIP.jl:355-360): one chip-wide GEMM
 int cip_sdp_large_prod(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *y, double *out) {
     const int r = cd.r, rp = w->rp;
