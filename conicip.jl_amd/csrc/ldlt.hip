@@ -20,7 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-// Outer block.  0 = automatic: 768 from order 4096 on when the panel chain is fused (the in-block updates, K = 128 tiles
+// Outer block.  0 = automatic: 896 (round 4; 768 before) from order 4096 on when the panel chain is fused (the in-block updates, K = 128 tiles
 // that a wider block has more of, then run beside the diagonal kernels and a trailing update with K = 768 passes over C
 // less often: same-session A/B at n = 8192, 512 / 768 / 1024 -> 130.6-132.0 / 134.5 / 133.9 KKT solves/s), else 512 (unfused
 // chain, round 1: 256 / 384 / 512 -> 107.7 / 107.0 / 109.1; 1024 -> 125 against 128).
@@ -42,7 +42,11 @@ static void fuse_env(void) {
 int cip_ldlt_outer_block_for(int Npad) {
     if (g_nbo > 0) return g_nbo;
     fuse_env();
-    return (Npad >= 4096 && g_fuse_diag) ? 768 : 512;    // not a function of the batch: lock-step groups reproduce the one-problem loop bit for bit
+    // Round 4 re-tuned the width on the current chain (same-session A/B, wide last block in force; CIP_LDLT_NBO_AUTO overrides):
+    // 640 / 768 / 896 / 1024 -> 185.4 / 189.1 / 191.3 / 188.7 KKT solves/s at n = 8192 (6 x 896 + 2816: one trailing update
+    // fewer, 60.1 TFLOP/s), config 3 (order 4608) 31.3 -> 30.0 ms, the literal 3x3 route at N = 16384 35.7 -> 35.8.
+    static const int nbo_auto = [] { const char *e = getenv("CIP_LDLT_NBO_AUTO"); const int v = e ? atoi(e) : 896; return (v >= 256 && v <= 1024 && v % CIP_NB == 0) ? v : 896; }();
+    return (Npad >= 4096 && g_fuse_diag) ? nbo_auto : 512;    // not a function of the batch: lock-step groups reproduce the one-problem loop bit for bit
 }
 #define CIP_NBO_MAX 1024
 #define CIP_TAIL_MAX 3072               // widest last block (CIP_LDLT_TAIL is clamped to it): Wbuf has room for it from order 4096 on
@@ -60,7 +64,7 @@ static int ldlt_tail_cols(void) {
 }
 static int outer_block_width(int Npad, int C0) {
     const int NBO = cip_ldlt_outer_block_for(Npad), left = Npad - C0;
-    if (g_nbo == 0 && NBO == 768 && left <= ldlt_tail_cols()) return left;
+    if (g_nbo == 0 && NBO >= 640 && left <= ldlt_tail_cols()) return left;
     return left < NBO ? left : NBO;
 }
 int cip_ldlt_outer_block(void) { return g_nbo; }

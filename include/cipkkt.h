@@ -246,7 +246,7 @@ int cip_assemble_only(cip_handle *h);                                   /* level
 /* stats: [0] factor calls, [1] solve calls, [2] last factor ms (assemble), [3] last factor ms (ldlt), [4] flops of last ldlt */
 int cip_stats(cip_handle *h, double *out8);
 int cip_set_timing(cip_handle *h, int enabled);
-int cip_set_ldlt_outer_block(int nbo);    /* 0 = automatic (768 from order 4096 on, else 512); returns the knob's value */
+int cip_set_ldlt_outer_block(int nbo);    /* 0 = automatic (896 from order 4096 on, else 512); returns the knob's value */
 /* tuning knob: widest block of the triangular solves' block-step form (128, 256, 512 or 1024; 0 = query).  Applies to
  * handles created afterwards; returns the previous value.  Lock-step batches use min(this, 256) for their handles. */
 int cip_set_solve_block_max(int b);

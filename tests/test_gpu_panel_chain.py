@@ -55,9 +55,9 @@ def test_fused_panel_chain_bitwise_equals_unfused(lib, N, quasi, mode):
     ws = torch.zeros(nbytes.value // 8 + 8, dtype=torch.float64, device="cuda")
     K0 = _spd(N, N + quasi + 11, quasi)
     prev = lib.cip_set_ldlt_fused_chain(0)
-    # the automatic outer block depends on the chain mode (768 fused, 512 not) and the block width changes the summation
+    # the automatic outer block depends on the chain mode (896 fused from order 4096 on, 512 else) and the block width changes the summation
     # order: pin the production width for both sides of the comparison
-    lib.cip_set_ldlt_outer_block(768 if N >= 4096 else 512)
+    lib.cip_set_ldlt_outer_block(896 if N >= 4096 else 512)
     try:
         ref = _factor(lib, K0, N, ws)
         lib.cip_set_ldlt_fused_chain(mode)
@@ -90,7 +90,7 @@ def test_default_chain_is_bit_reproducible_over_thousands_of_factorisations(lib,
     L.check(lib.cip_ldlt_workspace_bytes(N, C.byref(nbytes)))
     ws = torch.zeros(nbytes.value // 8 + 8, dtype=torch.float64, device="cuda")
     K0 = _spd(N, 5 * N + 1)
-    lib.cip_set_ldlt_outer_block(768 if N >= 4096 else 512)
+    lib.cip_set_ldlt_outer_block(896 if N >= 4096 else 512)
     prev = lib.cip_set_ldlt_fused_chain(0)
     try:
         unfused = torch.tril(_factor(lib, K0, N, ws).t()).clone()
