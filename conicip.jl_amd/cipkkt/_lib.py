@@ -92,6 +92,8 @@ SIGNATURES = {
                              [C.POINTER(CipOptions)] + [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(CipResult), C.c_int]),
     "cip_conicip_lockstep": (C.c_int, [C.c_int, C.POINTER(CipProblem)] + [C.POINTER(C.c_void_p)] * 3 +
                              [C.POINTER(CipOptions)] + [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(CipResult)]),
+    "cip_conicip_mixed": (C.c_int, [C.c_int, C.POINTER(CipProblem)] + [C.POINTER(C.c_void_p)] * 3 +
+                          [C.POINTER(CipOptions)] + [C.POINTER(C.c_void_p)] * 3 + [C.POINTER(CipResult), C.c_int]),
     "cip_release_cached_memory": (C.c_int, []),
     "cip_lockstep_stats": (C.c_int, [c_int_p]),
     "cip_conicip_many": (C.c_int, [C.POINTER(C.c_void_p), C.c_int] + [C.POINTER(C.c_void_p)] * 3 +

@@ -96,8 +96,8 @@ def _solve_problems_native(prs, device, in_flight, mode="auto"):
     mode "lockstep": `cip_conicip_lockstep` (csrc/lockstep.hip) -- problems of identical shape advance through the loop
     together, every step one launch with the problem index in the grid; "threads": `cip_conicip_problems`
     (csrc/batch.hip) -- `in_flight` host threads inside the library, each re-loading ONE handle on its own HIP stream
-    with the next problem of the queue; "auto": lock-step when the batch qualifies (same shape, no S cones; the
-    library answers CIP_E_UNSUPPORTED otherwise), else threads.  CIP_BATCH=threads|lockstep overrides "auto"."""
+    with the next problem of the queue; "auto": `cip_conicip_mixed` -- every group of problems that share a shape (and
+    hold no chip-wide S cone) in lock-step, the others through the threads.  CIP_BATCH=threads|lockstep overrides "auto"."""
     import ctypes as C
     from . import _lib as L
     from .driver import solution_from_result
@@ -137,16 +137,14 @@ def _solve_problems_native(prs, device, in_flight, mode="auto"):
         res = (L.CipResult * k)()
         if mode == "auto":
             mode = os.environ.get("CIP_BATCH", "auto")
-        done = False
-        if mode in ("auto", "lockstep") and k > 1:
-            rc = lib.cip_conicip_lockstep(k, structs, arr(cs), arr(bs), arr(ds), C.byref(opt), arr(ys), arr(ws), arr(vs), res)
-            if rc == 0:
-                done = True
-            elif rc != L.E_UNSUPPORTED or mode == "lockstep":
-                L.check(rc)
-        if not done:
+        if mode == "lockstep":
+            L.check(lib.cip_conicip_lockstep(k, structs, arr(cs), arr(bs), arr(ds), C.byref(opt), arr(ys), arr(ws), arr(vs), res))
+        elif mode == "threads":
             L.check(lib.cip_conicip_problems(k, structs, arr(cs), arr(bs), arr(ds), C.byref(opt), arr(ys), arr(ws), arr(vs),
                                              res, int(in_flight)))
+        else:
+            L.check(lib.cip_conicip_mixed(k, structs, arr(cs), arr(bs), arr(ds), C.byref(opt), arr(ys), arr(ws), arr(vs),
+                                          res, int(in_flight)))
     return [solution_from_result(res[i], ys[i][:dims[i][0]], ws[i][:dims[i][2]], vs[i][:dims[i][1]]) for i in range(k)]
 
 

@@ -313,7 +313,7 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
         h->cs.ns_small = (int)small.size();
         DMALLOC(h->cs.d_sidx_small, sizeof(int) * (small.size() + 1));
         if (!small.empty()) CIP_HIP_CHECK(hipMemcpyAsync(h->cs.d_sidx_small, small.data(), sizeof(int) * small.size(), hipMemcpyHostToDevice, s));
-        if (h->cs.nlarge > 0) { int rcl = cip_sdp_large_create(rmax_large, h->cs.nlarge, &h->cs.lg); if (rcl) return rcl; }
+        if (h->cs.nlarge > 0) { int rcl = cip_sdp_large_create(rmax_large, h->cs.nlarge, n, &h->cs.lg); if (rcl) return rcl; }
     }
     if (has_S) {
         const int per = n < 64 ? n : 64;

@@ -92,7 +92,7 @@ struct GemmArgs {
     double *C; long ldc;         // M x N
     int M, N, K;                 // M, N multiples of 128; K multiple of 16
     double alpha;
-    int lower;                   // 1: only tiles with bi >= bj (M == N)
+    int lower;                   // 1: only tiles with bi >= bj (M == N); 2 (batched overwrite form): only 64-tiles with bi <= bj
     // EPI_SYRKQ: C = Qin + acc for i,j < nvalid (lower tiles)
     const double *Qin; long ldq; int nvalid;
     // batching (EPI_ACCUM only): grid.y x grid.z independent problems, pointer strides in doubles
@@ -223,7 +223,7 @@ struct ConeSet {
 #define CIP_MAX_LARGE_S 8
 #define CIP_LARGE_S_MIN 133
 struct LargeWs;
-int cip_sdp_large_create(int rmax_large, int nlarge, LargeWs **out);
+int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out);
 void cip_sdp_large_destroy(LargeWs *w);
 int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, const double *v, const double *sv, double *scal,
                      double *lambda, int *flag);
@@ -275,3 +275,36 @@ int cip_copy_neg(hipStream_t s, int len, const double *x, double *y, double scal
 int cip_axpby_ps(hipStream_t s, int len, const double *alpha_host, const double *x, double beta, double *y);   // batch: alpha per problem
 int cip_zero(hipStream_t s, long len, double *y);                     // batch-aware memset(0) of doubles
 int cip_copy(hipStream_t s, long len, const double *x, double *y);    // batch-aware device-to-device copy
+
+// ---- wave-level sums without LDS permutes (DPP row operations + v_permlane16/32_swap): every lane ends with the same bits.
+// All lanes of the wave must be active.  (__shfl_xor is a ds_bpermute round trip per step: six dependent ones per 64-lane sum.)
+#ifdef __HIPCC__
+// sum over the 16 lanes of a DPP row, in every lane (xor 1, 2 as quad permutations, then the two mirrors)
+template <int CTRL>
+__device__ __forceinline__ double lz_dpp_add(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return x + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lz_sum16(double x) {
+    x = lz_dpp_add<0xB1>(x); x = lz_dpp_add<0x4E>(x); x = lz_dpp_add<0x141>(x); return lz_dpp_add<0x140>(x);
+}
+// sum over the wave's four 16-lane rows, in every lane (v_permlane16_swap / v_permlane32_swap of two copies)
+__device__ __forceinline__ double lz_sum_rows(double x) {
+    {
+        const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+        x = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    }
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+// sum over the two 16-lane rows of a 32-lane half (rows 0, 1 or rows 2, 3), in every lane
+__device__ __forceinline__ double lz_sum_row_pair(double x) {
+    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ double cip_wave_sum(double x) { return lz_sum_rows(lz_sum16(x)); }
+#endif

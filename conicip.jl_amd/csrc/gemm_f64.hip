@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_64_batched(GemmArgs g, CipBa
     if (!live) return;
     gemm_own_batch(g, oz);
     const int tm = g.M / SB;
+    if (g.lower == 2 && (blockIdx.x % tm) > (blockIdx.x / tm)) return;          // "upper only": tiles strictly below the diagonal are not wanted
     gemm_tile_64<EPI_STORE>(g, lds, (long)(blockIdx.x % tm) * SB, (long)(blockIdx.x / tm) * SB);
 }
 
@@ -293,15 +294,15 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     }
     const int tm = g.M / CIP_NB, tn = g.N / CIP_NB;
     long tiles;
-    if (g.lower) {
+    if (g.lower == 1) {
         if (g.M != g.N) { cip_set_error("gemm: lower needs M == N"); return -1; }
         tiles = (long)tm * (tm + 1) / 2;
     } else {
         tiles = (long)tm * tn;
     }
     const int by = g.by > 0 ? g.by : 1, bz = g.bz > 0 ? g.bz : 1;
-    if (by * bz > 1 || (g.overwrite && epi == EPI_ACCUM && !g.lower)) {
-        if (epi != EPI_ACCUM || g.lower) { cip_set_error("gemm: batching needs the plain accumulate form"); return -1; }
+    if (by * bz > 1 || (g.overwrite && epi == EPI_ACCUM && g.lower != 1)) {
+        if (epi != EPI_ACCUM || g.lower == 1 || (g.lower == 2 && !g.overwrite)) { cip_set_error("gemm: batching needs the plain accumulate form"); return -1; }
         if (g.overwrite) {
             cip_launch_b(k_gemm_nt_64_batched, dim3((unsigned)(4 * tiles), by, bz), dim3(256), 0, s, g);
             CIP_HIP_CHECK(hipGetLastError());

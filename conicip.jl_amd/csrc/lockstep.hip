@@ -22,6 +22,7 @@
 // Not supported in lock-step (the caller falls back to the thread pool of batch.hip): S cones of order >= 133 (their
 // chip-wide kernels own one workspace), problems of differing shape.
 #include "cip_driver.h"
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -50,6 +51,7 @@ __global__ void k_gather_info(const int *info, double *gather, CipBatch cb) {
     if (threadIdx.x < 4) gather[blockIdx.z * CIP_GATHER + INFO_SLOT + threadIdx.x] = (double)info[threadIdx.x];
 }
 
+static thread_local bool g_stats_accumulate = false;     // cip_conicip_mixed: the groups' statistics add up
 bool same_shape(const cip_problem &a, const cip_problem &b) {
     if (a.n != b.n || a.m != b.m || a.p != b.p || a.ncones != b.ncones || a.route != b.route) return false;
     if ((a.A == nullptr) != (b.A == nullptr) || (a.flags & CIP_FLAG_DEVICE_PTRS) != (b.flags & CIP_FLAG_DEVICE_PTRS)) return false;
@@ -117,9 +119,11 @@ unsigned long long full_mask(int B) { return B >= 64 ? ~0ull : ((1ull << B) - 1u
 // groups too (8 problems of order 2048, the per-rank shard of config 5 on 8 GPUs): 256 / 512 / 1024 -> 16.5 / 16.5 / 17.3 ms per
 // pass.  CIP_LOCKSTEP_SOLVE_BLOCK overrides; never above the process-wide limit.
 extern "C" int cip_lockstep_solve_block_for(int B) {
+    // groups of up to 8 problems: 512 (the sweeps are launch chains on a mostly idle chip: half the block steps; 8 problems of
+    // order 2048, 256 / 512 / 1024: 16.75 / 16.55 / 17.8 ms per pass); larger groups: 256 (the doubling GEMMs of a wider
+    // block are real work for 64 problems).  CIP_LOCKSTEP_SOLVE_BLOCK overrides both.
     const char *e = getenv("CIP_LOCKSTEP_SOLVE_BLOCK");
-    (void)B;
-    const int want = e ? atoi(e) : 256, glob = cip_solve_block_max_set(0);
+    const int want = e ? atoi(e) : (B <= 8 ? 512 : 256), glob = cip_solve_block_max_set(0);
     return want < glob ? want : glob;
 }
 // One lock-step group (B <= CIP_BATCH_MAX problems of the same shape).  Returns 0 and fills res / y / w / v of every
@@ -480,11 +484,70 @@ extern "C" int cip_conicip_lockstep(int count, const cip_problem *probs, const d
             return CIP_E_UNSUPPORTED;
         }
     if (cip_tl_builder) { cip_set_error("lock-step batch inside a graph recording"); return CIP_E_INVALID; }
-    g_last_stats[0] = g_last_stats[1] = g_last_stats[2] = 0;
+    if (!g_stats_accumulate) g_last_stats[0] = g_last_stats[1] = g_last_stats[2] = 0;
     for (int g0 = 0; g0 < count; g0 += CIP_BATCH_MAX) {
         const int B = (count - g0 < CIP_BATCH_MAX) ? (count - g0) : CIP_BATCH_MAX;
         const int rc = lockstep_group(B, probs + g0, c + g0, b ? b + g0 : nullptr, d ? d + g0 : nullptr, opt, y + g0,
                                       w ? w + g0 : nullptr, v ? v + g0 : nullptr, res + g0);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// Any mix of problems.  The ones that share a shape with at least one other problem of the batch (and qualify for
+// lock-step: no chip-wide S cone) advance together, shape group by shape group in order of first appearance; the rest go
+// through the thread pool (`in_flight` threads).  Results per problem are those of cip_conicip_lockstep / cip_conicip_problems.
+extern "C" int cip_conicip_mixed(int count, const cip_problem *probs, const double *const *c, const double *const *b,
+                                 const double *const *d, const cip_options *opt, double *const *y, double *const *w,
+                                 double *const *v, cip_result *res, int in_flight) {
+    if (count < 0 || (count > 0 && (!probs || !c || !y || !res))) { cip_set_error("cip_conicip_mixed: null argument"); return CIP_E_INVALID; }
+    if (count == 0) return 0;
+    auto lockstep_ok = [](const cip_problem &q) {
+        for (int c0 = 0; c0 < q.ncones; ++c0)
+            if (q.cone_type[c0] == CIP_CONE_S && q.cone_dim[c0] >= CIP_LARGE_S_MIN * (CIP_LARGE_S_MIN + 1) / 2) return false;
+        return true;
+    };
+    std::vector<std::vector<int>> bins;                         // bins[k][0] is the representative
+    for (int i = 0; i < count; ++i) {
+        if ((probs[i].m > 0 && (!b || !v || !b[i] || !v[i])) || (probs[i].p > 0 && (!d || !w || !d[i] || !w[i])) || !c[i] || !y[i]) {
+            cip_set_error("cip_conicip_mixed: null vector for problem %d", i);
+            return CIP_E_INVALID;
+        }
+        size_t k = 0;
+        for (; k < bins.size(); ++k)
+            if (same_shape(probs[bins[k][0]], probs[i])) break;
+        if (k == bins.size()) bins.emplace_back();
+        bins[k].push_back(i);
+    }
+    g_last_stats[0] = g_last_stats[1] = g_last_stats[2] = 0;
+    struct Acc { Acc() { g_stats_accumulate = true; } ~Acc() { g_stats_accumulate = false; } } acc;
+    std::vector<int> rest;
+    auto run = [&](const std::vector<int> &idx, bool lock) -> int {
+        const size_t k = idx.size();
+        std::vector<cip_problem> gp(k);
+        std::vector<const double *> gc(k), gb(k), gd(k);
+        std::vector<double *> gy(k), gw(k), gv(k);
+        std::vector<cip_result> gr(k);
+        for (size_t j = 0; j < k; ++j) {
+            const int i = idx[j];
+            gp[j] = probs[i]; gc[j] = c[i]; gy[j] = y[i];
+            gb[j] = b ? b[i] : nullptr; gv[j] = v ? v[i] : nullptr;
+            gd[j] = d ? d[i] : nullptr; gw[j] = w ? w[i] : nullptr;
+        }
+        const int rc = lock ? cip_conicip_lockstep((int)k, gp.data(), gc.data(), gb.data(), gd.data(), opt, gy.data(), gw.data(), gv.data(), gr.data())
+                            : cip_conicip_problems((int)k, gp.data(), gc.data(), gb.data(), gd.data(), opt, gy.data(), gw.data(), gv.data(), gr.data(), in_flight);
+        if (rc == 0 || !lock)                                   // the thread pool writes a status for every problem it reached
+            for (size_t j = 0; j < k; ++j) res[idx[j]] = gr[j];
+        return rc;
+    };
+    for (const auto &bin : bins) {
+        if (bin.size() < 2 || !lockstep_ok(probs[bin[0]])) { rest.insert(rest.end(), bin.begin(), bin.end()); continue; }
+        const int rc = run(bin, true);
+        if (rc) return rc;
+    }
+    if (!rest.empty()) {
+        std::sort(rest.begin(), rest.end());
+        const int rc = run(rest, false);
         if (rc) return rc;
     }
     return 0;

@@ -42,12 +42,13 @@ __device__ long g_lz_t[8];              // development: clocks per phase, summed
 #define LZ_T0() do { } while (0)
 #define LZ_T(i) do { } while (0)
 #endif
+#define LG_NPAD 4
 struct LargeWs {
     int rp = 0;                    // padded order (256 or 512)
     int chunk = 64;                // columns of A per batched congruence
     double *base = nullptr;        // one allocation
     double *Kz, *Ks, *Tz, *Ts, *G, *M1, *M2, *M3;      // rp x rp
-    double *Rip;                   // nlarge x 4 x rp x rp: Rinv, Rinv', R, R' of every large cone, zero padded
+    double *Rip;                   // nlarge x LG_NPAD x rp x rp: Rinv, Rinv', R, R' of every large cone, zero padded
     double *vec;                   // 12 x rp: lam, dg, of, xbuf[2], pbuf, ...
     double *batchX, *batchT;       // chunk x rp x rp each
     unsigned *ctr;                 // barrier counters / sweep flags (256 words)
@@ -195,6 +196,11 @@ __global__ void k_lg_flag(const int *info_a, const int *info_b, int *flag) {
     }
 }
 
+// sum over a group of tpp = 32 or 64 consecutive lanes (aligned), in every lane: DPP + lane swaps, no LDS permutes
+__device__ __forceinline__ double lg_sum_group(double x, int tpp) {
+    x = lz_sum16(x);
+    return tpp == 64 ? lz_sum_rows(x) : lz_sum_row_pair(x);
+}
 // ------------------------------------------------------------------------------------------ block one-sided Jacobi
 __host__ __device__ inline int lg_pitch(int rows) { return rows + ((4 - rows % 32) + 32) % 32; }   // == 4 (mod 32) doubles
 __device__ __forceinline__ double lg_rcp(double d) {
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsi
         for (int u = 0; u < EPL; ++u) { xv[u] = gp[part + u * tpp]; yv[u] = gq[part + u * tpp]; }
 #pragma unroll
         for (int u = 0; u < EPL; ++u) { a += xv[u] * xv[u]; bb += yv[u] * yv[u]; c += xv[u] * yv[u]; }
-        for (int o = tpp >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o); bb += __shfl_xor(bb, o); c += __shfl_xor(c, o); }
+        a = lg_sum_group(a, tpp); bb = lg_sum_group(bb, tpp); c = lg_sum_group(c, tpp);
         if (!(c * c > 1e-30 * (a * bb) && c != 0.0)) return 0;
         const double zeta = (bb - a) * 0.5 * lg_rcp(c);
         const double h2 = 1.0 + zeta * zeta;
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsi
                     double bq2 = 0.0;
 #pragma unroll
                     for (int u = 0; u < EPL; ++u) { const double y = gq0[part + u * tpp]; bq2 += y * y; }
-                    for (int o = tpp >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o); bq2 += __shfl_xor(bq2, o); }
+                    a = lg_sum_group(a, tpp); bq2 = lg_sum_group(bq2, tpp);
                     if (part == 0) s_nrm[pair] = bq2;
                 }
                 __syncthreads();
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsi
                     double yv[EPL], c = 0.0;
 #pragma unroll
                     for (int u = 0; u < EPL; ++u) { yv[u] = gq[part + u * tpp]; c += xv[u] * yv[u]; }
-                    for (int o = tpp >> 1; o > 0; o >>= 1) c += __shfl_xor(c, o);
+                    c = lg_sum_group(c, tpp);
                     const double bb = s_nrm[qi];
                     if (c * c > 1e-30 * (a * bb) && c != 0.0) {
                         const double zeta = (bb - a) * 0.5 * lg_rcp(c);
@@ -518,19 +524,28 @@ __global__ __launch_bounds__(LG_T) void k_lg_sturm(const double *dgg, const doub
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 int cip_sdp_large_padded(int r) { return r <= 256 ? 256 : (r <= 512 ? 512 : 1024); }
 
-int cip_sdp_large_create(int rmax_large, int nlarge, LargeWs **out) {
+int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out) {
     LargeWs *w = new LargeWs();
     const int rp = cip_sdp_large_padded(rmax_large);
     w->rp = rp;
-    if (rp > 512) w->chunk = 16;                               // (two batches of chunk matrices of 8 MB each)
     const size_t m2 = al256((size_t)rp * rp * 8);
-    size_t bytes = 8 * m2 + 4 * (size_t)nlarge * m2 + al256(12 * (size_t)rp * 8) + 2 * (size_t)w->chunk * m2 + al256(1024) +
+    // columns of A per batched congruence: all n of them when the two images fit 2 GB each (round 4: at order 256, n = 1024 the
+    // 16 chunks of 64 columns were 64 launches of 512 tiles -- two workgroups per CU, 40 TFLOP/s -- now two launches), at least 16
+    {
+        const size_t cap = ((size_t)2 << 30) / m2;
+        int c = ncols > 0 ? ncols : 64;
+        if ((size_t)c > cap) c = (int)cap;
+        if (c < 16) c = 16;
+        if (const char *e = getenv("CIP_LG_CHUNK")) if (atoi(e) >= 1) c = atoi(e);
+        w->chunk = c;
+    }
+    size_t bytes = 8 * m2 + LG_NPAD * (size_t)nlarge * m2 + al256(12 * (size_t)rp * 8) + 2 * (size_t)w->chunk * m2 + al256(1024) +
                    2 * al256(cip_ldlt_ws_bytes(rp));
     CIP_HIP_CHECK(hipMalloc((void **)&w->base, bytes));
     char *p = (char *)w->base;
     double **mats[8] = {&w->Kz, &w->Ks, &w->Tz, &w->Ts, &w->G, &w->M1, &w->M2, &w->M3};
     for (auto m : mats) { *m = (double *)p; p += m2; }
-    w->Rip = (double *)p; p += 4 * (size_t)nlarge * m2;
+    w->Rip = (double *)p; p += LG_NPAD * (size_t)nlarge * m2;
     w->vec = (double *)p; p += al256(12 * (size_t)rp * 8);
     w->batchX = (double *)p; p += (size_t)w->chunk * m2;
     w->batchT = (double *)p; p += (size_t)w->chunk * m2;
@@ -570,10 +585,12 @@ void cip_sdp_large_destroy(LargeWs *w) {
 
 static dim3 lg_grid(long n) { return dim3((unsigned)((n + 255) / 256)); }
 // C_b = A_b B_b'  (rp x rp each, 64x64 fp64-MFMA tiles); stride 0 = operand shared by the batch
-static int lg_gemm(hipStream_t s, double *C, long sC, const double *A, long sA, const double *B, long sB, int rp, int batch) {
+// upper: only the 64-tiles that touch i <= j are computed (the others keep what C held)
+static int lg_gemm(hipStream_t s, double *C, long sC, const double *A, long sA, const double *B, long sB, int rp, int batch, bool upper = false) {
     GemmArgs g = {};
     g.A = A; g.lda = rp; g.B = B; g.ldb = rp; g.C = C; g.ldc = rp;
     g.M = g.N = g.K = rp; g.alpha = 1.0; g.overwrite = 1; g.by = batch; g.bz = 1;
+    g.lower = upper ? 2 : 0;
     g.sAy = sA; g.sBy = sB; g.sCy = sC;
     return cip_launch_gemm(s, EPI_ACCUM, g);
 }
@@ -772,27 +789,6 @@ __global__ __launch_bounds__(512) void k_lg_tridiag1(const double *M, int ldm, c
 __device__ __forceinline__ double lz_rcp(double x) {
     const double r0 = __builtin_amdgcn_rcp(x);
     return fma(fma(-x, r0, 1.0), r0, r0);
-}
-// sum over the 16 lanes of a DPP row, in every lane (xor 1, 2 as quad permutations, then the two mirrors)
-template <int CTRL>
-__device__ __forceinline__ double lz_dpp_add(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
-    return x + __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double lz_sum16(double x) {
-    x = lz_dpp_add<0xB1>(x); x = lz_dpp_add<0x4E>(x); x = lz_dpp_add<0x141>(x); return lz_dpp_add<0x140>(x);
-}
-// sum over the wave's four 16-lane rows, in every lane (v_permlane16_swap / v_permlane32_swap of two copies)
-__device__ __forceinline__ double lz_sum_rows(double x) {
-    {
-        const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
-        const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
-        x = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
-    }
-    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
-    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
-    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
 }
 __device__ __forceinline__ double lz_sum256(double x, double *red, int slot) {      // sum over threads 0..255 (4 waves), all 512 threads call
     const int tid = threadIdx.x;
@@ -1158,7 +1154,7 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
     if ((rc = lg_gemm(s, w->Tz, 0, XTz, 0, w->M1, 0, rp, 1))) return rc;            // R    = Lz^-T U Lambda^1/2   (:206-208)
     if ((rc = lg_gemm(s, w->Ts, 0, w->M2, 0, w->M3, 0, rp, 1))) return rc;          // Rinv = Lambda^-1/2 U' Lz'
     double *R = scal + cd.soff, *Ri = R + (size_t)r * r;
-    hipLaunchKernelGGL(k_lg_store, lg_grid(n2 > cd.dim ? n2 : cd.dim), dim3(256), 0, s, w->Tz, w->Ts, R, Ri, w->Rip + 4 * (size_t)li * n2,
+    hipLaunchKernelGGL(k_lg_store, lg_grid(n2 > cd.dim ? n2 : cd.dim), dim3(256), 0, s, w->Tz, w->Ts, R, Ri, w->Rip + LG_NPAD * (size_t)li * n2,
                        lam, lambda ? lambda + cd.off : nullptr, r, rp, cd.dim);
     if (lambda) hipLaunchKernelGGL(k_lg_lambda_diag, lg_grid(r), dim3(256), 0, s, lam, lambda + cd.off, r);
     CIP_HIP_CHECK(hipGetLastError());
@@ -1169,7 +1165,7 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
 int cip_sdp_large_refresh(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, const double *scal) {
     const int r = cd.r, rp = w->rp;
     hipLaunchKernelGGL(k_lg_pad, lg_grid((long)rp * rp), dim3(256), 0, s, scal + cd.soff, scal + cd.soff + (size_t)r * r,
-                       w->Rip + 4 * (size_t)li * rp * rp, r, rp);
+                       w->Rip + LG_NPAD * (size_t)li * rp * rp, r, rp);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1252,14 +1248,14 @@ int cip_sdp_large_scale_At(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li
                            long ldwt) {
     const int r = cd.r, rp = w->rp;
     const long n2 = (long)rp * rp;
-    const double *Rip = w->Rip + 4 * (size_t)li * n2;
+    const double *Rip = w->Rip + LG_NPAD * (size_t)li * n2;
     int rc;
     for (int i0 = 0; i0 < n; i0 += w->chunk) {
         const int nb = (n - i0 < w->chunk) ? (n - i0) : w->chunk;
         dim3 gm((unsigned)((n2 + 255) / 256), nb);
         hipLaunchKernelGGL(k_lg_mat, gm, dim3(256), 0, s, At + i0 + (long)cd.aoff * ldat, ldat, 1L, w->batchX, r, rp, 0.0);
         if ((rc = lg_gemm(s, w->batchT, n2, Rip, 0, w->batchX, n2, rp, nb))) return rc;     // Rinv X      (X symmetric)
-        if ((rc = lg_gemm(s, w->batchX, n2, w->batchT, n2, Rip, 0, rp, nb))) return rc;     // (Rinv X) Rinv'
+        if ((rc = lg_gemm(s, w->batchX, n2, w->batchT, n2, Rip, 0, rp, nb, true))) return rc;     // (Rinv X) Rinv': k_lg_vecm reads i <= j only
         dim3 gv((unsigned)(((long)r * r + 255) / 256), nb);
         hipLaunchKernelGGL(k_lg_vecm, gv, dim3(256), 0, s, w->batchX, Wt + i0 + (long)cd.aoff * ldwt, ldwt, 1L, r, rp);
     }
@@ -1274,7 +1270,7 @@ int cip_sdp_large_apply(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, i
     const long n2 = (long)rp * rp;
     // pad[]: 0 Rinv, 1 Rinv', 2 R, 3 R'
     const int which = (mode == CIP_OP_F) ? 3 : (mode == CIP_OP_FT) ? 2 : (mode == CIP_OP_FINV) ? 1 : 0;
-    const double *Q = w->Rip + (4 * (size_t)li + which) * n2;
+    const double *Q = w->Rip + (LG_NPAD * (size_t)li + which) * n2;
     int rc;
     hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, x + cd.off, 1L, 0L, w->M1, r, rp, 0.0);
     if ((rc = lg_gemm(s, w->M2, 0, Q, 0, w->M1, 0, rp, 1))) return rc;              // Q X      (X symmetric)

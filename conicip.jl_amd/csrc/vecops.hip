@@ -7,11 +7,7 @@
 // consecutive addresses and results are deterministic (no atomics).
 #include "cip_internal.h"
 
-__device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ double wsum(double v) { return cip_wave_sum(v); }      // (round 4: DPP / lane swaps instead of six ds_bpermute round trips)
 
 // one wave per column, 4 columns per workgroup; 4 x 16-byte loads of the matrix in flight per lane (the first version
 // had one: the triangular solves ran at 2.1 TB/s)

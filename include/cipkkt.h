@@ -214,13 +214,20 @@ int cip_conicip_problems(int count, const cip_problem *probs, const double *cons
 /* the same, in LOCK-STEP: the problems must have identical shape (n, m, p, cone list, route, dense-or-CSR A) and no S
  * cone of matrix order >= 133; they advance through the loop together, every step ONE launch with the problem index in the grid (groups of up
  * to 64).  Results are bit-identical to cip_conicip on each problem run with the same solve block (lock-step handles use
- * min(cip_set_solve_block_max, 256): a standalone handle of order >= 1024 sums its triangular solves in wider blocks unless
- * cip_set_solve_block_max(256) is called first -- the difference is rounding).  Returns CIP_E_UNSUPPORTED (nothing written) when
+ * min(cip_set_solve_block_max, cip_lockstep_solve_block_for(B)): a standalone handle of order >= 1024 sums its triangular solves in wider blocks unless
+ * cip_set_solve_block_max(that value) is called first -- the difference is rounding).  Returns CIP_E_UNSUPPORTED (nothing written) when
  * the batch does not qualify -- fall back to cip_conicip_problems.  A problem whose factorisation meets a bad pivot leaves
  * the group and is solved by the one-problem loop afterwards. */
 int cip_conicip_lockstep(int count, const cip_problem *probs, const double *const *c, const double *const *bvec,
                          const double *const *d, const cip_options *opt, double *const *y, double *const *w,
                          double *const *v, cip_result *res);
+/* ANY mix of problems: those that share a shape with at least one other problem of the batch (and qualify for lock-step)
+ * advance together, shape group by shape group; the others go through cip_conicip_problems' thread pool (`in_flight`
+ * threads).  Per problem the result is that of the entry point it went through; cip_lockstep_stats adds up over the groups.
+ * (The reference solves one problem per conicIP call, src/ConicIP.jl:472-480: a batch is N independent calls.) */
+int cip_conicip_mixed(int count, const cip_problem *probs, const double *const *c, const double *const *bvec,
+                      const double *const *d, const cip_options *opt, double *const *y, double *const *w,
+                      double *const *v, cip_result *res, int in_flight);
 /* the arena of the last lock-step group is kept for the next call (allocation of several GB is slow); this frees it */
 int cip_release_cached_memory(void);
 /* diagnostics of the calling thread's last cip_conicip_lockstep: {groups, problems, problems that left their group} */
@@ -248,9 +255,9 @@ int cip_stats(cip_handle *h, double *out8);
 int cip_set_timing(cip_handle *h, int enabled);
 int cip_set_ldlt_outer_block(int nbo);    /* 0 = automatic (896 from order 4096 on, else 512); returns the knob's value */
 /* tuning knob: widest block of the triangular solves' block-step form (128, 256, 512 or 1024; 0 = query).  Applies to
- * handles created afterwards; returns the previous value.  Lock-step batches use min(this, 256) for their handles. */
+ * handles created afterwards; returns the previous value.  Lock-step batches use min(this, cip_lockstep_solve_block_for(B)) for their handles. */
 int cip_set_solve_block_max(int b);
-/* the solve-block limit cip_conicip_lockstep gives the handles of a group of B problems (256, never more than
+/* the solve-block limit cip_conicip_lockstep gives the handles of a group of B problems (512 for B <= 8, else 256; never more than
  * cip_set_solve_block_max's value; CIP_LOCKSTEP_SOLVE_BLOCK overrides): a one-problem run with this limit
  * reproduces the group's iterates bit for bit */
 int cip_lockstep_solve_block_for(int B);

@@ -158,6 +158,29 @@ def test_unsupported_batches_fall_back():
     assert ei.value.code == L.E_UNSUPPORTED
 
 
+def test_mixed_shapes_group_by_shape():
+    """`cip_conicip_mixed` (what mode "auto" calls): problems of three shapes interleaved -- the two shapes that occur more than
+    once advance in lock-step (two groups, 5 + 3 problems), the singleton goes through the thread pool; every result
+    bit-identical to the one-problem loop."""
+    from cipkkt import _lib as L
+    import ctypes as C
+    prs = []
+    for seed in range(5):
+        prs.append(_as_problem(P.random_mixed(n=40, nq=3, kq=6, p=4, seed=500 + seed)))
+    for seed in range(3):
+        prs.append(_as_problem(P.random_mixed(n=24, nq=2, kq=5, p=3, seed=600 + seed)))
+    prs.append(_as_problem(P.random_mixed(n=18, nq=1, kq=4, p=2, seed=700)))
+    order = [0, 5, 1, 8, 6, 2, 3, 7, 4]
+    prs = [prs[i] for i in order]
+    one = _solve(prs, "threads", in_flight=1)
+    mixed = _solve(prs, "auto")
+    st = (C.c_int * 3)()
+    L.load().cip_lockstep_stats(st)
+    assert list(st) == [2, 8, 0]
+    assert all(s.status == "Optimal" for s in one)
+    _assert_identical(mixed, one)
+
+
 def P_vecm_identity(r):
     from cipkkt.workloads import vecm_identity
     return vecm_identity(r)

@@ -1,5 +1,5 @@
 """config 5 on one GPU: lock-step batch against the thread pool (csrc/lockstep.hip vs csrc/batch.hip).
-usage: python tools/lockstep_time.py [count] [n] [passes] [lockstep|threads|both]"""
+usage: python tools/lockstep_time.py [count] [n] [passes] [lockstep|threads|both] [outer block]"""
 import os
 import sys
 import time
@@ -16,6 +16,9 @@ passes = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 dev = torch.device("cuda:0")
 prs = c5_batch(count=count, n=n, seed=4000, device=dev)
 which = sys.argv[4] if len(sys.argv) > 4 else "both"
+if len(sys.argv) > 5:
+    from cipkkt import _lib as L
+    L.load().cip_set_ldlt_outer_block(int(sys.argv[5]))
 for mode, inflight in (("lockstep", 1), ("threads", 8)):
     if which not in ("both", mode):
         continue
