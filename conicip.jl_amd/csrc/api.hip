@@ -130,6 +130,7 @@ static int upload_problem(cip_handle *h, const cip_problem *pr) {
     const bool dev = (pr->flags & CIP_FLAG_DEVICE_PTRS) != 0;
     hipStream_t s = h->stream;
     int rc;
+    cip_sdp_large_invalidate(h->cs.lg);                     // (the mat(a_i) images of the large S cones follow A)
     if ((rc = upload_matrix(h->Q, n, pr->Q, pr->ldq > 0 ? pr->ldq : n, n, n, dev, s))) return rc;
     if (p > 0) {
         if ((rc = upload_matrix(h->G, p, pr->G, pr->ldg > 0 ? pr->ldg : p, p, n, dev, s))) return rc;

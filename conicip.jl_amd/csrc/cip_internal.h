@@ -92,7 +92,7 @@ struct GemmArgs {
     double *C; long ldc;         // M x N
     int M, N, K;                 // M, N multiples of 128; K multiple of 16
     double alpha;
-    int lower;                   // 1: only tiles with bi >= bj (M == N); 2 (batched overwrite form): only 64-tiles with bi <= bj
+    int lower;                   // 1: only tiles with bi >= bj (M == N); 2 / 3 (batched overwrite form): only 64-tiles with bi <= bj / bi >= bj
     // EPI_SYRKQ: C = Qin + acc for i,j < nvalid (lower tiles)
     const double *Qin; long ldq; int nvalid;
     // batching (EPI_ACCUM only): grid.y x grid.z independent problems, pointer strides in doubles
@@ -224,6 +224,7 @@ struct ConeSet {
 #define CIP_LARGE_S_MIN 133
 struct LargeWs;
 int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out);
+void cip_sdp_large_invalidate(LargeWs *w);      // the problem's A was replaced: drop the cached mat(a_i) images
 void cip_sdp_large_destroy(LargeWs *w);
 int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, const double *v, const double *sv, double *scal,
                      double *lambda, int *flag);

@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_64_batched(GemmArgs g, CipBa
     gemm_own_batch(g, oz);
     const int tm = g.M / SB;
     if (g.lower == 2 && (blockIdx.x % tm) > (blockIdx.x / tm)) return;          // "upper only": tiles strictly below the diagonal are not wanted
+    if (g.lower == 3 && (blockIdx.x % tm) < (blockIdx.x / tm)) return;          // "lower only"
     gemm_tile_64<EPI_STORE>(g, lds, (long)(blockIdx.x % tm) * SB, (long)(blockIdx.x / tm) * SB);
 }
 
@@ -302,7 +303,7 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     }
     const int by = g.by > 0 ? g.by : 1, bz = g.bz > 0 ? g.bz : 1;
     if (by * bz > 1 || (g.overwrite && epi == EPI_ACCUM && g.lower != 1)) {
-        if (epi != EPI_ACCUM || g.lower == 1 || (g.lower == 2 && !g.overwrite)) { cip_set_error("gemm: batching needs the plain accumulate form"); return -1; }
+        if (epi != EPI_ACCUM || g.lower == 1 || (g.lower >= 2 && !g.overwrite)) { cip_set_error("gemm: batching needs the plain accumulate form"); return -1; }
         if (g.overwrite) {
             cip_launch_b(k_gemm_nt_64_batched, dim3((unsigned)(4 * tiles), by, bz), dim3(256), 0, s, g);
             CIP_HIP_CHECK(hipGetLastError());

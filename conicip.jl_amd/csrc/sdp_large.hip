@@ -51,6 +51,11 @@ struct LargeWs {
     double *Rip;                   // nlarge x LG_NPAD x rp x rp: Rinv, Rinv', R, R' of every large cone, zero padded
     double *vec;                   // 12 x rp: lam, dg, of, xbuf[2], pbuf, ...
     double *batchX, *batchT;       // chunk x rp x rp each
+    // mat(a_i) of every column of A, per large cone, built once per upload (A does not change between the factorisations of a
+    // problem): round 4 -- the strided pass over A' was 0.38 ms of every factorisation at order 256, n = 1024
+    double *amat = nullptr;        // nlarge x ncols x rp x rp (null when that exceeds 4 GB or the columns do not fit one batch)
+    int ncols = 0;
+    const double *amat_src[CIP_MAX_LARGE_S] = {};   // the A' the images were built from (null: not built)
     unsigned *ctr;                 // barrier counters / sweep flags (256 words)
     void *ldl_z = nullptr, *ldl_s = nullptr;
     LdltWorkspace wz, ws;
@@ -59,6 +64,7 @@ struct LargeWs {
 };
 
 __device__ __forceinline__ int lg_vidx(int i, int j, int r) { return i * r - i * (i - 1) / 2 + (j - i); }   // i <= j
+__device__ __forceinline__ long lg_rowoff(int i, int r) { return (long)i * r - (long)i * (i - 1) / 2; }       // vecm offset of (i, i)
 __device__ __forceinline__ double lg_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void lg_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -113,6 +119,41 @@ __global__ __launch_bounds__(256) void k_lg_vecm(const double *Y, double *out, l
     if (i > j) return;
     const double y = Y[(size_t)blockIdx.y * rp * rp + i + (long)j * rp];
     out[(long)blockIdx.y * ob + (long)lg_vidx(i, j, r) * os] = (i == j) ? y : y * LG_SQRT2;
+}
+// The same for a batch of nb matrices whose vecm images are the COLUMNS i0.. of a matrix with leading dimension `os` (W' = A'F^-1:
+// element e of matrix i goes to out[i + e os]): 64 entries x 64 matrices per workgroup through LDS, so that both sides move whole
+// cache lines -- entry (a, b) is read from the LOWER triangle, Y[b + a rp] (consecutive entries of a vecm row are consecutive
+// there; the batched GEMM in front computes the lower tiles), and 64 consecutive i are written per entry.  (One thread per entry
+// and matrix wrote 8 bytes every `os` doubles: 0.35 ms per factorisation at order 256, n = 1024.)
+__global__ __launch_bounds__(256) void k_lg_vecm_cols(const double *Y, int nb, double *out, long os, int r, int rp) {
+    __shared__ double tile[64][65];
+    const long dim = (long)r * (r + 1) / 2;
+    const long e0 = (long)blockIdx.x * 64;
+    const int i0 = blockIdx.y * 64;
+    {
+        const int el = threadIdx.x & 63, cq = threadIdx.x >> 6;
+        const long e = e0 + el;
+        if (e < dim) {
+            int a = (int)(((double)(2 * r + 1) - sqrt((double)(2 * r + 1) * (2 * r + 1) - 8.0 * (double)e)) * 0.5);
+            while (a > 0 && lg_rowoff(a, r) > e) --a;
+            while (lg_rowoff(a + 1, r) <= e) ++a;
+            const int b = a + (int)(e - lg_rowoff(a, r));
+            const double sc = (a == b) ? 1.0 : LG_SQRT2;
+            for (int k = 0; k < 16; ++k) {
+                const int il = cq + 4 * k;
+                if (i0 + il < nb) tile[el][il] = Y[(size_t)(i0 + il) * rp * rp + b + (long)a * rp] * sc;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int il = threadIdx.x & 63, eg = threadIdx.x >> 6;
+        if (i0 + il < nb)
+            for (int k = 0; k < 16; ++k) {
+                const int el = eg + 4 * k;
+                if (e0 + el < dim) out[(i0 + il) + (e0 + el) * os] = tile[el][il];
+            }
+    }
 }
 // out = vecm(Y + Y') of the leading r x r block (Jordan product X o Y = XY + YX from the one product XY)
 __global__ __launch_bounds__(256) void k_lg_vecm_sym(const double *Y, double *out, int r, int rp) {
@@ -539,7 +580,9 @@ int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out) {
         if (const char *e = getenv("CIP_LG_CHUNK")) if (atoi(e) >= 1) c = atoi(e);
         w->chunk = c;
     }
-    size_t bytes = 8 * m2 + LG_NPAD * (size_t)nlarge * m2 + al256(12 * (size_t)rp * 8) + 2 * (size_t)w->chunk * m2 + al256(1024) +
+    w->ncols = ncols;
+    const bool cache_mat = ncols > 0 && w->chunk >= ncols && (size_t)nlarge * ncols * m2 <= ((size_t)4 << 30) && !(getenv("CIP_LG_AMAT") && atoi(getenv("CIP_LG_AMAT")) == 0);
+    size_t bytes = (cache_mat ? (size_t)nlarge * ncols * m2 : 0) + 8 * m2 + LG_NPAD * (size_t)nlarge * m2 + al256(12 * (size_t)rp * 8) + 2 * (size_t)w->chunk * m2 + al256(1024) +
                    2 * al256(cip_ldlt_ws_bytes(rp));
     CIP_HIP_CHECK(hipMalloc((void **)&w->base, bytes));
     char *p = (char *)w->base;
@@ -549,6 +592,7 @@ int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out) {
     w->vec = (double *)p; p += al256(12 * (size_t)rp * 8);
     w->batchX = (double *)p; p += (size_t)w->chunk * m2;
     w->batchT = (double *)p; p += (size_t)w->chunk * m2;
+    if (cache_mat) { w->amat = (double *)p; p += (size_t)nlarge * ncols * m2; }
     w->ctr = (unsigned *)p; p += al256(1024);
     CIP_HIP_CHECK(hipMemset(w->ctr, 0, 1024));
     w->ldl_z = p; p += al256(cip_ldlt_ws_bytes(rp));
@@ -585,12 +629,54 @@ void cip_sdp_large_destroy(LargeWs *w) {
 
 static dim3 lg_grid(long n) { return dim3((unsigned)((n + 255) / 256)); }
 // C_b = A_b B_b'  (rp x rp each, 64x64 fp64-MFMA tiles); stride 0 = operand shared by the batch
-// upper: only the 64-tiles that touch i <= j are computed (the others keep what C held)
-static int lg_gemm(hipStream_t s, double *C, long sC, const double *A, long sA, const double *B, long sB, int rp, int batch, bool upper = false) {
+// ONE product C = A B' of order rp <= 256 (the congruences of apply / max-step / NT scaling: ~60 per iteration of config 4).  The
+// 64x64-tile kernel has 16 workgroups for it and walks K = 256 in each: 14 us on 16 of 256 CUs.  Here a workgroup owns one 16x16
+// tile of C (256 workgroups at order 256) and its four waves split the k range; operands go from global memory (L2: 0.5 MB per
+// matrix) straight into the MFMA lanes -- lane l supplies row l % 16, k = l / 16 of its operand tile -- no LDS staging; the three
+// partial accumulators of waves 1..3 are added to wave 0's in a fixed order.  Register q of lane l holds C[i0 + l % 16, j0 + l / 16 + 4 q]
+// (the operand order of gemm_tile_64: B's rows first).
+__global__ __launch_bounds__(256) void k_gemm_nt_small(const double *A, long lda, const double *B, long ldb, double *C, long ldc, int K) {
+    __shared__ double red[3][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int kq = K >> 2;
+    const double *a = A + (long)blockIdx.x * 16 + l15 + (long)(wave * kq + l4) * lda;
+    const double *b = B + (long)blockIdx.y * 16 + l15 + (long)(wave * kq + l4) * ldb;
+    v4d acc0 = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+    for (int k = 0; k < kq; k += 32) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { av[u] = a[(long)(k + 4 * u) * lda]; bv[u] = b[(long)(k + 4 * u) * ldb]; }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[u], av[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[u + 1], av[u + 1], acc1, 0, 0, 0);
+        }
+    }
+    acc0 += acc1;
+    if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wave - 1][q][lane] = acc0[q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            C[(long)blockIdx.x * 16 + l15 + ((long)blockIdx.y * 16 + l4 + 4 * q) * ldc] = ((acc0[q] + red[0][q][lane]) + red[1][q][lane]) + red[2][q][lane];
+    }
+}
+// part 2: only the 64-tiles that touch i <= j are computed (the others keep what C held); 3: only those that touch i >= j
+static int lg_gemm(hipStream_t s, double *C, long sC, const double *A, long sA, const double *B, long sB, int rp, int batch, int part = 0) {
+    static const int small = [] { const char *e = getenv("CIP_LG_SMALLGEMM"); return e ? atoi(e) : 1; }();
+    if (batch == 1 && part == 0 && rp <= 256 && small) {
+        hipLaunchKernelGGL(k_gemm_nt_small, dim3(rp / 16, rp / 16), dim3(256), 0, s, A, (long)rp, B, (long)rp, C, (long)rp, rp);
+        CIP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     GemmArgs g = {};
     g.A = A; g.lda = rp; g.B = B; g.ldb = rp; g.C = C; g.ldc = rp;
     g.M = g.N = g.K = rp; g.alpha = 1.0; g.overwrite = 1; g.by = batch; g.bz = 1;
-    g.lower = upper ? 2 : 0;
+    g.lower = part;
     g.sAy = sA; g.sBy = sB; g.sCy = sC;
     return cip_launch_gemm(s, EPI_ACCUM, g);
 }
@@ -1116,18 +1202,22 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
     hipLaunchKernelGGL(k_lg_tfac, lg_grid(n2), dim3(256), 0, s, w->Ks, w->ws.dvec, w->Ts, rp);
     if ((rc = lg_gemm(s, w->G, 0, w->Tz, 0, w->Ts, 0, rp, 1))) return rc;           // G = Lz' Ls          (:204)
     {
-        // column blocks of 16: rp / 32 workgroups (8 at order 256, 16 at 512), each with 2 b columns in LDS and rp / 8 lanes per
-        // column pair.  At order 256 the blocks were 32 wide in round 2 -- 4 workgroups of 1024 threads: a rotation round is bound
-        // by instruction issue on its CU (16 waves), so half the pairs per CU is nearly half the time per round, and twice the
-        // outer rounds (grid barrier + block exchange each) cost less than that buys (CIP_LG_JACOBI_B=32 restores it)
+        // column blocks of 8 at order 256 (16 workgroups of 256 threads; round 4, with the DPP sums: 4 / 8 / 16 / 32 wide ->
+        // 3.95 / 3.11 / 3.25 / 4.48 ms per NT scaling -- a rotation round is bound by the hand-over between the wave's lane groups
+        // (LDS + workgroup barrier: fewer waves per workgroup, shorter rounds), an outer round costs ~3 us (block exchange through
+        // L2 + grid barrier) and their number doubles as the blocks halve), 16 at order 512 (16 workgroups), 8 at order 1024.
+        // CIP_LG_JACOBI_B = 4 / 8 / 16 / 32 overrides at order 256.
         static const int bforce = [] { const char *e = getenv("CIP_LG_JACOBI_B"); return e ? atoi(e) : 0; }();
-        const int b = rp > 512 ? 8 : ((rp <= 256 && (bforce == 32 || bforce == 8)) ? bforce : 16);
+        const int b = rp > 512 ? 8 : (rp <= 256 ? ((bforce == 32 || bforce == 16 || bforce == 4) ? bforce : 8) : 16);
         const int nt = rp > 512 ? b * 64 : b * (rp / 8);           // 512 (order 256, b = 16), 256 (b = 8), 1024 (order 512) or 512 (order 1024: 64 lanes x 16 elements per column)
         const size_t shm = (size_t)2 * b * lg_pitch(rp) * sizeof(double);
         CIP_HIP_CHECK(hipMemsetAsync(w->ctr, 0, 1024, s));
         if (rp > 512) {
             if ((rc = lg_set_attr((const void *)k_lg_jacobi<512, 16>, shm))) return rc;
             hipLaunchKernelGGL((k_lg_jacobi<512, 16>), dim3(rp / b / 2), dim3(512), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
+        } else if (nt == 128) {
+            if ((rc = lg_set_attr((const void *)k_lg_jacobi<128>, shm))) return rc;
+            hipLaunchKernelGGL(k_lg_jacobi<128>, dim3(rp / b / 2), dim3(128), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
         } else if (nt == 256) {
             if ((rc = lg_set_attr((const void *)k_lg_jacobi<256>, shm))) return rc;
             hipLaunchKernelGGL(k_lg_jacobi<256>, dim3(rp / b / 2), dim3(256), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
@@ -1243,21 +1333,38 @@ int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const d
     return 0;
 }
 
-// Wt[i, off + e] = (F^-T a_i)_e = vecm(Rinv mat(a_i) Rinv')_e for every row i of At (= column of A), in chunks
+// Wt[i, off + e] = (F^-T a_i)_e = vecm(Rinv mat(a_i) Rinv')_e for every row i of At (= column of A): two batched GEMMs over all
+// columns (chunks when they do not fit), the second on the lower tiles only, then the tiled vecm pass; mat(a_i) comes from the
+// per-upload cache when the workspace has one
+void cip_sdp_large_invalidate(LargeWs *w) {
+    if (w) for (auto &p : w->amat_src) p = nullptr;
+}
 int cip_sdp_large_scale_At(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, int n, const double *At, long ldat, double *Wt,
                            long ldwt) {
     const int r = cd.r, rp = w->rp;
     const long n2 = (long)rp * rp;
     const double *Rip = w->Rip + LG_NPAD * (size_t)li * n2;
+    const long dim = (long)r * (r + 1) / 2;
     int rc;
+    const bool cached = w->amat && n == w->ncols && n <= w->chunk;
+    double *amat = cached ? w->amat + (size_t)li * n * n2 : nullptr;
+    if (cached && w->amat_src[li] != At) {
+        dim3 gm((unsigned)((n2 + 255) / 256), n);
+        hipLaunchKernelGGL(k_lg_mat, gm, dim3(256), 0, s, At + (long)cd.aoff * ldat, ldat, 1L, amat, r, rp, 0.0);
+        w->amat_src[li] = At;
+    }
     for (int i0 = 0; i0 < n; i0 += w->chunk) {
         const int nb = (n - i0 < w->chunk) ? (n - i0) : w->chunk;
-        dim3 gm((unsigned)((n2 + 255) / 256), nb);
-        hipLaunchKernelGGL(k_lg_mat, gm, dim3(256), 0, s, At + i0 + (long)cd.aoff * ldat, ldat, 1L, w->batchX, r, rp, 0.0);
-        if ((rc = lg_gemm(s, w->batchT, n2, Rip, 0, w->batchX, n2, rp, nb))) return rc;     // Rinv X      (X symmetric)
-        if ((rc = lg_gemm(s, w->batchX, n2, w->batchT, n2, Rip, 0, rp, nb, true))) return rc;     // (Rinv X) Rinv': k_lg_vecm reads i <= j only
-        dim3 gv((unsigned)(((long)r * r + 255) / 256), nb);
-        hipLaunchKernelGGL(k_lg_vecm, gv, dim3(256), 0, s, w->batchX, Wt + i0 + (long)cd.aoff * ldwt, ldwt, 1L, r, rp);
+        const double *X = amat;
+        if (!cached) {
+            dim3 gm((unsigned)((n2 + 255) / 256), nb);
+            hipLaunchKernelGGL(k_lg_mat, gm, dim3(256), 0, s, At + i0 + (long)cd.aoff * ldat, ldat, 1L, w->batchX, r, rp, 0.0);
+            X = w->batchX;
+        }
+        if ((rc = lg_gemm(s, w->batchT, n2, Rip, 0, X, n2, rp, nb))) return rc;                  // Rinv X      (X symmetric)
+        if ((rc = lg_gemm(s, w->batchX, n2, w->batchT, n2, Rip, 0, rp, nb, 3))) return rc;     // (Rinv X) Rinv': lower tiles, all k_lg_vecm_cols reads
+        dim3 gv((unsigned)((dim + 63) / 64), (unsigned)((nb + 63) / 64));
+        hipLaunchKernelGGL(k_lg_vecm_cols, gv, dim3(256), 0, s, w->batchX, nb, Wt + i0 + (long)cd.aoff * ldwt, ldwt, r, rp);
     }
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
@@ -1285,7 +1392,6 @@ int cip_sdp_large_apply(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, i
 // entries cancels) -- chip-wide, one workgroup per matrix row, instead of one workgroup walking mat / divide / vecm over r^2
 // entries (225 us at order 256).  k_lg_div_check raises flag[0] when y has a non-zero off-diagonal entry; k_lg_div_diag writes the
 // quotient when it has none; the general kernel (sdp.hip: k_sdp_div) runs behind them and returns at once unless the flag is up.
-__device__ __forceinline__ long lg_rowoff(int i, int r) { return (long)i * r - (long)i * (i - 1) / 2; }       // vecm offset of (i, i)
 __global__ __launch_bounds__(256) void k_lg_div_check(const double *y, int r, int *flag) {
     const int i = blockIdx.x;
     const double *row = y + lg_rowoff(i, r);

@@ -264,6 +264,49 @@ def test_large_s_cone_programs_walk_the_oracles_trajectory(r, n, p, seed):
     np.testing.assert_allclose(got.v, ref.v, rtol=1e-7, atol=1e-8)
 
 
+@pytest.mark.parametrize("csr", [False, True], ids=["denseA", "csrA"])
+def test_update_problem_drops_the_cached_column_images_of_a_large_cone(csr):
+    """The large-cone path keeps mat(a_i) of every column of A from one factorisation to the next (sdp_large.hip: built once per
+    upload).  cip_update_problem with another A on the same handle -- what the batch workers do between problems -- must give exactly
+    what a fresh handle gives: factor with A1 first (the images exist), update to A2, factor + solve, compare bit for bit."""
+    import ctypes as C
+    import cipkkt
+    import scipy.sparse as sp
+    from cipkkt import _lib as L
+    from cipkkt.kkt import make_problem
+    r, n = 140, 24
+    k = r * (r + 1) // 2
+    K = [("R", 5), ("S", k)]
+    m = 5 + k
+    rng = np.random.default_rng(77)
+
+    mask = np.random.default_rng(5).random((m, n)) < 0.3          # one sparsity pattern: a CSR handle is re-loaded with the same nnz
+
+    def problem(seed):
+        g = np.random.default_rng(seed)
+        M = g.standard_normal((n, n))
+        A = (1.0 + g.random((m, n))) * mask
+        return M @ M.T / n + np.eye(n), (sp.csr_matrix(A) if csr else A)
+
+    (Q1, A1), (Q2, A2) = problem(1), problem(2)
+    ks = cipkkt.KKTSystem(Q1, A1, None, K)
+    v, s = dev(interior(K, rng)), dev(interior(K, rng))
+    ks.set_scaling_from_iterate(v, s)
+    ks.factor()
+    pr, keep, _ = make_problem(Q2, A2, None, K, "schur", ks.device)
+    torch.cuda.synchronize()
+    L.check(ks.lib.cip_update_problem(ks.h, C.byref(pr)))
+    fresh = cipkkt.KKTSystem(Q2, A2, None, K)
+    x, z = rng.standard_normal(n), rng.standard_normal(m)
+    outs = []
+    for sysm in (ks, fresh):
+        sysm.set_scaling_from_iterate(v, s)
+        sysm.factor()
+        outs.append(np.concatenate(sysm.solve3x3(x, np.zeros(0), z)))
+    np.testing.assert_array_equal(outs[0], outs[1])
+    ks.close(); fresh.close()
+
+
 # ---- CSR A together with S cones on the device (round 4: no host-side densification)
 def test_reference_sparse_psd_projection_without_densification():
     """test/runtests.jl:527-552: project onto the PSD cone with A = sparse identity (6 x 6), one ("S", 6) cone -- through
