@@ -233,6 +233,23 @@ __global__ __launch_bounds__(256, 4) void k_syrk_splitk_64(GemmArgs g, CipBatch 
     g.ldc = g.M; g.Ct = nullptr;
     gemm_tile_64<EPI_STORE>(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB);
 }
+// The same on 128x128 tiles (two workgroups per CU): half the operand traffic per flop.  With K = m in the tens of thousands a
+// slice's operand panel (M x len doubles) is far larger than an XCD's L2 and every tile streams it again: the 64-tile form ran
+// at 36 TFLOP/s at M = 1024, K = 32896 (config 4).  CIP_SYRK_TILE = 64 / 128 forces a form.
+__global__ __launch_bounds__(256, 2) void k_syrk_splitk_128(GemmArgs g, CipBatch cb) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * LDS_TILE];   // 64 KB
+    bool live;
+    (void)gemm_batch_prologue(g, cb, live);
+    if (!live) return;
+    int bi, bj;
+    tile_coords((int)blockIdx.x, 1, g.M / CIP_NB, bi, bj);
+    const long k0 = (long)blockIdx.y * g.ksplit_len;
+    g.A += k0 * g.lda; g.B += k0 * g.ldb;
+    g.K = (g.K - k0 < g.ksplit_len) ? (int)(g.K - k0) : g.ksplit_len;
+    g.C = (double *)((char *)g.ksplit_ws + (long)(blockIdx.z / (g.bz > 0 ? g.bz : 1)) * cb.stride) + (long)blockIdx.y * g.M * g.M;
+    g.ldc = g.M; g.Ct = nullptr; g.overwrite = 1;
+    gemm_tile_128<EPI_ACCUM>(g, lds, bi, bj);
+}
 // C[i, j] = Qin[i, j] + sum_b image_b[i, j] for i >= j (by 64-tiles), i, j < nvalid; one thread per row pair of a 64 x 64 tile column
 __global__ __launch_bounds__(256) void k_syrk_reduce(GemmArgs g, CipBatch cb) {
     bool live;
@@ -255,11 +272,22 @@ __global__ __launch_bounds__(256) void k_syrk_reduce(GemmArgs g, CipBatch cb) {
         else *cp = qp[0] + g.alpha * acc.x;
     }
 }
+// 128-tile form of the split: few tiles and a K so long that the 64-tile form is bound by re-streaming its operands
+static bool syrk_split_128(int M, int K) {
+    static const int force = [] { const char *e = getenv("CIP_SYRK_TILE"); return e ? atoi(e) : 0; }();
+    if (force == 64) return false;
+    const long tm = M / CIP_NB, t128 = tm * (tm + 1) / 2;
+    if (force == 128) return t128 <= 256;
+    return t128 <= 64 && K >= 16384;
+}
 int cip_syrk_split(int M, int K, int *len) {
     static const int on = [] { const char *e = getenv("CIP_SYRK_SPLITK"); return e ? atoi(e) : 1; }();
     const long tm = M / CIP_NB, wgs = 4 * (tm * (tm + 1) / 2);
     int n = 1;
-    if (on && wgs < 640 && K >= 4096) { n = (int)((1280 + wgs - 1) / wgs); if (n > 16) n = 16; }
+    if (on && wgs < 640 && K >= 4096) {
+        if (syrk_split_128(M, K)) { n = (int)(512 / (wgs / 4)); if (n > 16) n = 16; if (n < 1) n = 1; }     // 512 slots of 64 KB of LDS
+        else { n = (int)((1280 + wgs - 1) / wgs); if (n > 16) n = 16; }
+    }
     int l = ((K + n - 1) / n + CIP_KT - 1) / CIP_KT * CIP_KT;
     n = (K + l - 1) / l;
     if (len) *len = l;
@@ -343,7 +371,8 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     if (epi == EPI_SYRKQ && g.lower && g_tile == 64 && g.ksplit_ws && g.ksplit_n > 1) {
         GemmArgs gs = g;
         gs.alpha = 1.0;                                          // (the images hold the plain products; alpha is applied by the reduction)
-        cip_launch_b(k_syrk_splitk_64, dim3((unsigned)(4 * tiles), (unsigned)g.ksplit_n), dim3(256), 0, s, gs);
+        if (syrk_split_128(g.M, g.K)) cip_launch_b(k_syrk_splitk_128, dim3((unsigned)tiles, (unsigned)g.ksplit_n), dim3(256), 0, s, gs);
+        else cip_launch_b(k_syrk_splitk_64, dim3((unsigned)(4 * tiles), (unsigned)g.ksplit_n), dim3(256), 0, s, gs);
         const long t64 = (long)(g.M / SB) * (g.M / SB + 1) / 2;
         cip_launch_b(k_syrk_reduce, dim3((unsigned)t64), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
