@@ -69,16 +69,20 @@ def main(d):
         for k in st:
             if k.startswith("k_lg_jacobi"):
                 jac = k
-        recs = [mfma("k_syrkq_64", st, float(m) * n * n, "Schur formation with the scaled A' (32896 x 1024)"),
+        syrk = "k_syrk_splitk_128" if "k_syrk_splitk_128" in st else ("k_syrk_splitk_64" if "k_syrk_splitk_64" in st else "k_syrkq_64")
+        recs = [mfma(syrk, st, float(m) * n * n, "Schur formation with the scaled A' (32896 x 1024): split-K images + fixed-order reduction"),
                 latency(jac, st, "one-sided block Jacobi of svd(Lz'Ls) (src/ConicIP.jl:204): serial rotation rounds, 255 per sweep at order 256",
-                        rounds_per_sweep=255, note="time per launch / (sweeps x 255) = time per rotation round; 8 workgroups") if jac else None,
+                        rounds_per_sweep=255, note="time per launch / (sweeps x 255) = time per rotation round; 16 workgroups of 8-column blocks, wave sums by DPP") if jac else None,
                 latency("k_lg_lanczos1", st, "max-step: extreme eigenvalue by Lanczos in one workgroup (src/ConicIP.jl:272-303)")]
         # the batched congruences A'F^-1: per factorisation n columns x 2 GEMMs x 2 rp^3 flop
         g = st.get("k_gemm_nt_64_batched")
         if g:
-            recs.append(dict(kernel="k_gemm_nt_64_batched", role="batched congruences Rinv X Rinv' for A'F^-1 (1024 columns, chunks of 64) and the S-cone LDL' block inverses",
+            recs.append(dict(kernel="k_gemm_nt_64_batched", role="batched congruences Rinv X Rinv' for A'F^-1 (all 1024 columns per launch, two launches per factorisation; the second on the lower tiles) and the S-cone LDL' block inverses (small launches under the same name)",
                              bound="mfma", launches=g["calls"], avg_launch_us=round(g["avg_us"], 2),
                              note="flops per factorisation of the congruences alone: %.3g (n x 2 x 2 rp^3)" % (n * 2 * 2.0 * r ** 3)))
+        recs.append(latency("k_gemm_nt_small", st, "single 256^3 products of apply / max-step / NT scaling: one 16x16 tile per workgroup, k split over the waves"))
+        recs.append(latency("k_lg_vecm_cols", st, "vecm of the 1024 congruence results into the columns of W' = A'F^-1 (64 entries x 64 matrices per workgroup through LDS)",
+                            hbm_bytes_per_launch=8.0 * (n * r * (r + 1) / 2) * 2))
         out["c4_sdp_r256"] = dict(workload='SDP: one ("S", 32896) cone (matrix order 256), n=1024, p=16', dominant=[x for x in recs if x], time_share=share(st))
     # ---- config 5, the per-rank shard at 8 GPUs: 8 problems of order 2048 in lock-step
     st = stats(os.path.join(d, "c5_b8_kernel_stats.csv"))

@@ -48,6 +48,11 @@ cp $OUT/c5ls/c5ls_kernel_stats.csv $OUT/c5_lockstep_kernel_stats.csv
 for c in 8 16 32 64; do CIP_LOCKSTEP_TIMING=1 python3 $R/tools/lockstep_time.py $c 2048 2 both 2>&1 | tail -5; done > $OUT/c5_shard_sizes.txt
 bash $R/tools/prof_lockstep.sh 8 2048 $OUT/c5b8 > $OUT/c5_b8_profile.txt 2>&1
 cp $OUT/c5b8/b8_kernel_stats.csv $OUT/c5_b8_kernel_stats.csv
+# per-iteration kernel timelines (launches, kernel time, idle time, gaps): config 4 and the 8-problem lock-step shard
+python3 $R/tools/loop_run.py c4 > $OUT/c4_loop_time.txt 2>/dev/null
+rm -rf /tmp/lr_c4; rocprofv3 --kernel-trace --output-format csv -d /tmp/lr_c4 -o t -- python3 $R/tools/loop_run.py c4 > /dev/null 2>&1
+python3 $R/tools/iter_timeline.py $(find /tmp/lr_c4 -name "*kernel_trace.csv" | head -1) k_lg_jacobi 30 > $OUT/c4_iter_timeline.txt 2>&1
+bash $R/tools/lockstep_trace.sh 8 2048 $OUT/lt8 > /dev/null 2>&1; cp $OUT/lt8/b8_timeline.txt $OUT/c5_b8_iter_timeline.txt
 python3 $R/tools/config_rooflines.py $OUT > $OUT/rooflines.json
-rm -rf $OUT/stats $OUT/pmc_* $OUT/c4 $OUT/c3 $OUT/c5ls $OUT/f33 $OUT/soc $OUT/c5b8 $OUT/diag_ab
+rm -rf $OUT/stats $OUT/pmc_* $OUT/c4 $OUT/c3 $OUT/c5ls $OUT/f33 $OUT/soc $OUT/c5b8 $OUT/diag_ab $OUT/lt8
 ls -la $OUT
