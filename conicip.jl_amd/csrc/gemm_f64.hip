@@ -202,16 +202,18 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_64_batched(GemmArgs g, CipBa
 }
 
 // Schur formation S = Q + Wt Wt' (lower tiles) in quarter tiles: the long-K (K = m) counterpart of the trailing update
+template <bool GLDS>
 __global__ __launch_bounds__(256, 4) void k_syrkq_64(GemmArgs g, CipBatch cb) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
     bool live;
     (void)gemm_batch_prologue(g, cb, live);
     if (!live) return;
+    if (GLDS) __builtin_amdgcn_s_setprio(3);
     int bi, bj;
     tile_coords((int)(blockIdx.x >> 2), 1, g.M / CIP_NB, bi, bj);
     const int sub = blockIdx.x & 3;
     if (bi == bj && sub == 2) return;
-    gemm_tile_64<EPI_SYRKQ>(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB);
+    gemm_tile_64<EPI_SYRKQ, GLDS>(g, lds, (long)bi * CIP_NB + (sub & 1) * SB, (long)bj * CIP_NB + (sub >> 1) * SB);
 }
 
 // The same with few output tiles and a long K -- config 4: S = 1024 x 1024 from K = m = 32896, 136 quarter tiles on a chip with
@@ -379,7 +381,11 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
         return 0;
     }
     if (epi == EPI_SYRKQ && g.lower && g_tile == 64) {
-        cip_launch_b(k_syrkq_64, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
+        // operands global -> LDS directly + raised wave priority, as the trailing update (round 4, config 3: 1.35 -> 1.28 ms per
+        // Schur formation, same-session A/B 4.17 -> 4.10 ms per iteration, same bits); CIP_SYRK_GLDS=0: register staging
+        static const int glds = [] { const char *e = getenv("CIP_SYRK_GLDS"); return e ? atoi(e) : 1; }();
+        if (glds && !(g.lda & 1) && !(g.ldb & 1) && !(((uintptr_t)g.A | (uintptr_t)g.B) & 15)) cip_launch_b(k_syrkq_64<true>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
+        else cip_launch_b(k_syrkq_64<false>, dim3((unsigned)(4 * tiles)), dim3(256), 0, s, g);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
