@@ -60,11 +60,13 @@ bool same_shape(const cip_problem &a, const cip_problem &b) {
     return true;
 }
 
-// One arena is kept between calls (a bench or a service solves batch after batch of the same shape; hipMalloc / hipFree
-// of several GB cost up to 0.6 s and synchronise the device).  cip_release_cached_memory() frees it.
+// Up to four arenas are kept between calls (a bench or a service solves batch after batch of the same shape, possibly from several
+// host threads at once; hipMalloc / hipFree of several GB cost up to 0.6 s and synchronise the device).
+// cip_release_cached_memory() frees them.
 struct ArenaCache {
     std::mutex mu;
-    char *ptr = nullptr; size_t bytes = 0; int device = -1;
+    struct Slot { char *ptr; size_t bytes; int device; };
+    std::vector<Slot> slots;
     // last probe: shape signature -> slab bytes
     std::vector<long> sig; size_t slab = 0;
 } g_cache;
@@ -74,8 +76,19 @@ int arena_acquire(size_t bytes, char **out, size_t *cap) {
     CIP_HIP_CHECK(hipGetDevice(&dev));
     {
         std::lock_guard<std::mutex> lk(g_cache.mu);
-        if (g_cache.ptr && g_cache.device == dev && g_cache.bytes >= bytes) { *out = g_cache.ptr; *cap = g_cache.bytes; g_cache.ptr = nullptr; g_cache.bytes = 0; return 0; }
-        if (g_cache.ptr) { (void)hipFree(g_cache.ptr); g_cache.ptr = nullptr; g_cache.bytes = 0; }
+        int best = -1;                                       // the smallest cached arena that fits
+        for (int i = 0; i < (int)g_cache.slots.size(); ++i) {
+            const auto &sl = g_cache.slots[i];
+            if (sl.device == dev && sl.bytes >= bytes && (best < 0 || sl.bytes < g_cache.slots[best].bytes)) best = i;
+        }
+        if (best >= 0) {
+            *out = g_cache.slots[best].ptr; *cap = g_cache.slots[best].bytes;
+            g_cache.slots.erase(g_cache.slots.begin() + best);
+            return 0;
+        }
+        // nothing fits: the cached arenas of this device make room (a larger batch follows a smaller one)
+        for (int i = (int)g_cache.slots.size() - 1; i >= 0; --i)
+            if (g_cache.slots[i].device == dev) { (void)hipFree(g_cache.slots[i].ptr); g_cache.slots.erase(g_cache.slots.begin() + i); }
     }
     CIP_HIP_CHECK(hipMalloc((void **)out, bytes));
     *cap = bytes;
@@ -85,8 +98,13 @@ void arena_release(char *ptr, size_t bytes) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_cache.mu);
-    if (g_cache.ptr) (void)hipFree(g_cache.ptr);
-    g_cache.ptr = ptr; g_cache.bytes = bytes; g_cache.device = dev;
+    if (g_cache.slots.size() >= 4) {                         // full: the smallest one goes
+        int small = 0;
+        for (int i = 1; i < (int)g_cache.slots.size(); ++i) if (g_cache.slots[i].bytes < g_cache.slots[small].bytes) small = i;
+        (void)hipFree(g_cache.slots[small].ptr);
+        g_cache.slots.erase(g_cache.slots.begin() + small);
+    }
+    g_cache.slots.push_back({ptr, bytes, dev});
 }
 std::vector<long> shape_signature(const cip_problem &pr, int solve_block) {
     std::vector<long> sg = {pr.n, pr.m, pr.p, pr.ncones, pr.route, pr.A == nullptr, solve_block, cip_ldlt_outer_block()};
@@ -555,7 +573,8 @@ extern "C" int cip_conicip_mixed(int count, const cip_problem *probs, const doub
 
 extern "C" int cip_release_cached_memory(void) {
     std::lock_guard<std::mutex> lk(g_cache.mu);
-    if (g_cache.ptr) { (void)hipFree(g_cache.ptr); g_cache.ptr = nullptr; g_cache.bytes = 0; }
+    for (auto &sl : g_cache.slots) (void)hipFree(sl.ptr);
+    g_cache.slots.clear();
     return 0;
 }
 
