@@ -1048,6 +1048,13 @@ extern "C" int cip_profile_thread_get(double *out3) {
 }
 extern "C" int cip_set_lazy_copy(int on) { return cip_lazy_copy_set(on); }
 extern "C" int cip_set_sdp_lanczos(int on) { return cip_sdp_large_lanczos(on); }
+extern "C" int cip_sdp_lanczos_fallbacks(cip_handle *h, int *count) {
+    if (!h || !count) { cip_set_error("bad argument"); return CIP_E_INVALID; }
+    int out2[2] = {0, 0};
+    const int rc = cip_sdp_large_cert_stats(h->stream, h->cs.lg, out2);
+    *count = out2[0];
+    return rc;
+}
 extern "C" int cip_set_ldlt_fused_chain(int on) { return cip_ldlt_set_fused_chain(on); }
 extern "C" int cip_set_ldlt_side_prep(int on) { return cip_ldlt_set_side_prep(on); }
 extern "C" int cip_set_solve_block_max(int b) { return cip_solve_block_max_set(b); }

@@ -156,6 +156,7 @@ struct LdltWorkspace {        // carved out of one device allocation
     // solve preparation beside the panel chain of the last (wide) outer block (ldlt.hip: cip_ldlt_factor): where the owner
     // keeps the side stream / events, created on first use (NULL: always behind the factorisation, on its own stream)
     struct LdltSide **side;
+    int no_prep;              // 1: the factor only (no block inverses for solves) -- inertia checks (sdp_large.hip)
 };
 struct LdltSide;
 void cip_ldlt_side_destroy(struct LdltSide *sd);
@@ -232,7 +233,8 @@ int cip_sdp_large_refresh(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li,
 int cip_sdp_large_apply(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, int mode, const double *x, double *out);
 int cip_sdp_large_prod(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *y, double *out);
 int cip_sdp_large_div(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *y, double *out, int *flag);
-int cip_sdp_large_lanczos(int on);                  // sdp_large.hip: Lanczos max-step on (1) / off (0), < 0 reads; returns the previous setting
+int cip_sdp_large_lanczos(int on);                  // sdp_large.hip: max-step eigenvalue by Lanczos (1), Lanczos + inertia certificate (2), tridiagonalisation (0); < 0 reads; returns the previous setting
+int cip_sdp_large_cert_stats(hipStream_t s, struct LargeWs *w, int *out2);     // {certificates failed -> fallbacks taken, 0}
 int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *d, double scale,
                           double *partial, int side = 0);
 bool cip_sdp_large_pairable(const LargeWs *w);            // the v- and s-side max-steps of a pair can run side by side

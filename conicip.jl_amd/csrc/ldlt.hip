@@ -514,6 +514,7 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
         }
     }
     if (sd && sd->nfork > 0) return side_fork(sd, s, K, Npad, ld, ws, Jdone, Npad / Bs);      // joined by the solves (cip_ldlt_side_join)
+    if (ws.no_prep) return 0;
     return build_solve_blocks(s, K, Npad, ld, ws, Jdone, Npad / Bs);
 }
 

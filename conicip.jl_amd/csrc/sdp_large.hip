@@ -506,7 +506,8 @@ __global__ __launch_bounds__(LG_T) void k_lg_tridiag(const double *M, int ldm, c
 // extreme eigenvalue of the tridiagonal (dg, of) by multisection on the Sturm count (one workgroup), then the max-step
 // verdict of maxstep_sdc (src/ConicIP.jl:272-303): partial[item] <- Inf / 1/(scale lambda_max) / the `nothing` variant
 __global__ __launch_bounds__(LG_T) void k_lg_sturm(const double *dgg, const double *ofg, int r, int want_max, double scale,
-                                                    const int *info, double *partial, int item) {
+                                                    const int *info, double *partial, int item, const int *gate = nullptr) {
+    if (gate && !gate[0]) return;
     __shared__ double dg[1024], of[1024], red[64];
     __shared__ int first;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -595,6 +596,7 @@ int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out) {
     if (cache_mat) { w->amat = (double *)p; p += (size_t)nlarge * ncols * m2; }
     w->ctr = (unsigned *)p; p += al256(1024);
     CIP_HIP_CHECK(hipMemset(w->ctr, 0, 1024));
+    CIP_HIP_CHECK(hipMemset(w->vec, 0, 12 * (size_t)rp * 8));
     w->ldl_z = p; p += al256(cip_ldlt_ws_bytes(rp));
     w->ldl_s = p;
     cip_ldlt_ws_carve(w->ldl_z, rp, &w->wz);
@@ -706,8 +708,9 @@ __device__ __forceinline__ void t1_extract(const double (&a)[8][16], double *xs,
 #pragma unroll
     for (int ai = KB / 2; ai < 8; ++ai) xs[32 * ai + tr] = a[ai][KB];
 }
-__global__ __launch_bounds__(512) void k_lg_tridiag1(const double *M, int ldm, const double *dscale, int r, double *dg, double *of) {
+__global__ __launch_bounds__(512) void k_lg_tridiag1(const double *M, int ldm, const double *dscale, int r, double *dg, double *of, const int *gate) {
     extern __shared__ double sh[];
+    if (gate && !gate[0]) return;                              // (the fallback behind a passed inertia certificate)
     double *rowp = sh, *colp = sh + 256 * 17;                 // partial sums: [i][tc] (pitch 17) and [tr][j]
     double *xs0 = colp + 32 * 256, *vs = xs0 + 512, *red = vs + 512;
     const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
@@ -884,7 +887,7 @@ __device__ __forceinline__ double lz_sum256(double x, double *red, int slot) {  
     return (red[slot * 4] + red[slot * 4 + 1]) + (red[slot * 4 + 2] + red[slot * 4 + 3]);
 }
 __global__ __launch_bounds__(512) void k_lg_lanczos1(const double *M, int ldm, const double *dscale, int r, int want_max, double scale,
-                                                      const int *info, double *partial, int item, double *Vg, int *stat) {
+                                                      const int *info, double *partial, int item, double *Vg, int *stat, double *cert, double cert_tol) {
     extern __shared__ double sh[];
     double *rowp = sh, *colp = sh + 256;                      // p = A v: row sums [i], column sums per wave [wave][j]
     double *vs = colp + 8 * 256, *wsv = vs + 256, *al = wsv + 256, *be = al + 256, *hb = be + 256, *zz = hb + 256;
@@ -894,7 +897,7 @@ __global__ __launch_bounds__(512) void k_lg_lanczos1(const double *M, int ldm, c
     const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
     const double INF = __builtin_inf();
     if (info && info[0]) {                                     // X not positive definite -> Inf (:277-280)
-        if (tid == 0) { partial[item] = INF; if (stat) stat[0] = 0; }
+        if (tid == 0) { partial[item] = INF; if (stat) stat[0] = 0; if (cert) { cert[0] = 0.0; cert[1] = 1.0; } }
         return;
     }
     LZ_T0();
@@ -1159,6 +1162,8 @@ __global__ __launch_bounds__(512) void k_lg_lanczos1(const double *M, int ldm, c
         if (want_max) { const double mx = ev * scale; partial[item] = (mx < 0.0) ? INF : 1.0 / mx; }
         else partial[item] = (ev > 0.0) ? 0.0 : -1.0 + ev;
         if (stat) stat[0] = m;
+        // the bound the inertia certificate checks: no eigenvalue beyond theta by more than 1e-9 |T| (the stop was at 1e-11 |T|)
+        if (cert) { const double tol = cert_tol * s_res[1] + 1e-300; cert[0] = want_max ? ev + tol : ev - tol; cert[1] = 0.0; }
         atomicAdd(g_lz_hist + (m >> 3 < 32 ? m >> 3 : 32), 1);       // histogram of step counts (CIP_LG_LANCZOS_STATS=1 prints it at destroy)
     }
 }
@@ -1170,7 +1175,7 @@ static int lg_tridiag(hipStream_t s, LargeWs *w, const double *M, const double *
     if (one_wg && r <= 256) {
         const size_t shm1 = T1_LDS_DOUBLES * sizeof(double);
         if ((rc = lg_set_attr((const void *)k_lg_tridiag1, shm1))) return rc;
-        hipLaunchKernelGGL(k_lg_tridiag1, dim3(1), dim3(512), shm1, s, M, w->rp, dscale, r, w->vec + 1 * w->rp, w->vec + 2 * w->rp);
+        hipLaunchKernelGGL(k_lg_tridiag1, dim3(1), dim3(512), shm1, s, M, w->rp, dscale, r, w->vec + 1 * w->rp, w->vec + 2 * w->rp, (const int *)nullptr);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -1260,13 +1265,14 @@ int cip_sdp_large_refresh(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li,
     return 0;
 }
 
-// 1 (default; CIP_LG_LANCZOS=0 changes it): the max-step's extreme eigenvalue by k_lg_lanczos1 at orders <= 256; 0: full
+// 2 (default; CIP_LG_LANCZOS changes it): the max-step's extreme eigenvalue by k_lg_lanczos1 at orders <= 256 + the inertia certificate
+// (lg_certify); 1: Lanczos alone; 3: certificate self-test; 0: full
 // tridiagonalisation + Sturm multisection at every order (A/B runs, tests).  on < 0 only reads; returns the previous setting
 #include <atomic>
 int cip_sdp_large_lanczos(int on) {
-    static std::atomic<int> mode{[] { const char *e = getenv("CIP_LG_LANCZOS"); return (e && atoi(e) == 0) ? 0 : 1; }()};
+    static std::atomic<int> mode{[] { const char *e = getenv("CIP_LG_LANCZOS"); const int v = e ? atoi(e) : 2; return (v >= 0 && v <= 3) ? v : 2; }()};
     const int prev = mode.load();
-    if (on == 0 || on == 1) mode.store(on);
+    if (on >= 0 && on <= 3) mode.store(on);
     return prev;
 }
 // The two max-steps of a pair (v side, s side: src/ConicIP.jl:708-709, :881-882, :927-928) are independent: side 1 works in the
@@ -1290,6 +1296,65 @@ int cip_sdp_large_join(hipStream_t s, LargeWs *w) {
     return 0;
 }
 // maxstep_sdc for one large cone: partial[cd.item]
+// ---- inertia certificate of the Lanczos max-step (mode 2; ADVICE r3: a Ritz value can settle on an interior eigenvalue when the
+// fixed start vector has no component along the extreme eigenvector).  With theta' = theta +- 1e-9 |T| from the kernel:
+//   B = theta' I - A (largest eigenvalue wanted)  or  A - theta' I (smallest)  must be positive definite
+// -- checked by the library's own LDL' with all-positive prescribed pivot signs (a wrong-sign or dead pivot raises info).  If it is
+// not, `gate` goes up and the tridiagonalisation + Sturm path behind it recomputes the verdict from the same scaled matrix
+// (both kernels return at once on a lowered gate).  cert[1] != 0: the Lanczos kernel answered Inf for an X outside the cone --
+// nothing to certify (B = I).  Asym: the matrix the Lanczos kernel saw (scaled, symmetrised), for the fallback.
+__global__ __launch_bounds__(256) void k_lg_cert_build(const double *M, int ldm, const double *dscale, int r, int rp, int want_max,
+                                                        const double *cert, double *B, double *Asym) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)rp * rp) return;
+    const int i = (int)(e % rp), j = (int)(e / rp);
+    double a = 0.0, b = (i == j) ? 1.0 : 0.0;
+    if (i < r && j < r) {
+        a = M[j + (long)i * ldm];
+        if (dscale) a = 0.5 * (M[i + (long)j * ldm] + a) * (rsqrt(dscale[i]) * rsqrt(dscale[j]));
+        if (cert[1] == 0.0) {
+            const double th = (i == j) ? cert[0] : 0.0;
+            b = want_max ? th - a : a - th;
+        }
+    }
+    B[e] = b;
+    Asym[e] = a;
+}
+__global__ void k_lg_cert_check(const int *info, int *gate, unsigned *count) {
+    if (threadIdx.x == 0) {
+        const int up = (info[0] != 0 || info[2] != 0) ? 1 : 0;
+        gate[0] = up;
+        if (up) atomicAdd(count, 1u);
+    }
+}
+static int lg_certify(hipStream_t s, LargeWs *w, const double *M3, const double *dscale, int r, int want_max, double scale,
+                      double *M1, double *M2, const LdltWorkspace &wx, double *partial, int item, int side) {
+    const int rp = w->rp;
+    const long n2 = (long)rp * rp;
+    int rc;
+    const double *cert = w->vec + 11 * rp + 2 * side;
+    int *gate = (int *)(w->ctr + 210 + side);
+    hipLaunchKernelGGL(k_lg_cert_build, lg_grid(n2), dim3(256), 0, s, M3, rp, dscale, r, rp, want_max, cert, M2, M1);
+    LdltWorkspace wc = wx;
+    wc.no_prep = 1; wc.lazyC = nullptr; wc.prof = nullptr;
+    if ((rc = cip_ldlt_factor(s, M2, rp, rp, wc))) return rc;
+    hipLaunchKernelGGL(k_lg_cert_check, dim3(1), dim3(64), 0, s, (const int *)wc.info, gate, (unsigned *)(w->vec + 11 * rp + 8));      // (w->ctr is cleared by every NT scaling)
+    // the fallback (one workgroup each, at once back unless the gate is up): side 1 of a pair has its own d / e vectors
+    double *dg = w->vec + (side ? 9 : 1) * rp, *of = w->vec + (side ? 10 : 2) * rp;
+    const size_t shm1 = T1_LDS_DOUBLES * sizeof(double);
+    if ((rc = lg_set_attr((const void *)k_lg_tridiag1, shm1))) return rc;
+    hipLaunchKernelGGL(k_lg_tridiag1, dim3(1), dim3(512), shm1, s, (const double *)M1, rp, (const double *)nullptr, r, dg, of, (const int *)gate);
+    hipLaunchKernelGGL(k_lg_sturm, dim3(1), dim3(LG_T), 0, s, dg, of, r, want_max, scale, (const int *)nullptr, partial, item, (const int *)gate);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int cip_sdp_large_cert_stats(hipStream_t s, LargeWs *w, int *out2) {
+    unsigned c = 0;
+    if (w) { CIP_HIP_CHECK(hipMemcpyAsync(&c, w->vec + 11 * w->rp + 8, sizeof(c), hipMemcpyDeviceToHost, s)); CIP_HIP_CHECK(hipStreamSynchronize(s)); }
+    out2[0] = (int)c; out2[1] = 0;
+    return 0;
+}
+
 int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *d, double scale,
                           double *partial, int side) {
     const int r = cd.r, rp = w->rp;
@@ -1300,14 +1365,18 @@ int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const d
     LdltWorkspace &wx = side ? w->ws : w->wz;
     int *const stat = (int *)(w->ctr + 200 + side);
     // CIP_LG_LANCZOS=0: the full tridiagonalisation + Sturm multisection at every order (A/B runs, tests)
-    const bool lz = cip_sdp_large_lanczos(-1) && r <= 256;
+    const int lzmode = cip_sdp_large_lanczos(-1);
+    const bool lz = lzmode && r <= 256;
+    double *const cert = (lz && lzmode >= 2) ? w->vec + 11 * rp + 2 * side : nullptr;          // mode 2: + inertia certificate
+    const double cert_tol = lzmode == 3 ? -1e-3 : 1e-9;      // mode 3 (self-test): the bound on the WRONG side of theta -- every certificate fails, every verdict comes from the fallback
     if (lz && (rc = lg_set_attr((const void *)k_lg_lanczos1, LZ_LDS_DOUBLES * sizeof(double)))) return rc;
     if (!d) {                                                                       // maxstep_sdc(x, nothing) :295-303
         hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, x + cd.off, 1L, 0L, M3, r, rp, 0.0);
         if (lz) {
             hipLaunchKernelGGL(k_lg_lanczos1, dim3(1), dim3(512), LZ_LDS_DOUBLES * sizeof(double), s, M3, rp, (const double *)nullptr, r, 0,
-                               1.0, (const int *)nullptr, partial, cd.item, M1, stat);
+                               1.0, (const int *)nullptr, partial, cd.item, M1, stat, cert, cert_tol);
             CIP_HIP_CHECK(hipGetLastError());
+            if (cert) return lg_certify(s, w, M3, nullptr, r, 0, 1.0, M1, M2, wx, partial, cd.item, side);
             return 0;
         }
         if ((rc = lg_tridiag(s, w, M3, nullptr, r))) return rc;
@@ -1323,8 +1392,9 @@ int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const d
     if ((rc = lg_gemm(s, M3, 0, M2, 0, Xi, 0, rp, 1))) return rc;             // inv(L) D inv(L)'
     if (lz) {                                                                       // ... scaled by d^-1/2 on both sides
         hipLaunchKernelGGL(k_lg_lanczos1, dim3(1), dim3(512), LZ_LDS_DOUBLES * sizeof(double), s, M3, rp, (const double *)wx.dvec, r, 1,
-                           scale, (const int *)wx.info, partial, cd.item, M1, stat);
+                           scale, (const int *)wx.info, partial, cd.item, M1, stat, cert, cert_tol);
         CIP_HIP_CHECK(hipGetLastError());
+        if (cert) return lg_certify(s, w, M3, wx.dvec, r, 1, scale, M1, M2, wx, partial, cd.item, side);
         return 0;
     }
     if ((rc = lg_tridiag(s, w, M3, wx.dvec, r))) return rc;

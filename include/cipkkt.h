@@ -275,9 +275,15 @@ int cip_set_ldlt_side_prep(int on);
  * itself (also CIP_LAZY_COPY=0).  Same factor bit for bit.  1 (default) on, 0 off; returns the previous setting. */
 int cip_set_lazy_copy(int on);
 /* S cones of order 133..256: the max-step's extreme eigenvalue (the reference's eigmin / eigmax, src/ConicIP.jl:272-303) by
-   Lanczos with full reorthogonalisation (1, default) or by a full tridiagonalisation + Sturm multisection (0); < 0 only
-   reads.  Returns the previous setting.  Same eigenvalue to ~1e-11 relative either way; for A/B runs and tests. */
+   Lanczos with full reorthogonalisation (1) or by a full tridiagonalisation + Sturm multisection (0); < 0 only
+   reads.  Returns the previous setting.  Same eigenvalue to ~1e-11 relative either way; for A/B runs and tests.
+   2 (DEFAULT): Lanczos + INERTIA CERTIFICATE -- a Krylov method started from a fixed vector can in principle settle on an interior
+   eigenvalue (no component along the extreme eigenvector); mode 2 checks with an LDL' of theta' I - A (theta' = theta + 1e-9 |T|)
+   that no eigenvalue lies beyond the returned one and recomputes the verdict by the tridiagonalisation when the check fails
+   (0.09 ms per iteration of config 4, 1 %; also CIP_LG_LANCZOS=2).  cip_sdp_lanczos_fallbacks: how often that happened on this handle.
+   3 (self-test): as 2 with the bound on the wrong side of theta, so that every certificate fails and every verdict is the fallback's. */
 int cip_set_sdp_lanczos(int on);
+int cip_sdp_lanczos_fallbacks(cip_handle *h, int *count);
 /* HIP-event timing of every LDL' trailing-update launch (bench.py roofline): enable, then read
  * out3 = [launches, total ms, total algorithmic flops (r(r+1)K per launch)] */
 int cip_profile_trailing(cip_handle *h, int enabled);

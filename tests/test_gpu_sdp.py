@@ -219,13 +219,79 @@ def test_lanczos_maxstep_against_lapack_on_hard_spectra(r):
         got_d, got_n = ks.maxstep(x, d), ks.maxstep(dn, None)
         lib.cip_set_sdp_lanczos(0)
         tri_d, tri_n = ks.maxstep(x, d), ks.maxstep(dn, None)
+        lib.cip_set_sdp_lanczos(2)                                     # Lanczos + inertia certificate: same verdicts, no fallback needed here
+        cer_d, cer_n = ks.maxstep(x, d), ks.maxstep(dn, None)
         lib.cip_set_sdp_lanczos(prev)
+        assert (cer_d, cer_n) == (got_d, got_n), (name, cer_d, got_d, cer_n, got_n)
         for got, tri, ref, what in ((got_d, tri_d, ref_d, "maxstep(x, d)"), (got_n, tri_n, ref_n, "maxstep(x, nothing)")):
             if np.isinf(ref):
                 assert np.isinf(got) and np.isinf(tri), (name, what)
             else:
                 assert got == pytest.approx(ref, rel=1e-10, abs=1e-12), (name, what, got, ref)
                 assert got == pytest.approx(tri, rel=1e-10, abs=1e-12), (name, what, got, tri)
+    import ctypes as C
+    nfb = C.c_int(-1)
+    _lib.check(lib.cip_sdp_lanczos_fallbacks(ks.h, C.byref(nfb)))
+    assert nfb.value == 0, nfb.value
+    ks.close()
+
+
+@pytest.mark.parametrize("r", [133, 256])
+def test_lanczos_inertia_certificate_catches_a_start_vector_without_the_extreme_direction(r):
+    """the Lanczos max-step starts from a FIXED vector v1; a direction whose extreme eigenvector is orthogonal to v1 is
+    invisible to the recurrence (until rounding brings it in), and the stop test -- a converged Ritz pair -- passes on the second
+    eigenvalue.  Such a direction is built here (v1 is cos(0.7 i + 0.3) + 1 / (1 + i), sdp_large.hip: k_lg_lanczos1): top eigenvalue
+    2.05 along u orthogonal to v1, 2.0 next, the rest in [0.2, 1].  Mode 2 (cip_set_sdp_lanczos(2)) must return LAPACK's answer,
+    through the certificate's fallback when plain Lanczos is fooled; mode 1's answer is recorded, not asserted (rounding may or may
+    not rescue it -- that is the point of the certificate)."""
+    import ctypes as C
+    import cipkkt
+    from cipkkt import _lib
+    lib = _lib.load()
+    k = r * (r + 1) // 2
+    ks = cipkkt.KKTSystem(np.eye(2), np.zeros((k, 2)), None, [("S", k)])
+    rng = np.random.default_rng(7 * r)
+    i = np.arange(r)
+    v1 = np.cos(0.7 * i + 0.3) + 1.0 / (1.0 + i)
+    v1 /= np.linalg.norm(v1)
+    u = rng.standard_normal(r); u -= (u @ v1) * v1; u /= np.linalg.norm(u)
+    # an orthonormal basis whose first vector is u: the other eigenvectors span u's complement (v1 lies in it)
+    Qm, _ = np.linalg.qr(np.column_stack([u, rng.standard_normal((r, r - 1))]))
+    Qm[:, 0] = u
+    lam = np.concatenate([[2.05, 2.0], np.linspace(0.2, 1.0, r - 2)])
+    D = (Qm * lam) @ Qm.T
+    D = 0.5 * (D + D.T)
+    x, d = dev(oc.vecm(np.eye(r))), dev(oc.vecm(D))
+    ref = oc.maxstep_sdc(oc.vecm(np.eye(r)), oc.vecm(D))
+    assert ref == pytest.approx(1.0 / np.linalg.eigvalsh(D)[-1], rel=1e-12)
+    prev = lib.cip_set_sdp_lanczos(1)
+    plain = ks.maxstep(x, d)
+    lib.cip_set_sdp_lanczos(2)
+    certified = ks.maxstep(x, d)
+    lib.cip_set_sdp_lanczos(prev)
+    nfb = C.c_int(-1)
+    _lib.check(lib.cip_sdp_lanczos_fallbacks(ks.h, C.byref(nfb)))
+    print("r = %d: LAPACK %.12f, plain Lanczos %.12f, certified %.12f, fallbacks %d" % (r, ref, plain, certified, nfb.value))
+    assert certified == pytest.approx(ref, rel=1e-10)
+    if abs(plain - ref) > 1e-8 * ref:                                # plain Lanczos was fooled: then the certificate must have fired
+        assert nfb.value >= 1
+    # (measured: rounding brings u into the recurrence and plain Lanczos finds 2.05 as well -- the fallback is not reached that way.)
+    # Self-test mode 3 puts the certificate's bound on the wrong side of theta: every certificate fails, the verdict must come from
+    # the gated tridiagonalisation + Sturm kernels and agree with LAPACK, for both variants and for the two sides of a pair
+    before = nfb.value
+    lib.cip_set_sdp_lanczos(3)
+    X = (Qm * (0.5 + rng.random(r))) @ Qm.T; X = 0.5 * (X + X.T)
+    xs = dev(oc.vecm(X))
+    forced = ks.maxstep(xs, d)
+    forced_n = ks.maxstep(dev(oc.vecm(D - 2.02 * np.eye(r))), None)
+    pair = ks.maxstep_pair(xs, d, x, d) if r <= 256 else None
+    lib.cip_set_sdp_lanczos(prev)
+    _lib.check(lib.cip_sdp_lanczos_fallbacks(ks.h, C.byref(nfb)))
+    assert nfb.value - before == (4 if pair else 2), (nfb.value, before)
+    assert forced == pytest.approx(oc.maxstep_sdc(oc.vecm(X), oc.vecm(D)), rel=1e-10)
+    assert forced_n == pytest.approx(oc.maxstep_sdc(oc.vecm(D - 2.02 * np.eye(r)), None), rel=1e-10)
+    if pair:
+        assert pair[0] == pytest.approx(forced, rel=1e-12) and pair[1] == pytest.approx(ref, rel=1e-10)
     ks.close()
 
 
