@@ -637,18 +637,38 @@ static dim3 lg_grid(long n) { return dim3((unsigned)((n + 255) / 256)); }
 // matrix) straight into the MFMA lanes -- lane l supplies row l % 16, k = l / 16 of its operand tile -- no LDS staging; the three
 // partial accumulators of waves 1..3 are added to wave 0's in a fixed order.  Register q of lane l holds C[i0 + l % 16, j0 + l / 16 + 4 q]
 // (the operand order of gemm_tile_64: B's rows first).
-__global__ __launch_bounds__(256) void k_gemm_nt_small(const double *A, long lda, const double *B, long ldb, double *C, long ldc, int K) {
+// BVEC: B is mat(xv) of a vecm vector (symmetric; zero outside the leading r x r block), read straight from the vector -- no k_lg_mat
+// pass; CVEC: the result goes out as vecm (entries i <= j < r, off-diagonal ones times sqrt 2; tiles below the diagonal are not
+// computed) -- no k_lg_vecm pass.  Same MFMAs on the same operands in the same order as the plain form: same bits.
+template <bool BVEC, bool CVEC>
+__global__ __launch_bounds__(256) void k_gemm_nt_small(const double *A, long lda, const double *B, long ldb, double *C, long ldc, int K, int r) {
     __shared__ double red[3][4][64];
+    if (CVEC && blockIdx.x > blockIdx.y) return;               // (16 i0 > 16 j0 + 15 for every entry of the tile)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int kq = K >> 2;
     const double *a = A + (long)blockIdx.x * 16 + l15 + (long)(wave * kq + l4) * lda;
     const double *b = B + (long)blockIdx.y * 16 + l15 + (long)(wave * kq + l4) * ldb;
+    const int jb = blockIdx.y * 16 + l15, kb0 = wave * kq + l4;      // BVEC: this lane's row of mat(xv) and its first k
     v4d acc0 = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
     for (int k = 0; k < kq; k += 32) {
         double av[8], bv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { av[u] = a[(long)(k + 4 * u) * lda]; bv[u] = b[(long)(k + 4 * u) * ldb]; }
+        for (int u = 0; u < 8; ++u) {
+            av[u] = a[(long)(k + 4 * u) * lda];
+            if (BVEC) {
+                const int kk = kb0 + k + 4 * u;
+                double v = 0.0;
+                if (jb < r && kk < r) {
+                    const int lo = jb < kk ? jb : kk, hi = jb < kk ? kk : jb;
+                    v = B[lg_vidx(lo, hi, r)];
+                    if (lo != hi) v *= LG_SQRT1_2;
+                }
+                bv[u] = v;
+            } else {
+                bv[u] = b[(long)(k + 4 * u) * ldb];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 8; u += 2) {
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[u], av[u], acc0, 0, 0, 0);
@@ -663,15 +683,22 @@ __global__ __launch_bounds__(256) void k_gemm_nt_small(const double *A, long lda
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            C[(long)blockIdx.x * 16 + l15 + ((long)blockIdx.y * 16 + l4 + 4 * q) * ldc] = ((acc0[q] + red[0][q][lane]) + red[1][q][lane]) + red[2][q][lane];
+        for (int q = 0; q < 4; ++q) {
+            const double c = ((acc0[q] + red[0][q][lane]) + red[1][q][lane]) + red[2][q][lane];
+            const int i = blockIdx.x * 16 + l15, j = blockIdx.y * 16 + l4 + 4 * q;
+            if (CVEC) { if (i <= j && j < r) C[lg_vidx(i, j, r)] = (i == j) ? c : c * LG_SQRT2; }
+            else C[i + (long)j * ldc] = c;
+        }
     }
 }
 // part 2: only the 64-tiles that touch i <= j are computed (the others keep what C held); 3: only those that touch i >= j
-static int lg_gemm(hipStream_t s, double *C, long sC, const double *A, long sA, const double *B, long sB, int rp, int batch, int part = 0) {
+static int lg_small_gemm(void) {
     static const int small = [] { const char *e = getenv("CIP_LG_SMALLGEMM"); return e ? atoi(e) : 1; }();
-    if (batch == 1 && part == 0 && rp <= 256 && small) {
-        hipLaunchKernelGGL(k_gemm_nt_small, dim3(rp / 16, rp / 16), dim3(256), 0, s, A, (long)rp, B, (long)rp, C, (long)rp, rp);
+    return small;
+}
+static int lg_gemm(hipStream_t s, double *C, long sC, const double *A, long sA, const double *B, long sB, int rp, int batch, int part = 0) {
+    if (batch == 1 && part == 0 && rp <= 256 && lg_small_gemm()) {
+        hipLaunchKernelGGL((k_gemm_nt_small<false, false>), dim3(rp / 16, rp / 16), dim3(256), 0, s, A, (long)rp, B, (long)rp, C, (long)rp, rp, rp);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -1449,6 +1476,13 @@ int cip_sdp_large_apply(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, i
     const int which = (mode == CIP_OP_F) ? 3 : (mode == CIP_OP_FT) ? 2 : (mode == CIP_OP_FINV) ? 1 : 0;
     const double *Q = w->Rip + (LG_NPAD * (size_t)li + which) * n2;
     int rc;
+    if (rp <= 256 && lg_small_gemm()) {
+        // two launches: mat(x) is read from the vector by the first product, the second writes vecm (k_gemm_nt_small<BVEC / CVEC>)
+        hipLaunchKernelGGL((k_gemm_nt_small<true, false>), dim3(rp / 16, rp / 16), dim3(256), 0, s, Q, (long)rp, x + cd.off, 0L, w->M2, (long)rp, rp, r);
+        hipLaunchKernelGGL((k_gemm_nt_small<false, true>), dim3(rp / 16, rp / 16), dim3(256), 0, s, (const double *)w->M2, (long)rp, Q, (long)rp, out + cd.off, 0L, rp, r);
+        CIP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, x + cd.off, 1L, 0L, w->M1, r, rp, 0.0);
     if ((rc = lg_gemm(s, w->M2, 0, Q, 0, w->M1, 0, rp, 1))) return rc;              // Q X      (X symmetric)
     if ((rc = lg_gemm(s, w->M3, 0, w->M2, 0, Q, 0, rp, 1))) return rc;              // (Q X) Q'
