@@ -59,6 +59,7 @@ struct LargeWs {
     unsigned *ctr;                 // barrier counters / sweep flags (256 words)
     void *ldl_z = nullptr, *ldl_s = nullptr;
     LdltWorkspace wz, ws;
+    int xz_z = 0, xz_s = 0;        // the upper triangles of their block inverses have been zeroed (they stay zero)
     hipStream_t s2 = nullptr;      // the s-side max-step of a pair runs here, beside the v-side one on the handle's stream
     hipEvent_t efork = nullptr, ejoin = nullptr;
 };
@@ -602,6 +603,7 @@ int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out) {
     cip_ldlt_ws_carve(w->ldl_z, rp, &w->wz);
     cip_ldlt_ws_carve(w->ldl_s, rp, &w->ws);
     w->wz.signs = w->ws.signs = PivotSigns{0, rp, rp};       // a Cholesky in disguise: every pivot must be positive
+    w->wz.x_zeroed = &w->xz_z; w->ws.x_zeroed = &w->xz_s;
     *out = w;
     return 0;
 }
@@ -1413,9 +1415,13 @@ int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const d
     }
     hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, x + cd.off, 1L, 0L, Kx, r, rp, 1.0);
     if ((rc = cip_ldlt_factor(s, Kx, rp, rp, wx))) return rc;                 // X = L D L'
-    hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, d + cd.off, 1L, 0L, M1, r, rp, 0.0);
     const double *Xi = (wx.Bs == CIP_NB) ? wx.Linv : wx.X;                // inv(L_unit)
-    if ((rc = lg_gemm(s, M2, 0, Xi, 0, M1, 0, rp, 1))) return rc;             // inv(L) D        (D symmetric)
+    if (rp <= 256 && lg_small_gemm()) {                                             // inv(L) D, D = mat(d) read from the vector
+        hipLaunchKernelGGL((k_gemm_nt_small<true, false>), dim3(rp / 16, rp / 16), dim3(256), 0, s, Xi, (long)rp, d + cd.off, 0L, M2, (long)rp, rp, r);
+    } else {
+        hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, d + cd.off, 1L, 0L, M1, r, rp, 0.0);
+        if ((rc = lg_gemm(s, M2, 0, Xi, 0, M1, 0, rp, 1))) return rc;             // inv(L) D        (D symmetric)
+    }
     if ((rc = lg_gemm(s, M3, 0, M2, 0, Xi, 0, rp, 1))) return rc;             // inv(L) D inv(L)'
     if (lz) {                                                                       // ... scaled by d^-1/2 on both sides
         hipLaunchKernelGGL(k_lg_lanczos1, dim3(1), dim3(512), LZ_LDS_DOUBLES * sizeof(double), s, M3, rp, (const double *)wx.dvec, r, 1,
