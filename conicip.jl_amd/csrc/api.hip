@@ -978,7 +978,7 @@ extern "C" int cip_ldlt_workspace_bytes(int N, size_t *bytes) {
 }
 extern "C" int cip_ldlt_factor_dev(void *stream, double *K, int N, int ld, void *workspace, int *info_host) {
     if (!K || !workspace || N <= 0 || N % CIP_NB || ld < N || ld % 2) { cip_set_error("bad argument"); return CIP_E_INVALID; }
-    LdltWorkspace ws;
+    LdltWorkspace ws{};
     cip_ldlt_ws_carve(workspace, N, &ws);
     int rc = cip_ldlt_factor((hipStream_t)stream, K, N, ld, ws);
     if (rc) return rc;
@@ -990,7 +990,7 @@ extern "C" int cip_ldlt_factor_dev(void *stream, double *K, int N, int ld, void 
 }
 extern "C" int cip_ldlt_solve_dev(void *stream, const double *K, int N, int ld, const void *workspace, double *rhs) {
     if (!K || !workspace || !rhs || N <= 0 || N % CIP_NB) { cip_set_error("bad argument"); return CIP_E_INVALID; }
-    LdltWorkspace ws;
+    LdltWorkspace ws{};
     cip_ldlt_ws_carve((void *)workspace, N, &ws);
     return cip_ldlt_solve((hipStream_t)stream, K, N, ld, ws, rhs);
 }

@@ -191,6 +191,7 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     ws->signs = PivotSigns{-1, 0, 0};
     ws->x_zeroed = nullptr;
     ws->side = nullptr;
+    ws->no_prep = 0;
 }
 
 // diag.hip
