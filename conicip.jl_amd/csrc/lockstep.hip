@@ -401,6 +401,7 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
         CK(cip_solve4x4_dev(h, lam, r.base, dz.base));
         for (int z = 0; z < B; ++z) if ((active >> z) & 1ull) ++n_solve[z];
         unsigned long long refine = active;
+        bool step_known = false;
         for (int it = 0; it < o.maxRefinementSteps && refine; ++it) {
             set_mask(refine);
             CK(kkt_apply(dz, rkkt, nullptr));
@@ -416,12 +417,27 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
             CK(axpby(NT, -1.0, rkkt.base, 1.0, rIr.base));
             const double *nx[4] = {rIr.y, rIr.w, rIr.v, rIr.s};
             const int nl[4] = {n, p, m, m};
+            // the step's two max-steps ride on this read-back (first pass only): when no problem asks for refinement -- the usual
+            // case -- dz is final and the iteration has saved a host round trip; otherwise they are taken again behind the loop
+            static const int spec_on = [] { const char *e = getenv("CIP_LOCKSTEP_SPEC_STEP"); return e ? atoi(e) : 1; }();
+            const bool spec = spec_on && it == 0 && m > 0 && B > 1;
+            if (spec) {
+                CK(cip_cones_maxstep(s, h->cs, zv.v, dz.v, 1.0 / (1.0 - o.DTB), nullptr, STEP_SLOT));
+                CK(cip_cones_maxstep(s, h->cs, zv.s, dz.s, 1.0 / (1.0 - o.DTB), nullptr, STEP_SLOT + 1));
+            }
             CK(cip_dots(s, 4, nx, nx, nl, h->dot_scratch, h->dot_ptrs, n2.data()));
             for (int z = 0; z < B; ++z) {
                 if (!((refine >> z) & 1ull)) continue;
                 const double *q = &n2[(size_t)z * 4];
                 const double rnorm = (nrm(q[0]) + (p > 0 ? nrm(q[1]) : 0.0) + (m > 0 ? nrm(q[2]) + nrm(q[3]) : 0.0)) / (n + 2 * m);   // :917
                 if (rnorm < o.refinementThreshold) refine &= ~(1ull << z);
+            }
+            if (spec && !refine) {
+                for (int z = 0; z < B; ++z) {
+                    av[z] = G.gather_host[(size_t)z * CIP_GATHER + STEP_SLOT];
+                    as[z] = G.gather_host[(size_t)z * CIP_GATHER + STEP_SLOT + 1];
+                }
+                step_known = true;
             }
             if (!refine) break;
             set_mask(refine);
@@ -434,10 +450,12 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
         // ------------------------------------------------------------ step (:927-932)
         for (int z = 0; z < B; ++z) alpha[z] = 1.0;
         if (m > 0) {
-            // (one round trip for the pair: the v side rides on the s side's read-back)
-            CK(cip_cones_maxstep(s, h->cs, zv.v, dz.v, 1.0 / (1.0 - o.DTB), nullptr, STEP_SLOT));
-            CK(cip_cones_maxstep(s, h->cs, zv.s, dz.s, 1.0 / (1.0 - o.DTB), as.data()));
-            for (int z = 0; z < B; ++z) av[z] = G.gather_host[(size_t)z * CIP_GATHER + STEP_SLOT];
+            if (!step_known) {
+                // (one round trip for the pair: the v side rides on the s side's read-back)
+                CK(cip_cones_maxstep(s, h->cs, zv.v, dz.v, 1.0 / (1.0 - o.DTB), nullptr, STEP_SLOT));
+                CK(cip_cones_maxstep(s, h->cs, zv.s, dz.s, 1.0 / (1.0 - o.DTB), as.data()));
+                for (int z = 0; z < B; ++z) av[z] = G.gather_host[(size_t)z * CIP_GATHER + STEP_SLOT];
+            }
             for (int z = 0; z < B; ++z) alpha[z] = std::fmin(std::fmin(av[z], 1.0), std::fmin(as[z], 1.0));
         }
         for (int z = 0; z < B; ++z) tmpB[z] = -alpha[z];
