@@ -373,6 +373,33 @@ def test_update_problem_drops_the_cached_column_images_of_a_large_cone(csr):
     ks.close(); fresh.close()
 
 
+def test_large_cone_schur_scaling_in_chunks_equals_the_one_batch_path(monkeypatch):
+    """A'F^-1 of a large S cone: by default all n columns go through ONE pair of batched GEMM launches from the cached mat(a_i)
+    images; when they do not fit the workspace (CIP_LG_CHUNK forces it here: 16 columns per batch, n = 40 -> three batches, no
+    image cache) the same kernels run batch by batch.  Same Schur matrix bit for bit, same solve."""
+    import cipkkt
+    r, n = 150, 40
+    k = r * (r + 1) // 2
+    K = [("R", 3), ("S", k)]
+    m = 3 + k
+    rng = np.random.default_rng(123)
+    M = rng.standard_normal((n, n))
+    Q, A = M @ M.T / n + np.eye(n), rng.standard_normal((m, n)) / np.sqrt(n)
+    v, s = dev(interior(K, rng)), dev(interior(K, rng))
+    x, z = rng.standard_normal(n), rng.standard_normal(m)
+    outs = []
+    for chunk in (None, "16"):
+        if chunk:
+            monkeypatch.setenv("CIP_LG_CHUNK", chunk)
+        ks = cipkkt.KKTSystem(Q, A, None, K)
+        ks.set_scaling_from_iterate(v, s)
+        ks.factor()
+        outs.append((ks.kkt_matrix(), np.concatenate(ks.solve3x3(x, np.zeros(0), z))))
+        ks.close()
+    np.testing.assert_array_equal(np.tril(outs[0][0]), np.tril(outs[1][0]))
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
 # ---- CSR A together with S cones on the device (round 4: no host-side densification)
 def test_reference_sparse_psd_projection_without_densification():
     """test/runtests.jl:527-552: project onto the PSD cone with A = sparse identity (6 x 6), one ("S", 6) cone -- through
