@@ -210,6 +210,36 @@ def test_s_cones_in_lockstep():
     _assert_identical(lock, one)
 
 
+def test_mixed_batch_with_small_and_large_s_cones():
+    """`cip_conicip_mixed` with S cones: three SDPs of one shape with small S cones (lock-step, one group), two with an S cone of
+    matrix order 133 (same shape as each other, but the chip-wide kernels of sdp_large.hip have one workspace: thread pool) and a
+    lone QP -- every result bit-identical to the one-problem loop, one lock-step group of three."""
+    import ctypes as C
+    from cipkkt import _lib as L
+    from cipkkt.workloads import c4_sdp
+    from oracle.cones import vecm
+    prs = []
+    for seed in range(3):
+        rng = np.random.default_rng(950 + seed)
+        n, r1 = 10, 7
+        k1 = r1 * (r1 + 1) // 2
+        M = rng.standard_normal((n, n))
+        prs.append(dict(Q=M @ M.T / n + 0.1 * np.eye(n), c=rng.standard_normal(n), A=rng.standard_normal((k1 + 4, n)) * 0.3,
+                        b=-np.concatenate([vecm(np.eye(r1)), np.ones(4)]), cone_dims=[("S", k1), ("R", 4)], G=None, d=None, kwargs={}))
+    for seed in (31, 32):
+        Q, c, A, b, K, G, d = c4_sdp(r=133, n=16, p=2, seed=seed)
+        prs.append(dict(Q=Q, c=c, A=A, b=b, cone_dims=K, G=G, d=d, kwargs={}))
+    prs.append(_as_problem(P.random_mixed(n=18, nq=1, kq=4, p=2, seed=701)))
+    prs = [prs[i] for i in (3, 0, 5, 1, 4, 2)]
+    one = _solve(prs, "threads", in_flight=1)
+    mixed = _solve(prs, "auto", in_flight=2)
+    st = (C.c_int * 3)()
+    L.load().cip_lockstep_stats(st)
+    assert list(st) == [1, 3, 0]
+    assert all(s.status == "Optimal" for s in one), [s.status for s in one]
+    _assert_identical(mixed, one)
+
+
 @pytest.mark.parametrize("count", [8, 24])
 def test_config5_reduced_lockstep_matches_threads(count):
     """BASELINE config 5 at reduced count: 8 / 24 x n = 2048 dense QPs generated in HBM (the per-rank shards at 8 GPUs, and a
