@@ -57,7 +57,8 @@ def main(d):
     st = stats(os.path.join(d, "c3_kernel_stats.csv"))
     if st:
         n, m = 4096, 4096
-        recs = [mfma("k_syrkq_64", st, float(m) * n * n, "Schur formation S = Q + (A'F^-1)(A'F^-1)' (src/kktsolvers.jl:33-34, :290)"),
+        syrk3 = next((k for k in st if k.startswith("k_syrkq_64")), "k_syrkq_64")          # (templated on the operand path since round 4)
+        recs = [mfma(syrk3, st, float(m) * n * n, "Schur formation S = Q + (A'F^-1)(A'F^-1)' (src/kktsolvers.jl:33-34, :290)"),
                 latency("k_ldlt_panel<true>", st, "LDL' panel launch (diag + TRSM + in-block update)"),
                 latency("k_scale_At", st, "A'F^-1 for 512 Q(8) cones: O(mn) beside the SYRK", hbm_bytes_per_launch=3.0 * 8 * m * n)]
         out["c3_socp_n4096"] = dict(workload="SOCP n=4096, 512 x Q(8), p=512, dense A; Schur order 4608", dominant=[r for r in recs if r], time_share=share(st))
