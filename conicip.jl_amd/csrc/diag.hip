@@ -958,21 +958,27 @@ __device__ __forceinline__ void panel_tile_jobs(const GemmArgs &g, double *lds, 
 template <bool UPD>
 __global__ __launch_bounds__(64 * PANEL_WAVES) void k_ldlt_panel(double *Kb, long ld, double *xm_out, double *dvec, double *dinv,
                                                                   int *info, int col0, PivotSigns sg, unsigned *ready, unsigned *stage,
-                                                                  unsigned *tileq, GemmArgs g, TrsmStrips tr, CipBatch cb) {
+                                                                  unsigned *tileq, GemmArgs g, TrsmStrips tr, int bt, CipBatch cb) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    // small lock-step groups (ldlt.hip: factor_outer_panels, up to 12 problems): problem z's workgroups follow those of the
-    // problems before it in dispatch order, so every wait is still for a workgroup dispatched earlier
-    CIP_BATCH_GUARD(cb);
-    CIP_BO7(cb, Kb, xm_out, dvec, dinv, info, ready, stage);
-    CIP_BO1(cb, tileq);
+    // small lock-step groups (ldlt.hip: factor_outer_panels, up to 12 problems).  bt == 0: the problem is blockIdx.z -- problem z's
+    // workgroups follow those of the problems before it in dispatch order.  bt = B > 0 (round 4): the problem index runs FASTEST,
+    // workgroup (role b, problem z) = blockIdx.x = b B + z: the diagonal kernels of all problems are dispatched first, then the
+    // producers of all problems, ...; in z-major order problem 7's diagonal kernel sat behind the ~280 workgroups of problems 0..6.
+    // Either way every wait is for a workgroup dispatched earlier (role b' < b of the same problem).
+    const unsigned bz = bt > 0 ? blockIdx.x % (unsigned)bt : blockIdx.z;
+    if (!((cb.mask >> bz) & 1ull)) return;
     {
-        const long off = (long)blockIdx.z * cb.stride;
+        const long off = (long)bz * cb.stride;
+        Kb = (double *)((char *)Kb + off); xm_out = (double *)((char *)xm_out + off); dvec = (double *)((char *)dvec + off);
+        dinv = (double *)((char *)dinv + off); info = (int *)((char *)info + off); ready = (unsigned *)((char *)ready + off);
+        stage = (unsigned *)((char *)stage + off); if (tileq) tileq = (unsigned *)((char *)tileq + off);
         g.A = (const double *)((const char *)g.A + off); g.B = (const double *)((const char *)g.B + off); g.C = (double *)((char *)g.C + off);
         tr.Ap = (double *)((char *)tr.Ap + off); tr.L11 = (const double *)((const char *)tr.L11 + off);
         tr.xm = (const double *)((const char *)tr.xm + off); tr.dinv = (const double *)((const char *)tr.dinv + off);
         tr.W = (double *)((char *)tr.W + off);
     }
-    const int b = (int)blockIdx.x;
+    const int b = bt > 0 ? (int)(blockIdx.x / (unsigned)bt) : (int)blockIdx.x;
+    const int nblocks = bt > 0 ? (int)(gridDim.x / (unsigned)bt) : (int)gridDim.x;
     if (b == 0) {
         diag_body<UPD, true, PANEL_WAVES>(sm, Kb, ld, xm_out, dvec, dinv, info, col0, sg, ready, stage, 36u);
         return;
@@ -997,7 +1003,7 @@ __global__ __launch_bounds__(64 * PANEL_WAVES) void k_ldlt_panel(double *Kb, lon
     GrpBar bar = {ctl + grp, 0u};
     double *lds = sm + grp * PANEL_GRP_DOUBLES;
     // the two halves of worker workgroup w start at once on tiles 2 w and 2 w + 1; everything else is drawn from the queue
-    const int w = b - first - tr.strips, nworkers = (int)gridDim.x - first - tr.strips;
+    const int w = b - first - tr.strips, nworkers = nblocks - first - tr.strips;
     const unsigned first_tile = w >= 0 ? (unsigned)(2 * w + grp) : PANEL_NONE;
     if (w < 0) {
         // a strip workgroup: the strip's rows of this panel's columns first receive the previous panel's update -- tiles
@@ -1212,6 +1218,10 @@ int cip_launch_panel(hipStream_t s, double *Kb, long ld, double *xm_out, double 
                      PivotSigns sg, unsigned *ready, unsigned *stage, unsigned *tileq, const GemmArgs *g, int rows, double *W, long ldw) {
     if (cip_kernels_init()) return -3;
     TrsmStrips tr = {Kb + CIP_NB, ld, Kb, xm_out, dinv, W, ldw, rows / 64};
+    // lock-step groups: problem index fastest in the dispatch order (CIP_PANEL_ZFAST=0: blockIdx.z, the order up to round 4's first half)
+    static const int zfast = [] { const char *e = getenv("CIP_PANEL_ZFAST"); return e ? atoi(e) : 1; }();
+    const int Bn = cip_in_batch() ? cip_tl_bz.B : 1;
+    const bool transposed = zfast && Bn > 1;
     if (g) {
         const int tm = g->M / SB, tn = g->N / SB;
         if (tm != tr.strips + 2 || tn < 2) { cip_set_error("panel launch: update / TRSM shapes disagree"); return -1; }
@@ -1228,11 +1238,15 @@ int cip_launch_panel(hipStream_t s, double *Kb, long ld, double *xm_out, double 
         if (workers < 1 && ntiles > 0 && tr.strips == 0) workers = 1;
         if (workers < 0) workers = 0;
         const long grid = 1 + PANEL_PRODUCERS + tr.strips + workers;
-        cip_launch_b(k_ldlt_panel<true>, dim3((unsigned)grid), dim3(64 * PANEL_WAVES), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg,
-                     ready, stage, tileq, *g, tr);
+        if (transposed) cip_launch(k_ldlt_panel<true>, dim3((unsigned)(grid * Bn)), dim3(64 * PANEL_WAVES), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info,
+                                   col0, sg, ready, stage, tileq, *g, tr, Bn, CipBatch{cip_tl_bz.stride, cip_tl_bz.mask});
+        else cip_launch_b(k_ldlt_panel<true>, dim3((unsigned)grid), dim3(64 * PANEL_WAVES), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg,
+                          ready, stage, tileq, *g, tr, 0);
     } else {
-        cip_launch_b(k_ldlt_panel<false>, dim3((unsigned)(1 + tr.strips)), dim3(64 * PANEL_WAVES), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv,
-                     info, col0, sg, ready, stage, tileq, GemmArgs{}, tr);
+        if (transposed) cip_launch(k_ldlt_panel<false>, dim3((unsigned)((1 + tr.strips) * Bn)), dim3(64 * PANEL_WAVES), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec,
+                                   dinv, info, col0, sg, ready, stage, tileq, GemmArgs{}, tr, Bn, CipBatch{cip_tl_bz.stride, cip_tl_bz.mask});
+        else cip_launch_b(k_ldlt_panel<false>, dim3((unsigned)(1 + tr.strips)), dim3(64 * PANEL_WAVES), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv,
+                          info, col0, sg, ready, stage, tileq, GemmArgs{}, tr, 0);
     }
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
