@@ -400,6 +400,11 @@ __device__ __forceinline__ void diag_tile_left(double *a, int it, int jt, int ns
 }
 
 // X block row `it` (runtime, wave-uniform): tiles kept in registers, statically indexed
+// P: pitch of the block image; XR: pitch of a row of a micro inverse in `xm` (tile = 16 XR doubles).  The accesses here run along
+// COLUMNS of the image (lane index l15 -> column): with the diagonal kernel's pitch 144 (288 dwords = 32 mod 64) sixteen lanes of a
+// half-wave shared four banks -- PMC: 0.88 LDS bank-conflict cycles per LDS-active cycle in k_diag_inverse_batched; with P = 130
+// (260 dwords = 4 mod 64) and XR = 17 the same reads are conflict-free (tools/pmc_sq.sh).
+template <int P, int XR>
 __device__ __forceinline__ void diag_inverse_row(double *a, const double *xm, int it, int l15, int g) {
     double XT[8][4];
 #pragma unroll
@@ -411,7 +416,7 @@ __device__ __forceinline__ void diag_inverse_row(double *a, const double *xm, in
     for (int t = 0; t < 8; ++t)
         if (t == it) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) XT[t][s] = xm[t * 256 + (g + 4 * s) * 16 + l15];
+            for (int s = 0; s < 4; ++s) XT[t][s] = xm[t * (16 * XR) + (g + 4 * s) * XR + l15];
         }
 #pragma unroll
     for (int jt = 6; jt >= 0; --jt) {
@@ -421,13 +426,13 @@ __device__ __forceinline__ void diag_inverse_row(double *a, const double *xm, in
             for (int kt = 7; kt >= 1; --kt) {
                 if (kt > jt && kt <= it) {
                     // Aop[cjt][k] = L[kt*16 + k][jt*16 + cjt]
-                    const double *lp = a + (kt * 16 + g) + (jt * 16 + l15) * DP;
+                    const double *lp = a + (kt * 16 + g) + (jt * 16 + l15) * P;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) acc = MFMA(lp[4 * s], XT[kt][s], acc);
                 }
             }
             // X[it][jt] = -S * Xm[jt]:  Aop[c'][k] = Xm[jt][k][c'] = xm[jt][c'*16 + k]
-            const double *xp = xm + jt * 256 + l15 * 16 + g;
+            const double *xp = xm + jt * (16 * XR) + l15 * XR + g;
             v4d r = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s = 0; s < 4; ++s) r = MFMA(xp[4 * s], acc[s], r);
@@ -440,11 +445,12 @@ __device__ __forceinline__ void diag_inverse_row(double *a, const double *xm, in
     for (int t = 0; t < 8; ++t)
         if (t < it) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) a[(t * 16 + g + 4 * s) + (it * 16 + l15) * DP] = XT[t][s];
+            for (int s = 0; s < 4; ++s) a[(t * 16 + g + 4 * s) + (it * 16 + l15) * P] = XT[t][s];
         }
 }
 
 // 128x128 block <-> LDS image, 16-byte accesses, all loads of a thread in flight before the first store
+template <int P = DP>
 __device__ __forceinline__ void diag_load_block(double *a, const double *Kb, long ld, int tid) {
     v2d tmp[32];
 #pragma unroll
@@ -459,7 +465,7 @@ __device__ __forceinline__ void diag_load_block(double *a, const double *Kb, lon
         v2d v = tmp[q];
         if (i < j) v.x = 0.0;                    // strictly upper part -> 0
         if (i + 1 < j) v.y = 0.0;
-        *(v2d *)(a + i + j * DP) = v;
+        *(v2d *)(a + i + j * P) = v;
     }
 }
 
@@ -1043,17 +1049,19 @@ __global__ __launch_bounds__(256) void k_diag_inverse_batched(const double *K, l
     CIP_BATCH_GUARD(cb);
     CIP_BO4(cb, K, xm_all, Linv, LinvT);
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int P = 130, XR = 17;                      // pitches of this kernel's own LDS images (see diag_inverse_row)
+    static_assert((CIP_NB * P + 8 * 16 * XR) * 8 <= DIAG2_LDS_BYTES, "the re-pitched images must fit the launch's LDS");
     double *a = sm;
-    double *xm = sm + XM_OFF;
+    double *xm = sm + CIP_NB * P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int jb = blockIdx.x;
-    diag_load_block(a, K + (long)jb * CIP_NB * (ld + 1), ld, tid);
+    diag_load_block<P>(a, K + (long)jb * CIP_NB * (ld + 1), ld, tid);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) xm[q * 256 + tid] = xm_all[(size_t)jb * 2048 + q * 256 + tid];
+    for (int q = 0; q < 8; ++q) xm[q * (16 * XR) + (tid >> 4) * XR + (tid & 15)] = xm_all[(size_t)jb * 2048 + q * 256 + tid];
     __syncthreads();
-    diag_inverse_row(a, xm, wave, l15, g);
-    diag_inverse_row(a, xm, 7 - wave, l15, g);
+    diag_inverse_row<P, XR>(a, xm, wave, l15, g);
+    diag_inverse_row<P, XR>(a, xm, 7 - wave, l15, g);
     __syncthreads();
     const int per = Bs / CIP_NB;
     const size_t ob = (size_t)(jb / per) * Bs * Bs + (size_t)(jb % per) * CIP_NB * (Bs + 1);
@@ -1063,11 +1071,11 @@ __global__ __launch_bounds__(256) void k_diag_inverse_batched(const double *K, l
         const int tr = r >> 4, tc = cc >> 4;
         double x, xt;
         if (tr == tc) {
-            x = xm[tr * 256 + (cc & 15) * 16 + (r & 15)];            // Xm[r][cc] (zero above the diagonal)
-            xt = xm[tr * 256 + (r & 15) * 16 + (cc & 15)];           // Xm[cc][r]
+            x = xm[tr * (16 * XR) + (cc & 15) * XR + (r & 15)];      // Xm[r][cc] (zero above the diagonal)
+            xt = xm[tr * (16 * XR) + (r & 15) * XR + (cc & 15)];     // Xm[cc][r]
         } else {
-            x = (tr > tc) ? a[cc + r * DP] : 0.0;                    // X[r][cc]
-            xt = (tc > tr) ? a[r + cc * DP] : 0.0;                   // X[cc][r]
+            x = (tr > tc) ? a[cc + r * P] : 0.0;                     // X[r][cc]
+            xt = (tc > tr) ? a[r + cc * P] : 0.0;                    // X[cc][r]
         }
         Li[r + (size_t)cc * Bs] = x;
         Lt[r + (size_t)cc * Bs] = xt;
