@@ -80,7 +80,7 @@ static void free_all(cip_handle *h) {
     if (h->ldlt_side) { cip_ldlt_side_destroy(h->ldlt_side); h->ldlt_side = nullptr; }
     if (h->gx_solve) { (void)hipGraphExecDestroy(h->gx_solve); h->gx_solve = nullptr; }
     if (h->cs.lg) { cip_sdp_large_destroy(h->cs.lg); h->cs.lg = nullptr; }
-    void *ptrs[] = {h->cs.d_bigq, h->cs.d_ritems, h->cs.d_sidx_small, h->cs.d_sidx, h->cs.d_sdpws, h->cs.d_sdpvec, h->cs.d_sdpflag, h->Q, h->symv_ws, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->kdiag, h->row_cone, h->G, h->Gt,
+    void *ptrs[] = {h->cs.d_bigq, h->cs.d_ritems, h->cs.d_packq, h->cs.d_sidx_small, h->cs.d_sidx, h->cs.d_sdpws, h->cs.d_sdpvec, h->cs.d_sdpflag, h->Q, h->symv_ws, h->A, h->At, h->A_rp, h->A_ci, h->A_v, h->T_rp, h->T_ci, h->T_v, h->kdiag, h->row_cone, h->G, h->Gt,
                     h->cs.d_cones, h->cs.d_items, h->cs.d_scal, h->cs.d_partial, h->cs.d_scalar, h->K, h->Wt, h->syrk_ws, h->Gm, h->AtS, h->WtS,
                     h->ws_base, h->rhs, h->mt1, h->mt2, h->mt3, h->nt1, h->pt1, h->dot_scratch, h->dot_ptrs, h->stage, h->drv, h->ref, h->c2x2};
     for (void *p : ptrs)
@@ -283,6 +283,14 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
     for (size_t it = 0; it < h->h_items.size(); ++it)
         if (h->h_cones[h->h_items[it].cone].type == CIP_CONE_R) h->st_ritems.push_back((int)it);
     h->cs.nritems = (int)h->st_ritems.size(); h->cs.d_ritems = nullptr;
+    h->st_packq.clear();
+    for (size_t it = 0; it < h->h_items.size(); ++it)
+        if (h->h_cones[h->h_items[it].cone].type == CIP_CONE_Q && h->h_items[it].width != 0) h->st_packq.push_back((int)it);
+    h->cs.npackq = (int)h->st_packq.size(); h->cs.d_packq = nullptr;
+    if (h->cs.npackq > 0) {
+        DMALLOC(h->cs.d_packq, sizeof(int) * h->st_packq.size());
+        CIP_HIP_CHECK(hipMemcpyAsync(h->cs.d_packq, h->st_packq.data(), sizeof(int) * h->st_packq.size(), hipMemcpyHostToDevice, s));
+    }
     if (h->cs.nritems > 0) {
         DMALLOC(h->cs.d_ritems, sizeof(int) * h->st_ritems.size());
         CIP_HIP_CHECK(hipMemcpyAsync(h->cs.d_ritems, h->st_ritems.data(), sizeof(int) * h->st_ritems.size(), hipMemcpyHostToDevice, s));

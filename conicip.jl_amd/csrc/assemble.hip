@@ -9,6 +9,7 @@
 // Only the lower triangle is written / referenced; K is padded to a multiple of 128 with an
 // identity block.
 #include "cip_handle.h"
+#include <atomic>
 #include "../../include/cipkkt.h"
 
 // rows >= n of the Schur-route matrix: G block, zero block, identity padding (lower part)
@@ -284,11 +285,17 @@ __global__ __launch_bounds__(256) void k_pad_identity(double *K, long ldk, int N
 // (EPI_LAZYC) and writes K.  Every entry of K goes through the same operations as with the full copy (bit-identical
 // factor): 115 -> 25 us per factorisation at n = 8192, 7 of the 86 ms of a config-5 pass.
 int cip_ldlt_outer_block_for(int Npad);
-static int g_lazy_copy = -1;              // CIP_LAZY_COPY / cip_set_lazy_copy: 1 (default) on, 0 off
+static std::atomic<int> g_lazy_copy{-1};  // CIP_LAZY_COPY / cip_set_lazy_copy: 1 (default) on, 0 off; read by worker threads
 int cip_lazy_copy_set(int on) {
-    if (g_lazy_copy < 0) { const char *e = getenv("CIP_LAZY_COPY"); g_lazy_copy = e ? (atoi(e) != 0) : 1; }
-    const int prev = g_lazy_copy;
-    if (on == 0 || on == 1) g_lazy_copy = on;
+    int prev = g_lazy_copy.load(std::memory_order_relaxed);
+    if (prev < 0) {                                                  // first use: the environment decides (racing threads agree)
+        const char *e = getenv("CIP_LAZY_COPY");
+        const int env = e ? (atoi(e) != 0) : 1;
+        int expect = -1;
+        g_lazy_copy.compare_exchange_strong(expect, env);
+        prev = g_lazy_copy.load(std::memory_order_relaxed);
+    }
+    if (on == 0 || on == 1) g_lazy_copy.store(on);
     return prev;
 }
 static int assemble_schur(cip_handle *h, bool lazy_ok) {
@@ -305,7 +312,8 @@ static int assemble_schur(cip_handle *h, bool lazy_ok) {
         g.ksplit_ws = h->syrk_ws; g.ksplit_n = h->syrk_n; g.ksplit_len = h->syrk_len;
         if ((rc = cip_launch_gemm(s, EPI_SYRKQ, g))) return rc;
     } else {
-        const int lazy_on = g_lazy_copy < 0 ? cip_lazy_copy_set(-1) : g_lazy_copy;
+        const int lazy_now = g_lazy_copy.load(std::memory_order_relaxed);
+        const int lazy_on = lazy_now < 0 ? cip_lazy_copy_set(-1) : lazy_now;
         bool all_r = h->m > 0 && h->nq == 0 && !h->cs.has_S;
         const int nb0 = cip_ldlt_outer_block_for(h->Npad);
         if (lazy_on && lazy_ok && all_r && h->A_one_per_row && p == 0 && h->Npad == n && n > nb0 && h->reg_rel <= 0.0 && h->kdiag &&

@@ -36,7 +36,7 @@ struct cip_handle {
     double *Gt = nullptr;           // n x p, ld n
 
     // host staging of the small tables and of the CSR arrays: asynchronous uploads read them after the call has returned
-    std::vector<int> st_rp, st_ci, st_trp, st_tci, st_rowcone, st_sidx, st_small, st_bigq, st_ritems;
+    std::vector<int> st_rp, st_ci, st_trp, st_tci, st_rowcone, st_sidx, st_small, st_bigq, st_ritems, st_packq;
     std::vector<double> st_av, st_tv;
     bool staging_live = false;
 

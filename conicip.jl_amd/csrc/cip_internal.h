@@ -206,6 +206,7 @@ struct ConeSet {
     int nbigq;                // Q cones of dimension > 64 (one work item each): the assembly gives them their own multi-workgroup kernels
     int nritems; int *d_ritems;   // the R cones' work items (chunks of <= 2048 rows): the Schur scaling splits each over 16 workgroups per row block
     int *d_bigq;              // device: their work-item indices (nbigq of them) -- those kernels' grids are per large cone, not per item
+    int npackq; int *d_packq; // the packs of small Q cones (lane-segment items): k_scale_At's grid covers exactly these
     // S cones (sdp.hip)
     int ns, rmax, kmax;       // number of S cones, largest matrix order / vectorised length
     int *d_sidx;              // device: cone index of every S cone

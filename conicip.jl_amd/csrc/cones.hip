@@ -195,14 +195,13 @@ __global__ __launch_bounds__(256) void k_apply(const ConeDesc *cones, const Work
 // an empty workgroup costs ~50 ns of dispatch, and config 3's 512 x Q(8) ran 130 -> 330 us when 15 of 16 workgroups of a
 // common grid exited at once)
 #define SCALE_AT_SPLIT 16
-__global__ __launch_bounds__(256) void k_scale_At(const ConeDesc *cones, const WorkItem *items, const double *scal,
+__global__ __launch_bounds__(256) void k_scale_At(const ConeDesc *cones, const WorkItem *items, const int *packq, const double *scal,
                                                    int n, const double *At, long ldat, double *Wt, long ldwt, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO3(cb, scal, At, Wt);
-    const WorkItem it = items[blockIdx.y];
-    const ConeDesc cd = cones[it.cone];
+    const WorkItem it = items[packq[blockIdx.y]];         // grid.y = the packs of small Q cones only
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || cd.type != CIP_CONE_Q || !it.width) return;
+    if (i >= n) return;
     const int ncone = it.len;                             // a pack of small cones: this thread's row through each of them
     for (int q = 0; q < ncone; ++q) {
         const ConeDesc qc = cones[it.cone + q];
@@ -486,7 +485,8 @@ int cip_cones_div(hipStream_t s, const ConeSet &cs, const double *x, const doubl
 // the call returns without a read-back -- they ride on the NEXT read-back of that buffer (lockstep.hip pairs the v- and
 // s-side max-steps and the dot products that follow them: one host round trip instead of three); alpha_host is not touched
 int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const double *d, double scale, double *alpha_host, int defer_slot) {
-    if (cs.nitems == 0) { for (int z = 0; z < (cip_tl_bz.B > 1 ? cip_tl_bz.B : 1); ++z) alpha_host[z] = __builtin_inf(); return 0; }
+    if (cs.nitems == 0) { if (alpha_host) for (int z = 0; z < (cip_tl_bz.B > 1 ? cip_tl_bz.B : 1); ++z) alpha_host[z] = __builtin_inf(); return 0; }
+    if (!alpha_host && !(cip_tl_bz.B > 1 && defer_slot >= 0)) { cip_set_error("cip_cones_maxstep: no destination for the minimum"); return CIP_E_INVALID; }
     cip_launch_b(k_maxstep, dim3(cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, x, d, scale, cs.d_partial);
     CIP_HIP_CHECK(hipGetLastError());
     if (cs.has_S) { int rc = cip_sdp_maxstep(s, cs, x, d, scale, cs.d_partial); if (rc) return rc; }
@@ -540,8 +540,8 @@ int cip_cones_identity(hipStream_t s, const ConeSet &cs, double *e) {
 }
 int cip_cones_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, long ldat, double *Wt, long ldwt) {
     if (cs.nitems == 0 || n == 0) return 0;
-    if (cs.nitems - cs.nritems - cs.nbigq - cs.ns > 0)              // (items that are packs of small Q cones)
-        cip_launch_b(k_scale_At, dim3((n + 255) / 256, cs.nitems), dim3(256), 0, s, cs.d_cones, cs.d_items, cs.d_scal, n, At, ldat, Wt, ldwt);
+    if (cs.npackq > 0)
+        cip_launch_b(k_scale_At, dim3((n + 255) / 256, cs.npackq), dim3(256), 0, s, cs.d_cones, cs.d_items, (const int *)cs.d_packq, cs.d_scal, n, At, ldat, Wt, ldwt);
     if (cs.nritems > 0)
         cip_launch_b(k_scale_At_r, dim3(((n + 255) / 256) * SCALE_AT_SPLIT, cs.nritems), dim3(256), 0, s, cs.d_cones, cs.d_items,
                            (const int *)cs.d_ritems, cs.d_scal, n, At, ldat, Wt, ldwt);

@@ -24,9 +24,9 @@
 // that a wider block has more of, then run beside the diagonal kernels and a trailing update with K = 768 passes over C
 // less often: same-session A/B at n = 8192, 512 / 768 / 1024 -> 130.6-132.0 / 134.5 / 133.9 KKT solves/s), else 512 (unfused
 // chain, round 1: 256 / 384 / 512 -> 107.7 / 107.0 / 109.1; 1024 -> 125 against 128).
-static int g_nbo = 0;
 #include <atomic>
 #include <mutex>
+static std::atomic<int> g_nbo{0};         // read by the library's worker threads (batch.hip) while a caller may set it
 static std::atomic<int> g_fuse_diag{-1};
 static std::once_flag g_fuse_once;
 // 0: diag -> TRSM -> in-block update, three launches per panel; 1: the update inside the next diagonal kernel's launch
@@ -40,7 +40,7 @@ static void fuse_env(void) {
     });
 }
 int cip_ldlt_outer_block_for(int Npad) {
-    if (g_nbo > 0) return g_nbo;
+    { const int v = g_nbo.load(std::memory_order_relaxed); if (v > 0) return v; }
     fuse_env();
     // Round 4 re-tuned the width on the current chain (same-session A/B, wide last block in force; CIP_LDLT_NBO_AUTO overrides):
     // 640 / 768 / 896 / 1024 -> 185.4 / 189.1 / 191.3 / 188.7 KKT solves/s at n = 8192 (6 x 896 + 2816: one trailing update

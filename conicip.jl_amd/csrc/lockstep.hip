@@ -57,6 +57,12 @@ bool same_shape(const cip_problem &a, const cip_problem &b) {
     if ((a.A == nullptr) != (b.A == nullptr) || (a.flags & CIP_FLAG_DEVICE_PTRS) != (b.flags & CIP_FLAG_DEVICE_PTRS)) return false;
     for (int c = 0; c < a.ncones; ++c)
         if (a.cone_type[c] != b.cone_type[c] || a.cone_dim[c] != b.cone_dim[c]) return false;
+    // CSR A: the slab layout depends on the number of non-zeros -- part of the shape when the row pointers can be read here
+    // (host memory); device-resident row pointers are caught by the slab-layout check of lockstep_group instead
+    auto host_rowptr = [](const cip_problem &q) {
+        return q.A == nullptr && q.m > 0 && q.A_rowptr && ((q.flags & CIP_FLAG_CSR_HOST) || !(q.flags & CIP_FLAG_DEVICE_PTRS));
+    };
+    if (host_rowptr(a) && host_rowptr(b) && a.A_rowptr[a.m] != b.A_rowptr[b.m]) return false;
     return true;
 }
 
@@ -132,10 +138,9 @@ unsigned long long full_mask(int B) { return B >= 64 ? ~0ull : ((1ull << B) - 1u
 
 }   // namespace
 
-// Solve-block limit of a lock-step group's handles: 256 whatever the group size (a block step is one launch for all problems,
-// and the doubled block inverses -- 1.5 GFLOP per n = 2048 factorisation at 1024 -- are what cost).  Round 4 measured the small
-// groups too (8 problems of order 2048, the per-rank shard of config 5 on 8 GPUs): 256 / 512 / 1024 -> 16.5 / 16.5 / 17.3 ms per
-// pass.  CIP_LOCKSTEP_SOLVE_BLOCK overrides; never above the process-wide limit.
+// Solve-block limit of a lock-step call's handles, chosen from the size of the WHOLE call (count), not per group of 64: every
+// problem of one cip_conicip_lockstep call is solved with the same block, so a problem's bits do not depend on which group
+// it lands in (72 problems = 64 + 8: both groups take 256).  Never above the process-wide limit.
 extern "C" int cip_lockstep_solve_block_for(int B) {
     // groups of up to 8 problems: 512 (the sweeps are launch chains on a mostly idle chip: half the block steps; 8 problems of
     // order 2048, 256 / 512 / 1024: 16.75 / 16.55 / 17.8 ms per pass); larger groups: 256 (the doubling GEMMs of a wider
@@ -146,7 +151,7 @@ extern "C" int cip_lockstep_solve_block_for(int B) {
 }
 // One lock-step group (B <= CIP_BATCH_MAX problems of the same shape).  Returns 0 and fills res / y / w / v of every
 // problem, or an error code (nothing meaningful written).
-static int lockstep_group(int B, const cip_problem *probs, const double *const *c, const double *const *b,
+static int lockstep_group(int B, int call_count, const cip_problem *probs, const double *const *c, const double *const *b,
                           const double *const *d, const cip_options *opt_in, double *const *y, double *const *w,
                           double *const *v, cip_result *res) {
     const auto t_start = std::chrono::steady_clock::now();
@@ -169,7 +174,7 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
         int saved;
         explicit SolveBlockScope(int B_) : saved(cip_tl_solve_block_max) { cip_tl_solve_block_max = cip_lockstep_solve_block_for(B_); }
         ~SolveBlockScope() { cip_tl_solve_block_max = saved; }
-    } solve_block_scope(B);
+    } solve_block_scope(call_count);
     // ---- slab size: create problem 0 once with ordinary allocations and count what it asked for
     size_t slab = 0;
     // CSR: the slab depends on the number of non-zeros -- part of the signature when the row pointers are host memory
@@ -291,6 +296,17 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
         return 0;
     };
     std::vector<double> av(B), as(B), tmpB(B);
+    // A max-step whose minima ride on the next read-back of the gather buffer (slot `slot` of every problem's row).  A group of
+    // ONE problem is not a batch for the kernels (cip_tl_bz.B == 1: no gather buffer behind k_min_reduce), so it takes the
+    // one-problem read-back and `direct[0]` holds the result on return; fetch_step() is then a no-op for that slot.
+    auto maxstep_deferred = [&](const double *x, const double *dd, double scale, int slot, double *direct) -> int {
+        if (B == 1) return cip_cones_maxstep(s, h->cs, x, dd, scale, direct);
+        return cip_cones_maxstep(s, h->cs, x, dd, scale, nullptr, slot);
+    };
+    auto fetch_step = [&](int slot, std::vector<double> &dst) {
+        if (B == 1) return;
+        for (int z = 0; z < B; ++z) dst[z] = G.gather_host[(size_t)z * CIP_GATHER + slot];
+    };
 
     // ---------------------------------------------------------------- initial point (:704-713)
     CK(cip_zero(s, (long)driver_doubles(n, m, p), h->drv));
@@ -314,9 +330,9 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
         CK(cip_solve4x4_dev(h, e, r0.base, zv.base));
         for (int z = 0; z < B; ++z) if ((active >> z) & 1ull) ++n_solve[z];
         if (m > 0) {
-            CK(cip_cones_maxstep(s, h->cs, zv.v, nullptr, 1.0, nullptr, STEP_SLOT));
+            CK(maxstep_deferred(zv.v, nullptr, 1.0, STEP_SLOT, av.data()));
             CK(cip_cones_maxstep(s, h->cs, zv.s, nullptr, 1.0, as.data()));
-            for (int z = 0; z < B; ++z) av[z] = G.gather_host[(size_t)z * CIP_GATHER + STEP_SLOT];
+            fetch_step(STEP_SLOT, av);
             for (int z = 0; z < B; ++z) { av[z] = -av[z]; as[z] = -as[z]; }
             CK(cip_axpby_ps(s, m, av.data(), e, 1.0, zv.v));
             CK(cip_axpby_ps(s, m, as.data(), e, 1.0, zv.s));
@@ -366,16 +382,14 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
         if (m > 0) {
             // one host round trip for the three results (round 4; it was three): the two max-steps leave their minima in slots
             // STEP_SLOT, STEP_SLOT + 1 of the gather buffer, which comes back with the dot products
-            CK(cip_cones_maxstep(s, h->cs, zv.v, daff.v, 1.0, nullptr, STEP_SLOT));
-            CK(cip_cones_maxstep(s, h->cs, zv.s, daff.s, 1.0, nullptr, STEP_SLOT + 1));
+            CK(maxstep_deferred(zv.v, daff.v, 1.0, STEP_SLOT, av.data()));
+            CK(maxstep_deferred(zv.s, daff.s, 1.0, STEP_SLOT + 1, as.data()));
             const double *qx[4] = {zv.v, zv.v, daff.v, daff.v};
             const double *qy[4] = {zv.s, daff.s, zv.s, daff.s};
             const int ql[4] = {m, m, m, m};
             CK(cip_dots(s, 4, qx, qy, ql, h->dot_scratch, h->dot_ptrs, q4.data()));
-            for (int z = 0; z < B; ++z) {
-                av[z] = G.gather_host[(size_t)z * CIP_GATHER + STEP_SLOT];
-                as[z] = G.gather_host[(size_t)z * CIP_GATHER + STEP_SLOT + 1];
-            }
+            fetch_step(STEP_SLOT, av);
+            fetch_step(STEP_SLOT + 1, as);
             for (int z = 0; z < B; ++z) {
                 if (!((active >> z) & 1ull)) continue;
                 const double a_aff = std::fmin(std::fmin(av[z], 1.0), as[z]);
@@ -452,9 +466,9 @@ static int lockstep_group(int B, const cip_problem *probs, const double *const *
         if (m > 0) {
             if (!step_known) {
                 // (one round trip for the pair: the v side rides on the s side's read-back)
-                CK(cip_cones_maxstep(s, h->cs, zv.v, dz.v, 1.0 / (1.0 - o.DTB), nullptr, STEP_SLOT));
+                CK(maxstep_deferred(zv.v, dz.v, 1.0 / (1.0 - o.DTB), STEP_SLOT, av.data()));
                 CK(cip_cones_maxstep(s, h->cs, zv.s, dz.s, 1.0 / (1.0 - o.DTB), as.data()));
-                for (int z = 0; z < B; ++z) av[z] = G.gather_host[(size_t)z * CIP_GATHER + STEP_SLOT];
+                fetch_step(STEP_SLOT, av);
             }
             for (int z = 0; z < B; ++z) alpha[z] = std::fmin(std::fmin(av[z], 1.0), std::fmin(as[z], 1.0));
         }
@@ -523,7 +537,7 @@ extern "C" int cip_conicip_lockstep(int count, const cip_problem *probs, const d
     if (!g_stats_accumulate) g_last_stats[0] = g_last_stats[1] = g_last_stats[2] = 0;
     for (int g0 = 0; g0 < count; g0 += CIP_BATCH_MAX) {
         const int B = (count - g0 < CIP_BATCH_MAX) ? (count - g0) : CIP_BATCH_MAX;
-        const int rc = lockstep_group(B, probs + g0, c + g0, b ? b + g0 : nullptr, d ? d + g0 : nullptr, opt, y + g0,
+        const int rc = lockstep_group(B, count, probs + g0, c + g0, b ? b + g0 : nullptr, d ? d + g0 : nullptr, opt, y + g0,
                                       w ? w + g0 : nullptr, v ? v + g0 : nullptr, res + g0);
         if (rc) return rc;
     }
@@ -579,6 +593,9 @@ extern "C" int cip_conicip_mixed(int count, const cip_problem *probs, const doub
     for (const auto &bin : bins) {
         if (bin.size() < 2 || !lockstep_ok(probs[bin[0]])) { rest.insert(rest.end(), bin.begin(), bin.end()); continue; }
         const int rc = run(bin, true);
+        // a bin that turns out not to qualify (same shape, yet a different slab layout: CSR arrays in device memory with differing
+        // numbers of non-zeros) has written nothing: its problems join the thread pool's share instead of failing the batch
+        if (rc == CIP_E_UNSUPPORTED) { rest.insert(rest.end(), bin.begin(), bin.end()); continue; }
         if (rc) return rc;
     }
     if (!rest.empty()) {

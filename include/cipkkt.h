@@ -257,9 +257,10 @@ int cip_set_ldlt_outer_block(int nbo);    /* 0 = automatic (896 from order 4096 
 /* tuning knob: widest block of the triangular solves' block-step form (128, 256, 512 or 1024; 0 = query).  Applies to
  * handles created afterwards; returns the previous value.  Lock-step batches use min(this, cip_lockstep_solve_block_for(B)) for their handles. */
 int cip_set_solve_block_max(int b);
-/* the solve-block limit cip_conicip_lockstep gives the handles of a group of B problems (512 for B <= 8, else 256; never more than
+/* the solve-block limit cip_conicip_lockstep gives the handles of a call of B problems in all (512 for B <= 8, else 256 -- chosen
+ * from the size of the whole call, so the groups of 64 it is cut into all use the same one; never more than
  * cip_set_solve_block_max's value; CIP_LOCKSTEP_SOLVE_BLOCK overrides): a one-problem run with this limit
- * reproduces the group's iterates bit for bit */
+ * reproduces the call's iterates bit for bit */
 int cip_lockstep_solve_block_for(int B);
 /* panel chain of the serial schedule (also CIP_FUSE_DIAG): 3 (default) = one launch per 128-column panel -- diagonal kernel,
  * the previous panel's in-block update and this panel's TRSM, the TRSM following the diagonal kernel micro-panel by
@@ -291,7 +292,7 @@ int cip_profile_get(cip_handle *h, double *out3);
 /* the same for every factorisation the CALLING THREAD enqueues on handles without a profile of their own (the handles of
  * cip_conicip_lockstep live inside the call): flops count every live problem of a lock-step launch */
 int cip_profile_trailing_thread(int enabled);
-int cip_profile_thread_get(double *out3);   /* tuning knob: outer block of the blocked LDL' (multiple of 128); returns the value in use */
+int cip_profile_thread_get(double *out3);
 
 #ifdef __cplusplus
 }

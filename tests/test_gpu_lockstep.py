@@ -15,13 +15,13 @@ pytestmark = pytest.mark.gpu
 
 
 def _solve(prs, mode, in_flight=4):
-    """the thread-pool reference runs with the solve-block limit the lock-step group uses for its handles (256 unless
-    CIP_LOCKSTEP_SOLVE_BLOCK says otherwise; groups are formed of at most 64 problems): the block size changes the summation order of the
+    """the thread-pool reference runs with the solve-block limit the lock-step group uses for its handles (chosen from the size of the whole call: 512 up to 8 problems,
+    else 256, unless CIP_LOCKSTEP_SOLVE_BLOCK says otherwise): the block size changes the summation order of the
     triangular solves, and the comparison below is bit for bit"""
     from cipkkt import _lib as L
     from cipkkt.batch import _solve_problems_native
     lib = L.load()
-    prev = lib.cip_set_solve_block_max(lib.cip_lockstep_solve_block_for(min(len(prs), 64))) if mode == "threads" else None
+    prev = lib.cip_set_solve_block_max(lib.cip_lockstep_solve_block_for(len(prs))) if mode == "threads" else None
     try:
         return _solve_problems_native(prs, torch.device("cuda:0"), in_flight, mode)
     finally:
@@ -138,6 +138,115 @@ def test_more_than_64_problems_two_groups():
     one = _solve(prs, "threads", in_flight=4)
     lock = _solve(prs, "lockstep")
     _assert_identical(lock, one)
+
+
+@pytest.mark.parametrize("count", [1, 2, 65])
+def test_groups_of_one_problem(count):
+    """a lock-step call of ONE problem, and 65 problems = a full group + a tail group of one (round-4 advisor finding: the
+    tail group's max-steps wrote through a null pointer).  A group of one is not a batch for the kernels (no gather buffer):
+    its max-steps take the one-problem read-back.  Mixed cones so that m > 0 and every max-step kind runs."""
+    prs = [_as_problem(P.random_mixed(n=16, nq=1, kq=4, p=2, seed=800 + seed)) for seed in range(count)]
+    one = _solve(prs, "threads", in_flight=4)
+    lock = _solve(prs, "lockstep")
+    assert all(s.status == "Optimal" for s in lock)
+    _assert_identical(lock, one)
+    auto = _solve(prs, "auto")                  # cip_conicip_mixed: one bin (a lone problem goes through the thread pool)
+    _assert_identical(auto, one)
+
+
+def test_group_of_one_box_qp_csr():
+    """the config-5 family (CSR A = I, R cones only: lazy copy, fused element-wise kernels of solve4x4) as a group of one"""
+    from cipkkt.workloads import c5_batch
+    prs = c5_batch(count=1, n=384, seed=4100)
+    one = _solve(prs, "threads", in_flight=1)
+    lock = _solve(prs, "lockstep")
+    _assert_identical(lock, one)
+    assert lock[0].status == "Optimal"
+
+
+def _csr_problem(n, m, nnz_extra, seed):
+    """R-cone QP behind a CSR A with m >= n rows: an identity part plus `nnz_extra` further entries"""
+    rng = np.random.default_rng(seed)
+    M = rng.standard_normal((n, n))
+    Q = M @ M.T / n + 0.1 * np.eye(n)
+    extra = rng.choice((m - n) * (n - 1), size=nnz_extra, replace=False)   # distinct positions away from column 0, which every extra row holds
+    rows = list(range(n)) + list(range(n, m)) + [n + int(e) // (n - 1) for e in extra]
+    cols = list(range(n)) + [0] * (m - n) + [1 + int(e) % (n - 1) for e in extra]
+    vals = [1.0] * n + [0.5] * (m - n) + list(0.3 * rng.standard_normal(nnz_extra))
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(m, n)).tocsr()
+    return dict(Q=Q, c=rng.standard_normal(n), A=A, b=-np.ones(m), cone_dims=[("R", m)], G=None, d=None, kwargs={})
+
+
+def test_mixed_batch_csr_same_shape_differing_nnz():
+    """CSR problems of one (n, m, p, cones) shape whose A differ in the number of non-zeros do not share a slab layout: the
+    number of non-zeros is part of the binning key (host row pointers), so `cip_conicip_mixed` forms one lock-step group per
+    count and nothing fails (round-4 advisor finding: the whole batch raised CIP_E_UNSUPPORTED)"""
+    import ctypes as C
+    from cipkkt import _lib as L
+    prs = [_csr_problem(24, 30, e, 40 + i) for i, e in enumerate((5, 9, 5, 9, 5, 13))]
+    nnz = [pr["A"].nnz for pr in prs]
+    assert nnz[0] == nnz[2] == nnz[4] and nnz[1] == nnz[3] and len(set(nnz)) == 3, nnz
+    one = _solve(prs, "threads", in_flight=1)
+    mixed = _solve(prs, "auto")
+    st = (C.c_int * 3)()
+    L.load().cip_lockstep_stats(st)
+    assert list(st)[:2] == [2, 5], list(st)           # groups of 3 and 2; the lone one through the thread pool
+    assert all(s.status == "Optimal" for s in one), [s.status for s in one]
+    _assert_identical(mixed, one)
+    with pytest.raises(L.CipError) as ei:             # asked for as ONE lock-step call: refused, nothing written
+        _solve(prs, "lockstep")
+    assert ei.value.code == L.E_UNSUPPORTED
+
+
+def test_mixed_batch_device_csr_differing_nnz_falls_back_to_the_thread_pool():
+    """the same with the CSR arrays in DEVICE memory (no CIP_FLAG_CSR_HOST): the library cannot read the counts when it forms
+    the bins, the lock-step group finds out at the slab-layout check -- and the bin's problems must then be solved by the
+    thread pool instead of failing the batch"""
+    import ctypes as C
+    from cipkkt import _lib as L
+    from cipkkt.driver import solution_from_result
+    from cipkkt.kkt import make_problem
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    prs = [_csr_problem(24, 30, e, 60 + i) for i, e in enumerate((5, 11, 5))]
+    assert prs[0]["A"].nnz == prs[2]["A"].nnz != prs[1]["A"].nnz
+    k = len(prs)
+    prev = lib.cip_set_solve_block_max(lib.cip_lockstep_solve_block_for(k))
+    try:
+        one = _solve_problems_native_plain(prs)
+        structs = (L.CipProblem * k)()
+        keep = []
+        for i, pr in enumerate(prs):
+            st, kp, _ = make_problem(pr["Q"], pr["A"], None, pr["cone_dims"], "schur", dev)
+            csr = pr["A"].tocsr()
+            csr.sort_indices()
+            dv = [torch.from_numpy(np.ascontiguousarray(x, dtype=dt)).to(dev)
+                  for x, dt in ((csr.indptr, np.int32), (csr.indices, np.int32), (csr.data, np.float64))]
+            st.A_rowptr, st.A_colind, st.A_val = (C.c_void_p(x.data_ptr()) for x in dv)
+            st.flags = L.FLAG_DEVICE_PTRS
+            structs[i] = st
+            keep += [kp, dv]
+        torch.cuda.synchronize()
+        vp = C.c_void_p * k
+        cs = [np.ascontiguousarray(pr["c"]) for pr in prs]
+        bs = [np.ascontiguousarray(pr["b"]) for pr in prs]
+        ys = [np.zeros(24) for _ in prs]
+        vs = [np.zeros(30) for _ in prs]
+        zs = [np.zeros(1) for _ in prs]
+        arr = lambda xs: vp(*[x.ctypes.data for x in xs])
+        res = (L.CipResult * k)()
+        opt = L.CipOptions(1e-6, 0.01, -1.0, -1.0, 3, 100, 0)
+        L.check(lib.cip_conicip_mixed(k, structs, arr(cs), arr(bs), arr(zs), C.byref(opt), arr(ys), arr(zs), arr(vs), res, 2))
+    finally:
+        lib.cip_set_solve_block_max(prev)
+    got = [solution_from_result(res[i], ys[i], zs[i][:0], vs[i]) for i in range(k)]
+    assert all(s.status == "Optimal" for s in got), [s.status for s in got]
+    _assert_identical(got, one)
+
+
+def _solve_problems_native_plain(prs):
+    from cipkkt.batch import _solve_problems_native
+    return _solve_problems_native(prs, torch.device("cuda:0"), 1, "threads")
 
 
 def test_unsupported_batches_fall_back():
