@@ -72,7 +72,7 @@ def launch_ranks(n_gpus):
     import socket
     import subprocess
     have = torch.cuda.device_count()            # counts devices without initialising the runtime
-    if have < n_gpus:
+    if have < n_gpus and not (os.environ.get("CIP_BENCH_SHARE_GPU") and have >= 1):
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this box" % (n_gpus, have))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -174,7 +174,11 @@ def cpu_baseline(Q_host, n, solves_per_factor, budget_s=100.0):
         t3 = time.perf_counter()
         return dict(level1=t1 - t0, factor=t2 - t1, solves=t3 - t2)
 
-    def strong(nn):
+    def strong(nn, variant="potrf"):
+        """variant "potrf": LAPACK dpotrf + dpotrs; "blocked-syrk" / "blocked-gemm": the right-looking blocked Cholesky of
+        oracle/blocked_chol.py (block 512: dpotrf on the diagonal block, dtrsm, the trailing update as one dsyrk / as dgemms per
+        block column) + two dtrsm per solve -- the flops sit in level-3 BLAS, which threads where potrf's panels do not"""
+        from oracle.blocked_chol import blocked_cholesky, cholesky_solve
         F = scaling(nn)
         dinv = 1.0 / F.Blocks[0].diag ** 2
         idx = np.arange(nn)
@@ -184,15 +188,22 @@ def cpu_baseline(Q_host, n, solves_per_factor, budget_s=100.0):
             S[idx, idx] += dinv
             rhs = [rng.standard_normal(nn) for _ in range(solves_per_factor)]
             t0 = time.perf_counter()
-            cf = sla.cho_factor(S, lower=True, overwrite_a=True, check_finite=False)
+            if variant == "potrf":
+                cf = sla.cho_factor(S, lower=True, overwrite_a=True, check_finite=False)
+            else:
+                if blocked_cholesky(S, 512, "syrk" if variant == "blocked-syrk" else "gemm"):
+                    raise RuntimeError("blocked Cholesky: not positive definite")
             t1 = time.perf_counter()
             for r in rhs:
-                sla.cho_solve(cf, r, overwrite_b=True, check_finite=False)
+                if variant == "potrf":
+                    sla.cho_solve(cf, r, overwrite_b=True, check_finite=False)
+                else:
+                    cholesky_solve(S, r)
             t2 = time.perf_counter()
             cur = (t1 - t0, t2 - t1)
             if best is None or sum(cur) < sum(best):
                 best = cur
-            del S, cf
+            del S
         return best
 
     # ladder: n/2 first (an eighth of the work); the full size only if eight times that fits the budget
@@ -212,6 +223,21 @@ def cpu_baseline(Q_host, n, solves_per_factor, budget_s=100.0):
         limiter.restore_original_limits()
         limiter = threadpool_limits(limits=cores_potrf)
     t_potrf, t_potrs = strong(n)
+    variants = {"potrf": dict(threads=cores_potrf, factor_s=t_potrf, solves_s=t_potrs, gflops=n ** 3 / 3.0 / t_potrf / 1e9)}
+    # round-4 review: potrf reached 41 % of the host's dgemm rate.  The blocked factorisation runs at the dgemm probe's thread
+    # count (its flops are dsyrk / dgemm) and the fastest of the three is the strong leg.
+    if limiter is not None:
+        limiter.restore_original_limits()
+        limiter = threadpool_limits(limits=cores)
+    for var in ("blocked-syrk", "blocked-gemm"):
+        try:
+            tf_, ts_ = strong(n, var)
+            variants[var] = dict(threads=cores, factor_s=tf_, solves_s=ts_, gflops=n ** 3 / 3.0 / tf_ / 1e9)
+        except Exception as e:                      # (scipy without the cython_blas capsules: keep potrf)
+            variants[var] = dict(error=repr(e))
+    strong_variant = min((k for k in variants if "factor_s" in variants[k]), key=lambda k: variants[k]["factor_s"] + variants[k]["solves_s"])
+    t_potrf, t_potrs = variants[strong_variant]["factor_s"], variants[strong_variant]["solves_s"]
+    cores_potrf = variants[strong_variant]["threads"]
     strong_s = t_potrf + t_potrs
     sample = ("1 factorisation + %d solves of the kktsolver_qr restatement at n=%d%s (level-1 setup %.2fs excluded); "
               "strong variant measured at n=%d"
@@ -228,17 +254,24 @@ def cpu_baseline(Q_host, n, solves_per_factor, budget_s=100.0):
                 strong_cpu_value=1.0 / strong_s, strong_cpu_seconds_per_step=strong_s,
                 strong_cpu_potrf_s=t_potrf, strong_cpu_potrs_s=t_potrs, strong_cpu_threads=cores_potrf,
                 strong_cpu_gflops=n ** 3 / 3.0 / t_potrf / 1e9,
-                strong_cpu_note="Schur + LAPACK Cholesky (same elimination route as the GPU, src/kktsolvers.jl:281-338): "
-                                "potrf and %d potrs at n=%d timed separately, best of two, S formed outside the timed "
-                                "region, thread count = fastest of a potrf probe at n=4096; strong_cpu_gflops = n^3/3 / "
-                                "t_potrf, to be read against host_dgemm_gflops" % (solves_per_factor, n))
+                strong_cpu_variant=strong_variant, strong_cpu_variants=variants,
+                strong_over_dgemm=(n ** 3 / 3.0 / t_potrf / 1e9 / dgemm_gflops) if dgemm_gflops else None,
+                strong_cpu_note="Schur + Cholesky on the host (same elimination route as the GPU, src/kktsolvers.jl:281-338): the "
+                                "FASTEST of LAPACK potrf (+ potrs) and a right-looking blocked Cholesky over dtrsm / dsyrk / dgemm "
+                                "(block 512, oracle/blocked_chol.py; + 2 dtrsm per solve); factorisation and %d solves at n=%d timed "
+                                "separately, best of two, S formed outside the timed region; potrf at the fastest thread count "
+                                "of a potrf probe at n=4096, the blocked forms at the dgemm probe's; strong_over_dgemm = "
+                                "strong_cpu_gflops / host_dgemm_gflops (a Cholesky cannot beat the GEMM it is made of)"
+                                % (solves_per_factor, n))
 
 
 def live_pmc_traffic(args):
     """HBM-side bytes per trailing-update launch MEASURED IN THIS RUN: two child processes under `rocprofv3 --pmc` (FETCH_SIZE,
     then WRITE_SIZE: separate passes, counters only -- no tracing beside them, MI355X_MICROARCH.md), each running this script on
-    the same workload for three steps without the CPU leg.  Started BEFORE this process touches the GPU (children, never an
-    exec).  Returns (bytes per launch, launches) or (None, reason); the caller then falls back to the committed passes."""
+    the same workload for three steps (one of them its warm-up: same kernels, same shapes -- the averages include it) without
+    the CPU leg.  Started BEFORE this process initialises the GPU for itself (children, never an exec; the parent has only
+    counted devices so far).  Returns (bytes per trailing-update launch, launches, bytes per solve4x4 or None) or
+    (None, reason, None); the caller then falls back to the committed passes and says so (`traffic_measured_live`)."""
     import csv
     import glob
     import shutil
@@ -249,6 +282,9 @@ def live_pmc_traffic(args):
         return None, "rocprofv3 not found"
     tot = {}
     nl = {}
+    gv = {}
+    N = args.n if args.route == "schur" else 2 * args.n
+    small, big = 256 * 256, 256 * ((N - 1024) // 4)          # k_gemv_t grids of the triangular sweeps (see pmc_solve_traffic)
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="cip_pmc_", dir="/tmp")
@@ -260,22 +296,34 @@ def live_pmc_traffic(args):
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 shutil.rmtree(d, ignore_errors=True)
-                return None, "rocprofv3 --pmc %s child failed (rc %d)" % (ctr, r.returncode)
+                return None, "rocprofv3 --pmc %s child failed (rc %d)" % (ctr, r.returncode), None
             t, k = 0.0, 0
+            g_tot, g_small = 0.0, 0
             with open(files[0]) as f:
                 for row in csv.DictReader(f):
-                    if row["Counter_Name"] == ctr and row["Kernel_Name"].replace("void ", "").startswith(TRAILING_KERNELS):
+                    if row["Counter_Name"] != ctr:
+                        continue
+                    name = row["Kernel_Name"].replace("void ", "")
+                    if name.startswith(TRAILING_KERNELS):
                         t += float(row["Counter_Value"]); k += 1
+                    elif name.startswith("k_gemv_t") and N % 1024 == 0 and int(row["Grid_Size"]) <= big:
+                        g_tot += float(row["Counter_Value"]); g_small += int(row["Grid_Size"]) == small
             shutil.rmtree(d, ignore_errors=True)
             if k == 0:
-                return None, "no trailing-update dispatch in the %s pass" % ctr
+                return None, "no trailing-update dispatch in the %s pass" % ctr, None
             tot[ctr], nl[ctr] = t, k
+            gv[ctr] = (g_tot, g_small)
         if nl["FETCH_SIZE"] != nl["WRITE_SIZE"]:
-            return None, "the two passes saw different launch counts"
+            return None, "the two passes saw different launch counts", None
         # gfx950: FETCH_SIZE counts half the bytes of wide streaming reads -> doubled (MI355X_MICROARCH.md, section HBM); both in KiB
-        return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / nl["FETCH_SIZE"], nl["FETCH_SIZE"]
+        solve_bytes = None
+        per = 2 * (N // 1024 + 1)                            # k_gemv_t dispatches of the 1024-column grid per solve
+        (gf, n1), (gw, n2) = gv["FETCH_SIZE"], gv["WRITE_SIZE"]
+        if n1 > 0 and n1 == n2 and n1 % per == 0:
+            solve_bytes = (2.0 * gf + gw) * 1024.0 / (n1 // per)
+        return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / nl["FETCH_SIZE"], nl["FETCH_SIZE"], solve_bytes
     except Exception as e:                                   # never let the measurement of a side figure take the bench down
-        return None, "live PMC pass failed: %r" % (e,)
+        return None, "live PMC pass failed: %r" % (e,), None
 
 
 def pmc_traffic_per_launch():
@@ -330,6 +378,121 @@ def pmc_solve_traffic(N):
         return None
 
 
+def plugin_boundary(ks, v_mid, s_mid, lam, spf, reps=5):
+    """What a `ccall` caller of the three plugin levels gets at this size (src/ConicIP.jl:667, :682, :688): every call with HOST
+    pointers, synchronous, fresh output arrays per level-3 call as the reference requires (:690) -- the path
+    integration/ConicIPHIP's `kktsolver_hip` drives.  Untimed region of the bench (never `value`)."""
+    n, m, p = ks.n, ks.m, ks.p
+    ks.set_scaling_from_iterate(v_mid, s_mid, lam)
+    packed = ks.get_scaling_packed()                       # the packed F a Julia shim reads off the Block (R: sqrt(s/v), :598)
+    rng = np.random.default_rng(5)
+    x, y, z = rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(m)
+    ks.set_scaling_packed(packed); ks.factor(check=True); ks.solve3x3(x, y, z)      # warm
+    t2 = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        ks.set_scaling_packed(packed)                      # cip_set_scaling_packed: host pointer, 8 m bytes up
+        ks.factor(check=True)                              # cip_factor + cip_check_factor: assembly + LDL', waited for
+        t2.append(time.perf_counter() - t0)
+    t3 = []
+    for _ in range(reps * 2):
+        t0 = time.perf_counter()
+        ks.solve3x3(x, y, z)                               # cip_solve3x3: 8 (n + p + m) bytes up, as many down, fresh outputs
+        t3.append(time.perf_counter() - t0)
+    l2, l3 = float(np.median(t2)), float(np.median(t3))
+    return {"level2_ms": l2 * 1e3, "level3_ms": l3 * 1e3, "solves_per_factor": spf,
+            "kkt_solves_per_s": 1.0 / (l2 + spf * l3),
+            "bytes_per_level2_call": 8 * packed.size, "bytes_per_level3_call": 16 * (n + p + m),
+            "note": "host-pointer C ABI as ccall drives it: level 2 = cip_set_scaling_packed + cip_factor + cip_check_factor, "
+                    "level 3 = cip_solve3x3 (synchronous, fresh output vectors); medians of %d / %d calls; the level-3 call is "
+                    "the 3x3 solve alone -- the 4x4 -> 3x3 reduction (src/ConicIP.jl:684-692) stays with the caller's loop"
+                    % (reps, 2 * reps)}
+
+
+def host_loop_through_plugin(Qh, c, A, b, cone_dims, route):
+    """CPU-baseline leg (the only place bench.py touches oracle/): the REFERENCE-SHAPED HOST LOOP -- the oracle's restatement of
+    src/ConicIP.jl:468-939, i.e. what a Julia user's `conicIP(...; kktsolver = kktsolver_hip)` executes on the host: cone algebra,
+    five Q*y / A*y products per iteration and five per refinement pass on the CPU -- with the PRODUCT's plugin as its kktsolver.
+    Wall-clock to converge, to be read beside the native loop's (`converge.wall_s`)."""
+    import cipkkt
+    from oracle.conicip import conicIP as oracle_conicIP
+    ksolver = cipkkt.kktsolver_hip if route == "schur" else cipkkt.kktsolver_hip_full3x3
+    holder = {}
+
+    def kkt(Q, A_, G, cd):
+        t0 = time.perf_counter()
+        gen = ksolver(Q, A_, G, cd)
+        holder["level1_s"] = time.perf_counter() - t0
+        holder["gen"] = gen
+        return gen
+    t0 = time.perf_counter()
+    sol = oracle_conicIP(Qh, c, A, b, cone_dims, optTol=1e-6, kktsolver=kkt)
+    wall = time.perf_counter() - t0
+    holder["gen"].system.close()
+    return {"wall_s": wall, "level1_s": holder["level1_s"], "loop_s": wall - holder["level1_s"], "iters": sol.Iter,
+            "status": sol.status, "n_factor": getattr(sol, "n_factor", None), "n_solve": getattr(sol, "n_solve", None),
+            "blas_threads": os.cpu_count() or 1,
+            "note": "oracle.conicIP (host restatement of the reference's loop) with kktsolver = cipkkt.kktsolver_hip: level 1 "
+                    "(upload of Q, A) once, then one level-2 call per iteration + the initial point and 2-3 level-3 calls per "
+                    "iteration through host pointers; the host's own work is the loop's numpy mat-vecs and cone algebra"}
+
+
+def secondary_config(name, lib, device):
+    """BASELINE configs[2] / configs[3] on this GPU, after the timed region: the native loop (cip_conicip) to convergence on the
+    stated workload -- one warm-up solve, one timed solve, one more with HIP events around the dominant kernels (thread
+    profile slots, include/cipkkt.h: cip_profile_kernel_thread)."""
+    import cipkkt
+    from cipkkt import workloads
+    C = cipkkt._lib.C
+    if name == "c3":
+        Q, c, A, b, K, G, d = workloads.c3_socp()
+        what = "SOCP n=4096, 512 x (Q,8) (m=4096), dense A, p=512: Schur order 4608"
+    else:
+        Q, c, A, b, K, G, d = workloads.c4_sdp(256, 1024, 16)
+        what = 'SDP: one ("S", 32896) cone = matrix order 256, n=1024, dense A, p=16'
+    n, m = Q.shape[0], A.shape[0]
+    t0 = time.perf_counter()
+    ks = cipkkt.KKTSystem(Q, A, G, K, device=device)
+    torch.cuda.synchronize()
+    level1_s = time.perf_counter() - t0
+    try:
+        cipkkt.conicIP(Q, c, A, b, K, G, d, optTol=1e-6, system=ks)                       # warm-up
+        sol = cipkkt.conicIP(Q, c, A, b, K, G, d, optTol=1e-6, system=ks)                 # timed: the loop's own wall clock
+        for slot in (0, 1, 2):
+            lib.cip_profile_kernel_thread(slot, 1)
+        cipkkt.conicIP(Q, c, A, b, K, G, d, optTol=1e-6, system=ks)
+        prof = {}
+        for slot, key in ((0, "trailing"), (1, "syrk"), (2, "jacobi")):
+            o3 = (C.c_double * 3)()
+            cipkkt._lib.check(lib.cip_profile_kernel_thread_get(slot, o3))
+            prof[key] = (o3[0], o3[1], o3[2])
+            lib.cip_profile_kernel_thread(slot, 0)
+    finally:
+        ks.close()
+    out = {"workload": what, "status": sol.status, "iters": sol.Iter, "n_factor": sol.n_factor, "n_solve": sol.n_solve,
+           "wall_s": sol.wall_s, "ms_per_iter": 1e3 * sol.wall_s / max(1, sol.Iter), "level1_s": level1_s}
+
+    def mfma(key, kernel):
+        l, ms, fl = prof[key]
+        if l <= 0 or ms <= 0:
+            return None
+        ach = fl / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / FP64_MFMA_PEAK_TFLOPS, "launches": l, "avg_launch_ms": ms / l, "algorithmic_flops_per_launch": fl / l,
+                "traffic": None}
+    out["roofline"] = mfma("syrk", "Schur formation S = Q + (A'F^-1)(A'F^-1)' (m n^2 flop; %s)"
+                           % ("k_syrkq_64" if name == "c3" else "k_syrk_splitk_128 images + k_syrk_reduce"))
+    out["roofline_trailing"] = mfma("trailing", "LDL' trailing update k_ldlt_trailing_64")
+    if name == "c4" and prof["jacobi"][0] > 0:
+        l, ms, _ = prof["jacobi"]
+        out["nt_scaling_svd"] = {"bound": "latency", "kernel": "one-sided Jacobi of svd(Lz'Ls) (src/ConicIP.jl:204)",
+                                 "launches": l, "avg_launch_ms": ms / l, "share_of_iteration": (ms / l) / max(1e-9, out["ms_per_iter"])}
+    fx = fixture_iters("c3_socp_seed11" if name == "c3" else "c4_sdp_r256_seed5")
+    if fx is not None and isinstance(fx, dict) and "Iter" in fx:
+        out["iters_cpu"] = fx["Iter"]
+    return out
+
+
 def c5_cpu_baseline(seed=4000, n=2048):
     """Bounded CPU leg of the batch workload: problem 0 of config 5 (n = 2048) through the oracle's conicIP with
     pivot(kktsolver_2x2) (src/kktsolvers.jl:281-349) on the host cores -- a few seconds."""
@@ -373,6 +536,8 @@ def main():
     ap.add_argument("--batch-mode", default="lockstep", choices=["lockstep", "threads"],
                     help="c5: lock-step batch (one launch per step for all problems of the rank) or host threads + streams")
     ap.add_argument("--no-c5", action="store_true", help="c2: skip the single-GPU config-5 figure")
+    ap.add_argument("--no-secondary", action="store_true", help="c2: skip the configs[2] / configs[3] runs after the timed region")
+    ap.add_argument("--no-plugin-boundary", action="store_true", help="c2: skip the host-pointer plugin-level timings")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="c2: do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes before the GPU is "
                          "touched); replay the committed passes instead")
@@ -388,22 +553,33 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
-    live_traffic = (None, "not requested")
+    live_traffic = (None, "not requested", None)
     if (world == 1 and args.gpus == 1 and (args.workload in (None, "c2")) and not args.no_live_pmc and not args.no_cpu_baseline
             and not os.environ.get("CIP_BENCH_PMC_CHILD") and torch.cuda.device_count() > 0):
-        # (only in the full default run -- the A/B and profiling invocations pass --no-cpu-baseline -- and before this process
-        #  initialises the GPU: torch.cuda.device_count() does not)
+        # (only in the full default run -- the A/B and profiling invocations pass --no-cpu-baseline.  The children are fresh
+        #  subprocesses started before this process makes its first HIP call that creates a context -- so far it has only
+        #  counted devices -- and it never execs: each child opens the GPU for itself)
         live_traffic = live_pmc_traffic(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the KKT path has no CPU fallback)")
+    # CIP_BENCH_SHARE_GPU=1 (tests only): every rank on cuda:0 and the process group on gloo -- RCCL refuses two ranks on one
+    # device -- so that rank != 0's shard generation, the rank-0-alone pass behind the barrier and the reductions run on real
+    # kernels on a one-GPU box.  Not a measurement: the ranks share the chip.
+    share_gpu = bool(os.environ.get("CIP_BENCH_SHARE_GPU")) and world > 1
+    if share_gpu:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    reduce_device = torch.device("cpu") if share_gpu else device
     dist = None
     if world > 1 or os.environ.get("CIP_BENCH_FORCE_DIST"):     # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)   # nccl == RCCL on ROCm
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)   # nccl == RCCL on ROCm
 
     import cipkkt
     from cipkkt import workloads
@@ -417,7 +593,7 @@ def main():
 
     def config5(steps, warmup, rank_=rank, world_=world, dist_=None):
         stats, el = run_config5(rank_, world_, dist_, device, steps, warmup, count=64, n=2048, seed=4000,
-                                in_flight=args.in_flight)
+                                in_flight=args.in_flight, reduce_device=reduce_device)
         return dict(value=stats["n_factor"] * steps / el, unit="KKT solves/s", ms_per_pass=el / steps * 1e3,
                     problems_per_s=64 * steps / el, n_optimal=stats["n_optimal"], n_problems=stats["n_problems"],
                     iters=stats["iters"], n_factor=stats["n_factor"], n_solve=stats["n_solve"],
@@ -438,7 +614,7 @@ def main():
         c5 = config5(args.steps, args.warmup, dist_=dist)
         ranks_seen = 1
         if dist is not None:
-            one = torch.ones(1, dtype=torch.float64, device=device)
+            one = torch.ones(1, dtype=torch.float64, device=reduce_device)
             dist.all_reduce(one, op=dist.ReduceOp.SUM)
             ranks_seen = int(round(float(one.item())))
         if rank == 0:
@@ -476,7 +652,7 @@ def main():
                                           "step = one pass over the batch" % world,
                               "parallelism": ("problem-per-GPU x%d, lock-step batch per GPU" % world) if args.batch_mode == "lockstep"
                                              else "problem-per-GPU x%d, %d in flight per GPU" % (world, args.in_flight)},
-                   "ranks_seen": ranks_seen,
+                   "ranks_seen": ranks_seen, "ranks_share_one_gpu": share_gpu,
                    "batch": c5, "roofline": roof}
             if c5_one is not None:
                 out["c5_single_gpu"] = c5_one
@@ -551,11 +727,20 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = ks.profile_get()
     ks.profile_trailing(False)
+    ks.check_factor()
+    # what the HIP events around every trailing-update launch cost the number above: the same K steps again without them
+    # (same session A/B; round-4 review)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed_noprof = time.perf_counter() - t0
     ks.check_factor()
 
     # separate factor / solve split (untimed region, for the report)
@@ -570,10 +755,25 @@ def main():
     torch.cuda.synchronize()
     solve_ms = (time.perf_counter() - t1) / 5 * 1e3
 
+    pb = None
+    if rank == 0 and not args.no_plugin_boundary and not os.environ.get("CIP_BENCH_PMC_CHILD"):
+        pb = plugin_boundary(ks, v_mid, s_mid, lam, spf)
     ks.close()
     c5_single = None
     if world == 1 and not args.no_c5 and n == 8192 and args.route == "schur":
         c5_single = config5(2, 1)                     # single-GPU config-5 figure, for cross-checking a SCALE run
+    Qh = Q.cpu().numpy() if (rank == 0 and not args.no_cpu_baseline) else None
+    secondary = None
+    if (world == 1 and rank == 0 and not args.no_secondary and n == 8192 and args.route == "schur"
+            and not os.environ.get("CIP_BENCH_PMC_CHILD")):
+        del Q
+        torch.cuda.empty_cache()
+        secondary = {}
+        for name in ("c3", "c4"):
+            try:
+                secondary[name] = secondary_config(name, lib, device)
+            except Exception as e:                   # a side figure never takes the bench line down
+                secondary[name] = {"error": repr(e)}
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
@@ -604,7 +804,8 @@ def main():
                                "achieved": (8.0 * N * (N + 1) + 16.0 * N * min(1024, ks.Npad)) / (solve_ms * 1e-3) / 1e9,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": (8.0 * N * (N + 1) + 16.0 * N * min(1024, ks.Npad)) / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "traffic": pmc_solve_traffic(ks.Npad),
+                               "traffic": live_traffic[2] if live_traffic[2] is not None else pmc_solve_traffic(ks.Npad),
+                               "traffic_measured_live": live_traffic[2] is not None,
                                "note": "algorithmic bytes of one solve = L read once per sweep (8 N (N+1)) + the 1024-wide block "
                                        "inverses (16 N Bs); time = whole cip_solve4x4 call (cone division, A'/A products, "
                                        "two sweeps), host-timed average of 5"},
@@ -615,8 +816,9 @@ def main():
                          "clock_limited_peak": FP64_MFMA_CLOCK_LIMITED_TFLOPS,
                          "frac_of_clock_limited_peak": ach / FP64_MFMA_CLOCK_LIMITED_TFLOPS,
                          "traffic": live_traffic[0] if live_traffic[0] is not None else pmc_traffic_per_launch(),
+                         "traffic_measured_live": live_traffic[0] is not None,
                          "traffic_source": (("MEASURED in this run: two child passes of this script under rocprofv3 --pmc (FETCH_SIZE, "
-                                             "WRITE_SIZE; %d trailing-update launches each) before the timed process touched the GPU"
+                                             "WRITE_SIZE; %d trailing-update launches each, the children's warm-up step included) before the timed process touched the GPU"
                                              % live_traffic[1]) if live_traffic[0] is not None else
                                             ((os.path.relpath(pdir, ROOT) + "/final_pmc_{fetch,write}.csv: REPLAYED from the committed "
                                               "rocprofv3 --pmc passes of this same command, not measured in this run (live pass: %s)"
@@ -626,14 +828,29 @@ def main():
                          "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(1.0, prof["launches"]),
                          "algorithmic_flops_per_launch_avg": prof["flops"] / max(1.0, prof["launches"])},
         }
+        out["profiling_cost"] = {"ms_per_step_with_trailing_events": ms_per_step,
+                                 "ms_per_step_without": elapsed_noprof / args.steps * 1e3,
+                                 "note": "`value` is measured WITH the per-launch HIP events of the roofline inside the timed "
+                                         "region (contract); the same steps again without them, same session"}
+        if pb is not None:
+            out["plugin_boundary"] = pb
+        if secondary is not None:
+            out["secondary"] = secondary
         out["config"]["seed"] = 1234
         out["config"]["rng"] = "SplitMix64 + Box-Muller (cipkkt/workloads.py), generated in HBM"
         if c5_single is not None:
             out["c5_single_gpu"] = c5_single
         if not args.no_cpu_baseline:
-            Qh = Q.cpu().numpy()
             cb = cpu_baseline(Qh, n, spf)
             out["cpu_baseline"] = cb
+            if pb is not None and not args.no_converge:
+                try:
+                    hl = host_loop_through_plugin(Qh, c_host, A, b, cone_dims, args.route)
+                    hl["native_loop_wall_s"] = converge_s
+                    hl["iters_native"] = iters
+                    pb["host_loop"] = hl
+                except Exception as e:
+                    pb["host_loop"] = {"error": repr(e)}
             out["gpu_over_cpu"] = (value / world) / cb["value"]                       # against the reference-faithful kktsolver_qr leg
             out["gpu_over_strong_cpu"] = (value / world) / cb["strong_cpu_value"]     # against Schur + LAPACK Cholesky: the honest ratio
         print(json.dumps(out), flush=True)

@@ -113,6 +113,8 @@ SIGNATURES = {
     "cip_lockstep_solve_block_for": (C.c_int, [C.c_int]),
     "cip_profile_trailing_thread": (C.c_int, [C.c_int]),
     "cip_profile_thread_get": (C.c_int, [c_double_p]),
+    "cip_profile_kernel_thread": (C.c_int, [C.c_int, C.c_int]),
+    "cip_profile_kernel_thread_get": (C.c_int, [C.c_int, c_double_p]),
     "cip_set_lazy_copy": (C.c_int, [C.c_int]),
     "cip_set_sdp_lanczos": (C.c_int, [C.c_int]),
     "cip_sdp_lanczos_fallbacks": (C.c_int, [C.c_void_p, c_int_p]),

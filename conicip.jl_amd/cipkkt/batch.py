@@ -148,7 +148,8 @@ def _solve_problems_native(prs, device, in_flight, mode="auto"):
     return [solution_from_result(res[i], ys[i][:dims[i][0]], ws[i][:dims[i][2]], vs[i][:dims[i][1]]) for i in range(k)]
 
 
-def solve_batch(problems, solve_fn=None, rank=0, world=1, dist=None, device=None, concurrency=1, native=False):
+def solve_batch(problems, solve_fn=None, rank=0, world=1, dist=None, device=None, concurrency=1, native=False,
+                reduce_device=None):
     """problems: list of dicts(Q, c, A, b, cone_dims, G, d, kwargs).  Each rank solves its
     shard with `solve_fn` (default: the HIP-backed cipkkt.conicIP) and the statistics are
     reduced over ranks:  SUM(iters, n_factor, n_solve, n_optimal, n_problems), MAX(wall).
@@ -196,7 +197,8 @@ def solve_batch(problems, solve_fn=None, rank=0, world=1, dist=None, device=None
                      len(sols)], dtype=np.float64)
     mx = np.array([wall], dtype=np.float64)
     if dist is not None:                 # also with one rank (bench.py's CIP_BENCH_FORCE_DIST exercises RCCL on one GPU)
-        tdev = device if device is not None else "cpu"
+        # the statistics travel as tensors on `reduce_device` (default: the compute device -- RCCL; "cpu" under gloo)
+        tdev = reduce_device if reduce_device is not None else (device if device is not None else "cpu")
         ts = torch.as_tensor(sums, device=tdev)
         tm = torch.as_tensor(mx, device=tdev)
         dist.all_reduce(ts, op=dist.ReduceOp.SUM)
@@ -208,7 +210,7 @@ def solve_batch(problems, solve_fn=None, rank=0, world=1, dist=None, device=None
 
 
 def run_config5(rank, world, dist, device, steps, warmup, problems=None, count=64, n=2048, seed=4000, in_flight=4,
-                solve_fn=None, barrier=None):
+                solve_fn=None, barrier=None, reduce_device=None):
     """BASELINE config 5 as a timed job (bench.py --gpus N, N > 1; `--workload c5` on one GPU): `count` independent
     problems, problem i -> rank i mod world, every rank's shard resident in HBM before the timed region; a step is one
     pass over the whole batch (each rank its shard, `in_flight` problems at once through cip_conicip_problems).
@@ -227,7 +229,7 @@ def run_config5(rank, world, dist, device, steps, warmup, problems=None, count=6
 
     def one_pass(reduce):
         return solve_batch(problems, solve_fn=solve_fn, rank=rank, world=world, dist=dist if reduce else None,
-                           device=device, concurrency=in_flight, native=solve_fn is None)
+                           device=device, concurrency=in_flight, native=solve_fn is None, reduce_device=reduce_device)
 
     for _ in range(warmup):
         one_pass(False)
@@ -244,7 +246,7 @@ def run_config5(rank, world, dist, device, steps, warmup, problems=None, count=6
         release_cached_memory()                        # the lock-step arena (GBs) is not kept beyond the job
     busy_min = busy_max = busy
     if dist is not None:
-        dev = device if device is not None else "cpu"
+        dev = reduce_device if reduce_device is not None else (device if device is not None else "cpu")
         t = torch.tensor([elapsed, busy, -busy], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, busy_max, busy_min = float(t[0].item()), float(t[1].item()), -float(t[2].item())

@@ -1047,6 +1047,18 @@ extern "C" int cip_profile_get(cip_handle *h, double *out3) {
     if (!h || !out3 || !h->ws.prof) { cip_set_error("profiling not enabled"); return CIP_E_INVALID; }
     return cip_ldlt_profile_collect(h->ws.prof, &out3[0], &out3[1], &out3[2]);
 }
+// HIP-event timing of further dominant kernels on the calling thread (cip_conicip runs on the caller's thread):
+// slot 0 = LDL' trailing update (== cip_profile_trailing_thread), 1 = Schur formation with a dense A, 2 = one-sided Jacobi of
+// a large S cone's NT scaling.  out3 = [launches, total ms, total algorithmic flops (0 for the latency-bound Jacobi)]
+extern "C" int cip_profile_kernel_thread(int slot, int enabled) {
+    if (cip_prof_slot_enable(slot, enabled)) { cip_set_error("cip_profile_kernel_thread: no slot %d", slot); return CIP_E_INVALID; }
+    return 0;
+}
+extern "C" int cip_profile_kernel_thread_get(int slot, double *out3) {
+    if (!out3) return CIP_E_INVALID;
+    if (cip_prof_slot_collect(slot, &out3[0], &out3[1], &out3[2])) { cip_set_error("slot %d: profiling not enabled", slot); return CIP_E_INVALID; }
+    return 0;
+}
 // the calling thread's own trailing-update profile: covers factorisations of handles it does not hold (lock-step batches)
 extern "C" int cip_profile_trailing_thread(int enabled) { return cip_ldlt_profile_thread(enabled); }
 extern "C" int cip_profile_thread_get(double *out3) {

@@ -310,7 +310,10 @@ static int assemble_schur(cip_handle *h, bool lazy_ok) {
         g.C = h->K; g.ldc = h->ldk; g.M = h->npad; g.N = h->npad; g.K = h->mpad;
         g.alpha = 1.0; g.lower = 1; g.Qin = h->Q; g.ldq = n; g.nvalid = n;
         g.ksplit_ws = h->syrk_ws; g.ksplit_n = h->syrk_n; g.ksplit_len = h->syrk_len;
+        // (algorithmic work of the Schur formation: m n^2 flop on the lower half)
+        if ((rc = cip_prof_slot_begin(CIP_PROF_SYRK, s, (double)h->m * (double)n * (double)n * (cip_in_batch() ? (double)__builtin_popcountll(cip_tl_bz.mask) : 1.0)))) return rc;
         if ((rc = cip_launch_gemm(s, EPI_SYRKQ, g))) return rc;
+        if ((rc = cip_prof_slot_end(CIP_PROF_SYRK, s))) return rc;
     } else {
         const int lazy_now = g_lazy_copy.load(std::memory_order_relaxed);
         const int lazy_on = lazy_now < 0 ? cip_lazy_copy_set(-1) : lazy_now;

@@ -128,6 +128,14 @@ void cip_ldlt_profile_destroy(LdltProfile *p);
 int cip_ldlt_profile_collect(LdltProfile *p, double *launches, double *ms, double *flops);
 int cip_ldlt_profile_thread(int enabled);      // a profile of the calling host thread (lock-step batches: bench.py, config 5)
 int cip_ldlt_profile_thread_collect(double *launches, double *ms, double *flops);
+// per-thread event timing of further dominant kernels (ldlt.hip): slot 1 Schur formation, slot 2 large-S Jacobi
+#define CIP_PROF_SLOTS 3
+#define CIP_PROF_SYRK 1
+#define CIP_PROF_JACOBI 2
+int cip_prof_slot_enable(int slot, int enabled);
+int cip_prof_slot_collect(int slot, double *launches, double *ms, double *work);
+int cip_prof_slot_begin(int slot, hipStream_t s, double work);
+int cip_prof_slot_end(int slot, hipStream_t s);
 
 // Expected pivot signs of a quasi-definite matrix in its static order: positive for columns in [p0, p1) and for the
 // identity padding (>= N), negative elsewhere; p0 < 0: unknown, no sign check (stand-alone LDL' entry points)

@@ -126,6 +126,36 @@ int cip_ldlt_profile_thread_collect(double *launches, double *ms, double *flops)
     return cip_ldlt_profile_collect(g_tl_prof, launches, ms, flops);
 }
 
+// The same event-pair timing for other dominant kernels of the secondary configurations, per calling thread (bench.py's
+// `secondary` object: cip_conicip runs on the caller's thread): slot 1 = Schur formation (assemble.hip, dense A), slot 2 = the
+// one-sided Jacobi of a large S cone's NT scaling (sdp_large.hip).  Slot 0 is the trailing update's thread profile above.
+static thread_local LdltProfile *g_tl_aux[CIP_PROF_SLOTS] = {nullptr, nullptr, nullptr};
+int cip_prof_slot_enable(int slot, int enabled) {
+    if (slot == 0) return cip_ldlt_profile_thread(enabled);
+    if (slot < 0 || slot >= CIP_PROF_SLOTS) return -1;
+    if (enabled && !g_tl_aux[slot]) g_tl_aux[slot] = cip_ldlt_profile_create();
+    if (!enabled && g_tl_aux[slot]) { cip_ldlt_profile_destroy(g_tl_aux[slot]); g_tl_aux[slot] = nullptr; }
+    return 0;
+}
+int cip_prof_slot_collect(int slot, double *launches, double *ms, double *flops) {
+    if (slot == 0) return cip_ldlt_profile_thread_collect(launches, ms, flops);
+    if (slot < 0 || slot >= CIP_PROF_SLOTS) return -1;
+    return cip_ldlt_profile_collect(g_tl_aux[slot], launches, ms, flops);
+}
+// begin / end around a launch (or a launch set); no-ops unless the calling thread switched the slot on
+int cip_prof_slot_begin(int slot, hipStream_t s, double work) {
+    LdltProfile *p = (slot > 0 && slot < CIP_PROF_SLOTS && !cip_tl_builder) ? g_tl_aux[slot] : nullptr;
+    if (!p) return 0;
+    int rc = prof_event(p, s);
+    if (rc) return rc;
+    p->flops.push_back(work);
+    return 0;
+}
+int cip_prof_slot_end(int slot, hipStream_t s) {
+    LdltProfile *p = (slot > 0 && slot < CIP_PROF_SLOTS && !cip_tl_builder) ? g_tl_aux[slot] : nullptr;
+    return p ? prof_event(p, s) : 0;
+}
+
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // solve block: largest of {1024, 512, 256, 128} that divides the (128-padded) order

@@ -1246,6 +1246,7 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
         const int nt = rp > 512 ? b * 64 : b * (rp / 8);           // 512 (order 256, b = 16), 256 (b = 8), 1024 (order 512) or 512 (order 1024: 64 lanes x 16 elements per column)
         const size_t shm = (size_t)2 * b * lg_pitch(rp) * sizeof(double);
         CIP_HIP_CHECK(hipMemsetAsync(w->ctr, 0, 1024, s));
+        if ((rc = cip_prof_slot_begin(CIP_PROF_JACOBI, s, 0.0))) return rc;
         if (rp > 512) {
             if ((rc = lg_set_attr((const void *)k_lg_jacobi<512, 16>, shm))) return rc;
             hipLaunchKernelGGL((k_lg_jacobi<512, 16>), dim3(rp / b / 2), dim3(512), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
@@ -1262,6 +1263,7 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
             if ((rc = lg_set_attr((const void *)k_lg_jacobi<1024>, shm))) return rc;
             hipLaunchKernelGGL(k_lg_jacobi<1024>, dim3(rp / b / 2), dim3(1024), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
         }
+        if ((rc = cip_prof_slot_end(CIP_PROF_JACOBI, s))) return rc;
     }
     if (getenv("CIP_LG_DEBUG")) {
         unsigned hc[64];

@@ -293,6 +293,14 @@ int cip_profile_get(cip_handle *h, double *out3);
  * cip_conicip_lockstep live inside the call): flops count every live problem of a lock-step launch */
 int cip_profile_trailing_thread(int enabled);
 int cip_profile_thread_get(double *out3);
+/* the same event-pair timing for the dominant kernels of the other configurations, per calling thread: slot 0 = the trailing
+ * update (as above), 1 = Schur formation S = Q + (A'F^-1)(A'F^-1)' with a dense A (m n^2 flop per call; src/kktsolvers.jl:33-34,
+ * :290), 2 = the one-sided Jacobi of a large S cone's NT scaling (src/ConicIP.jl:204; latency-bound, flops reported as 0) */
+#define CIP_PROFILE_TRAILING 0
+#define CIP_PROFILE_SYRK     1
+#define CIP_PROFILE_JACOBI   2
+int cip_profile_kernel_thread(int slot, int enabled);
+int cip_profile_kernel_thread_get(int slot, double *out3);
 
 #ifdef __cplusplus
 }

@@ -80,3 +80,51 @@ def test_config5_line_through_rccl_on_one_rank():
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
     # identical iteration counts to the oracle over the whole batch (tests/golden/fullsize_trajectories.json)
     assert d["iters_cpu"] == d["iters_gpu"], (d["iters_cpu"], d["iters_gpu"])
+
+
+def test_two_ranks_on_one_gpu():
+    """The N > 1 path with TWO ranks on real kernels (no 8-GPU node is available to the builder): `torch.distributed.run
+    --nproc-per-node 2 bench.py --gpus 2 --workload c5` with CIP_BENCH_SHARE_GPU=1 -- both ranks on cuda:0, process group on
+    gloo (RCCL refuses two ranks per device).  Exercises rank 1's shard generation (problems 1, 3, 5, ...), the
+    rank-0-alone pass behind the barrier, the SUM / MAX reductions over two ranks and the per-rank busy times.  Not a
+    scaling measurement: the ranks share the chip."""
+    env = dict(os.environ, CIP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29733", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--workload", "c5", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    d = _json_line(r)                                       # exactly one line: rank 1 prints nothing
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["ranks_share_one_gpu"] is True
+    assert d["scaling"] == "strong" and d["dtype"] == "f64"
+    assert d["batch"]["n_problems"] == 64 and d["batch"]["n_optimal"] == 64        # both shards, reduced with SUM
+    assert d["iters_cpu"] == d["iters_gpu"], (d["iters_cpu"], d["iters_gpu"])      # the oracle's counts over the whole batch
+    assert d["batch"]["n_factor"] == 627                                           # = the one-GPU run's (tests/test_gpu_lockstep.py)
+    assert "c5_single_gpu" in d and d["c5_single_gpu"]["n_problems"] == 64 and d["c5_single_gpu"]["n_optimal"] == 64
+    assert d["speedup_vs_c5_single_gpu"] > 0
+    lo, hi = d["batch"]["rank_busy_ms_min"], d["batch"]["rank_busy_ms_max"]
+    assert 0 < lo <= hi <= d["ms_per_step"] * 1.001 + 1.0
+    assert abs(d["value"] - d["batch"]["n_factor"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+
+
+def test_default_line_carries_the_round5_objects():
+    """plugin_boundary (host-pointer level-2 / level-3 timings + the reference-shaped host loop through the plugin), the
+    profiling-cost A/B and the explicit measured-vs-replayed flags -- at a reduced order so that the CPU legs take seconds;
+    `secondary` (configs 3 and 4) only runs at the headline size and is covered by the driver's own bench run."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "1024", "--steps", "3", "--warmup", "1", "--no-c5",
+                        "--no-live-pmc"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    d = _json_line(r)
+    pb = d["plugin_boundary"]
+    assert pb["level2_ms"] > 0 and pb["level3_ms"] > 0 and pb["kkt_solves_per_s"] > 0
+    assert abs(pb["kkt_solves_per_s"] - 1e3 / (pb["level2_ms"] + pb["solves_per_factor"] * pb["level3_ms"])) < 1e-6 * pb["kkt_solves_per_s"]
+    hl = pb["host_loop"]
+    assert hl["status"] == "Optimal" and hl["iters"] == d["converge"]["iters"] == hl["iters_native"], hl
+    assert hl["wall_s"] > 0 and hl["native_loop_wall_s"] == d["converge"]["wall_s"]
+    assert d["roofline"]["traffic_measured_live"] is False and d["roofline_solve"]["traffic_measured_live"] is False
+    pc = d["profiling_cost"]
+    assert pc["ms_per_step_with_trailing_events"] == d["ms_per_step"] and pc["ms_per_step_without"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["strong_cpu_variant"] in cb["strong_cpu_variants"] and "potrf" in cb["strong_cpu_variants"]
+    assert cb["strong_cpu_value"] > 0
