@@ -154,3 +154,41 @@ def test_oracle_miles_counterexamples():
 def test_product_miles_counterexamples():
     import cipkkt
     check_miles(cipkkt.preprocess_conicIP)
+
+
+def test_full_row_rank_certificate_agrees_with_the_pivoted_qr():
+    """round 5: the n x n Gram-matrix certificate that lets the pre-solve skip the (dense) pivoted QR of [Q A' G'] -- it may only
+    say "full row rank" when the reference's criterion (every |R_ii| of the pivoted QR of the Frobenius-normalised matrix above
+    1e-8, src/preprocessor.jl:19-23) keeps every row; "not certified" is always allowed."""
+    from cipkkt import preprocess as pp
+    rng = np.random.default_rng(3)
+    n = 40
+    Q = rng.standard_normal((n, n)); Q = Q @ Q.T / n
+    A = sp.identity(n, format="csr")
+    assert pp._full_row_rank([Q, A.T.tocsr(), np.zeros((n, 0))], 1e-8)                 # box QP: [Q I] has full row rank
+    rows, ok = pp.imcols(np.hstack([Q, A.toarray().T]), rng.standard_normal(n))
+    assert ok and rows == list(range(n))
+    # rank deficient: Q = 0 and A' = [I; I] leave n of 2n rows independent -> never certified
+    Z = np.zeros((2 * n, 2 * n))
+    A2 = sp.hstack([sp.identity(n), sp.identity(n)], format="csr")
+    assert not pp._full_row_rank([Z, A2.T.tocsr()], 1e-8)
+    rows, ok = pp.imcols(np.hstack([Z, A2.T.toarray()]), np.ones(2 * n))
+    assert len(rows) == n
+    # nearly dependent rows (sigma_min / ||M||_F ~ 1e-7 < the certificate's margin 1e-6, above the reference's 1e-8): not certified
+    G = rng.standard_normal((3, n))
+    G[2] = G[0] + 1e-6 * rng.standard_normal(n)
+    assert not pp._full_row_rank([G], 1e-8)
+    assert pp._full_row_rank([rng.standard_normal((3, n))], 1e-8)
+    assert not pp._full_row_rank([np.zeros((3, n))], 1e-8)
+
+
+def test_presolve_refuses_a_dense_qr_beyond_the_size_limit(monkeypatch):
+    """a rank-deficient program whose [Q A' G'] is larger than DENSE_QR_LIMIT raises a ValueError that names the shape instead
+    of allocating an n x (n + m + p) dense matrix (limit lowered here so that the case is small)"""
+    from cipkkt import preprocess as pp
+    monkeypatch.setattr(pp, "DENSE_QR_LIMIT", 500)
+    n = 10
+    Q = np.zeros((2 * n, 2 * n))
+    A = sp.hstack([sp.identity(n), sp.identity(n)], format="csr")
+    with pytest.raises(ValueError, match=r"20 x 30"):
+        pp.preprocess_conicIP(Q, -np.ones(2 * n), A, np.zeros(n), [("R", n)])
