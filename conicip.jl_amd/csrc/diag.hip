@@ -29,6 +29,9 @@
 #ifdef DIAG_TIMING
 __device__ long g_diag_t[8 * 8];                 // [kb][slot]: s_memtime stamps (tools/diag_bench.hip)
 #define DIAG_STAMP(kb, slot, cond) do { if (cond) g_diag_t[(kb) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifndef DIAG_TIMING_TID
+#define DIAG_TIMING_TID 64                       // first lane of the helper wave whose phases are stamped (wave 1; 128, 192, 320, 384, 448 for the others)
+#endif
 #else
 #define DIAG_STAMP(kb, slot, cond) do { } while (0)
 #endif
@@ -133,9 +136,24 @@ __device__ __forceinline__ void stepa_pivots(v4d &U, v4d &L, double (&dd)[4]) {
         // the block lives in ONE 16-lane row: a[j][j] and a[k][j] reach the row's lanes by DPP row broadcast (v_mov_b64_dpp /
         // v_fmac_f64_dpp, VALU latency) instead of v_readlane -> SGPR -> VALU (28 clocks on every pivot's chain)
         const double d = row_bcast_t<diag_perm(4 * JB + GJ)>(U[GJ]);
-        dd[GJ] = d;                                    // kept for the output: the in-place MFMAs turn a NaN multiplier into NaNs in
+#ifdef DIAG_NEWTON2
+        const double rho = fast_rcp(d);
+#else
+        // Round 5: ONE Newton step on the chain.  A lone wave pays 6 clocks per fp64 instruction whether it depends on its
+        // predecessor or not, and 17 for v_rcp_f64 (tools/issue_probe.hip): the reciprocal with two Newton steps was 47 of a
+        // pivot's ~150 clocks.  v_rcp_f64 is good to 2^-25, one step leaves <= 11 ulp (two are correctly rounded;
+        // tools/rcp_probe.hip) -- and the factor stays backward stable because the STORED pivot is defined from the reciprocal
+        // that was used, not the other way round: every multiplier is l = u * rho and every update subtracts u_k u_i rho, so what
+        // was computed is exactly consistent with d := 1 / rho, which is what is stored (two Newton steps, off the chain, at the end
+        // of the micro-block), together with rho itself as 1/d.  Against the textbook pivot that d is a relative perturbation of
+        // the matrix's own diagonal entry a[j][j] of <= 11 ulp.  Different rounding than rounds 2-4 (the chain forms of the library
+        // share this code and stay bit-identical to each other).  -DDIAG_NEWTON2 builds the old form for the A/B tools.
+        double rho = __builtin_amdgcn_rcp(d);
+        rho = fma(rho, fma(-d, rho, 1.0), rho);
+#endif
+        dd[GJ] = rho;                                  // kept for the output: the in-place MFMAs turn a NaN multiplier into NaNs in
                                                        // FINISHED columns too (0 * NaN), and the first bad pivot must be reported at its own column
-        L[GJ] = U[GJ] * fast_rcp(d);                   // multipliers l_ij = a_ij / d_j (the diagonal lane holds d/d: never stored)
+        L[GJ] = U[GJ] * rho;                           // multipliers l_ij = a_ij * rho_j (the diagonal lane: never stored)
         stepa_update<JB, GJ, GJ + 1>(U, U, L);         // U[gk] -= a[k][j] * l_ij, a[k][j] (k = 4JB + gk) from the row's lane that holds row k
         stepa_pivots<JB, GJ + 1>(U, L, dd);
     }
@@ -193,15 +211,60 @@ __device__ __forceinline__ void stepa_round(v4d &U, v4d &X, v4d &L, double (&dd)
     }
 }
 #ifndef DIAG_STEP_A_REF
-__device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int lane, int *info, int col0, PivotSigns sg) {
+// Round 5: the serial wave's step C -- the last rank-16 update of the NEXT diagonal micro-block, C -= (L D) L' with L = the
+// tile's own rows of micro-panel kb -- computed straight into step A's register layout (lane (l15, g), register q = element
+// (row P(l15), column 4g + q)): the operand lanes read row P(l15) instead of row l15, the MFMAs are the same four on the same
+// numbers in the same k order (bit-identical to diag_step_c), and the tile never makes the LDS round trip between C and A.
+__device__ __forceinline__ v4d diag_step_c_perm(const double *a, int kb, int l15, int g, const double (&d4)[4]) {
+    const int c = kb * 16, t0 = (kb + 1) * 16, row = diag_perm(l15);
+    const double *cp = a + (t0 + row) + (t0 + 4 * g) * DP;
+    const double *pl = a + (t0 + row) + (c + g) * DP;
+    v4d acc = (v4d){cp[0], cp[DP], cp[2 * DP], cp[3 * DP]};
+    double v[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[s] = pl[4 * s * DP];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = MFMA(v[s], -(v[s] * d4[s]), acc);
+    return acc;
+}
+// Round 5: the serial wave's B and C in one piece.  Its B tile is L21 = the NEXT diagonal micro-block's rows of micro-panel kb
+// (W = U21 inv(L11)', L21 = W D^-1: 4 MFMAs), and its C step needs exactly that tile as BOTH operands (C11 -= (L21 D) L21'):
+// the accumulator layout of v_mfma_f64_16x16x4_f64 is also its operand layout, so L21 goes from B's accumulator registers
+// straight into C's MFMAs -- written to LDS (for the helpers, who read it after the B count) but never read back -- and the
+// C11 tile's loads are issued in front of B.  Rows permuted by P throughout (see diag_step_c_perm): the result is step A's
+// register tile.  Same MFMAs on the same numbers in the same order as diag_step_b + diag_step_c: same bits.
+__device__ __forceinline__ v4d diag_step_bc_perm(double *a, int kb, int l15, int g, const double (&xa)[4], const double (&di4)[4],
+                                                 const double (&d4)[4]) {
+    const int c = kb * 16, t0 = (kb + 1) * 16, row = diag_perm(l15);
+    double *pl = a + (t0 + row) + (c + g) * DP;
+    const double *cp = a + (t0 + row) + (t0 + 4 * g) * DP;
+    double u[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) u[s] = pl[4 * s * DP];
+    v4d acc2 = (v4d){cp[0], cp[DP], cp[2 * DP], cp[3 * DP]};
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = MFMA(xa[s], u[s], acc);
+    double v[4], w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[q] = acc[q] * di4[q]; pl[4 * q * DP] = v[q]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = -(v[q] * d4[q]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc2 = MFMA(v[s], w[s], acc2);
+    return acc2;
+}
+template <bool PRELOADED = false>
+__device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int lane, int *info, int col0, PivotSigns sg,
+                                            v4d U0 = (v4d){0.0, 0.0, 0.0, 0.0}) {
     const int l15 = lane & 15, g = lane >> 4;
     const int c = kb * 16;
     const int row = diag_perm(l15);                            // the tile row / X column this lane holds
     v4d U, X, L = (v4d){0.0, 0.0, 0.0, 0.0};
-    double dd[4] = {0.0, 0.0, 0.0, 0.0};                       // lane group jb: the four pivots d_j of its block
+    double dd[4] = {0.0, 0.0, 0.0, 0.0};                       // lane group jb: the reciprocals rho_j of the four pivots of its block
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        U[q] = a[(c + row) + (c + 4 * g + q) * DP];
+        U[q] = PRELOADED ? U0[q] : a[(c + row) + (c + 4 * g + q) * DP];
         X[q] = (4 * g + q == row) ? 1.0 : 0.0;
     }
     double *scr = xm + kb * 256;                               // [set][kk][l15], three sets: this slot is written at the very end
@@ -216,13 +279,18 @@ __device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int l
         stepa_round<3>(U, X, L, dd, scr, l15, g);
     }
     STEPA_STAMP(17);
-    double dsel = 0.0;
+    double rsel = 0.0;                                         // the reciprocal the lane's diagonal pivot was used with
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int col = 4 * g + q;
-        const double v = (col == row) ? dd[q] : L[q];          // d on the diagonal, l_ij below (above: not stored)
+        if (col == row) rsel = dd[q];
+    }
+    const double dsel = fast_rcp(rsel);                        // the stored pivot d := 1 / rho (correctly rounded in all but 1 of 4000 cases)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int col = 4 * g + q;
+        const double v = (col == row) ? dsel : L[q];           // d on the diagonal, l_ij below (above: not stored)
         if (col <= row) a[(c + row) + (c + col) * DP] = v;
-        if (col == row) dsel = dd[q];
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) xm[kb * 256 + row * 16 + 4 * g + q] = X[q];      // xm[k = cc][jj = r] = X[r][cc]
@@ -243,7 +311,7 @@ __device__ __forceinline__ void diag_step_a(double *a, double *xm, int kb, int l
         if (mdead && lane == __ffsll((long long)mdead) - 1) atomicCAS(info + 2, 0, col + 1);
         if (diag_lane) {
             a[128 + (c + row) * DP] = dsel;
-            a[129 + (c + row) * DP] = fast_rcp(dsel);
+            a[129 + (c + row) * DP] = rsel;
         }
     }
 }
@@ -381,7 +449,14 @@ __device__ __forceinline__ void diag_step_c_multi(double *a, int kb, int idx, in
 __device__ __forceinline__ void diag_tile_left(double *a, int it, int jt, int nsteps, int l15, int g) {
     double *cp = a + (it * 16 + l15) + (jt * 16 + g) * DP;
     const double *pj = a + (jt * 16 + l15) + g * DP, *pi = a + (it * 16 + l15) + g * DP, *pd = a + 128 + g * DP;
+    // Round 5: TWO accumulation chains.  With one accumulator and fresh operands per MFMA a step's four MFMAs cost ~100 clocks each
+    // (tools/diag_bench -DDIAG_TIMING; back to back on fixed registers they issue every 64, tools/issue_probe.hip), and from
+    // micro-panel 3 on the helpers, not the serial wave, bound the diagonal kernel (3100 ticks of tiles at kb = 3 beside 3850 of
+    // C + A, and the helpers also store the panel).  Now the k-slices alternate between acc (which starts from C) and acc2
+    // (which starts from zero), C' = acc + acc2 at the end: 3100 -> 2100 ticks.  A different summation order than rounds 3-4 --
+    // the same for every tile of every chain form of the library, all of which run this code.
     v4d acc = (v4d){cp[0], cp[4 * DP], cp[8 * DP], cp[12 * DP]};
+    v4d acc2 = (v4d){0.0, 0.0, 0.0, 0.0};
     double lj[4], li[4], dv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { lj[k] = pj[4 * k * DP]; li[k] = pi[4 * k * DP]; dv[k] = pd[4 * k * DP]; }
@@ -390,13 +465,15 @@ __device__ __forceinline__ void diag_tile_left(double *a, int it, int jt, int ns
         const int o = (s + 1 < nsteps ? 16 * (s + 1) : 16 * s) * DP;      // (the last step re-reads its own operands: no branch around the loads)
 #pragma unroll
         for (int k = 0; k < 4; ++k) { nj[k] = pj[o + 4 * k * DP]; ni[k] = pi[o + 4 * k * DP]; nd[k] = pd[o + 4 * k * DP]; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc = MFMA(lj[k], -(li[k] * dv[k]), acc);
+        acc = MFMA(lj[0], -(li[0] * dv[0]), acc);
+        acc2 = MFMA(lj[1], -(li[1] * dv[1]), acc2);
+        acc = MFMA(lj[2], -(li[2] * dv[2]), acc);
+        acc2 = MFMA(lj[3], -(li[3] * dv[3]), acc2);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { lj[k] = nj[k]; li[k] = ni[k]; dv[k] = nd[k]; }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cp[4 * q * DP] = acc[q];
+    for (int q = 0; q < 4; ++q) cp[4 * q * DP] = acc[q] + acc2[q];
 }
 
 // X block row `it` (runtime, wave-uniform): tiles kept in registers, statically indexed
@@ -615,6 +692,7 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
             }
         }
     } else if (!(DIAG_SKIP & 16) && (NW == 4 || tid < 256)) diag_load_block(a, Kb, ld, tid);
+    if (tid < 3) *(unsigned *)(a + 130 + tid) = 0u;                     // the phase counts of the loop below (pitch padding of column 0; rows 128 / 129 hold d and 1/d)
     __syncthreads();
 
     // Schedule per 16-column micro-panel kb (A(0) first):
@@ -628,6 +706,89 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
     if (wave == 0) diag_step_a(a, xm, 0, lane, info, col0, sg);
     __syncthreads();
     PANEL_STAMP(6, WAIT && PUB && tid == 0);                            // A(0) done, B(0) starts
+#ifndef DIAG_STEP_A_REF
+    if constexpr (NW > 4) {
+        // Round 5: the micro-panel loop WITHOUT workgroup barriers.  What each wave really waits for:
+        //   serial wave, step kb : the helpers' tiles of step kb-1 (its B tile (kb+1, kb) and its C tile (kb+1, kb+1) are among them)
+        //   helpers, step kb     : A(kb) (the micro inverse, d, 1/d), the tiles of step kb-1 (their B tiles), then everybody's B(kb)
+        // With a barrier behind B and one at the end of the step the serial wave also waited for the helpers' B tiles (which it
+        // never reads; two helper waves share a SIMD and an MFMA pipe: 130-590 ticks per step) and for their panel stores (up to
+        // 1500 ticks at the step whose four tiles put two tile waves on one SIMD).  Now every working wave counts itself on an LDS
+        // word when a phase's LDS writes are done (the DS operations of a wave complete in order) and a reader polls the word it
+        // needs; the helpers do their tiles FIRST and write the finished micro-panel back afterwards, beside the next step.
+        // tools/diag_bench: 21.2 -> 19.x us per kernel with the other round-5 changes.  The polls are bounded (never hang the GPU).
+        unsigned *bflag = (unsigned *)(a + 130), *tflag = (unsigned *)(a + 131), *aflag = (unsigned *)(a + 132);
+        auto count = [&](unsigned *f) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        auto wait_for = [&](unsigned *f, unsigned want) {
+            if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+                const long t0 = __builtin_amdgcn_s_memtime();
+                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memtime() - t0 > 2000000000L) { atomicCAS(info + 3, 0, -8); break; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+        if (!idle) {
+            for (int kb = 0; kb < 7; ++kb) {
+                const int c = kb * 16;
+                if (wave != 0) wait_for(aflag, (unsigned)kb);                  // A(kb): counted by the serial wave (A(0): the barrier above)
+                wait_for(tflag, (unsigned)(kb * NH));                          // the helpers' tiles of step kb - 1
+                double xa[4], di4[4], d4[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    xa[s] = xm[kb * 256 + (g + 4 * s) * 16 + l15];       // Aop[jj = l15][k = g + 4s]
+                    di4[s] = a[129 + (c + g + 4 * s) * DP];
+                    d4[s] = a[128 + (c + g + 4 * s) * DP];
+                }
+                DIAG_STAMP(kb, 0, tid == 0);                                  // wave 0: starts B(kb)
+                DIAG_STAMP(kb, 4, tid == DIAG_TIMING_TID);
+                v4d U1 = (v4d){0.0, 0.0, 0.0, 0.0};
+                if (!(DIAG_SKIP & 4)) {
+                    // (kb+1, kb+1): steps 0 .. kb-1 were applied by a helper during step kb-1, step kb is this wave's
+                    if (wave == 0) U1 = diag_step_bc_perm(a, kb, l15, g, xa, di4, d4);
+                    else { for (int it = kb + 2 + hid; it < 8; it += NH) diag_step_b(a, it, c, l15, g, xa, di4); }
+                }
+                DIAG_STAMP(kb, 1, tid == 0);                                  // B (serial wave: B + C) done
+                DIAG_STAMP(kb, 5, tid == DIAG_TIMING_TID);
+                count(bflag);
+                DIAG_STAMP(kb, 2, tid == 0);
+                if (wave == 0) {
+                    if (!(DIAG_SKIP & 4)) diag_step_a<true>(a, xm, kb + 1, lane, info, col0, sg, U1);
+                    else diag_step_a(a, xm, kb + 1, lane, info, col0, sg);
+                    count(aflag);
+                    PANEL_STAMP(20 + kb, WAIT && PUB && tid == 0);              // A(kb + 1) done
+                    DIAG_STAMP(kb, 3, tid == 0);                              // C11 + A(kb+1) done
+                } else if (!(DIAG_SKIP & 4)) {
+                    wait_for(bflag, (unsigned)((kb + 1) * (NH + 1)));         // everybody's B(kb): the tiles below read them
+                    DIAG_STAMP(kb, 6, tid == DIAG_TIMING_TID);                // helper: B of all waves seen
+                    // left-looking: the tiles that are needed NEXT -- column kb+1 below its diagonal tile (the panel of step kb+1) and
+                    // the diagonal tile (kb+2, kb+2) (wave 0's C11 of step kb+1) -- receive all their steps 0 .. kb now
+                    const int ncol = 6 - kb;
+                    const int ntl = ncol + (kb + 2 <= 7 ? 1 : 0);
+                    for (int t = hid; t < ntl; t += NH) {
+                        const int it = t < ncol ? kb + 2 + t : kb + 2, jt = t < ncol ? kb + 1 : kb + 2;
+                        diag_tile_left(a, it, jt, kb + 1, l15, g);
+                    }
+                    count(tflag);
+                    DIAG_STAMP(kb, 7, tid == DIAG_TIMING_TID);                // helper: tiles done and counted
+                    // micro-panel kb is final: written back (and published) now, beside the serial wave's step and the next B
+                    if (!(DIAG_SKIP & 16)) diag_store_panel<PUB>(a, Kb, ld, c, hid * 64 + lane, 64 * NH);
+                    if (PUB) {
+                        diag_publish_micro(a, xm, xm_out, dvec, dinv, kb, hid * 64 + lane, 64 * NH);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the wave's stores have landed -> its count
+                        if (lane == 0) atomicAdd(stage, 1u);
+                    }
+                } else count(tflag);
+            }
+        }
+        __syncthreads();                                                       // A(7) and the helpers' last stores
+    } else
+#endif
+    {
     for (int kb = 0; kb < 7; ++kb) {
         const int c = kb * 16;
         double xa[4], di4[4], d4[4];
@@ -638,7 +799,7 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
             d4[s] = a[128 + (c + g + 4 * s) * DP];
         }
         DIAG_STAMP(kb, 0, tid == 0);                                  // wave 0: past the barrier that follows A(kb)
-        DIAG_STAMP(kb, 4, tid == 64);
+        DIAG_STAMP(kb, 4, tid == DIAG_TIMING_TID);
         if (!(DIAG_SKIP & 4))
         {
             if (NW == 4) { for (int it = kb + 1 + wave; it < 8; it += 4) diag_step_b(a, it, c, l15, g, xa, di4); }
@@ -646,20 +807,35 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
             else if (!idle) { for (int it = kb + 2 + hid; it < 8; it += NH) diag_step_b(a, it, c, l15, g, xa, di4); }
         }
         DIAG_STAMP(kb, 1, tid == 0);                                  // B done
-        DIAG_STAMP(kb, 5, tid == 64);
+        DIAG_STAMP(kb, 5, tid == DIAG_TIMING_TID);
         __syncthreads();
         DIAG_STAMP(kb, 2, tid == 0);                                  // past the B barrier
         if (wave == 0) {
             // (kb+1, kb+1): steps 0 .. kb-1 were applied by a helper during step kb-1, step kb is this wave's
+#ifdef DIAG_STEP_A_REF
             if (!(DIAG_SKIP & 4)) diag_step_c(a, kb + 1, kb + 1, c, l15, g, d4);
             diag_step_a(a, xm, kb + 1, lane, info, col0, sg);
+#else
+            if (!(DIAG_SKIP & 4)) diag_step_a<true>(a, xm, kb + 1, lane, info, col0, sg, diag_step_c_perm(a, kb, l15, g, d4));
+            else diag_step_a(a, xm, kb + 1, lane, info, col0, sg);
+#endif
             DIAG_STAMP(kb, 3, tid == 0);                              // C11 + A(kb+1) done
+            PANEL_STAMP(20 + kb, WAIT && PUB && tid == 0);
         } else if (!(DIAG_SKIP & 4) && !idle) {
             // micro-panel kb is final (A(kb) and B(kb) are behind the barrier): the helper waves write it back now, under
             // wave 0's serial step, instead of in a store phase at the end of the kernel
-            if (!(DIAG_SKIP & 16)) diag_store_panel<PUB>(a, Kb, ld, c, hid * 64 + lane, 64 * NH);
-            if (PUB) diag_publish_micro(a, xm, xm_out, dvec, dinv, kb, hid * 64 + lane, 64 * NH);
-            DIAG_STAMP(kb, 6, tid == 64);                             // helper: panel stores issued
+            // (round 5) from micro-panel 3 on two or more helpers have no tile below: they alone write the panel back, the tile
+            // waves go straight to their tiles
+            const int ntile_waves = 7 - kb < NH ? 7 - kb : NH;           // = min(ntl, NH), ntl as computed below
+            const int nfree = NH - ntile_waves;
+            const bool split = NW > 4 && nfree >= 2;
+            const bool storer = !split || hid >= ntile_waves;
+            const int st_t = split ? (hid - ntile_waves) * 64 + lane : hid * 64 + lane, st_n = split ? 64 * nfree : 64 * NH;
+            if (storer) {
+                if (!(DIAG_SKIP & 16)) diag_store_panel<PUB>(a, Kb, ld, c, st_t, st_n);
+                if (PUB) diag_publish_micro(a, xm, xm_out, dvec, dinv, kb, st_t, st_n);
+            }
+            DIAG_STAMP(kb, 6, tid == DIAG_TIMING_TID);                // helper: panel stores issued
 #ifndef DIAG_STEP_A_REF
             // left-looking: the tiles that are needed NEXT -- column kb+1 below its diagonal tile (the panel of step kb+1) and
             // the diagonal tile (kb+2, kb+2) (wave 0's C11 of step kb+1) -- receive all their steps 0 .. kb now
@@ -679,16 +855,25 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
                 else diag_step_c_multi<1>(a, kb, idx, NH, c, l15, g, d4);
             }
 #endif
-            DIAG_STAMP(kb, 7, tid == 64);                             // helper: C tiles done
+            #ifndef DIAG_TIMING_END
+            DIAG_STAMP(kb, 7, tid == DIAG_TIMING_TID);                // helper: C tiles done
+#endif
             if (PUB) {                                            // the wave's stores have landed -> its count
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) atomicAdd(stage, 1u);
             }
-            // L' of the micro-panel: behind the count (nobody waits for these stores; placed in front of it they held every
-            // helper at the count's vmcnt(0) for a store round trip and the panel launches ran 1.3 us longer)
-            if (!(DIAG_SKIP & 16)) diag_store_panel_T(a, Kb, ld, c, hid * 64 + lane, 64 * NH);
+            // L' of the micro-panel: NOT here (round 5).  Nobody reads the upper triangle before the solves, and the helper waves
+            // -- two per SIMD, the serial wave alone on the fourth -- are what the serial wave waits for at this barrier from
+            // micro-panel 2 on (tools/diag_bench -DDIAG_TIMING -DDIAG_TIMING_END -DDIAG_TIMING_TID=..: a helper with a tile on a SIMD
+            // that hosts two tile waves needs 5100 ticks for stores + tile + transposed stores beside the serial wave's 3900).
+            // The whole block's transpose is written by all the waves behind the last micro-panel, under the tail of the launch's
+            // TRSM strips, which follow this workgroup one stage behind.
+#ifdef DIAG_TIMING_END
+            DIAG_STAMP(kb, 7, tid == DIAG_TIMING_TID);                // (instead of "tiles done": the helper's whole phase, transposed stores included)
+#endif
         }
         __syncthreads();
+    }
     }
     PANEL_STAMP(7, WAIT && PUB && tid == 0);                            // last pivot done
     if (PUB) {
@@ -698,12 +883,15 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
         __syncthreads();
         if (tid == 0) atomicAdd(stage, (unsigned)NH);
         PANEL_STAMP(8, WAIT && tid == 0);
-        diag_store_panel_T(a, Kb, ld, 112, tid, 64 * NW);
+        // (round 5: the diagonal block's own transpose is NOT written any more.  The solves read L' from the upper triangle only
+        //  OUTSIDE their Bs-wide diagonal blocks (ldlt.hip: cip_ldlt_solve, K + C0 + (C0 + Bs) ld; Bs >= 128), the diagonal blocks
+        //  go through the explicit block inverses: these 128 x 128 transposes -- 1.3 us at the tail of every panel launch since
+        //  round 4 -- had no reader.  The strips still store theirs: wave_store_T.)
         return;
     }
 
     // ---- last micro-panel, d and the micro inverses out; the strictly upper part of K is left untouched
-    if (!(DIAG_SKIP & 16)) { diag_store_panel(a, Kb, ld, 112, tid, 64 * NW); diag_store_panel_T(a, Kb, ld, 112, tid, 64 * NW); }
+    if (!(DIAG_SKIP & 16)) diag_store_panel(a, Kb, ld, 112, tid, 64 * NW);
     if (tid < CIP_NB) {
         dvec[tid] = a[128 + tid * DP];
         dinv[tid] = a[129 + tid * DP];

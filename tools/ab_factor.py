@@ -17,7 +17,7 @@ for r in range(rounds):
             env[k] = v
         elif path != "default":
             env["CIPKKT_LIB"] = os.path.abspath(path)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-c5", "--n", n, "--steps", "20", "--warmup", "3"],
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-c5", "--no-secondary", "--no-plugin-boundary", "--n", n, "--steps", "20", "--warmup", "3"],
                              capture_output=True, text=True, env=env)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not line:

@@ -23,3 +23,5 @@ for rep in range(3):
     assert lib.cip_debug_panel_stamps(t) == 0
     t0 = t[0]
     print("rep", rep, " | ".join("%s %.2f" % (names[i], (t[i] - t0) / 100.0) for i in (0, 9, 4, 2, 6, 7, 8, 12, 13, 14, 15, 16, 17, 18, 19) if t[i]))
+    if t[20]:
+        print("      serial wave, A(1..7) done at", " ".join("%.2f" % ((t[20 + k] - t0) / 100.0) for k in range(7)))

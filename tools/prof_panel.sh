@@ -6,7 +6,7 @@ for a in "$@"; do
   name=${a%%=*}; path=${a#*=}
   [ "$path" = default ] && unset CIPKKT_LIB || export CIPKKT_LIB=$R/$path
   rm -rf /tmp/pp_$name
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp_$name -o t -- python3 $R/bench.py --no-cpu-baseline --no-c5 --no-converge --steps 10 --warmup 2 > $OUT/$name.json 2> $OUT/$name.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp_$name -o t -- python3 $R/bench.py --no-cpu-baseline --no-c5 --no-converge --no-secondary --no-plugin-boundary --steps 10 --warmup 2 > $OUT/$name.json 2> $OUT/$name.err
   f=$(find /tmp/pp_$name -name "*kernel_stats.csv" | head -1)
   cp $f $OUT/${name}_kernel_stats.csv
   echo "== $name"; python3 - "$f" <<'PY'
