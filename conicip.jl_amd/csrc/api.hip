@@ -402,6 +402,7 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
     DMALLOC(h->mt1, sizeof(double) * m); DMALLOC(h->mt2, sizeof(double) * m); DMALLOC(h->mt3, sizeof(double) * m);
     DMALLOC(h->nt1, sizeof(double) * n); DMALLOC(h->pt1, sizeof(double) * p);
     DMALLOC(h->dot_scratch, sizeof(double) * (32 * 32 + 64));
+    CIP_HIP_CHECK(hipMemsetAsync(h->dot_scratch + 32 * 32 + 32, 0, sizeof(double) * 32, s));      // the completion counters of vecops.hip: k_dots
     DMALLOC(h->dot_ptrs, 32 * 32);
     DMALLOC(h->stage, sizeof(double) * 2 * (size_t)(n + p + m));
     CIP_HIP_CHECK(hipEventCreate(&h->ev0)); CIP_HIP_CHECK(hipEventCreate(&h->ev1)); CIP_HIP_CHECK(hipEventCreate(&h->ev2));
@@ -868,6 +869,14 @@ extern "C" int cip_solve2x2(cip_handle *h, const double *y, const double *w, dou
     return 0;
 }
 
+// diag F (the packed scaling) when the cone set is R cones only -- the native loops then fuse the cone operations of their
+// element-wise chains into the vector kernels (vecops.hip: k_loop_*); NULL otherwise (or with CIP_LOOP_FUSED_R=0)
+const double *cip_loop_all_r(cip_handle *h) {
+    static const int on = [] { const char *e = getenv("CIP_LOOP_FUSED_R"); return e ? atoi(e) : 1; }();
+    if (!on || h->m <= 0) return nullptr;
+    for (int q = 0; q < h->cs.ncones; ++q) if (h->h_cones[q].type != CIP_CONE_R) return nullptr;
+    return h->cs.d_scal;
+}
 // solve4x4 (src/ConicIP.jl:684-692):  q = r.s (./) lambda ; t1 = F'q ; (dy,dw,dv) = solve3x3(r.y, r.w, r.v + t1) ;
 // ds = t1 - F'(F dv).   r, dz are contiguous (y[n], w[p], v[m], s[m]).
 extern "C" int cip_solve4x4_dev(cip_handle *h, const double *lambda, const double *r, double *dz) {

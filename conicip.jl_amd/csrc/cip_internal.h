@@ -287,6 +287,15 @@ int cip_copy_neg(hipStream_t s, int len, const double *x, double *y, double scal
 int cip_axpby_ps(hipStream_t s, int len, const double *alpha_host, const double *x, double beta, double *y);   // batch: alpha per problem
 int cip_zero(hipStream_t s, long len, double *y);                     // batch-aware memset(0) of doubles
 int cip_copy(hipStream_t s, long len, const double *x, double *y);    // batch-aware device-to-device copy
+struct cip_handle;
+const double *cip_loop_all_r(cip_handle *h);     // api.hip: the packed scaling = diag F when every cone is an R cone (and CIP_LOOP_FUSED_R != 0), else NULL
+// the element-wise chains of the interior-point loop, one kernel each (vecops.hip; f != NULL: all cones R, cone operations fused in)
+int cip_loop_resid(hipStream_t s, int n, int m, int p, double *rl, const double *zs, const double *c, const double *d, const double *b,
+                   const double *lam, const double *f, double *r0, double *Gy, double *Ays);
+int cip_loop_corr(hipStream_t s, int n, int m, int p, const double *r0, const double *daff, const double *mb3, const double *e,
+                  const double *f, const double *sigmu_host, double *r);
+int cip_loop_refine(hipStream_t s, int n, int m, int p, double *rk, const double *dz, const double *r, const double *lam,
+                    const double *mb2, const double *mb3, const double *f, double *rIr);
 
 // ---- wave-level sums without LDS permutes (DPP row operations + v_permlane16/32_swap): every lane ends with the same bits.
 // All lanes of the wave must be active.  (__shfl_xor is a ds_bpermute round trip per step: six dependent ones per 64-lane sum.)

@@ -81,6 +81,7 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
     if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(d_d, d_host, sizeof(double) * p, hipMemcpyHostToDevice, h->stream));
     const Norms nm = host_norms(n, m, p, c_host, b_host, d_host);
     const double conedim = cone_degree(h);                                          // (:547-552); e (:559-565) below
+    const double *f = cip_loop_all_r(h);            // diag F when every cone is an R cone (the loop's cone operations are then fused into its vector kernels), else NULL
     int rc;
 #define CK(x) do { if ((rc = (x)) != 0) return rc; } while (0)
     if (m > 0) CK(cip_cone_identity_dev(h, e));
@@ -121,17 +122,23 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
         IterRange iter_range;
         if (m > 0) CK(cip_set_scaling_from_iterate_dev(h, z.v, z.s, lam));             // :732-735 (F, lambda = F v)
         CK(cip_factor(h)); ++n_factor;                                                 // :737 -> :682
-        if (m > 0) CK(cip_cone_prod_dev(h, lam, lam, rleft.s));                        // :746
+        // (round 5) the element-wise part of :746-753 is one kernel (vecops.hip: k_loop_resid) behind the mat-vecs; with R cones
+        // only (f != NULL) lam o lam is formed there too
+        if (m > 0 && !f) CK(cip_cone_prod_dev(h, lam, lam, rleft.s));                  // :746
         CK(cip_gemv_dev(h, CIP_MAT_Q, 0, 1.0, z.y, 0.0, Qy));                          // needed by the certificates
-        CK(D.kkt_apply(z, rleft, Qy));                                                 // :747-750
-        CIP_HIP_CHECK(hipMemsetAsync(pinf, 0, sizeof(double) * n, h->stream));
-        if (p > 0) { CK(cip_gemv_dev(h, CIP_MAT_G, 1, 1.0, z.w, 0.0, pinf)); CK(D.copy(p, rleft.w, Gy)); }
-        if (m > 0) { CK(cip_gemv_dev(h, CIP_MAT_A, 1, -1.0, z.v, 1.0, pinf)); CK(D.copy(m, rleft.v, Ays)); }
-        // r0 = rleft - (c, d, b, 0)   (:753)
-        CK(D.copy(D.NT, rleft.base, r0.base));
-        CK(D.axpby(n, -1.0, c_d, 1.0, r0.y));
-        CK(D.axpby(p, -1.0, d_d, 1.0, r0.w));
-        CK(D.axpby(m, -1.0, b_d, 1.0, r0.v));
+        CK(D.copy(n, Qy, rleft.y));                                                    // :747-750: Q y + G'w - A'v, G y, A y (- s: in the kernel)
+        if (p > 0) {
+            CK(cip_gemv_dev(h, CIP_MAT_G, 1, 1.0, z.w, 1.0, rleft.y));
+            CK(cip_gemv_dev(h, CIP_MAT_G, 0, 1.0, z.y, 0.0, rleft.w));
+            CK(cip_gemv_dev(h, CIP_MAT_G, 1, 1.0, z.w, 0.0, pinf));
+        }
+        if (m > 0) {
+            CK(cip_gemv_dev(h, CIP_MAT_A, 1, -1.0, z.v, 1.0, rleft.y));
+            CK(cip_gemv_dev(h, CIP_MAT_A, 0, 1.0, z.y, 0.0, rleft.v));
+            CK(cip_gemv_dev(h, CIP_MAT_A, 1, -1.0, z.v, p > 0 ? 1.0 : 0.0, pinf));     // pinf = G'w - A'v (a zero start when p == 0: the same bits)
+        } else if (p == 0) CIP_HIP_CHECK(hipMemsetAsync(pinf, 0, sizeof(double) * n, h->stream));
+        // rleft.v -= s, [rleft.s = lam o lam], Gy = rleft.w, Ays = rleft.v, r0 = rleft - (c, d, b, 0)   (:753)
+        CK(cip_loop_resid(h->stream, n, m, p, rleft.base, z.s, c_d, d_d, b_d, lam, f, r0.base, Gy, Ays));
 
         const double *px[16] = {z.v, c_d, r0.y, r0.v, r0.s, z.y, z.w, z.v, d_d, b_d, pinf, z.y, z.v, Ays, Gy, Qy};
         const double *py[16] = {z.s, z.y, r0.y, r0.v, r0.s, Qy, r0.w, r0.v, z.w, z.v, pinf, z.y, z.v, Ays, Gy, Qy};
@@ -172,30 +179,37 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
         }
 
         // ------------------------------------------------------------ corrector (:893-901)
-        CK(D.copy(D.NT, r0.base, r.base));
-        if (m > 0) {
+        // r = r0 ; r.s += (F^-T d_aff.s) o (F d_aff.v) - sigma mu e     -- one kernel (vecops.hip: k_loop_corr); the cone operations in
+        // front of it unless every cone is an R cone
+        if (m > 0 && !f) {
             CK(cip_apply_F_dev(h, CIP_OP_FINVT, daff.s, mb1));                         // F^-T d_aff.s
             CK(cip_apply_F_dev(h, CIP_OP_F, daff.v, mb2));                             // F d_aff.v
             CK(cip_cone_prod_dev(h, mb1, mb2, mb3));
-            // lc = -(mb3 - sigma mu e) ; r.s = rleft.s - lc
-            CK(D.axpby(m, 1.0, mb3, 1.0, r.s));
-            CK(D.axpby(m, -sigma * mu, e, 1.0, r.s));
         }
+        if (m > 0) { const double sm = sigma * mu; CK(cip_loop_corr(h->stream, n, m, p, r0.base, daff.base, mb3, e, f, &sm, r.base)); }
+        else CK(D.copy(D.NT, r0.base, r.base));
 
         // ------------------------------------------------------------ Newton step + refinement (:907-921)
         CK(cip_solve4x4_dev(h, lam, r.base, dz.base)); ++n_solve;
         for (int it = 0; it < o.maxRefinementSteps; ++it) {
-            CK(D.kkt_apply(dz, rkkt));
-            if (m > 0) {
-                CK(cip_apply_F_dev(h, CIP_OP_F, dz.v, mb1));
-                CK(cip_cone_prod_dev(h, lam, mb1, mb2));
-                CK(cip_apply_F_dev(h, CIP_OP_FINVT, dz.s, mb1));
-                CK(cip_cone_prod_dev(h, lam, mb1, mb3));
-                CK(D.copy(m, mb2, rkkt.s));
-                CK(D.axpby(m, 1.0, mb3, 1.0, rkkt.s));
+            // rkkt = K dz (mat-vecs), then rkkt.v -= dz.s, rkkt.s = lam o (F dz.v) + lam o (F^-T dz.s), rIr = r - rkkt: one kernel
+            // (vecops.hip: k_loop_refine)
+            CK(cip_gemv_dev(h, CIP_MAT_Q, 0, 1.0, dz.y, 0.0, rkkt.y));
+            if (p > 0) {
+                CK(cip_gemv_dev(h, CIP_MAT_G, 1, 1.0, dz.w, 1.0, rkkt.y));
+                CK(cip_gemv_dev(h, CIP_MAT_G, 0, 1.0, dz.y, 0.0, rkkt.w));
             }
-            CK(D.copy(D.NT, r.base, rIr.base));
-            CK(D.axpby(D.NT, -1.0, rkkt.base, 1.0, rIr.base));
+            if (m > 0) {
+                CK(cip_gemv_dev(h, CIP_MAT_A, 1, -1.0, dz.v, 1.0, rkkt.y));
+                CK(cip_gemv_dev(h, CIP_MAT_A, 0, 1.0, dz.y, 0.0, rkkt.v));
+                if (!f) {
+                    CK(cip_apply_F_dev(h, CIP_OP_F, dz.v, mb1));
+                    CK(cip_cone_prod_dev(h, lam, mb1, mb2));
+                    CK(cip_apply_F_dev(h, CIP_OP_FINVT, dz.s, mb1));
+                    CK(cip_cone_prod_dev(h, lam, mb1, mb3));
+                }
+            }
+            CK(cip_loop_refine(h->stream, n, m, p, rkkt.base, dz.base, r.base, lam, mb2, mb3, f, rIr.base));
             const double *nx[4] = {rIr.y, rIr.w, rIr.v, rIr.s};
             const int nl[4] = {n, p, m, m};
             double n2[4];

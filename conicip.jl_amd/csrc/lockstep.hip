@@ -231,6 +231,7 @@ static int lockstep_group(int B, int call_count, const cip_problem *probs, const
     double *e = V.e, *lam = V.lam, *mb1 = V.mb1, *mb2 = V.mb2, *mb3 = V.mb3;
     double *Qy = V.Qy, *pinf = V.pinf, *Ays = V.Ays, *Gy = V.Gy;
     const double conedim = cone_degree(h);
+    const double *f = cip_loop_all_r(h);                   // diag F of problem 0 (the kernels shift it per problem) when every cone is an R cone
 
     // ---- per-problem host state
     std::vector<Norms> nm(B);
@@ -347,16 +348,21 @@ static int lockstep_group(int B, int call_count, const cip_problem *probs, const
         h->assembled = h->factored = false;
         CK(factor());                                                                      // :737 -> :682
         const unsigned long long factored_mask = active;
-        if (m > 0) CK(cip_cones_prod(s, h->cs, lam, lam, rleft.s));                        // :746
+        // (round 5: the element-wise chains are the one-problem loop's fused kernels, driver.hip / vecops.hip: k_loop_*)
+        if (m > 0 && !f) CK(cip_cones_prod(s, h->cs, lam, lam, rleft.s));                  // :746
         CK(cip_gemv_dev(h, CIP_MAT_Q, 0, 1.0, zv.y, 0.0, Qy));
-        CK(kkt_apply(zv, rleft, Qy));                                                      // :747-750
-        CK(cip_zero(s, n, pinf));
-        if (p > 0) { CK(cip_gemv_dev(h, CIP_MAT_G, 1, 1.0, zv.w, 0.0, pinf)); CK(copy(p, rleft.w, Gy)); }
-        if (m > 0) { CK(cip_gemv_dev(h, CIP_MAT_A, 1, -1.0, zv.v, 1.0, pinf)); CK(copy(m, rleft.v, Ays)); }
-        CK(copy(NT, rleft.base, r0.base));                                                 // :753
-        CK(axpby(n, -1.0, c_d, 1.0, r0.y));
-        CK(axpby(p, -1.0, d_d, 1.0, r0.w));
-        CK(axpby(m, -1.0, b_d, 1.0, r0.v));
+        CK(copy(n, Qy, rleft.y));                                                          // :747-750
+        if (p > 0) {
+            CK(cip_gemv_dev(h, CIP_MAT_G, 1, 1.0, zv.w, 1.0, rleft.y));
+            CK(cip_gemv_dev(h, CIP_MAT_G, 0, 1.0, zv.y, 0.0, rleft.w));
+            CK(cip_gemv_dev(h, CIP_MAT_G, 1, 1.0, zv.w, 0.0, pinf));
+        }
+        if (m > 0) {
+            CK(cip_gemv_dev(h, CIP_MAT_A, 1, -1.0, zv.v, 1.0, rleft.y));
+            CK(cip_gemv_dev(h, CIP_MAT_A, 0, 1.0, zv.y, 0.0, rleft.v));
+            CK(cip_gemv_dev(h, CIP_MAT_A, 1, -1.0, zv.v, p > 0 ? 1.0 : 0.0, pinf));
+        } else if (p == 0) CK(cip_zero(s, n, pinf));
+        CK(cip_loop_resid(s, n, m, p, rleft.base, zv.s, c_d, d_d, b_d, lam, f, r0.base, Gy, Ays));       // :753
         const double *px[16] = {zv.v, c_d, r0.y, r0.v, r0.s, zv.y, zv.w, zv.v, d_d, b_d, pinf, zv.y, zv.v, Ays, Gy, Qy};
         const double *py[16] = {zv.s, zv.y, r0.y, r0.v, r0.s, Qy, r0.w, r0.v, zv.w, zv.v, pinf, zv.y, zv.v, Ays, Gy, Qy};
         const int ln[16] = {m, n, n, m, m, n, p, m, p, m, n, n, m, m, p, n};
@@ -401,15 +407,15 @@ static int lockstep_group(int B, int call_count, const cip_problem *probs, const
         }
 
         // ------------------------------------------------------------ corrector (:893-901)
-        CK(copy(NT, r0.base, r.base));
-        if (m > 0) {
+        if (m > 0 && !f) {
             CK(cip_cones_apply(s, h->cs, CIP_OP_FINVT, daff.s, mb1));
             CK(cip_cones_apply(s, h->cs, CIP_OP_F, daff.v, mb2));
             CK(cip_cones_prod(s, h->cs, mb1, mb2, mb3));
-            CK(axpby(m, 1.0, mb3, 1.0, r.s));
-            for (int z = 0; z < B; ++z) tmpB[z] = -sigma[z] * mu[z];
-            CK(cip_axpby_ps(s, m, tmpB.data(), e, 1.0, r.s));
         }
+        if (m > 0) {
+            for (int z = 0; z < B; ++z) tmpB[z] = sigma[z] * mu[z];
+            CK(cip_loop_corr(s, n, m, p, r0.base, daff.base, mb3, e, f, tmpB.data(), r.base));
+        } else CK(copy(NT, r0.base, r.base));
 
         // ------------------------------------------------------------ Newton step + refinement (:907-921)
         CK(cip_solve4x4_dev(h, lam, r.base, dz.base));
@@ -418,17 +424,22 @@ static int lockstep_group(int B, int call_count, const cip_problem *probs, const
         bool step_known = false;
         for (int it = 0; it < o.maxRefinementSteps && refine; ++it) {
             set_mask(refine);
-            CK(kkt_apply(dz, rkkt, nullptr));
-            if (m > 0) {
-                CK(cip_cones_apply(s, h->cs, CIP_OP_F, dz.v, mb1));
-                CK(cip_cones_prod(s, h->cs, lam, mb1, mb2));
-                CK(cip_cones_apply(s, h->cs, CIP_OP_FINVT, dz.s, mb1));
-                CK(cip_cones_prod(s, h->cs, lam, mb1, mb3));
-                CK(copy(m, mb2, rkkt.s));
-                CK(axpby(m, 1.0, mb3, 1.0, rkkt.s));
+            CK(cip_gemv_dev(h, CIP_MAT_Q, 0, 1.0, dz.y, 0.0, rkkt.y));
+            if (p > 0) {
+                CK(cip_gemv_dev(h, CIP_MAT_G, 1, 1.0, dz.w, 1.0, rkkt.y));
+                CK(cip_gemv_dev(h, CIP_MAT_G, 0, 1.0, dz.y, 0.0, rkkt.w));
             }
-            CK(copy(NT, r.base, rIr.base));
-            CK(axpby(NT, -1.0, rkkt.base, 1.0, rIr.base));
+            if (m > 0) {
+                CK(cip_gemv_dev(h, CIP_MAT_A, 1, -1.0, dz.v, 1.0, rkkt.y));
+                CK(cip_gemv_dev(h, CIP_MAT_A, 0, 1.0, dz.y, 0.0, rkkt.v));
+                if (!f) {
+                    CK(cip_cones_apply(s, h->cs, CIP_OP_F, dz.v, mb1));
+                    CK(cip_cones_prod(s, h->cs, lam, mb1, mb2));
+                    CK(cip_cones_apply(s, h->cs, CIP_OP_FINVT, dz.s, mb1));
+                    CK(cip_cones_prod(s, h->cs, lam, mb1, mb3));
+                }
+            }
+            CK(cip_loop_refine(s, n, m, p, rkkt.base, dz.base, r.base, lam, mb2, mb3, f, rIr.base));
             const double *nx[4] = {rIr.y, rIr.w, rIr.v, rIr.s};
             const int nl[4] = {n, p, m, m};
             // the step's two max-steps ride on this read-back (first pass only): when no problem asks for refinement -- the usual

@@ -165,14 +165,16 @@ __global__ __launch_bounds__(256) void k_lg_vecm_sym(const double *Y, double *ou
     const double y = Y[i + (long)j * rp] + Y[j + (long)i * rp];
     out[lg_vidx(i, j, r)] = (i == j) ? y : y * LG_SQRT2;
 }
-// T = (L D^1/2)' as a dense matrix, from the factored K (unit L strictly below, L' mirrored above, d separately):
+// T = (L D^1/2)' as a dense matrix, from the factored K (unit L strictly below the diagonal, d separately):
 //   T[i, k] = L[k, i] sqrt(d_i)  (k > i),  sqrt(d_i) on the diagonal, 0 below
+// L is read from the LOWER triangle (round 5: the factorisation no longer mirrors the 128 x 128 diagonal blocks into the upper
+// triangle -- the solves never read them there -- and this kernel was the one reader; a strided read of a <= 8 MB matrix)
 __global__ __launch_bounds__(256) void k_lg_tfac(const double *K, const double *d, double *T, int rp) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (long)rp * rp) return;
     const int i = (int)(e % rp), k = (int)(e / rp);
     const double sd = sqrt(d[i]);
-    T[e] = (i < k) ? K[e] * sd : (i == k ? sd : 0.0);
+    T[e] = (i < k) ? K[k + (long)i * rp] * sd : (i == k ? sd : 0.0);
 }
 // lam[j] = || G[:, j] ||   (one wave per column)
 __global__ __launch_bounds__(256) void k_lg_colnorm(const double *G, double *lam, int rp) {

@@ -196,6 +196,40 @@ __global__ __launch_bounds__(64) void k_dots2(const double *partial, double *out
     }
 }
 
+// Round 5: both stages in ONE launch.  The block that completes a dot's DOT_NB partial sums (a counter per dot, left at zero again
+// for the next call) adds them up exactly as k_dots2 does -- the partials read with agent-scope loads: they were written by other
+// CUs, and this CU's vector cache may still hold the previous call's values at the same addresses.  Same bits, one dependent
+// launch (~4 us) less per dot-product group, three or four groups per interior-point iteration.  CIP_DOTS_FUSED=0: two launches.
+__global__ __launch_bounds__(256) void k_dots(const DotPtrs *p, double *partial, unsigned *cnt, double *out, double *gather, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    __shared__ double sh[4];
+    __shared__ unsigned last;
+    DotPtrs d = p[blockIdx.y];
+    CIP_BO3(cb, d.x, d.y, partial);
+    CIP_BO2(cb, cnt, out);
+    double s = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < d.len; i += (long)DOT_NB * 256) s += d.x[i] * d.y[i];
+    s = wsum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&partial[blockIdx.y * DOT_NB + blockIdx.x], (sh[0] + sh[1]) + (sh[2] + sh[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        last = __hip_atomic_fetch_add(&cnt[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == DOT_NB - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        double t = (threadIdx.x < DOT_NB) ? __hip_atomic_load(&partial[blockIdx.y * DOT_NB + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        t = wsum(t);
+        if (threadIdx.x == 0) {
+            out[blockIdx.y] = t;
+            if (gather) gather[blockIdx.z * CIP_GATHER + blockIdx.y] = t;
+            __hip_atomic_store(&cnt[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 #define DOT_MAX 32
 int cip_dots(hipStream_t s, int count, const double *const *x_host, const double *const *y_host, const int *len_host,
              double *scratch_dev, void *ptrs_dev, double *out_host) {
@@ -209,12 +243,19 @@ int cip_dots(hipStream_t s, int count, const double *const *x_host, const double
     double *partial = scratch_dev;
     double *out = scratch_dev + DOT_MAX * DOT_NB;
     const CipBatchCtx &bc = cip_tl_bz;
-    cip_launch_b(k_dots1, dim3(DOT_NB, count), dim3(256), 0, s, (const DotPtrs *)ptrs_dev, partial);
     CipHostScratch hs;
     int rc;
     if ((rc = cip_host_scratch(&hs))) return rc;
     const bool direct = bc.B <= 1 && count <= 512;                 // one problem: the sums go straight to the host
-    cip_launch_b(k_dots2, dim3(count), dim3(64), 0, s, (const double *)partial, direct ? hs.dev : out, bc.B > 1 ? bc.gather_dev : (double *)nullptr);
+    static const int fused = [] { const char *e = getenv("CIP_DOTS_FUSED"); return e ? atoi(e) : 1; }();
+    if (fused) {
+        unsigned *cnt = (unsigned *)(scratch_dev + DOT_MAX * DOT_NB + DOT_MAX);         // zeroed when the scratch was allocated; every call leaves it zero
+        cip_launch_b(k_dots, dim3(DOT_NB, count), dim3(256), 0, s, (const DotPtrs *)ptrs_dev, partial, cnt, direct ? hs.dev : out,
+                     bc.B > 1 ? bc.gather_dev : (double *)nullptr);
+    } else {
+        cip_launch_b(k_dots1, dim3(DOT_NB, count), dim3(256), 0, s, (const DotPtrs *)ptrs_dev, partial);
+        cip_launch_b(k_dots2, dim3(count), dim3(64), 0, s, (const double *)partial, direct ? hs.dev : out, bc.B > 1 ? bc.gather_dev : (double *)nullptr);
+    }
     CIP_HIP_CHECK(hipGetLastError());
     if (bc.B > 1) {
         // out_host: B x count, problem-major; masked-off problems keep whatever the gather buffer held (callers ignore them)
@@ -268,11 +309,16 @@ int cip_wait(hipStream_t s) {
     }
 }
 
+// y = alpha x + beta y as ONE explicit operation: the product beta y rounded, then a fused multiply-add -- written out so that the
+// fused kernels of the interior-point loop below (round 5) reproduce a chain of k_axpby launches bit for bit
+__device__ __forceinline__ double axpby_op(double alpha, double x, double beta, double y) {
+    return fma(alpha, x, beta == 0.0 ? 0.0 : beta * y);
+}
 __global__ __launch_bounds__(256) void k_axpby(int len, double alpha, const double *x, double beta, double *y, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO2(cb, x, y);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < len; i += (long)gridDim.x * 256)
-        y[i] = alpha * x[i] + (beta == 0.0 ? 0.0 : beta * y[i]);
+        y[i] = axpby_op(alpha, x[i], beta, y[i]);
 }
 int cip_axpby(hipStream_t s, int len, double alpha, const double *x, double beta, double *y) {
     if (len <= 0) return 0;
@@ -292,7 +338,7 @@ __global__ __launch_bounds__(256) void k_axpby_ps(int len, CipScal64 alpha, cons
     CIP_BO2(cb, x, y);
     const double a = alpha.v[blockIdx.z];
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < len; i += (long)gridDim.x * 256)
-        y[i] = a * x[i] + (beta == 0.0 ? 0.0 : beta * y[i]);
+        y[i] = axpby_op(a, x[i], beta, y[i]);
 }
 int cip_axpby_ps(hipStream_t s, int len, const double *alpha_host, const double *x, double beta, double *y) {
     if (len <= 0) return 0;
@@ -403,6 +449,118 @@ int cip_s4_post_r(hipStream_t s, int m, int n, int p, const double *f, const dou
     int len = m > n ? m : n;
     if (p > len) len = p;
     cip_launch_b(k_s4_post_r, dim3((len + 255) / 256), dim3(256), 0, s, m, n, p, f, t, rhs, u_dense, A_rp, A_ci, A_v, dy, dw, dv, ds);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round 5: the element-wise chains of the interior-point loop as ONE kernel each (src/ConicIP.jl:746-753, :893-901, :912-917).
+// An iteration was 117 launches of which ~45 were 3-6 us element-wise kernels whose work is a fraction of their launch slot
+// (profiles/r4/c5_b8_iter_timeline.txt).  Each kernel below applies, per element, exactly the operations of the launches it
+// replaces in their order (axpby_op for every axpby / copy -- a copy is axpby(1, x, 0, .) --, the R-cone formulas of cones.hip:
+// product x * y, F x = x * f, F^-T x = x / f), so the per-operation loop of cipkkt/driver.py, which still issues the separate
+// launches through the C ABI, and the two native loops that use these kernels walk the same bits (tests/test_gpu_driver.py).
+// `f` != NULL: every cone is an R cone (f = the packed scaling = diag F) and the cone operations of the chain are fused in as well;
+// f == NULL: the caller has run the cone kernels and passes their results.
+// (No contraction here either: this file's `fp contract(off)` pragma above holds to its end; fma() is explicit.)
+struct LoopDims { int n, m, p; };
+// residual chain.  In: rl = (Q y + G'w - A'v, G y, A y, [lam o lam]) with rl.s filled only when f == NULL; z.s; c, d, b; lam.
+// Out: rl.v = A y - s, [rl.s = lam o lam], Gy = copy(rl.w), Ays = copy(rl.v), r0 = copy(rl) - (c, d, b, 0)
+__global__ __launch_bounds__(256) void k_loop_resid(LoopDims D, double *rl, const double *zs, const double *c, const double *d, const double *b,
+                                                     const double *lam, const double *f, double *r0, double *Gy, double *Ays, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO8(cb, rl, zs, c, d, b, lam, r0, Gy);
+    CIP_BO1(cb, Ays);
+    if (f) CIP_BO1(cb, f);
+    const long NT = (long)D.n + D.p + 2L * D.m;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < NT; i += (long)gridDim.x * 256) {
+        if (i < D.n) {
+            r0[i] = axpby_op(-1.0, c[i], 1.0, axpby_op(1.0, rl[i], 0.0, 0.0));
+        } else if (i < D.n + D.p) {
+            const long j = i - D.n;
+            const double w = rl[i];
+            Gy[j] = axpby_op(1.0, w, 0.0, 0.0);
+            r0[i] = axpby_op(-1.0, d[j], 1.0, axpby_op(1.0, w, 0.0, 0.0));
+        } else if (i < D.n + D.p + D.m) {
+            const long j = i - D.n - D.p;
+            const double v = axpby_op(-1.0, zs[j], 1.0, rl[i]);              // A y - s
+            rl[i] = v;
+            Ays[j] = axpby_op(1.0, v, 0.0, 0.0);
+            r0[i] = axpby_op(-1.0, b[j], 1.0, axpby_op(1.0, v, 0.0, 0.0));
+        } else {
+            const long j = i - D.n - D.p - D.m;
+            double sv;
+            if (f) { sv = lam[j] * lam[j]; rl[i] = sv; } else sv = rl[i];
+            r0[i] = axpby_op(1.0, sv, 0.0, 0.0);
+        }
+    }
+}
+// corrector right-hand side: r = copy(r0); r.s += mb3; r.s -= sigma mu e, with mb3 = (F^-T daff.s) o (F daff.v) given
+// (f == NULL) or formed here (all R cones)
+__global__ __launch_bounds__(256) void k_loop_corr(LoopDims D, const double *r0, const double *daff, const double *mb3, const double *e,
+                                                    const double *f, CipScal64 sigmu, double *r, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO5(cb, r0, daff, mb3, e, r);
+    if (f) CIP_BO1(cb, f);
+    const long NT = (long)D.n + D.p + 2L * D.m, so = (long)D.n + D.p + D.m, vo = (long)D.n + D.p;
+    const double sm = sigmu.v[blockIdx.z];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < NT; i += (long)gridDim.x * 256) {
+        double x = axpby_op(1.0, r0[i], 0.0, 0.0);
+        if (i >= so) {
+            const long j = i - so;
+            double t3;
+            if (f) { const double fj = f[j]; const double t1 = daff[so + j] / fj, t2 = daff[vo + j] * fj; t3 = t1 * t2; }
+            else t3 = mb3[j];
+            x = axpby_op(1.0, t3, 1.0, x);
+            x = axpby_op(-sm, e[j], 1.0, x);
+        }
+        r[i] = x;
+    }
+}
+// refinement residual: rk = (Q dy + G'dw - A'dv, G dy, A dy, .) in; rk.v -= dz.s; rk.s = lam o (F dz.v) + lam o (F^-T dz.s) (given as
+// mb2, mb3 when f == NULL); rIr = copy(r) - rk
+__global__ __launch_bounds__(256) void k_loop_refine(LoopDims D, double *rk, const double *dz, const double *r, const double *lam,
+                                                      const double *mb2, const double *mb3, const double *f, double *rIr, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO7(cb, rk, dz, r, lam, mb2, mb3, rIr);
+    if (f) CIP_BO1(cb, f);
+    const long NT = (long)D.n + D.p + 2L * D.m, so = (long)D.n + D.p + D.m, vo = (long)D.n + D.p;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < NT; i += (long)gridDim.x * 256) {
+        double k = rk[i];
+        if (i >= so) {
+            const long j = i - so;
+            double t2, t3;
+            if (f) { const double fj = f[j], lj = lam[j]; t2 = lj * (dz[vo + j] * fj); t3 = lj * (dz[so + j] / fj); }
+            else { t2 = mb2[j]; t3 = mb3[j]; }
+            k = axpby_op(1.0, t3, 1.0, axpby_op(1.0, t2, 0.0, 0.0));
+            rk[i] = k;
+        } else if (i >= vo) {
+            k = axpby_op(-1.0, dz[so + (i - vo)], 1.0, k);
+            rk[i] = k;
+        }
+        rIr[i] = axpby_op(-1.0, k, 1.0, axpby_op(1.0, r[i], 0.0, 0.0));
+    }
+}
+static int loop_grid(long NT) { long nb = (NT + 255) / 256; return (int)(nb > 2048 ? 2048 : (nb < 1 ? 1 : nb)); }
+int cip_loop_resid(hipStream_t s, int n, int m, int p, double *rl, const double *zs, const double *c, const double *d, const double *b,
+                   const double *lam, const double *f, double *r0, double *Gy, double *Ays) {
+    cip_launch_b(k_loop_resid, dim3(loop_grid((long)n + p + 2L * m)), dim3(256), 0, s, LoopDims{n, m, p}, rl, zs, c, d, b, lam, f, r0, Gy, Ays);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+// sigmu_host: one value, or B values in a lock-step batch
+int cip_loop_corr(hipStream_t s, int n, int m, int p, const double *r0, const double *daff, const double *mb3, const double *e,
+                  const double *f, const double *sigmu_host, double *r) {
+    CipScal64 a;
+    const int B = cip_tl_bz.B > 1 ? cip_tl_bz.B : 1;
+    for (int z = 0; z < CIP_BATCH_MAX; ++z) a.v[z] = z < B ? sigmu_host[z] : 0.0;
+    cip_launch_b(k_loop_corr, dim3(loop_grid((long)n + p + 2L * m)), dim3(256), 0, s, LoopDims{n, m, p}, r0, daff, mb3, e, f, a, r);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int cip_loop_refine(hipStream_t s, int n, int m, int p, double *rk, const double *dz, const double *r, const double *lam,
+                    const double *mb2, const double *mb3, const double *f, double *rIr) {
+    cip_launch_b(k_loop_refine, dim3(loop_grid((long)n + p + 2L * m)), dim3(256), 0, s, LoopDims{n, m, p}, rk, dz, r, lam, mb2, mb3, f, rIr);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }
