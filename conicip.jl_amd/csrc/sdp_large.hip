@@ -57,6 +57,11 @@ struct LargeWs {
     int ncols = 0;
     const double *amat_src[CIP_MAX_LARGE_S] = {};   // the A' the images were built from (null: not built)
     unsigned *ctr;                 // barrier counters / sweep flags (256 words)
+    // round 5: warm start of the one-sided Jacobi (see cip_sdp_large_nt): the right singular vectors of the previous NT scaling of
+    // every large cone, and three work matrices
+    double *Vw = nullptr;          // nlarge x rp x rp
+    double *G0 = nullptr, *W1 = nullptr, *W2 = nullptr;
+    int have_v[CIP_MAX_LARGE_S] = {};
     void *ldl_z = nullptr, *ldl_s = nullptr;
     LdltWorkspace wz, ws;
     int xz_z = 0, xz_s = 0;        // the upper triangles of their block inverses have been zeroed (they stay zero)
@@ -243,6 +248,7 @@ __global__ void k_lg_flag(const int *info_a, const int *info_b, int *flag) {
 // sum over a group of tpp = 32 or 64 consecutive lanes (aligned), in every lane: DPP + lane swaps, no LDS permutes
 __device__ __forceinline__ double lg_sum_group(double x, int tpp) {
     x = lz_sum16(x);
+    if (tpp == 16) return x;
     return tpp == 64 ? lz_sum_rows(x) : lz_sum_row_pair(x);
 }
 // ------------------------------------------------------------------------------------------ block one-sided Jacobi
@@ -586,12 +592,14 @@ int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out) {
     }
     w->ncols = ncols;
     const bool cache_mat = ncols > 0 && w->chunk >= ncols && (size_t)nlarge * ncols * m2 <= ((size_t)4 << 30) && !(getenv("CIP_LG_AMAT") && atoi(getenv("CIP_LG_AMAT")) == 0);
-    size_t bytes = (cache_mat ? (size_t)nlarge * ncols * m2 : 0) + 8 * m2 + LG_NPAD * (size_t)nlarge * m2 + al256(12 * (size_t)rp * 8) + 2 * (size_t)w->chunk * m2 + al256(1024) +
+    size_t bytes = (cache_mat ? (size_t)nlarge * ncols * m2 : 0) + 8 * m2 + (3 + (size_t)nlarge) * m2 + LG_NPAD * (size_t)nlarge * m2 + al256(12 * (size_t)rp * 8) + 2 * (size_t)w->chunk * m2 + al256(1024) +
                    2 * al256(cip_ldlt_ws_bytes(rp));
     CIP_HIP_CHECK(hipMalloc((void **)&w->base, bytes));
     char *p = (char *)w->base;
     double **mats[8] = {&w->Kz, &w->Ks, &w->Tz, &w->Ts, &w->G, &w->M1, &w->M2, &w->M3};
     for (auto m : mats) { *m = (double *)p; p += m2; }
+    w->G0 = (double *)p; p += m2; w->W1 = (double *)p; p += m2; w->W2 = (double *)p; p += m2;
+    w->Vw = (double *)p; p += (size_t)nlarge * m2;
     w->Rip = (double *)p; p += LG_NPAD * (size_t)nlarge * m2;
     w->vec = (double *)p; p += al256(12 * (size_t)rp * 8);
     w->batchX = (double *)p; p += (size_t)w->chunk * m2;
@@ -1223,6 +1231,29 @@ static int lg_tridiag(hipStream_t s, LargeWs *w, const double *M, const double *
     return 0;
 }
 
+// dst = src' (optionally row j of dst scaled by 1 / sc[j]^2), rp x rp through a 32 x 33 LDS tile
+__global__ __launch_bounds__(256) void k_lg_transpose(const double *src, double *dst, int rp, const double *sc) {
+    __shared__ double t[32][33];
+    const int bi = blockIdx.x * 32, bj = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int q = 0; q < 32; q += 8) t[ty + q][tx] = src[(bi + tx) + (long)(bj + ty + q) * rp];        // t[j][i] = src[i, j]
+    __syncthreads();
+    for (int q = 0; q < 32; q += 8) {
+        const int j = bj + tx, i = bi + ty + q;                                                      // dst[j, i] = src[i, j]
+        double v = t[tx][ty + q];
+        if (sc) { const double s1 = sc[j]; v = v / (s1 * s1); }
+        dst[j + (long)i * rp] = v;
+    }
+}
+// M <- 1.5 I - 0.5 M   (the Newton-Schulz factor of V <- V (3 I - V'V) / 2)
+__global__ __launch_bounds__(256) void k_lg_ns(double *M, int rp) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)rp * rp) return;
+    M[e] = ((e % rp) == (e / rp) ? 1.5 : 0.0) - 0.5 * M[e];
+}
+static int lg_warm(void) {
+    static const int on = [] { const char *e = getenv("CIP_LG_WARM"); return e ? atoi(e) : 1; }();
+    return on;
+}
 // nestod_sdc for one large cone (index li among the large cones)
 int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, const double *v, const double *sv, double *scal,
                      double *lambda, int *flag) {
@@ -1237,6 +1268,29 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
     hipLaunchKernelGGL(k_lg_tfac, lg_grid(n2), dim3(256), 0, s, w->Kz, w->wz.dvec, w->Tz, rp);
     hipLaunchKernelGGL(k_lg_tfac, lg_grid(n2), dim3(256), 0, s, w->Ks, w->ws.dvec, w->Ts, rp);
     if ((rc = lg_gemm(s, w->G, 0, w->Tz, 0, w->Ts, 0, rp, 1))) return rc;           // G = Lz' Ls          (:204)
+    // Round 5: WARM START of the one-sided Jacobi.  svd(G) = U Sigma V' is needed for U and Sigma only (:204-208), and the
+    // Jacobi below may start from G W for ANY orthogonal W: the left singular vectors and the singular values are those of G.
+    // Between two interior-point iterations the NT scaling moves little, so with W = the right singular vectors V of the previous
+    // scaling of this cone the columns of G W are already nearly orthogonal and the sweeps drop from 8 to 2-4 (each sweep of order
+    // 256 is 255 latency-bound rotation rounds, 0.38 ms: the NT scaling was 30 % of config 4's iteration).  V is not tracked
+    // through the rotations: afterwards, with the columns A_f = U Sigma in hand, V = G' A_f Sigma^-2 is one GEMM; before it is
+    // used again one Newton-Schulz step V <- V (3 I - V'V) / 2 restores its orthogonality to rounding (G' U Sigma^-1 is orthogonal
+    // only to cond(G) eps, and a W that is not orthogonal would change the answer by that much).  Four extra 256^3 products per
+    // scaling (~5 us each).  The first scaling after the packed scaling was replaced from outside (cip_set_scaling_identity at the
+    // start of every interior-point solve, cip_set_scaling_packed) starts cold: a solve's results do not depend on what the handle
+    // did before.  CIP_LG_WARM=0 switches it off.
+    const dim3 tg(rp / 32, rp / 32);
+    double *Vw = w->Vw + (size_t)li * n2;
+    const bool keep_v = lg_warm() != 0;
+    if (keep_v) CIP_HIP_CHECK(hipMemcpyAsync(w->G0, w->G, sizeof(double) * n2, hipMemcpyDeviceToDevice, s));
+    if (keep_v && w->have_v[li]) {
+        hipLaunchKernelGGL(k_lg_transpose, tg, dim3(256), 0, s, (const double *)Vw, w->W1, rp, (const double *)nullptr);      // V'
+        if ((rc = lg_gemm(s, w->W2, 0, w->W1, 0, w->W1, 0, rp, 1))) return rc;                                              // V'V
+        hipLaunchKernelGGL(k_lg_ns, lg_grid(n2), dim3(256), 0, s, w->W2, rp);                                               // 1.5 I - 0.5 V'V (symmetric)
+        if ((rc = lg_gemm(s, w->W1, 0, Vw, 0, w->W2, 0, rp, 1))) return rc;                                                 // Vn = V (1.5 I - 0.5 V'V)
+        hipLaunchKernelGGL(k_lg_transpose, tg, dim3(256), 0, s, (const double *)w->W1, w->W2, rp, (const double *)nullptr);  // Vn'
+        if ((rc = lg_gemm(s, w->G, 0, w->G0, 0, w->W2, 0, rp, 1))) return rc;                                               // G <- G Vn
+    }
     {
         // column blocks of 8 at order 256 (16 workgroups of 256 threads; round 4, with the DPP sums: 4 / 8 / 16 / 32 wide ->
         // 3.95 / 3.11 / 3.25 / 4.48 ms per NT scaling -- a rotation round is bound by the hand-over between the wave's lane groups
@@ -1249,7 +1303,12 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
         const size_t shm = (size_t)2 * b * lg_pitch(rp) * sizeof(double);
         CIP_HIP_CHECK(hipMemsetAsync(w->ctr, 0, 1024, s));
         if ((rc = cip_prof_slot_begin(CIP_PROF_JACOBI, s, 0.0))) return rc;
-        if (rp > 512) {
+        if (rp == 256 && bforce == 116) {                  // A/B form (round 5): 16-column blocks, 16 lanes x 16 elements per column, 4 waves, 8 workgroups -- half the
+                                                           // outer rounds, shorter lane sums, and SLOWER: config 4 8.41 against 8.03 ms per iteration
+            const size_t shm16 = (size_t)2 * 16 * lg_pitch(rp) * sizeof(double);
+            if ((rc = lg_set_attr((const void *)k_lg_jacobi<256, 16>, shm16))) return rc;
+            hipLaunchKernelGGL((k_lg_jacobi<256, 16>), dim3(rp / 16 / 2), dim3(256), shm16, s, w->G, rp, 16, w->ctr, (int *)(w->ctr + 128));
+        } else if (rp > 512) {
             if ((rc = lg_set_attr((const void *)k_lg_jacobi<512, 16>, shm))) return rc;
             hipLaunchKernelGGL((k_lg_jacobi<512, 16>), dim3(rp / b / 2), dim3(512), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
         } else if (nt == 128) {
@@ -1277,6 +1336,12 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
     }
     double *lam = w->vec;
     hipLaunchKernelGGL(k_lg_colnorm, dim3((rp + 3) / 4), dim3(256), 0, s, w->G, lam, rp);
+    if (keep_v) {                                                                                                           // V = G0' (A_f Sigma^-2) for the next call
+        hipLaunchKernelGGL(k_lg_transpose, tg, dim3(256), 0, s, (const double *)w->G, w->W1, rp, (const double *)lam);        // (A_f Sigma^-2)'
+        hipLaunchKernelGGL(k_lg_transpose, tg, dim3(256), 0, s, (const double *)w->G0, w->W2, rp, (const double *)nullptr);   // G0'
+        if ((rc = lg_gemm(s, Vw, 0, w->W2, 0, w->W1, 0, rp, 1))) return rc;
+        w->have_v[li] = 1;
+    }
     hipLaunchKernelGGL(k_lg_build, lg_grid(n2), dim3(256), 0, s, w->G, lam, w->wz.dvec, w->Kz, w->M1, w->M2, w->M3, rp);
     const double *XTz = (w->wz.Bs == CIP_NB) ? w->wz.LinvT : w->wz.XT;             // inv(Lz_unit)' (one block = the matrix)
     if ((rc = lg_gemm(s, w->Tz, 0, XTz, 0, w->M1, 0, rp, 1))) return rc;            // R    = Lz^-T U Lambda^1/2   (:206-208)
@@ -1292,6 +1357,7 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
 // padded Rinv after the host replaced the packed scaling
 int cip_sdp_large_refresh(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, const double *scal) {
     const int r = cd.r, rp = w->rp;
+    w->have_v[li] = 0;                                     // the next NT scaling of this cone starts its Jacobi cold
     hipLaunchKernelGGL(k_lg_pad, lg_grid((long)rp * rp), dim3(256), 0, s, scal + cd.soff, scal + cd.soff + (size_t)r * r,
                        w->Rip + LG_NPAD * (size_t)li * rp * rp, r, rp);
     CIP_HIP_CHECK(hipGetLastError());

@@ -199,7 +199,9 @@ __global__ __launch_bounds__(64) void k_dots2(const double *partial, double *out
 // Round 5: both stages in ONE launch.  The block that completes a dot's DOT_NB partial sums (a counter per dot, left at zero again
 // for the next call) adds them up exactly as k_dots2 does -- the partials read with agent-scope loads: they were written by other
 // CUs, and this CU's vector cache may still hold the previous call's values at the same addresses.  Same bits, one dependent
-// launch (~4 us) less per dot-product group, three or four groups per interior-point iteration.  CIP_DOTS_FUSED=0: two launches.
+// launch (~4 us) less per dot-product group, three or four groups per interior-point iteration -- and NOT faster: the in-launch
+// hand-off (write-through store, wait, atomic, coherent re-load) costs what the launch boundary does (8 / 64 problems of order 2048
+// in lock-step: 16.7 / 79.8 ms per pass against 15.9 / 78.3 with two launches).  Off by default; CIP_DOTS_FUSED=1 selects it.
 __global__ __launch_bounds__(256) void k_dots(const DotPtrs *p, double *partial, unsigned *cnt, double *out, double *gather, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     __shared__ double sh[4];
@@ -213,13 +215,16 @@ __global__ __launch_bounds__(256) void k_dots(const DotPtrs *p, double *partial,
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
+        // written through (agent-scope store), waited for, then counted: NO release / acquire fences -- on this chip an agent-scope
+        // release is an L2 write-back, and tens of thousands of blocks doing one each made a 64-problem lock-step pass 8 % slower
+        // than the two-launch form (the library's other in-launch hand-offs are built the same way: diag.hip st_pub / ld_pub)
         __hip_atomic_store(&partial[blockIdx.y * DOT_NB + blockIdx.x], (sh[0] + sh[1]) + (sh[2] + sh[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         last = __hip_atomic_fetch_add(&cnt[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == DOT_NB - 1;
     }
     __syncthreads();
     if (last && threadIdx.x < 64) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("" ::: "memory");
         double t = (threadIdx.x < DOT_NB) ? __hip_atomic_load(&partial[blockIdx.y * DOT_NB + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         t = wsum(t);
         if (threadIdx.x == 0) {
@@ -247,7 +252,7 @@ int cip_dots(hipStream_t s, int count, const double *const *x_host, const double
     int rc;
     if ((rc = cip_host_scratch(&hs))) return rc;
     const bool direct = bc.B <= 1 && count <= 512;                 // one problem: the sums go straight to the host
-    static const int fused = [] { const char *e = getenv("CIP_DOTS_FUSED"); return e ? atoi(e) : 1; }();
+    static const int fused = [] { const char *e = getenv("CIP_DOTS_FUSED"); return e ? atoi(e) : 0; }();
     if (fused) {
         unsigned *cnt = (unsigned *)(scratch_dev + DOT_MAX * DOT_NB + DOT_MAX);         // zeroed when the scratch was allocated; every call leaves it zero
         cip_launch_b(k_dots, dim3(DOT_NB, count), dim3(256), 0, s, (const DotPtrs *)ptrs_dev, partial, cnt, direct ? hs.dev : out,

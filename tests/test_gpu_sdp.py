@@ -468,3 +468,108 @@ def test_csr_A_with_mixed_R_Q_S_cones_equals_dense_A(route):
         N = n + p
         np.testing.assert_allclose(np.tril(Kc[:N, :N]), np.tril(Kd[:N, :N]), rtol=1e-12, atol=1e-12 * np.abs(Kd).max())
         kd.close(); kc.close()
+
+
+# ------------------------------------------------------------------ the edges of the S-cone envelope (round-4 review, item 7)
+def _sdp_problem(r, n=4, extra_small=0):
+    k = r * (r + 1) // 2
+    from cipkkt.workloads import vecm_identity
+    return dict(Q=np.eye(n), c=np.ones(n), A=np.zeros((k, n)), b=-vecm_identity(r), cone_dims=[("S", k)], G=None, d=None, kwargs={})
+
+
+def test_s_cone_above_order_1024_is_refused_cleanly():
+    """the reference has no limit on the matrix order (src/ConicIP.jl:196-210); this library stops at 1024.  A larger cone must
+    be REFUSED at level 1 -- CIP_E_UNSUPPORTED, a message naming the cone, no handle -- not mis-handled.  Only the cone table
+    is inspected before the refusal (no 4 GB upload of A)."""
+    import ctypes as C
+    from cipkkt import _lib as L
+    lib = L.load()
+    r = 1025
+    k = r * (r + 1) // 2
+    ct = (C.c_int * 1)(L.CONE_S if hasattr(L, "CONE_S") else 2)
+    cd = (C.c_int * 1)(k)
+    Q = np.eye(2, order="F")
+    A = np.zeros((1, 1))                                   # never read: the cone table is checked first
+    pr = L.CipProblem()
+    pr.n, pr.m, pr.p, pr.ncones = 2, k, 0, 1
+    pr.cone_type, pr.cone_dim = ct, cd
+    pr.Q, pr.ldq = C.c_void_p(Q.ctypes.data), 2
+    pr.A, pr.lda = C.c_void_p(A.ctypes.data), k
+    pr.G, pr.ldg = None, 1
+    pr.route, pr.flags = L.ROUTE_SCHUR, 0
+    h = C.c_void_p()
+    rc = lib.cip_create_ex(C.byref(pr), C.byref(h))
+    assert rc == L.E_UNSUPPORTED, rc
+    assert not h.value                                     # nothing to destroy
+    assert b"1025" in lib.cip_last_error() and b"1024" in lib.cip_last_error()
+
+
+def test_more_than_eight_large_s_cones_are_refused_cleanly():
+    """nine S cones of order 133 (the chip-wide kernels keep one workspace set per large cone, at most 8): CIP_E_UNSUPPORTED
+    from level 1, no handle; eight are accepted"""
+    import cipkkt
+    from cipkkt import _lib as L
+    from cipkkt.workloads import vecm_identity
+    r = 133
+    k = r * (r + 1) // 2
+    n = 3
+
+    def build(count):
+        rng = np.random.default_rng(count)
+        A = rng.standard_normal((count * k, n)) * 0.01
+        return np.eye(n), A, [("S", k)] * count
+
+    Q, A, K = build(9)
+    with pytest.raises(L.CipError) as ei:
+        cipkkt.KKTSystem(Q, A, None, K)
+    assert ei.value.code == L.E_UNSUPPORTED and "S cones" in str(ei.value)
+    Q, A, K = build(8)
+    ks = cipkkt.KKTSystem(Q, A, None, K)
+    ks.close()
+
+
+def test_lockstep_refusal_of_large_s_cones_writes_nothing_and_mixed_routes_them():
+    """a lock-step call on problems with a chip-wide S cone answers CIP_E_UNSUPPORTED and leaves the caller's result and
+    solution buffers untouched; cip_conicip_mixed solves the same problems through the thread pool"""
+    import ctypes as C
+    from cipkkt import _lib as L
+    from cipkkt.kkt import make_problem
+    from cipkkt.workloads import c4_sdp
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    prs = []
+    for seed in (41, 42):
+        Q, c, A, b, K, G, d = c4_sdp(r=133, n=12, p=2, seed=seed)
+        prs.append(dict(Q=Q, c=c, A=A, b=b, cone_dims=K, G=G, d=d))
+    k = len(prs)
+    structs = (L.CipProblem * k)()
+    keep = []
+    for i, pr in enumerate(prs):
+        st, kp, _ = make_problem(pr["Q"], pr["A"], pr["G"], pr["cone_dims"], "schur", dev)
+        structs[i] = st
+        keep.append(kp)
+    torch.cuda.synchronize()
+    vp = C.c_void_p * k
+    m, n, p = prs[0]["A"].shape[0], 12, 2
+    cs = [np.ascontiguousarray(pr["c"]) for pr in prs]
+    bs = [np.ascontiguousarray(pr["b"]) for pr in prs]
+    ds = [np.ascontiguousarray(pr["d"]) for pr in prs]
+    sentinel = 12345.678
+    ys = [np.full(n, sentinel) for _ in prs]
+    ws = [np.full(p, sentinel) for _ in prs]
+    vs = [np.full(m, sentinel) for _ in prs]
+    arr = lambda xs: vp(*[x.ctypes.data for x in xs])
+    res = (L.CipResult * k)()
+    for i in range(k):
+        res[i].status, res[i].iter = 77, 88
+    opt = L.CipOptions(1e-6, 0.01, -1.0, -1.0, 3, 100, 0)
+    rc = lib.cip_conicip_lockstep(k, structs, arr(cs), arr(bs), arr(ds), C.byref(opt), arr(ys), arr(ws), arr(vs), res)
+    assert rc == L.E_UNSUPPORTED
+    assert all(np.all(y == sentinel) for y in ys) and all(np.all(v == sentinel) for v in vs) and all(np.all(w == sentinel) for w in ws)
+    assert all(res[i].status == 77 and res[i].iter == 88 for i in range(k))
+    L.check(lib.cip_conicip_mixed(k, structs, arr(cs), arr(bs), arr(ds), C.byref(opt), arr(ys), arr(ws), arr(vs), res, 2))
+    st3 = (C.c_int * 3)()
+    lib.cip_lockstep_stats(st3)
+    assert list(st3) == [0, 0, 0]                          # no lock-step group was formed: both went through the thread pool
+    assert all(res[i].status == 1 for i in range(k)), [res[i].status for i in range(k)]       # CIP_STATUS_OPTIMAL
+    assert not any(np.any(y == sentinel) for y in ys)
