@@ -233,18 +233,25 @@ __device__ __forceinline__ v4d diag_step_c_perm(const double *a, int kb, int l15
 // straight into C's MFMAs -- written to LDS (for the helpers, who read it after the B count) but never read back -- and the
 // C11 tile's loads are issued in front of B.  Rows permuted by P throughout (see diag_step_c_perm): the result is step A's
 // register tile.  Same MFMAs on the same numbers in the same order as diag_step_b + diag_step_c: same bits.
-__device__ __forceinline__ v4d diag_step_bc_perm(double *a, int kb, int l15, int g, const double (&xa)[4], const double (&di4)[4],
-                                                 const double (&d4)[4]) {
+struct BcOperands { double u[4]; v4d c; };
+__device__ __forceinline__ BcOperands diag_step_bc_load(const double *a, int kb, int l15, int g) {
+    const int c = kb * 16, t0 = (kb + 1) * 16, row = diag_perm(l15);
+    const double *pl = a + (t0 + row) + (c + g) * DP;
+    const double *cp = a + (t0 + row) + (t0 + 4 * g) * DP;
+    BcOperands o;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) o.u[s] = pl[4 * s * DP];
+    o.c = (v4d){cp[0], cp[DP], cp[2 * DP], cp[3 * DP]};
+    return o;
+}
+__device__ __forceinline__ v4d diag_step_bc_perm(double *a, int kb, int l15, int g, const BcOperands &o, const double (&xa)[4],
+                                                 const double (&di4)[4], const double (&d4)[4]) {
     const int c = kb * 16, t0 = (kb + 1) * 16, row = diag_perm(l15);
     double *pl = a + (t0 + row) + (c + g) * DP;
-    const double *cp = a + (t0 + row) + (t0 + 4 * g) * DP;
-    double u[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) u[s] = pl[4 * s * DP];
-    v4d acc2 = (v4d){cp[0], cp[DP], cp[2 * DP], cp[3 * DP]};
+    v4d acc2 = o.c;
     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int s = 0; s < 4; ++s) acc = MFMA(xa[s], u[s], acc);
+    for (int s = 0; s < 4; ++s) acc = MFMA(xa[s], o.u[s], acc);
     double v[4], w[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { v[q] = acc[q] * di4[q]; pl[4 * q * DP] = v[q]; }
@@ -658,42 +665,90 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
                 __builtin_amdgcn_s_sleep(1);
                 if (__builtin_amdgcn_s_memtime() - t0 > 2000000000L) { atomicCAS(info + 3, 0, -9); break; }   // ~1 s of shader clock: never hang the GPU
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // (round 5) NO agent-scope acquire here: it is a buffer_inv of this CU's vector cache, whose completion the wait below then
+            // sat out (~1.7 us, MI355X_MICROARCH.md fence table) -- and nothing in this workgroup reads the block through that cache: the
+            // producers stored every byte write-through (st_pub) and drained before counting, and every load below is an sc1 buffer load
+            // to registers (the guide's "valid form" without the acquire)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             PANEL_STAMP(4, PUB);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // 16-byte loads that bypass the non-coherent caches (buffer load with the sc1 policy bit = agent scope)
         typedef int v4i_t __attribute__((ext_vector_type(4)));
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)Kb, 0, 0x7fffffff, 0x00020000);
-        {
-            // every wave of the workgroup takes part (eight waves: 16 loads per thread instead of 32 on four), and the pairs
-            // that lie wholly above the diagonal are not fetched at all
-            constexpr int LT = (NW == 4) ? 256 : 512, PER = 8192 / LT;
+        auto put = [&](int e, v4i_t t) {
+            const int i = 2 * (e & 63), j = e >> 6;
+            v2d v = __builtin_bit_cast(v2d, t);
+            if (i < j) v.x = 0.0;                                    // strictly upper part -> 0
+            if (i + 1 < j) v.y = 0.0;
+            *(v2d *)(a + i + j * DP) = v;
+        };
+        auto get = [&](int e) -> v4i_t {                              // pair index e: rows 2 (e & 63), + 1; column e >> 6; pairs wholly above the diagonal are not fetched
+            const int i = 2 * (e & 63), j = e >> 6;
+            if (i + 1 >= j) return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((i + (long)j * ld) * 8), 0, 16);
+            return (v4i_t){0, 0, 0, 0};
+        };
+        if constexpr (NW > 4) {
+            // Round 5: the first micro-panel's columns FIRST.  A workgroup fetches a freshly written 72 KB from the other XCDs' side at
+            // ~65 GB/s (MI355X_MICROARCH.md, handoff-payload): 2.3 us between "ready" and "block in LDS", all of it in front of A(0).
+            // A(0) needs columns 0..15 only: all eight waves fetch those (two loads per thread), one barrier, the serial wave starts,
+            // and the other seven waves fetch columns 16..127 beside it (the barrier behind A(0) is in front of their first use).
+            {
+                v4i_t t0 = get(tid), t1 = get(512 + tid);
+                put(tid, t0); put(512 + tid, t1);
+            }
+            if (tid < 3) *(unsigned *)(a + 130 + tid) = 0u;
+            __syncthreads();
+            if (wave != 0) {
+                constexpr int REST = 64 * (NW - 1), PER = (8192 - 1024 + REST - 1) / REST;
+                v4i_t t[PER];
+#pragma unroll
+                for (int q = 0; q < PER; ++q) { const int e = 1024 + q * REST + (tid - 64); t[q] = e < 8192 ? get(e) : (v4i_t){0, 0, 0, 0}; }
+#pragma unroll
+                for (int q = 0; q < PER; ++q) { const int e = 1024 + q * REST + (tid - 64); if (e < 8192) put(e, t[q]); }
+            }
+        } else {
+            // every wave of the workgroup takes part, and the pairs that lie wholly above the diagonal are not fetched at all
+            constexpr int LT = 256, PER = 8192 / LT;
             if (tid < LT) {
                 v4i_t t[PER];
 #pragma unroll
-                for (int q = 0; q < PER; ++q) {
-                    const int e = q * LT + tid;                      // pair index: rows 2*(e&63), +1 ; column e>>6
-                    const int i = 2 * (e & 63), j = e >> 6;
-                    const long off = (i + (long)j * ld) * 8;
-                    t[q] = (v4i_t){0, 0, 0, 0};
-                    if (i + 1 >= j) t[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);
-                }
+                for (int q = 0; q < PER; ++q) t[q] = get(q * LT + tid);
 #pragma unroll
-                for (int q = 0; q < PER; ++q) {
-                    const int e = q * LT + tid;
-                    const int i = 2 * (e & 63), j = e >> 6;
-                    v2d v = __builtin_bit_cast(v2d, t[q]);
-                    if (i < j) v.x = 0.0;                            // strictly upper part -> 0
-                    if (i + 1 < j) v.y = 0.0;
-                    *(v2d *)(a + i + j * DP) = v;
-                }
+                for (int q = 0; q < PER; ++q) put(q * LT + tid, t[q]);
             }
         }
+    } else if (NW > 4 && !(DIAG_SKIP & 16)) {
+        // (first panel of an outer block, standalone diagonal kernel: plain loads, the same two phases)
+        auto put = [&](int e, v2d v) {
+            const int i = 2 * (e & 63), j = e >> 6;
+            if (i < j) v.x = 0.0;
+            if (i + 1 < j) v.y = 0.0;
+            *(v2d *)(a + i + j * DP) = v;
+        };
+        auto get = [&](int e) -> v2d {
+            const int i = 2 * (e & 63), j = e >> 6;
+            return (i + 1 >= j) ? *(const v2d *)(Kb + i + (long)j * ld) : (v2d){0.0, 0.0};
+        };
+        {
+            v2d t0 = get(tid), t1 = get(512 + tid);
+            put(tid, t0); put(512 + tid, t1);
+        }
+        if (tid < 3) *(unsigned *)(a + 130 + tid) = 0u;
+        __syncthreads();
+        if (wave != 0) {
+            constexpr int REST = 64 * (NW - 1), PER = (8192 - 1024 + REST - 1) / REST;
+            v2d t[PER];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { const int e = 1024 + q * REST + (tid - 64); t[q] = e < 8192 ? get(e) : (v2d){0.0, 0.0}; }
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { const int e = 1024 + q * REST + (tid - 64); if (e < 8192) put(e, t[q]); }
+        }
     } else if (!(DIAG_SKIP & 16) && (NW == 4 || tid < 256)) diag_load_block(a, Kb, ld, tid);
-    if (tid < 3) *(unsigned *)(a + 130 + tid) = 0u;                     // the phase counts of the loop below (pitch padding of column 0; rows 128 / 129 hold d and 1/d)
-    __syncthreads();
+    if (!(NW > 4 && (WAIT || !(DIAG_SKIP & 16)))) {
+        if (tid < 3) *(unsigned *)(a + 130 + tid) = 0u;                 // the phase counts of the loop below (pitch padding of column 0; rows 128 / 129 hold d and 1/d)
+        __syncthreads();
+    }
 
     // Schedule per 16-column micro-panel kb (A(0) first):
     //   B(kb)   all waves   : L tiles of the panel rows below (round-robin over the waves)
@@ -718,8 +773,11 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
         // needs; the helpers do their tiles FIRST and write the finished micro-panel back afterwards, beside the next step.
         // tools/diag_bench: 21.2 -> 19.x us per kernel with the other round-5 changes.  The polls are bounded (never hang the GPU).
         unsigned *bflag = (unsigned *)(a + 130), *tflag = (unsigned *)(a + 131), *aflag = (unsigned *)(a + 132);
+        // (everything handed over here lives in LDS, and the DS operations of a wave are executed in order: the count's ds_add is
+        //  behind the wave's stores without an s_waitcnt -- a workgroup-scope release would be one, ~100 clocks on the serial wave twice
+        //  per step -- and a poll that has matched is in front of the loads that follow it.  The fences only pin the compiler's order.)
         auto count = [&](unsigned *f) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             if (lane == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
         auto wait_for = [&](unsigned *f, unsigned want) {
@@ -730,37 +788,79 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
                     if (__builtin_amdgcn_s_memtime() - t0 > 2000000000L) { atomicCAS(info + 3, 0, -8); break; }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
         if (!idle) {
             for (int kb = 0; kb < 7; ++kb) {
                 const int c = kb * 16;
-                if (wave != 0) wait_for(aflag, (unsigned)kb);                  // A(kb): counted by the serial wave (A(0): the barrier above)
-                wait_for(tflag, (unsigned)(kb * NH));                          // the helpers' tiles of step kb - 1
                 double xa[4], di4[4], d4[4];
+                BcOperands bo;
+                if (wave == 0) {
+                    // the serial wave: the poll for the helpers' tiles of step kb - 1 and EVERY operand of its B + C in ONE LDS round trip
+                    // (the DS operations of a wave return in order; its own A(kb) stores are in front of them).  The tiles are normally
+                    // long done -- if not, wait and load the two tile operands again.
+                    const unsigned tf = __hip_atomic_load(tflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    xa[s] = xm[kb * 256 + (g + 4 * s) * 16 + l15];       // Aop[jj = l15][k = g + 4s]
-                    di4[s] = a[129 + (c + g + 4 * s) * DP];
-                    d4[s] = a[128 + (c + g + 4 * s) * DP];
+                    for (int s = 0; s < 4; ++s) {
+                        xa[s] = xm[kb * 256 + (g + 4 * s) * 16 + l15];
+                        di4[s] = a[129 + (c + g + 4 * s) * DP];
+                        d4[s] = a[128 + (c + g + 4 * s) * DP];
+                    }
+                    bo = diag_step_bc_load(a, kb, l15, g);
+                    if (tf < (unsigned)(kb * NH)) {
+                        wait_for(tflag, (unsigned)(kb * NH));
+                        bo = diag_step_bc_load(a, kb, l15, g);
+                    } else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                } else {
+                    wait_for(aflag, (unsigned)kb);                             // A(kb): counted by the serial wave (A(0): the barrier above)
+                    wait_for(tflag, (unsigned)(kb * NH));                      // the helpers' tiles of step kb - 1
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        xa[s] = xm[kb * 256 + (g + 4 * s) * 16 + l15];       // Aop[jj = l15][k = g + 4s]
+                        di4[s] = a[129 + (c + g + 4 * s) * DP];
+                        d4[s] = a[128 + (c + g + 4 * s) * DP];
+                    }
                 }
                 DIAG_STAMP(kb, 0, tid == 0);                                  // wave 0: starts B(kb)
                 DIAG_STAMP(kb, 4, tid == DIAG_TIMING_TID);
                 v4d U1 = (v4d){0.0, 0.0, 0.0, 0.0};
                 if (!(DIAG_SKIP & 4)) {
                     // (kb+1, kb+1): steps 0 .. kb-1 were applied by a helper during step kb-1, step kb is this wave's
-                    if (wave == 0) U1 = diag_step_bc_perm(a, kb, l15, g, xa, di4, d4);
+                    if (wave == 0) U1 = diag_step_bc_perm(a, kb, l15, g, bo, xa, di4, d4);
                     else { for (int it = kb + 2 + hid; it < 8; it += NH) diag_step_b(a, it, c, l15, g, xa, di4); }
                 }
                 DIAG_STAMP(kb, 1, tid == 0);                                  // B (serial wave: B + C) done
                 DIAG_STAMP(kb, 5, tid == DIAG_TIMING_TID);
                 count(bflag);
                 DIAG_STAMP(kb, 2, tid == 0);
+                if (PUB && wave != 0 && kb > 0) {
+                    // the stage count of micro-panel kb - 1, whose write-through stores this wave issued at the end of the last step:
+                    // they have had the serial wave's A(kb) and this B to land (waiting for them right behind the stores put a store
+                    // round trip -- 1.5-2 us inside a busy launch -- on every helper's step, and the serial wave then waited for the
+                    // helpers' tiles)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) atomicAdd(stage, 1u);
+                }
                 if (wave == 0) {
                     if (!(DIAG_SKIP & 4)) diag_step_a<true>(a, xm, kb + 1, lane, info, col0, sg, U1);
                     else diag_step_a(a, xm, kb + 1, lane, info, col0, sg);
                     count(aflag);
                     PANEL_STAMP(20 + kb, WAIT && PUB && tid == 0);              // A(kb + 1) done
+                    if (PUB && kb == 6) {
+                        // the LAST stage of the launch's TRSM strips needs the last micro inverse and 1/d only (no column of L lies below
+                        // the last diagonal tile): the serial wave publishes them itself the moment A(7) is done and counts the stage for
+                        // all the helpers -- not behind a workgroup barrier, the write-back of the last tile by all waves and their drain
+                        // (the strips' last stage is the tail of every panel launch)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) st_pub(xm_out + 7 * 256 + lane + 64 * q, xm[7 * 256 + lane + 64 * q]);
+                        if (lane < 16) {
+                            st_pub(dvec + 112 + lane, a[128 + (112 + lane) * DP]);
+                            st_pub(dinv + 112 + lane, a[129 + (112 + lane) * DP]);
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0) atomicAdd(stage, (unsigned)NH);
+                        PANEL_STAMP(8, WAIT && tid == 0);
+                    }
                     DIAG_STAMP(kb, 3, tid == 0);                              // C11 + A(kb+1) done
                 } else if (!(DIAG_SKIP & 4)) {
                     wait_for(bflag, (unsigned)((kb + 1) * (NH + 1)));         // everybody's B(kb): the tiles below read them
@@ -777,12 +877,12 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
                     DIAG_STAMP(kb, 7, tid == DIAG_TIMING_TID);                // helper: tiles done and counted
                     // micro-panel kb is final: written back (and published) now, beside the serial wave's step and the next B
                     if (!(DIAG_SKIP & 16)) diag_store_panel<PUB>(a, Kb, ld, c, hid * 64 + lane, 64 * NH);
-                    if (PUB) {
-                        diag_publish_micro(a, xm, xm_out, dvec, dinv, kb, hid * 64 + lane, 64 * NH);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the wave's stores have landed -> its count
-                        if (lane == 0) atomicAdd(stage, 1u);
-                    }
+                    if (PUB) diag_publish_micro(a, xm, xm_out, dvec, dinv, kb, hid * 64 + lane, 64 * NH);      // (counted in the next step)
                 } else count(tflag);
+            }
+            if (PUB && wave != 0) {                                            // micro-panel 6's count
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) atomicAdd(stage, 1u);
             }
         }
         __syncthreads();                                                       // A(7) and the helpers' last stores
@@ -876,6 +976,12 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
     }
     }
     PANEL_STAMP(7, WAIT && PUB && tid == 0);                            // last pivot done
+    if (PUB && NW > 4) {
+#ifndef DIAG_STEP_A_REF
+        diag_store_panel<true>(a, Kb, ld, 112, tid, 64 * NW);              // the last diagonal tile (the stage was counted by the serial wave in the loop)
+        return;
+#endif
+    }
     if (PUB) {
         diag_store_panel<true>(a, Kb, ld, 112, tid, 64 * NW);
         diag_publish_micro(a, xm, xm_out, dvec, dinv, 7, tid, 64 * NW);
