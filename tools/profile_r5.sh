@@ -17,7 +17,7 @@ for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES
 done
 # the diagonal kernel: round 4's (built from the r4 source kept as a variant, when it travels) against this round's; the probes
 for b in diag_bench_new diag_bench_tim64 issue_probe rcp_probe; do [ -x $R/tools/$b ] && { echo "== $b"; $R/tools/$b; }; done > $OUT/diag_probes.txt 2>&1
-[ -f $R/conicip.jl_amd/build/variants/libcipkkt_r4diag.so ] && python3 $R/tools/ab_factor.py r4diag=conicip.jl_amd/build/variants/libcipkkt_r4diag.so r5=default --rounds 3 > $OUT/ab_diag.txt 2>&1
+[ -f $R/conicip.jl_amd/build/variants/libcipkkt_r4diag.so ] && python3 $R/tools/ab_factor.py r4diag=$R/conicip.jl_amd/build/variants/libcipkkt_r4diag.so r5=default --rounds 3 > $OUT/ab_diag.txt 2>&1
 [ -f $R/conicip.jl_amd/build/variants/libcipkkt_r4diag.so ] && bash $R/tools/prof_panel.sh r4diag=conicip.jl_amd/build/variants/libcipkkt_r4diag.so r5=default > $OUT/prof_panel_ab.txt 2>&1
 bash $R/tools/panel_trace.sh r5=default > $OUT/panel_trace.txt 2>&1
 python3 $R/tools/solve_time.py > $OUT/solve_time.txt 2>&1
