@@ -504,9 +504,9 @@ def test_s_cone_above_order_1024_is_refused_cleanly():
     assert b"1025" in lib.cip_last_error() and b"1024" in lib.cip_last_error()
 
 
-def test_more_than_eight_large_s_cones_are_refused_cleanly():
-    """nine S cones of order 133 (the chip-wide kernels keep one workspace set per large cone, at most 8): CIP_E_UNSUPPORTED
-    from level 1, no handle; eight are accepted"""
+def test_more_than_64_large_s_cones_are_refused_cleanly():
+    """65 S cones of order 133 (the chip-wide kernels keep one set of padded matrices per large cone, at most 64 -- 8 until
+    round 5): CIP_E_UNSUPPORTED from level 1, no handle; nine (refused until round 5) are accepted AND solved"""
     import cipkkt
     from cipkkt import _lib as L
     from cipkkt.workloads import vecm_identity
@@ -519,13 +519,19 @@ def test_more_than_eight_large_s_cones_are_refused_cleanly():
         A = rng.standard_normal((count * k, n)) * 0.01
         return np.eye(n), A, [("S", k)] * count
 
-    Q, A, K = build(9)
+    Q, A, K = build(65)
     with pytest.raises(L.CipError) as ei:
         cipkkt.KKTSystem(Q, A, None, K)
     assert ei.value.code == L.E_UNSUPPORTED and "S cones" in str(ei.value)
-    Q, A, K = build(8)
-    ks = cipkkt.KKTSystem(Q, A, None, K)
-    ks.close()
+    Q, A, K = build(9)
+    b = -np.concatenate([vecm_identity(r)] * 9)
+    sol = cipkkt.conicIP(Q, np.array([1.0, -0.5, 0.25]), A, b, K, optTol=1e-6)
+    assert sol.status == "Optimal", sol.status
+    # optimality of the 9-cone program: dual residual Q y - c - A'v = 0, complementarity v's = 0 (s = A y - b)
+    y, v = sol.y, sol.v
+    sres = A @ y - b
+    assert np.linalg.norm(Q @ y - np.array([1.0, -0.5, 0.25]) - A.T @ v) <= 1e-5 * (1 + np.linalg.norm(v))
+    assert abs(v @ sres) <= 1e-4 * (1 + abs(sol.pobj))
 
 
 def test_lockstep_refusal_of_large_s_cones_writes_nothing_and_mixed_routes_them():
