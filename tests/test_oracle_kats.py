@@ -286,3 +286,43 @@ def test_oracle_no_cones():
     sol = conicIP(Q, c, np.zeros((0, n)), np.zeros(0), [])
     assert sol.status == "Optimal"
     np.testing.assert_allclose(sol.y, np.linalg.solve(Q, c), rtol=1e-12)
+
+
+@pytest.mark.parametrize("r", [17, 40, 96])
+def test_s_cone_primitives_by_their_defining_properties_at_larger_orders(r):
+    """The reference pins the S cone at one order-6 projection (test/runtests.jl:527-552); everything the GPU path is compared with
+    above that order is this oracle.  So the oracle's S-cone primitives are pinned here, at orders well above 6, by properties
+    that DEFINE them and are computed independently of the restatement (numpy eigen-decompositions, no shared code):
+      nestod_sdc (src/ConicIP.jl:196-210): R'ZR = R^-1 S R^-T = Lambda, diagonal, positive, and Lambda^2 = eig(Z S);
+      maxstep_sdc (:272-293): X - alpha D is PSD and singular at alpha, not PSD beyond; inf when D is not positive anywhere;
+      dsdc (:347-353): Y O + O Y = X;   xsdc (:355-360): X Y + Y X (no 1/2)."""
+    rng = np.random.default_rng(1000 + r)
+
+    def spd(scale=1.0):
+        M = rng.standard_normal((r, r))
+        return scale * (M @ M.T / r + 0.3 * np.eye(r))
+    Z, S = spd(), spd(2.0)
+    R = cones.nestod_sdc(cones.vecm(Z), cones.vecm(S))
+    Ri = np.linalg.inv(R)
+    L1, L2 = R.T @ Z @ R, Ri @ S @ Ri.T
+    lam = np.diag(L1)
+    assert np.all(lam > 0)
+    off = L1 - np.diag(lam)
+    assert np.abs(off).max() <= 1e-11 * lam.max() and np.abs(L2 - np.diag(lam)).max() <= 1e-10 * lam.max()
+    ev = np.sort(np.linalg.eigvals(Z @ S).real)                          # an independent route to Lambda^2
+    np.testing.assert_allclose(np.sort(lam ** 2), ev, rtol=1e-9)
+    # F v = F^-T s = lambda for F = VecCongurance(R) (src/ConicIP.jl:35-40, :735)
+    np.testing.assert_allclose(cones.vecm(R.T @ Z @ R), cones.vecm(Ri @ S @ Ri.T), rtol=1e-9, atol=1e-11)
+    # max step
+    X = spd()
+    D = rng.standard_normal((r, r)); D = D + D.T
+    a = cones.maxstep_sdc(cones.vecm(X), cones.vecm(D))
+    assert np.isfinite(a) and a > 0
+    w = np.linalg.eigvalsh(X - a * D)
+    assert abs(w[0]) <= 1e-9 * w[-1] and np.linalg.eigvalsh(X - 1.001 * a * D)[0] < 0 < np.linalg.eigvalsh(X - 0.999 * a * D)[0]
+    assert np.isinf(cones.maxstep_sdc(cones.vecm(X), cones.vecm(-spd())))   # d negative definite: no bound along -d
+    # Jordan product and division
+    Y = spd()
+    O = cones.mat(cones.dsdc(cones.vecm(X), cones.vecm(Y)))
+    np.testing.assert_allclose(Y @ O + O @ Y, X, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(cones.mat(cones.xsdc(cones.vecm(X), cones.vecm(Y))), X @ Y + Y @ X, rtol=1e-12, atol=1e-12)
