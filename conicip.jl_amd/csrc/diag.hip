@@ -1092,6 +1092,7 @@ struct TrsmStrips {
     const double *xm, *dinv;          // micro inverses / 1/d of the block (published by workgroup 0)
     double *W; long ldw;
     int strips;                       // rows / 64
+    int pair;                         // round 5, k_ldlt_panel<true> in lock-step groups: a strip workgroup carries TWO strips (see the kernel)
 };
 __device__ __forceinline__ unsigned strip_wait(unsigned v, unsigned target, const unsigned *stage, unsigned *slot, int *info) {
     if (v >= target) return v;
@@ -1303,14 +1304,29 @@ __global__ __launch_bounds__(64 * PANEL_WAVES) void k_ldlt_panel(double *Kb, lon
     GrpBar bar = {ctl + grp, 0u};
     double *lds = sm + grp * PANEL_GRP_DOUBLES;
     // the two halves of worker workgroup w start at once on tiles 2 w and 2 w + 1; everything else is drawn from the queue
-    const int w = b - first - tr.strips, nworkers = nblocks - first - tr.strips;
+    // pair mode (lock-step groups whose strip workgroups would not all fit the chip: every workgroup of this launch owns a CU's
+    // whole LDS): a strip workgroup's two groups are strips 2 k and 2 k + 1 -- each does both update tiles of its own rows, then its
+    // TRSM -- instead of strip k and a tile group: half as many strip workgroups.  8 problems of order 2048: 320 -> 200 workgroups
+    // per panel launch (256 CUs), 36 -> 3x us per launch.  The tiles and the TRSM are the same functions: same bits.
+    const int nswg = tr.pair ? (tr.strips + 1) / 2 : tr.strips;
+    const int w = b - first - nswg, nworkers = nblocks - first - nswg;
     const unsigned first_tile = w >= 0 ? (unsigned)(2 * w + grp) : PANEL_NONE;
     if (w < 0) {
         // a strip workgroup: the strip's rows of this panel's columns first receive the previous panel's update -- tiles
         // (2 + strip, 0) and (2 + strip, 1), one per group, side by side (the head of the launch's critical path); then group 0
         // is the strip and group 1 a tile group
-        const int strip = b - first;
+        const int strip = tr.pair ? 2 * (b - first) + grp : b - first;
         __builtin_amdgcn_s_setprio(3);
+        if (tr.pair) {
+            if (strip < tr.strips) {
+                gemm_tile_64_k128_grp<false>(g, lds, (long)(2 + strip) * SB, 0L, gt, bar, nullptr, nullptr);
+                gemm_tile_64_k128_grp<false>(g, lds, (long)(2 + strip) * SB, (long)SB, gt, bar, nullptr, nullptr);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // a TRSM wave's rows were written by all four waves of the group
+                grp_barrier(bar);
+                trsm_strip_pipelined<true>(tr, strip, stage, nullptr, info, lds);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        } else {
         gemm_tile_64_k128_grp<false>(g, lds, (long)(2 + strip) * SB, (long)grp * SB, gt, bar, nullptr, nullptr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // a TRSM wave's rows were written by all eight waves
         grp_barrier(bar);
@@ -1324,6 +1340,7 @@ __global__ __launch_bounds__(64 * PANEL_WAVES) void k_ldlt_panel(double *Kb, lon
             PANEL_STAMP(14, threadIdx.x == 0 && strip == tr.strips - 1);
         }
         __builtin_amdgcn_s_setprio(0);
+        }
     }
     PANEL_STAMP(15, w == 0 && threadIdx.x == 0);                          // worker 0: starts on tiles
     PANEL_STAMP(17, w < 0 && b == first && threadIdx.x == 256);            // strip 0's second half: starts on tiles
@@ -1519,7 +1536,7 @@ int cip_launch_diag_upd(hipStream_t s, double *Kb, long ld, double *xm_out, doub
 int cip_launch_panel(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
                      PivotSigns sg, unsigned *ready, unsigned *stage, unsigned *tileq, const GemmArgs *g, int rows, double *W, long ldw) {
     if (cip_kernels_init()) return -3;
-    TrsmStrips tr = {Kb + CIP_NB, ld, Kb, xm_out, dinv, W, ldw, rows / 64};
+    TrsmStrips tr = {Kb + CIP_NB, ld, Kb, xm_out, dinv, W, ldw, rows / 64, 0};
     // lock-step groups: problem index fastest in the dispatch order (CIP_PANEL_ZFAST=0: blockIdx.z, the order up to round 4's first half)
     static const int zfast = [] { const char *e = getenv("CIP_PANEL_ZFAST"); return e ? atoi(e) : 1; }();
     const int Bn = cip_in_batch() ? cip_tl_bz.B : 1;
@@ -1535,11 +1552,20 @@ int cip_launch_panel(hipStream_t s, double *Kb, long ld, double *xm_out, double 
             return cus;
         }();
         const long ntiles = (long)tm * (tn - 2) - ((long)tn * (tn - 1) / 2 - 1);   // lower tiles of columns 2 .. tn-1
-        long workers = ncu / (cip_in_batch() ? cip_tl_bz.B : 1) - 1 - PANEL_PRODUCERS - tr.strips;
+        // (off by default: 8 problems of order 2048 15.9 -> 15.3 ms per pass in one session, 15.2 -> 15.5 in the next -- inside the noise;
+        //  CIP_PANEL_PAIR=1 selects it)
+        static const int pair_on = [] { const char *e = getenv("CIP_PANEL_PAIR"); return e ? atoi(e) : 0; }();
+        // ... when the unpaired launch does not fit the chip AND the paired one leaves at least four worker workgroups per problem: the
+        // strips' second halves were tile groups, and without workers the update tiles queue up behind the TRSMs (16 problems of order
+        // 2048: 23.5 ms per pass unpaired, 24.5-25.2 paired; 8 problems: 15.9 -> 15.3)
+        tr.pair = (pair_on && Bn > 1 && (long)Bn * (1 + PANEL_PRODUCERS + tr.strips) > ncu &&
+                   ncu / Bn - 1 - PANEL_PRODUCERS - (tr.strips + 1) / 2 >= 4) ? 1 : 0;
+        const int nswg = tr.pair ? (tr.strips + 1) / 2 : tr.strips;
+        long workers = ncu / (cip_in_batch() ? cip_tl_bz.B : 1) - 1 - PANEL_PRODUCERS - nswg;
         if (workers > (ntiles + 1) / 2) workers = (ntiles + 1) / 2;
         if (workers < 1 && ntiles > 0 && tr.strips == 0) workers = 1;
         if (workers < 0) workers = 0;
-        const long grid = 1 + PANEL_PRODUCERS + tr.strips + workers;
+        const long grid = 1 + PANEL_PRODUCERS + nswg + workers;
         if (transposed) cip_launch(k_ldlt_panel<true>, dim3((unsigned)(grid * Bn)), dim3(64 * PANEL_WAVES), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info,
                                    col0, sg, ready, stage, tileq, *g, tr, Bn, CipBatch{cip_tl_bz.stride, cip_tl_bz.mask});
         else cip_launch_b(k_ldlt_panel<true>, dim3((unsigned)grid), dim3(64 * PANEL_WAVES), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg,
