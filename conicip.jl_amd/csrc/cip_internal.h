@@ -262,7 +262,7 @@ int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const d
 // one wait; large S cones: the two sides on two streams
 int cip_sdp_scale_At(hipStream_t s, const ConeSet &cs, int n, const double *At, long ldat, double *Wt, long ldwt);   // sdp.hip: the S cones' columns only
 int cip_cones_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const double *d1, const double *x2, const double *d2,
-                       double scale, double *alpha_host2);
+                       double scale, double *alpha_host2, int defer_slot = -1);
 int cip_sdp_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const double *d1, double *p1, const double *x2,
                      const double *d2, double *p2, double scale);
 int cip_cones_identity(hipStream_t s, const ConeSet &cs, double *e);

@@ -509,8 +509,12 @@ int cip_cones_maxstep(hipStream_t s, const ConeSet &cs, const double *x, const d
     alpha_host[0] = hs.host[0];
     return 0;
 }
+// defer_slot >= 0 (one problem only; round 5): the two minima go to slots defer_slot, defer_slot + 1 of the calling thread's
+// host-mapped scratch (cip_host_scratch) and the call returns WITHOUT waiting -- the native loop reads them behind the wait of the
+// dot products it enqueues next (one host round trip instead of two); alpha_host2 is not touched
 int cip_cones_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const double *d1, const double *x2, const double *d2,
-                       double scale, double *alpha_host2) {
+                       double scale, double *alpha_host2, int defer_slot) {
+    if (defer_slot >= 0 && (cs.nitems == 0 || cip_in_batch())) { cip_set_error("cip_cones_maxstep2: deferred form needs cones and one problem"); return CIP_E_INVALID; }
     if (cs.nitems == 0 || cip_in_batch()) {                        // (a lock-step group gathers per problem: two plain calls)
         const int B = cip_tl_bz.B > 1 ? cip_tl_bz.B : 1;
         int rc = cip_cones_maxstep(s, cs, x1, d1, scale, alpha_host2);
@@ -525,9 +529,11 @@ int cip_cones_maxstep2(hipStream_t s, const ConeSet &cs, const double *x1, const
     CipHostScratch hs;
     int rc;
     if ((rc = cip_host_scratch(&hs))) return rc;
-    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)p1, cs.nslots, hs.dev, (double *)nullptr, 0);
-    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)p2, cs.nslots, hs.dev + 1, (double *)nullptr, 0);
+    const int so = defer_slot >= 0 ? defer_slot : 0;
+    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)p1, cs.nslots, hs.dev + so, (double *)nullptr, 0);
+    cip_launch_b(k_min_reduce, dim3(1), dim3(256), 0, s, (const double *)p2, cs.nslots, hs.dev + so + 1, (double *)nullptr, 0);
     CIP_HIP_CHECK(hipGetLastError());
+    if (defer_slot >= 0) return 0;
     if ((rc = cip_wait(s))) return rc;       // both minima went straight into the host-mapped scratch
     alpha_host2[0] = hs.host[0]; alpha_host2[1] = hs.host[1];
     return 0;

@@ -81,6 +81,9 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
     if (p > 0) CIP_HIP_CHECK(hipMemcpyAsync(d_d, d_host, sizeof(double) * p, hipMemcpyHostToDevice, h->stream));
     const Norms nm = host_norms(n, m, p, c_host, b_host, d_host);
     const double conedim = cone_degree(h);                                          // (:547-552); e (:559-565) below
+    CipHostScratch hs;
+    if (cip_host_scratch(&hs)) { cip_set_error("cip_conicip: host scratch"); return CIP_E_HIP; }
+    constexpr int MS_SLOT = 64;                     // slots of the host-mapped scratch the deferred max-step pairs use (the dot products use 0 .. 31)
     const double *f = cip_loop_all_r(h);            // diag F when every cone is an R cone (the loop's cone operations are then fused into its vector kernels), else NULL
     int rc;
 #define CK(x) do { if ((rc = (x)) != 0) return rc; } while (0)
@@ -164,15 +167,16 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
         CK(cip_solve4x4_dev(h, lam, r0.base, daff.base)); ++n_solve;
         double a_aff = 1.0, sigma = 0.0;
         if (m > 0) {
-            double ap[2];
-            CK(cip_maxstep_pair_dev(h, z.v, daff.v, z.s, daff.s, 1.0, ap));
-            const double a1 = ap[0], a2 = ap[1];
-            a_aff = std::fmin(std::fmin(a1, 1.0), a2);
+            // (round 5) one host round trip for the pair of max-steps and the four dot products: the minima are left in the host-mapped
+            // scratch without a wait and read behind the dots' wait (as the lock-step loop does since round 4)
+            CK(cip_cones_maxstep2(h->stream, h->cs, z.v, daff.v, z.s, daff.s, 1.0, nullptr, MS_SLOT));
             const double *qx[4] = {z.v, z.v, daff.v, daff.v};
             const double *qy[4] = {z.s, daff.s, z.s, daff.s};
             const int ql[4] = {m, m, m, m};
             double q4[4];
             CK(cip_dots_dev(h, 4, qx, qy, ql, q4));
+            const double a1 = hs.host[MS_SLOT], a2 = hs.host[MS_SLOT + 1];
+            a_aff = std::fmin(std::fmin(a1, 1.0), a2);
             const double rho = (q4[0] - a_aff * q4[1] - a_aff * q4[2] + a_aff * a_aff * q4[3]) / mubar;   // fts :162-163, :886
             const double cl = std::fmax(0.0, std::fmin(1.0, rho));
             sigma = std::pow(cl, 3.0);          // as the Python driver's `** 3` (the two loops agree to the last bit)
@@ -191,6 +195,8 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
 
         // ------------------------------------------------------------ Newton step + refinement (:907-921)
         CK(cip_solve4x4_dev(h, lam, r.base, dz.base)); ++n_solve;
+        bool step_known = false;
+        double step_a[2] = {0.0, 0.0};
         for (int it = 0; it < o.maxRefinementSteps; ++it) {
             // rkkt = K dz (mat-vecs), then rkkt.v -= dz.s, rkkt.s = lam o (F dz.v) + lam o (F^-T dz.s), rIr = r - rkkt: one kernel
             // (vecops.hip: k_loop_refine)
@@ -213,9 +219,16 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
             const double *nx[4] = {rIr.y, rIr.w, rIr.v, rIr.s};
             const int nl[4] = {n, p, m, m};
             double n2[4];
+            // the step's two max-steps ride on the first refinement test's read-back: when no refinement is asked for -- the usual
+            // case -- dz is final and the iteration has saved a host round trip; otherwise they are taken again behind the loop
+            const bool spec = it == 0 && m > 0;
+            if (spec) CK(cip_cones_maxstep2(h->stream, h->cs, z.v, dz.v, z.s, dz.s, 1.0 / (1.0 - o.DTB), nullptr, MS_SLOT));
             CK(cip_dots_dev(h, 4, nx, nx, nl, n2));
             const double rnorm = (nrm(n2[0]) + (p > 0 ? nrm(n2[1]) : 0.0) + (m > 0 ? nrm(n2[2]) + nrm(n2[3]) : 0.0)) / (n + 2 * m);   // :917 (norm(v4x1) :61)
-            if (rnorm < o.refinementThreshold) break;
+            if (rnorm < o.refinementThreshold) {
+                if (spec) { step_known = true; step_a[0] = hs.host[MS_SLOT]; step_a[1] = hs.host[MS_SLOT + 1]; }
+                break;
+            }
             CK(cip_solve4x4_dev(h, lam, rIr.base, dzr.base)); ++n_solve;
             CK(D.axpby(D.NT, 1.0, dzr.base, 1.0, dz.base));                            // :920
         }
@@ -223,9 +236,8 @@ extern "C" int cip_conicip(cip_handle *h, const double *c_host, const double *b_
         // ------------------------------------------------------------ step (:927-932)
         double alpha = 1.0;
         if (m > 0) {
-            double ap[2];
-            CK(cip_maxstep_pair_dev(h, z.v, dz.v, z.s, dz.s, 1.0 / (1.0 - o.DTB), ap));
-            const double a_v = ap[0], a_s = ap[1];
+            if (!step_known) CK(cip_maxstep_pair_dev(h, z.v, dz.v, z.s, dz.s, 1.0 / (1.0 - o.DTB), step_a));
+            const double a_v = step_a[0], a_s = step_a[1];
             alpha = std::fmin(std::fmin(a_v, 1.0), std::fmin(a_s, 1.0));
         }
         CK(D.axpby(D.NT, -alpha, dz.base, 1.0, z.base));
