@@ -171,10 +171,63 @@ __device__ long g_stepa_t[32];
 #else
 #define STEPA_STAMP(i) do { } while (0)
 #endif
+
+#ifdef DIAG_STEPA_PAIR
+// ---------------------------------------------------------------------------------------------------------------------
+// A/B form (round 5, NOT the default: it lost): TWO COLUMNS PER CHAIN LINK.  Inside a block of four the pivots are taken in
+// pairs (j, j + 1).  With a = a[j][j], b = a[j+1][j], c = a[j+1][j+1] (three DPP row broadcasts, independent of each other) the
+// second pivot of the pair is the Schur complement c - b^2 / a = det / a, det = a c - b^2, so its reciprocal is a * (1 / det) --
+// it does not wait for 1/a: the two reciprocal chains run side by side.  Built on the assumption that the serial wave is bound
+// by its dependency chain; tools/issue_probe.hip says a lone wave pays 6 clocks per fp64 instruction dependent or not, and this
+// form has MORE instructions: 808 against 616 ticks per block of four pivots, step A 4170 against 3960 per micro-block
+// (tools/stepa_probe.hip built with -DDIAG_STEPA_PAIR; residual 1.6e-16).  Kept for the probe only.
+template <int N>
+__device__ __forceinline__ void fmac_bcast_neg_s(double &acc, double x, double y) {
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(y), "n"(N));
+}
+#define PAIR_FMAC(N, ACC, X_, Y_) do { double t_ = ACC; fmac_bcast_neg_s<N>(t_, X_, Y_); ACC = t_; } while (0)
+template <int JB, int GJ>
+__device__ __forceinline__ void stepa_pair(v4d &U, v4d &X, v4d &L, double (&rho)[4]) {
+    constexpr int LA = diag_perm(4 * JB + GJ), LB = diag_perm(4 * JB + GJ + 1);      // lanes (of the 16-lane row) that hold rows j, j + 1
+    const double a = row_bcast_t<LA>(U[GJ]);
+    const double b = row_bcast_t<LB>(U[GJ]);
+    const double c = row_bcast_t<LB>(U[GJ + 1]);
+    const double det = fma(a, c, -(b * b));
+    double rdet = __builtin_amdgcn_rcp(det);
+    rdet = fma(rdet, fma(-det, rdet, 1.0), rdet);
+    double ra = __builtin_amdgcn_rcp(a);
+    ra = fma(ra, fma(-a, ra, 1.0), ra);
+    const double r2 = a * rdet;
+    rho[GJ] = ra;
+    rho[GJ + 1] = r2;
+    L[GJ] = U[GJ] * ra;
+    U[GJ + 1] = fma(-b, L[GJ], U[GJ + 1]);                     // column j + 1 as the later columns see it (b is already in every lane)
+    L[GJ + 1] = U[GJ + 1] * r2;
+    X[GJ + 1] = fma(-(b * ra), X[GJ], X[GJ + 1]);              // X[j+1][:] -= l[j+1][j] X[j][:]
+    if constexpr (GJ == 0) {
+        PAIR_FMAC(diag_perm(4 * JB + 2), U[2], U[0], L[0]);
+        PAIR_FMAC(diag_perm(4 * JB + 3), U[3], U[0], L[0]);
+        PAIR_FMAC(diag_perm(4 * JB + 2), U[2], U[1], L[1]);
+        PAIR_FMAC(diag_perm(4 * JB + 3), U[3], U[1], L[1]);
+        PAIR_FMAC(diag_perm(4 * JB + 2), X[2], L[0], X[0]);
+        PAIR_FMAC(diag_perm(4 * JB + 3), X[3], L[0], X[0]);
+        PAIR_FMAC(diag_perm(4 * JB + 2), X[2], L[1], X[1]);
+        PAIR_FMAC(diag_perm(4 * JB + 3), X[3], L[1], X[1]);
+    }
+}
+#endif
 template <int JB>
 __device__ __forceinline__ void stepa_round(v4d &U, v4d &X, v4d &L, double (&dd)[4], double *scr, int l15, int g) {
     STEPA_STAMP(1 + 4 * JB);
     if (g == JB) {
+#ifdef DIAG_STEPA_PAIR
+        stepa_pair<JB, 0>(U, X, L, dd);
+        stepa_pair<JB, 2>(U, X, L, dd);
+        if (JB < 3) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) { scr[kk * 16 + l15] = L[kk]; scr[64 + kk * 16 + l15] = U[kk]; scr[128 + kk * 16 + l15] = X[kk]; }
+        }
+#else
         stepa_pivots<JB, 0>(U, L, dd);
         if (JB < 3) {
 #pragma unroll
@@ -189,6 +242,7 @@ __device__ __forceinline__ void stepa_round(v4d &U, v4d &X, v4d &L, double (&dd)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) scr[128 + kk * 16 + l15] = X[kk];
         }
+#endif
     }
     STEPA_STAMP(2 + 4 * JB);
     if (JB < 3) {
