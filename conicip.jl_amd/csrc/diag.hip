@@ -1243,7 +1243,7 @@ __device__ __forceinline__ void trsm_strip_pipelined(const TrsmStrips &tr, int s
 // of three 64x64 tiles (3.4 us of MFMAs per wave behind an LDS staging pass).  Same k order from a zero accumulator and the
 // same C + alpha acc as gemm_tile_64_k128: identical bits (the 16x16 tiles above the diagonal, which nobody reads, are
 // left alone).  Written through; one count per wave on `ready` (36 = complete).
-__device__ __forceinline__ void diag_block_producer(const GemmArgs &g, int tile, unsigned *ready) {
+__device__ __forceinline__ void diag_block_producer(const GemmArgs &g, int tile, unsigned *ready, int col0 = 0) {
     const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
     int it = 0;
     while ((it + 1) * (it + 2) / 2 <= tile) ++it;              // row-major over the lower triangle of the 8 x 8 tile grid
@@ -1260,14 +1260,30 @@ __device__ __forceinline__ void diag_block_producer(const GemmArgs &g, int tile,
         lb[ks] = bp[(long)(4 * ks) * g.ldb];
     }
     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#ifdef PANEL_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PANEL_STAMP(10, tile == 0 && lane == 0);                       // (timing build) producer of tile (0, 0): operands in registers
+#endif
 #pragma unroll
     for (int ks = 0; ks < 32; ++ks) acc = MFMA(lb[ks], wa[ks], acc);
 #pragma unroll
     for (int q = 0; q < 4; ++q) st_pub(cp + (long)(4 * q) * g.ldc, cpre[q] + g.alpha * acc[q]);
+    PANEL_STAMP(11, tile == 0 && lane == 0);                       // MFMAs done, stores issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PANEL_STAMP(21 + 7, tile == 0 && lane == 0);                   // stores landed (slot 28)
     if (lane == 0) atomicAdd(ready, 1u);
 }
-#define PANEL_PRODUCERS 9               // 36 tiles, one per wave, four waves per workgroup: one wave per SIMD (two would share its MFMA pipe)
+// 36 tiles, one per wave.  Round 5: ONE wave per producer workgroup (36 workgroups), not four (9).  A producer wave fetches 32 KB of
+// operands (its tile's 16 rows of W and of L, K = 128) that the previous launch's strips wrote on other XCDs, and a workgroup fetches
+// such bytes at ~65 GB/s whatever its wave count (MI355X_MICROARCH.md, handoff-payload): with four waves the operands were in the
+// registers 2.7-3.2 us after the launch's start (tools/panel_stamps.py), the 32 MFMAs take 1.0.  The producers are gone after ~3 us
+// and the tile workers behind them in the grid take their CUs (the launcher still budgets PANEL_PRODUCER_CUS for them: the grid may
+// exceed the chip by the difference -- only workers, who wait for nobody, are dispatched late).  -DPANEL_PRODUCERS=9 restores.
+#ifndef PANEL_PRODUCERS
+#define PANEL_PRODUCERS 36
+#endif
+#define PANEL_PRODUCER_WAVES (36 / PANEL_PRODUCERS)
+#define PANEL_PRODUCER_CUS 9
 // Round 3, the update tiles as a QUEUE.  The launch's LDS size is the diagonal kernel's (160 KB), so every workgroup has a
 // CU to itself -- and at the top of the matrix 126 strips held 126 CUs for the whole launch although they mostly wait, while
 // the 1000 update tiles of the block's second panel queued for the other 120 (56 / 47 / 39-us launches where the chain needs
@@ -1347,7 +1363,7 @@ __global__ __launch_bounds__(64 * PANEL_WAVES) void k_ldlt_panel(double *Kb, lon
     if (b <= PANEL_PRODUCERS) {
         __builtin_amdgcn_s_setprio(3);
         PANEL_STAMP(9, threadIdx.x == 0 && b == 1);
-        if (threadIdx.x < 256) diag_block_producer(g, (b - 1) * 4 + (int)(threadIdx.x >> 6), ready);
+        if (threadIdx.x < 64 * PANEL_PRODUCER_WAVES) diag_block_producer(g, (b - 1) * PANEL_PRODUCER_WAVES + (int)(threadIdx.x >> 6), ready, col0);
         return;
     }
     const int first = 1 + PANEL_PRODUCERS;
@@ -1612,10 +1628,10 @@ int cip_launch_panel(hipStream_t s, double *Kb, long ld, double *xm_out, double 
         // ... when the unpaired launch does not fit the chip AND the paired one leaves at least four worker workgroups per problem: the
         // strips' second halves were tile groups, and without workers the update tiles queue up behind the TRSMs (16 problems of order
         // 2048: 23.5 ms per pass unpaired, 24.5-25.2 paired; 8 problems: 15.9 -> 15.3)
-        tr.pair = (pair_on && Bn > 1 && (long)Bn * (1 + PANEL_PRODUCERS + tr.strips) > ncu &&
-                   ncu / Bn - 1 - PANEL_PRODUCERS - (tr.strips + 1) / 2 >= 4) ? 1 : 0;
+        tr.pair = (pair_on && Bn > 1 && (long)Bn * (1 + PANEL_PRODUCER_CUS + tr.strips) > ncu &&
+                   ncu / Bn - 1 - PANEL_PRODUCER_CUS - (tr.strips + 1) / 2 >= 4) ? 1 : 0;
         const int nswg = tr.pair ? (tr.strips + 1) / 2 : tr.strips;
-        long workers = ncu / (cip_in_batch() ? cip_tl_bz.B : 1) - 1 - PANEL_PRODUCERS - nswg;
+        long workers = ncu / (cip_in_batch() ? cip_tl_bz.B : 1) - 1 - PANEL_PRODUCER_CUS - nswg;
         if (workers > (ntiles + 1) / 2) workers = (ntiles + 1) / 2;
         if (workers < 1 && ntiles > 0 && tr.strips == 0) workers = 1;
         if (workers < 0) workers = 0;

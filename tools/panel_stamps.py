@@ -15,13 +15,13 @@ lib = _lib.load()
 if len(sys.argv) > 2:
     lib.cip_debug_panel_col(int(sys.argv[2]))          # stamp the launch of the panel at this column only
 names = {0: "wg0 entry", 4: "ready seen", 2: "block in LDS", 6: "A(0) done", 7: "last pivot", 8: "wg0 end", 9: "producer wg1 entry",
-         10: "producer (0,0) counted", 11: "producer (7,7) counted", 12: "strip 0 update tiles done", 13: "strip 0 TRSM done",
+         10: "producer (0,0): operands in", 11: "its MFMAs done", 28: "its stores landed", 12: "strip 0 update tiles done", 13: "strip 0 TRSM done",
          14: "last strip TRSM done", 15: "worker 0 starts", 16: "worker 0 dry", 17: "strip 0 helper starts", 18: "strip 0 helper dry", 19: "last worker dry"}
 for rep in range(3):
     ks.factor(); torch.cuda.synchronize()
     t = (ctypes.c_long * 32)()
     assert lib.cip_debug_panel_stamps(t) == 0
     t0 = t[0]
-    print("rep", rep, " | ".join("%s %.2f" % (names[i], (t[i] - t0) / 100.0) for i in (0, 9, 4, 2, 6, 7, 8, 12, 13, 14, 15, 16, 17, 18, 19) if t[i]))
+    print("rep", rep, " | ".join("%s %.2f" % (names[i], (t[i] - t0) / 100.0) for i in (0, 9, 10, 11, 28, 4, 2, 6, 7, 8, 12, 13, 14, 15, 16, 17, 18, 19) if t[i]))
     if t[20]:
         print("      serial wave, A(1..7) done at", " ".join("%.2f" % ((t[20 + k] - t0) / 100.0) for k in range(7)))
