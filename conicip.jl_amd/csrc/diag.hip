@@ -1147,6 +1147,7 @@ struct TrsmStrips {
     double *W; long ldw;
     int strips;                       // rows / 64
     int pair;                         // round 5, k_ldlt_panel<true> in lock-step groups: a strip workgroup carries TWO strips (see the kernel)
+    int nprod;                        // producer workgroups of k_ldlt_panel<true>: 36 (one wave each; one problem) or 9 (four waves each; lock-step groups)
 };
 __device__ __forceinline__ unsigned strip_wait(unsigned v, unsigned target, const unsigned *stage, unsigned *slot, int *info) {
     if (v >= target) return v;
@@ -1279,10 +1280,11 @@ __device__ __forceinline__ void diag_block_producer(const GemmArgs &g, int tile,
 // registers 2.7-3.2 us after the launch's start (tools/panel_stamps.py), the 32 MFMAs take 1.0.  The producers are gone after ~3 us
 // and the tile workers behind them in the grid take their CUs (the launcher still budgets PANEL_PRODUCER_CUS for them: the grid may
 // exceed the chip by the difference -- only workers, who wait for nobody, are dispatched late).  -DPANEL_PRODUCERS=9 restores.
+// Lock-step groups keep nine producer workgroups of four waves per problem: B x 36 workgroups in front of the strips cost more than
+// the faster fetch buys (8 / 16 problems of order 2048: 15.2 / 23.9 ms per pass with 9, 15.4 / 25.5 with 36).
 #ifndef PANEL_PRODUCERS
 #define PANEL_PRODUCERS 36
 #endif
-#define PANEL_PRODUCER_WAVES (36 / PANEL_PRODUCERS)
 #define PANEL_PRODUCER_CUS 9
 // Round 3, the update tiles as a QUEUE.  The launch's LDS size is the diagonal kernel's (160 KB), so every workgroup has a
 // CU to itself -- and at the top of the matrix 126 strips held 126 CUs for the whole launch although they mostly wait, while
@@ -1360,13 +1362,14 @@ __global__ __launch_bounds__(64 * PANEL_WAVES) void k_ldlt_panel(double *Kb, lon
         trsm_strip_pipelined<false>(tr, b - 1, stage, (unsigned *)sm, info, sm + 64);
         return;
     }
-    if (b <= PANEL_PRODUCERS) {
+    if (b <= tr.nprod) {
         __builtin_amdgcn_s_setprio(3);
         PANEL_STAMP(9, threadIdx.x == 0 && b == 1);
-        if (threadIdx.x < 64 * PANEL_PRODUCER_WAVES) diag_block_producer(g, (b - 1) * PANEL_PRODUCER_WAVES + (int)(threadIdx.x >> 6), ready, col0);
+        const int pw = 36 / tr.nprod;                       // waves per producer workgroup
+        if ((int)threadIdx.x < 64 * pw) diag_block_producer(g, (b - 1) * pw + (int)(threadIdx.x >> 6), ready, col0);
         return;
     }
-    const int first = 1 + PANEL_PRODUCERS;
+    const int first = 1 + tr.nprod;
     const int grp = (int)(threadIdx.x >> 8), gt = (int)(threadIdx.x & 255);
     unsigned *ctl = (unsigned *)(sm + 2 * PANEL_GRP_DOUBLES);
     if (threadIdx.x < 5) ctl[threadIdx.x] = 0u;
@@ -1606,7 +1609,7 @@ int cip_launch_diag_upd(hipStream_t s, double *Kb, long ld, double *xm_out, doub
 int cip_launch_panel(hipStream_t s, double *Kb, long ld, double *xm_out, double *dvec, double *dinv, int *info, int col0,
                      PivotSigns sg, unsigned *ready, unsigned *stage, unsigned *tileq, const GemmArgs *g, int rows, double *W, long ldw) {
     if (cip_kernels_init()) return -3;
-    TrsmStrips tr = {Kb + CIP_NB, ld, Kb, xm_out, dinv, W, ldw, rows / 64, 0};
+    TrsmStrips tr = {Kb + CIP_NB, ld, Kb, xm_out, dinv, W, ldw, rows / 64, 0, PANEL_PRODUCER_CUS};
     // lock-step groups: problem index fastest in the dispatch order (CIP_PANEL_ZFAST=0: blockIdx.z, the order up to round 4's first half)
     static const int zfast = [] { const char *e = getenv("CIP_PANEL_ZFAST"); return e ? atoi(e) : 1; }();
     const int Bn = cip_in_batch() ? cip_tl_bz.B : 1;
@@ -1635,7 +1638,8 @@ int cip_launch_panel(hipStream_t s, double *Kb, long ld, double *xm_out, double 
         if (workers > (ntiles + 1) / 2) workers = (ntiles + 1) / 2;
         if (workers < 1 && ntiles > 0 && tr.strips == 0) workers = 1;
         if (workers < 0) workers = 0;
-        const long grid = 1 + PANEL_PRODUCERS + nswg + workers;
+        tr.nprod = Bn > 1 ? PANEL_PRODUCER_CUS : PANEL_PRODUCERS;
+        const long grid = 1 + tr.nprod + nswg + workers;
         if (transposed) cip_launch(k_ldlt_panel<true>, dim3((unsigned)(grid * Bn)), dim3(64 * PANEL_WAVES), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info,
                                    col0, sg, ready, stage, tileq, *g, tr, Bn, CipBatch{cip_tl_bz.stride, cip_tl_bz.mask});
         else cip_launch_b(k_ldlt_panel<true>, dim3((unsigned)grid), dim3(64 * PANEL_WAVES), DIAG2_LDS_BYTES, s, Kb, ld, xm_out, dvec, dinv, info, col0, sg,
