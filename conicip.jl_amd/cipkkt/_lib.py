@@ -110,6 +110,7 @@ SIGNATURES = {
     "cip_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "cip_set_ldlt_outer_block": (C.c_int, [C.c_int]),
     "cip_set_solve_block_max": (C.c_int, [C.c_int]),
+    "cip_set_solve_fused": (C.c_int, [C.c_int]),
     "cip_lockstep_solve_block_for": (C.c_int, [C.c_int]),
     "cip_profile_trailing_thread": (C.c_int, [C.c_int]),
     "cip_profile_thread_get": (C.c_int, [c_double_p]),

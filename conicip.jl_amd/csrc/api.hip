@@ -1087,4 +1087,5 @@ extern "C" int cip_sdp_lanczos_fallbacks(cip_handle *h, int *count) {
 extern "C" int cip_set_ldlt_fused_chain(int on) { return cip_ldlt_set_fused_chain(on); }
 extern "C" int cip_set_ldlt_side_prep(int on) { return cip_ldlt_set_side_prep(on); }
 extern "C" int cip_set_solve_block_max(int b) { return cip_solve_block_max_set(b); }
+extern "C" int cip_set_solve_fused(int mode) { return cip_solve_fused_set(mode); }
 extern "C" int cip_set_ldlt_outer_block(int nbo) { cip_ldlt_set_outer_block(nbo); return cip_ldlt_outer_block(); }

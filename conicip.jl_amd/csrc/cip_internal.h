@@ -149,6 +149,11 @@ struct LdltWorkspace {        // carved out of one device allocation
     int Bs;                   // solve block: largest of {1024,512,256,128} dividing Npad
     double *X, *XT;           // (Npad/Bs) x Bs x Bs   inverse (and its transpose) of each Bs x Bs unit-lower diagonal block
     double *Tt;               // (Npad/Bs) x (Bs/2)^2  scratch of the block-inverse doubling
+    // one launch per block step (round 5, ldlt.hip: k_solve_step): the pre-multiplied off-diagonal neighbours of every solve block,
+    //   MT_J = (X_J L_{J,J-1})'  (J >= 1, forward sweep)   and   PT_J = L_{J+1,J} X_J  (J <= nbk - 2, backward sweep),
+    // (Npad/Bs) x Bs x Bs each; `fused` == 0: two launches per block step, MT / PT unused (NULL)
+    double *MT, *PT;
+    int fused;
     double *zbuf;             // Npad scratch
     int *x_zeroed;            // host flag owned by the handle (NULL: zero X/XT on every factorisation)
     double *dinv;             // Npad   1/d
@@ -174,6 +179,7 @@ int cip_ldlt_set_side_prep(int on);       // 1 (default): solve preparation besi
 int cip_ldlt_set_fused_chain(int on);     // 1 (default): diag + previous in-block update in one launch; returns the previous setting
 int cip_solve_block(int Npad);
 int cip_solve_block_max_set(int b);              // 128 | 256 | 512 | 1024 (0: query); returns the previous limit
+int cip_solve_fused_set(int mode);               // 0 (default): two launches per block step; 1: one (pre-multiplied neighbours) for solve blocks <= 512; 2: always; < 0: query.  Returns the previous mode
 extern thread_local int cip_tl_solve_block_max;  // > 0: this thread's limit for handles it creates
 size_t cip_ldlt_ws_bytes(int Npad);
 void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws);

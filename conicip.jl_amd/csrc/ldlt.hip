@@ -26,6 +26,7 @@
 // chain, round 1: 256 / 384 / 512 -> 107.7 / 107.0 / 109.1; 1024 -> 125 against 128).
 #include <atomic>
 #include <mutex>
+#include <vector>
 static std::atomic<int> g_nbo{0};         // read by the library's worker threads (batch.hip) while a caller may set it
 static std::atomic<int> g_fuse_diag{-1};
 static std::once_flag g_fuse_once;
@@ -73,7 +74,6 @@ void cip_ldlt_set_outer_block(int nbo) {
 }
 
 // ---- optional instrumentation: HIP events around every trailing-update launch (bench.py roofline)
-#include <vector>
 struct LdltProfile {
     std::vector<hipEvent_t> pool;     // event pairs
     size_t used = 0;
@@ -179,6 +179,28 @@ int cip_solve_block(int Npad) {
     return CIP_NB;
 }
 
+// One launch per block step of the triangular sweeps (k_solve_step) instead of two: needs the pre-multiplied neighbour blocks
+// MT / PT (k_solve_premul, 2 (Npad/Bs - 1) triangular Bs^3 products per factorisation).  Mode 0 (default): two launches per step;
+// 1: one launch for solve blocks of at most 512 columns; 2: always.  CIP_SOLVE_FUSED.
+// Measured (round 5, same session, tools/ab_solve_fused.sh): the sweeps get 20 % faster -- solve4x4 at n = 8192 0.208 -> 0.165 ms
+// with 17 launches instead of 32 -- and every configuration gets SLOWER, because the products cost more than the launches they
+// save at the two to three solves an interior-point iteration makes per factorisation: n = 8192 15.7 GFLOP on the side stream,
+// +0.24 ms per step exposed (196.2 -> 190.3 KKT solves/s); lock-step shards of 8 / 64 problems of order 2048 15.2 -> 16.5 /
+// 78.0 -> 80.5 ms per pass (+28 % flops per factorisation); config 3 3.93 -> 4.0 ms per iteration.  It pays from about six
+// solves per factorisation on: off by default, kept for callers that solve many right-hand sides with one factor.
+static std::atomic<int> g_solve_fused{-1};
+int cip_solve_fused_set(int mode) {
+    if (g_solve_fused.load() < 0) { const char *e = getenv("CIP_SOLVE_FUSED"); int v = -1; g_solve_fused.compare_exchange_strong(v, e ? atoi(e) : 0); }
+    const int prev = g_solve_fused.load();
+    if (mode == 0 || mode == 1 || mode == 2) g_solve_fused.store(mode);
+    return prev;
+}
+static int solve_fused_for(int Npad, int Bs) {
+    const int mode = cip_solve_fused_set(-1);
+    if (Npad / Bs < 2) return 0;
+    return mode == 2 || (mode == 1 && Bs <= 512);
+}
+
 size_t cip_ldlt_ws_bytes(int Npad) {
     const size_t nblk = Npad / CIP_NB;
     size_t b = 0;
@@ -191,6 +213,7 @@ size_t cip_ldlt_ws_bytes(int Npad) {
         b += al256(nbk * (size_t)Bs * Bs * 8) * 2;       // X, XT
         b += al256(nbk * (size_t)(Bs / 2) * (Bs / 2) * 8 + 256);   // Tt
         b += al256((size_t)Npad * 8);                    // zbuf
+        if (solve_fused_for(Npad, Bs)) b += al256(nbk * (size_t)Bs * Bs * 8) * 2;   // MT, PT
     }
     b += al256((size_t)Npad * 8) * 3;                    // dinv, dvec, tmp
     b += al256(64 + 12 * nblk);                          // info (16 ints) + a `ready`, a `stage` and a tile-queue counter per 128-block (fused panel launches)
@@ -211,6 +234,12 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
         ws->XT = (double *)p;    p += al256(nbk * (size_t)ws->Bs * ws->Bs * 8);
         ws->Tt = (double *)p;    p += al256(nbk * (size_t)(ws->Bs / 2) * (ws->Bs / 2) * 8 + 256);
         ws->zbuf = (double *)p;  p += al256((size_t)Npad * 8);
+        ws->fused = solve_fused_for(Npad, ws->Bs);
+        ws->MT = ws->PT = nullptr;
+        if (ws->fused) {
+            ws->MT = (double *)p;  p += al256(nbk * (size_t)ws->Bs * ws->Bs * 8);
+            ws->PT = (double *)p;  p += al256(nbk * (size_t)ws->Bs * ws->Bs * 8);
+        }
     }
     ws->dinv = (double *)p;  p += al256((size_t)Npad * 8);
     ws->dvec = (double *)p;  p += al256((size_t)Npad * 8);
@@ -364,6 +393,49 @@ static int ensure_x_zeroed(hipStream_t s, int Npad, const LdltWorkspace &ws) {
     if (ws.x_zeroed && (!cip_in_batch() || cip_tl_bz.mask == (cip_tl_bz.B >= 64 ? ~0ull : ((1ull << cip_tl_bz.B) - 1)))) *ws.x_zeroed = 1;
     return 0;
 }
+// The pre-multiplied neighbours of the one-launch block steps (k_solve_step), both kinds in ONE launch, 64 x 64 tiles:
+//   blockIdx.y <  nm:  MT_J = U_{J-1,J} XT_J,  J = jm0 + blockIdx.y       (U = L' from the upper triangle; XT_J upper triangular:
+//                      column tile j0 needs k < j0 + 64 only)
+//   blockIdx.y >= nm:  PT_J = L_{J+1,J} X_J,   J = jp0 + blockIdx.y - nm  (X_J lower triangular: k >= j0 only)
+#include "cip_gemm_tile.h"
+__global__ __launch_bounds__(256, 4) void k_solve_premul(const double *K, long ld, const double *X, const double *XT, double *MT,
+                                                         double *PT, int Bs, int jm0, int nm, int jp0, CipBatch cb) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 2 * CIP_KT * SB];   // 32 KB
+    CIP_BATCH_GUARD(cb);
+    CIP_BO5(cb, K, X, XT, MT, PT);
+    const int tm = Bs / SB;
+    const long i0 = (long)(blockIdx.x % tm) * SB, j0 = (long)(blockIdx.x / tm) * SB;
+    const long bs2 = (long)Bs * Bs;
+    GemmArgs g = {};
+    g.alpha = 1.0; g.ldb = Bs; g.ldc = Bs; g.lda = ld;
+    if ((int)blockIdx.y < nm) {
+        const long J = jm0 + blockIdx.y;
+        g.A = K + (J - 1) * Bs + J * Bs * ld;               // A[i, k] = U[C_{J-1} + i, C_J + k] = L[C_J + k, C_{J-1} + i]
+        g.B = X + J * bs2;                                   // B[j, k] = X_J[j, k] = XT_J[k, j]: zero for k > j
+        g.C = MT + J * bs2;
+        g.K = (int)(j0 + SB);
+    } else {
+        const long J = jp0 + ((int)blockIdx.y - nm);
+        g.A = K + (J + 1) * Bs + J * Bs * ld + j0 * ld;     // A[i, k] = L[C_{J+1} + i, C_J + k], k from j0 on
+        g.B = XT + J * bs2 + j0 * Bs;                        // B[j, k] = XT_J[j, k] = X_J[k, j]: zero for k < j
+        g.C = PT + J * bs2;
+        g.K = (int)(Bs - j0);
+    }
+    gemm_tile_64<EPI_STORE>(g, lds, i0, j0);
+}
+static int build_solve_premul(hipStream_t s, double *K, long ld, const LdltWorkspace &ws, int nbk_all, int J0, int J1) {
+    if (!ws.fused) return 0;
+    const int Bs = ws.Bs;
+    const double *X = (Bs == CIP_NB) ? ws.Linv : ws.X, *XT = (Bs == CIP_NB) ? ws.LinvT : ws.XT;
+    const int jm0 = J0 > 1 ? J0 : 1, nm = J1 - jm0 > 0 ? J1 - jm0 : 0;                       // MT_J, J in [max(J0, 1), J1)
+    const int jp1 = J1 < nbk_all - 1 ? J1 : nbk_all - 1, np = jp1 - J0 > 0 ? jp1 - J0 : 0;  // PT_J, J in [J0, min(J1, nbk - 1))
+    if (nm + np == 0) return 0;
+    const int tm = Bs / SB;
+    cip_launch_b(k_solve_premul, dim3((unsigned)(tm * tm), (unsigned)(nm + np)), dim3(256), 0, s, (const double *)K, ld, X, XT, ws.MT, ws.PT, Bs, jm0, nm, J0);
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // [J0, J1): the range of Bs-wide diagonal blocks to prepare (their columns are final), all of them by default.  The mirror
 // covers the same columns (every row below them).  Ranges are independent of each other (own slices of X / XT / Tt).
 static int build_solve_blocks(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws, int J0 = 0, int J1 = -1) {
@@ -382,8 +454,10 @@ static int build_solve_blocks(hipStream_t s, double *K, int Npad, long ld, const
     const int per = Bs / CIP_NB;
     const double *xm0 = ws.Xm + (size_t)J0 * per * 2048;
     const double *Kd = K + (long)J0 * Bs * (ld + 1);
-    if (Bs == CIP_NB)                                                   // X == Linv, XT == LinvT
-        return cip_launch_diag_inverse(s, Kd, ld, nbk, xm0, ws.Linv + (size_t)J0 * CIP_NB * CIP_NB, ws.LinvT + (size_t)J0 * CIP_NB * CIP_NB, CIP_NB);
+    if (Bs == CIP_NB) {                                                 // X == Linv, XT == LinvT
+        if ((rc = cip_launch_diag_inverse(s, Kd, ld, nbk, xm0, ws.Linv + (size_t)J0 * CIP_NB * CIP_NB, ws.LinvT + (size_t)J0 * CIP_NB * CIP_NB, CIP_NB))) return rc;
+        return build_solve_premul(s, K, ld, ws, Npad / Bs, J0, J1);
+    }
     const long bs2 = (long)Bs * Bs, tt2 = (long)(Bs / 2) * (Bs / 2);
     double *X0 = ws.X + (size_t)J0 * bs2, *XT0 = ws.XT + (size_t)J0 * bs2, *Tt0 = ws.Tt + (size_t)J0 * tt2;
     // the inverses of the 128-blocks, written straight into the diagonal of X / XT
@@ -409,7 +483,7 @@ static int build_solve_blocks(hipStream_t s, double *K, int Npad, long ld, const
         if ((rc = cip_launch_gemm(s, EPI_ACCUM, g))) return rc;
         g.Ct = nullptr;
     }
-    return 0;
+    return build_solve_premul(s, K, ld, ws, Npad / Bs, J0, J1);
 }
 
 // ---- solve preparation BESIDE the panel chain (round 4).  The block inverses and the mirror image of columns that are
@@ -566,6 +640,91 @@ __global__ __launch_bounds__(256) void k_scale_vec(int n, const double *x, const
 // block's inputs wait for each other on a counter and compute its product while the rest of the grid streams the update:
 // bit-identical, 17 launches instead of 31 -- and 0.36 ms: the fan-in of 256 workgroups plus the coherent reload under a
 // streaming load costs ~11 us per step, more than the launch it replaces, as MI355X_MICROARCH.md's price list says).
+//
+// Round 5: ONE launch per block step.  With the neighbour blocks pre-multiplied by the block inverse (k_solve_premul),
+//   forward   y_J = X_J r_J - (X_J L_{J,J-1}) y_{J-1},   r_J = b_J - sum_{I < J-1} L_{JI} y_I,
+// nothing in step J depends on anything younger than y_{J-1}: the launch that forms y_J (part a) also applies y_{J-1} to the rows
+// below block J (part b), and block J's own share of that update is the pre-multiplied term.  Mirror image for L' x = D^-1 y.
+// Npad / Bs launches per sweep instead of 2 Npad / Bs - 1, the D^-1 scaling rides on the forward sweep's stores; the bytes are
+// the same (MT_J / PT_J are read instead of L_{J,J-1} / L_{J+1,J}), the triangular halves of X no longer read as zeros.
+struct SolveStepArgs {
+    const double *T, *M, *v, *u;      // (a) out[j] = T[:, j] . v  -  M[:, j] . u   for j < Bs (T, M: Bs x Bs, pitch Bs; M == NULL: first step)
+    double *out, *out2; const double *dsc;   // out2 != NULL: out2[j] = out[j] * dsc[j]
+    int Bs, tri;                      // tri 1: T[:, j] is zero below row j (XT_J); 2: above row j (X_J)
+    const double *Bm; long ldb; double *tgt; int ncols;   // (b) tgt[c] -= Bm[0:Bs, c] . u   for c < ncols
+};
+// this lane's share of a[r0:r1] . x[r0:r1]; r0, r1 multiples of 128, 16-byte aligned operands; four 16-byte loads in flight
+__device__ __forceinline__ double lane_dot(const double *a, const double *x, int r0, int r1, int lane) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int i = r0 + lane * 2;
+    for (; i + 384 < r1; i += 512) {
+        const v2d a0 = *(const v2d *)(a + i), a1 = *(const v2d *)(a + i + 128), a2 = *(const v2d *)(a + i + 256), a3 = *(const v2d *)(a + i + 384);
+        const v2d x0 = *(const v2d *)(x + i), x1 = *(const v2d *)(x + i + 128), x2 = *(const v2d *)(x + i + 256), x3 = *(const v2d *)(x + i + 384);
+        s0 = fma(a0.x, x0.x, s0); s1 = fma(a0.y, x0.y, s1);
+        s2 = fma(a1.x, x1.x, s2); s3 = fma(a1.y, x1.y, s3);
+        s0 = fma(a2.x, x2.x, s0); s1 = fma(a2.y, x2.y, s1);
+        s2 = fma(a3.x, x3.x, s2); s3 = fma(a3.y, x3.y, s3);
+    }
+    for (; i < r1; i += 128) {
+        const v2d av = *(const v2d *)(a + i), xv = *(const v2d *)(x + i);
+        s0 = fma(av.x, xv.x, s0); s1 = fma(av.y, xv.y, s1);
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(256) void k_solve_step(SolveStepArgs a, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO4(cb, a.T, a.M, a.v, a.u);
+    CIP_BO5(cb, a.out, a.out2, a.dsc, a.Bm, a.tgt);
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j < a.Bs) {
+        const int r0 = a.tri == 1 ? 0 : (j & ~127), r1 = a.tri == 1 ? ((j + 128) & ~127) : a.Bs;
+        double s = lane_dot(a.T + (long)j * a.Bs, a.v, r0, r1, lane);
+        if (a.M) s -= lane_dot(a.M + (long)j * a.Bs, a.u, 0, a.Bs, lane);
+        s = cip_wave_sum(s);
+        if (lane == 0) {
+            a.out[j] = s;
+            if (a.out2) a.out2[j] = s * a.dsc[j];
+        }
+        return;
+    }
+    const int c = j - a.Bs;
+    if (c >= a.ncols) return;
+    const double s = cip_wave_sum(lane_dot(a.Bm + (long)c * a.ldb, a.u, 0, a.Bs, lane));
+    if (lane == 0) a.tgt[c] -= s;
+}
+static int solve_fused(hipStream_t s, const double *K, int Npad, long ld, const LdltWorkspace &ws, double *rhs) {
+    const int Bs = ws.Bs, nbk = Npad / Bs;
+    const double *X = (Bs == CIP_NB) ? ws.Linv : ws.X, *XT = (Bs == CIP_NB) ? ws.LinvT : ws.XT;
+    const size_t bs2 = (size_t)Bs * Bs;
+    double *y = ws.tmp, *z = ws.zbuf;
+    int rc;
+    for (int J = 0; J < nbk; ++J) {
+        const long C0 = (long)J * Bs;
+        if ((rc = cip_ldlt_side_join(s, ws, J))) return rc;
+        SolveStepArgs a = {};
+        a.T = XT + J * bs2; a.v = rhs + C0; a.out = y + C0; a.out2 = z + C0; a.dsc = ws.dinv + C0; a.Bs = Bs; a.tri = 1;
+        if (J > 0) {
+            a.M = ws.MT + J * bs2; a.u = y + C0 - Bs;
+            a.ncols = Npad - (int)C0 - Bs;
+            a.Bm = K + (C0 - Bs) + (C0 + Bs) * ld; a.ldb = ld; a.tgt = rhs + C0 + Bs;
+        }
+        cip_launch_b(k_solve_step, dim3((unsigned)((Bs + a.ncols + 3) / 4)), dim3(256), 0, s, a);
+    }
+    for (int J = nbk - 1; J >= 0; --J) {
+        const long C0 = (long)J * Bs;
+        SolveStepArgs a = {};
+        a.T = X + J * bs2; a.v = z + C0; a.out = rhs + C0; a.Bs = Bs; a.tri = 2;
+        if (J < nbk - 1) {
+            a.M = ws.PT + J * bs2; a.u = rhs + C0 + Bs;
+            a.ncols = (int)C0;
+            a.Bm = K + (C0 + Bs); a.ldb = ld; a.tgt = z;
+        }
+        cip_launch_b(k_solve_step, dim3((unsigned)((Bs + a.ncols + 3) / 4)), dim3(256), 0, s, a);
+    }
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 int cip_ldlt_solve(hipStream_t s, const double *K, int Npad, long ld, const LdltWorkspace &ws, double *rhs) {
     const int Bs = ws.Bs;
     const int nbk = Npad / Bs;
@@ -574,6 +733,7 @@ int cip_ldlt_solve(hipStream_t s, const double *K, int Npad, long ld, const Ldlt
     const size_t bs2 = (size_t)Bs * Bs;
     int rc;
     double *y = ws.tmp, *z = ws.zbuf;
+    if (ws.fused && !(ld & 1) && !(((uintptr_t)K | (uintptr_t)rhs) & 15)) return solve_fused(s, K, Npad, ld, ws, rhs);
     for (int J = 0; J < nbk; ++J) {
         const long C0 = (long)J * Bs;
         if ((rc = cip_ldlt_side_join(s, ws, J))) return rc;          // (a no-op once every group has been waited for)

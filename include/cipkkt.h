@@ -257,6 +257,13 @@ int cip_set_ldlt_outer_block(int nbo);    /* 0 = automatic (896 from order 4096 
 /* tuning knob: widest block of the triangular solves' block-step form (128, 256, 512 or 1024; 0 = query).  Applies to
  * handles created afterwards; returns the previous value.  Lock-step batches use min(this, cip_lockstep_solve_block_for(B)) for their handles. */
 int cip_set_solve_block_max(int b);
+/* block steps of the triangular sweeps (also CIP_SOLVE_FUSED): 0 (default) = two launches per step (block product, then the
+ * update of everything below / above); 1 = ONE launch per block step for solve blocks of at most 512 columns -- the neighbour
+ * blocks X_J L_{J,J-1} / L_{J+1,J} X_J are formed with the block inverses at factorisation time, so a step depends on the
+ * previous step's result only (sweeps 20 % faster, factorisation dearer: pays from about six solves per factorisation on);
+ * 2 = for every block width.  Applies to handles created afterwards; the two forms differ in rounding.  Returns the
+ * previous mode (other values: query). */
+int cip_set_solve_fused(int mode);
 /* the solve-block limit cip_conicip_lockstep gives the handles of a call of B problems in all (512 for B <= 8, else 256 -- chosen
  * from the size of the whole call, so the groups of 64 it is cut into all use the same one; never more than
  * cip_set_solve_block_max's value; CIP_LOCKSTEP_SOLVE_BLOCK overrides): a one-problem run with this limit

@@ -138,6 +138,52 @@ def test_ldlt_quasidefinite(lib):
     assert np.all(D[:n] > 0) and np.all(D[n:] < 0)
 
 
+@pytest.mark.parametrize("N,bmax", [(384, 128), (640, 128), (1536, 512), (2048, 256), (2048, 512), (3072, 1024)])
+def test_ldlt_solve_one_launch_per_block_step(lib, N, bmax):
+    """The triangular sweeps with the pre-multiplied neighbour blocks (one launch per block step, cip_set_solve_fused) against the
+    two-launch form and against numpy: same backward error, results equal to rounding.  Quasi-definite matrix (both pivot signs)."""
+    from cipkkt import _lib as L
+    rng = np.random.default_rng(N + bmax)
+    n = N - N // 4
+    M = rng.standard_normal((n, n))
+    Kmat = np.zeros((N, N))
+    Kmat[:n, :n] = M @ M.T / n + np.eye(n)
+    G = rng.standard_normal((N - n, n))
+    Kmat[n:, :n] = G
+    Kmat[:n, n:] = G.T
+    x_true = rng.standard_normal(N)
+    rhs = Kmat @ x_true
+    prev_b = lib.cip_set_solve_block_max(bmax)
+    prev_f = lib.cip_set_solve_fused(-1)
+    out = {}
+    try:
+        for mode in (0, 2):
+            lib.cip_set_solve_fused(mode)
+            nbytes = C.c_size_t()
+            L.check(lib.cip_ldlt_workspace_bytes(N, C.byref(nbytes)))
+            ws = torch.zeros(nbytes.value // 8 + 8, dtype=torch.float64, device="cuda")
+            dK = colmajor_dev(Kmat)
+            info = C.c_int(-1)
+            L.check(lib.cip_ldlt_factor_dev(None, dK.data_ptr(), N, N, ws.data_ptr(), C.byref(info)))
+            assert info.value == 0
+            xs = []
+            for rep in range(2):                      # (twice: the sweeps must leave the prepared blocks alone)
+                drhs = dev(rhs)
+                L.check(lib.cip_ldlt_solve_dev(None, dK.data_ptr(), N, N, ws.data_ptr(), drhs.data_ptr()))
+                torch.cuda.synchronize()
+                xs.append(drhs.cpu().numpy())
+            np.testing.assert_array_equal(xs[0], xs[1])
+            out[mode] = xs[0]
+    finally:
+        lib.cip_set_solve_fused(prev_f)
+        lib.cip_set_solve_block_max(prev_b)
+    nK = np.linalg.norm(Kmat, 2)
+    for mode, x in out.items():
+        res = np.linalg.norm(Kmat @ x - rhs) / (nK * np.linalg.norm(x))
+        assert res < 1e-14, "mode %d: normwise backward error %g" % (mode, res)
+    assert np.linalg.norm(out[0] - out[2]) <= 1e-11 * np.linalg.norm(out[0])
+
+
 def test_ldlt_reports_zero_pivot(lib):
     from cipkkt import _lib as L
     N = 128
