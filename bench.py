@@ -538,6 +538,8 @@ def main():
     ap.add_argument("--no-c5", action="store_true", help="c2: skip the single-GPU config-5 figure")
     ap.add_argument("--no-secondary", action="store_true", help="c2: skip the configs[2] / configs[3] runs after the timed region")
     ap.add_argument("--no-plugin-boundary", action="store_true", help="c2: skip the host-pointer plugin-level timings")
+    ap.add_argument("--profile-stride", type=int, default=4,
+                    help="c2: HIP events around the trailing-update launches of every k-th timed step (1 = every step)")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="c2: do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes before the GPU is "
                          "touched); replay the committed passes instead")
@@ -713,7 +715,11 @@ def main():
     for _ in range(args.warmup):
         step()
     ks.check_factor()
-    ks.profile_trailing(True)
+    # roofline events INSIDE the timed region (contract), sampled: every trailing-update launch of every `stride`-th step is
+    # bracketed by a HIP-event pair on the launch stream (the first timed step included).  An event pair costs the chain ~8 us;
+    # round 4 timed every step (0.9 % of `value`, `profiling_cost`), the sampled form perturbs a `stride`-th as much.
+    prof_stride = max(1, min(args.profile_stride, args.steps))
+    ks.profile_trailing(prof_stride)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -830,8 +836,10 @@ def main():
         }
         out["profiling_cost"] = {"ms_per_step_with_trailing_events": ms_per_step,
                                  "ms_per_step_without": elapsed_noprof / args.steps * 1e3,
+                                 "profiled_steps": (args.steps + prof_stride - 1) // prof_stride, "profile_stride": prof_stride,
                                  "note": "`value` is measured WITH the per-launch HIP events of the roofline inside the timed "
-                                         "region (contract); the same steps again without them, same session"}
+                                         "region (contract): every trailing-update launch of every `profile_stride`-th timed step; "
+                                         "the same steps again without any events, same session"}
         if pb is not None:
             out["plugin_boundary"] = pb
         if secondary is not None:

@@ -291,7 +291,8 @@ class KKTSystem:
                     nbo=out[5], N=out[6], Npad=out[7])
 
     def profile_trailing(self, on):
-        L.check(self.lib.cip_profile_trailing(self.h, int(bool(on))))
+        """HIP events around the trailing-update launches: True / 1 = every factorisation, k > 1 = every k-th, False = off."""
+        L.check(self.lib.cip_profile_trailing(self.h, int(on)))
 
     def profile_get(self):
         out = (C.c_double * 3)()

@@ -1048,6 +1048,7 @@ extern "C" int cip_set_timing(cip_handle *h, int enabled) {
 extern "C" int cip_profile_trailing(cip_handle *h, int enabled) {
     if (!h) return CIP_E_INVALID;
     if (enabled && !h->ws.prof) h->ws.prof = cip_ldlt_profile_create();
+    if (enabled) cip_ldlt_profile_stride(h->ws.prof, enabled);      // enabled = k > 1: every k-th factorisation (the first one included)
     if (!enabled && h->ws.prof) { cip_ldlt_profile_destroy(h->ws.prof); h->ws.prof = nullptr; }
     return 0;
 }

@@ -124,6 +124,7 @@ int cip_wait(hipStream_t s);
 struct LdltProfile;           // optional per-launch event timing of the trailing-update kernel (ldlt.hip)
 LdltProfile *cip_ldlt_profile_create(void);
 void cip_ldlt_profile_destroy(LdltProfile *p);
+void cip_ldlt_profile_stride(LdltProfile *p, int stride);     // time every stride-th factorisation only (default 1: all)
 // synchronises; adds the elapsed time of every recorded trailing-update launch to the totals
 int cip_ldlt_profile_collect(LdltProfile *p, double *launches, double *ms, double *flops);
 int cip_ldlt_profile_thread(int enabled);      // a profile of the calling host thread (lock-step batches: bench.py, config 5)

@@ -79,7 +79,10 @@ struct LdltProfile {
     size_t used = 0;
     std::vector<double> flops;        // algorithmic flops of each recorded launch
     double tot_launches = 0, tot_ms = 0, tot_flops = 0;
+    int stride = 1;                   // every stride-th factorisation is timed (an event pair costs its launch ~8 us of chain)
+    long nfact = 0;                   // factorisations seen
 };
+void cip_ldlt_profile_stride(LdltProfile *p, int stride) { if (p) { p->stride = stride > 1 ? stride : 1; p->nfact = 0; } }
 LdltProfile *cip_ldlt_profile_create(void) { return new LdltProfile(); }
 void cip_ldlt_profile_destroy(LdltProfile *p) {
     if (!p) return;
@@ -561,6 +564,8 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
     if ((rc = zero_fill(s, ws.info, 64 + 12 * (size_t)(Npad / CIP_NB)))) return rc;
     if ((rc = ensure_x_zeroed(s, Npad, ws))) return rc;
     const int Bs = ws.Bs;
+    LdltProfile *prof_this = ws.prof ? ws.prof : (cip_tl_builder ? nullptr : g_tl_prof);
+    if (prof_this && (prof_this->nfact++ % prof_this->stride) != 0) prof_this = nullptr;      // a sampled profile skips this factorisation
     LdltSide *sd = nullptr;
     int Jdone = 0;                                           // solve blocks [0, Jdone) are prepared or being prepared on the side stream
     // serial right-looking schedule: panels of the outer block, then ONE trailing update
@@ -607,7 +612,7 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
                 epi = EPI_LAZYC;
                 g.Qin = ws.lazyC + r0 + (long)r0 * ws.lazy_ld; g.ldq = ws.lazy_ld; g.Cdiag = ws.lazy_diag + r0;
             }
-            LdltProfile *prof = ws.prof ? ws.prof : (cip_tl_builder ? nullptr : g_tl_prof);
+            LdltProfile *prof = prof_this;
             if (prof) {
                 if ((rc = prof_event(prof, s))) return rc;
                 const double r = (double)(Npad - r0);

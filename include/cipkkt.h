@@ -292,8 +292,10 @@ int cip_set_lazy_copy(int on);
    3 (self-test): as 2 with the bound on the wrong side of theta, so that every certificate fails and every verdict is the fallback's. */
 int cip_set_sdp_lanczos(int on);
 int cip_sdp_lanczos_fallbacks(cip_handle *h, int *count);
-/* HIP-event timing of every LDL' trailing-update launch (bench.py roofline): enable, then read
- * out3 = [launches, total ms, total algorithmic flops (r(r+1)K per launch)] */
+/* HIP-event timing of the LDL' trailing-update launches (bench.py roofline): enable, then read
+ * out3 = [launches, total ms, total algorithmic flops (r(r+1)K per launch)].  enabled = 1: every launch of every factorisation;
+ * enabled = k > 1: of every k-th factorisation, starting with the next one (an event pair costs the chain ~8 us: a sampled
+ * profile perturbs the timed region a k-th as much); 0: off (drops the totals) */
 int cip_profile_trailing(cip_handle *h, int enabled);
 int cip_profile_get(cip_handle *h, double *out3);
 /* the same for every factorisation the CALLING THREAD enqueues on handles without a profile of their own (the handles of
