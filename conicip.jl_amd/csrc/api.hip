@@ -88,7 +88,6 @@ static void free_all(cip_handle *h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
-    if (h->ev_info) (void)hipEventDestroy(h->ev_info);
     if (h->info_host) (void)hipHostFree(h->info_host);
     if (h->ws.prof) { cip_ldlt_profile_destroy(h->ws.prof); h->ws.prof = nullptr; }
 }
@@ -406,7 +405,6 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
     DMALLOC(h->dot_ptrs, 32 * 32);
     DMALLOC(h->stage, sizeof(double) * 2 * (size_t)(n + p + m));
     CIP_HIP_CHECK(hipEventCreate(&h->ev0)); CIP_HIP_CHECK(hipEventCreate(&h->ev1)); CIP_HIP_CHECK(hipEventCreate(&h->ev2));
-    CIP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_info, hipEventDisableTiming));
     // (the pinned pivot-flag words are allocated by the first factorisation: pinned allocations cost ~0.1 ms each, and the
     //  64 handles of a lock-step group never use theirs)
     if ((rc = cip_cones_identity_scaling(s, h->cs))) return rc;
@@ -563,6 +561,36 @@ static int graph_run(cip_handle *h, hipGraphExec_t *exec, F &&enqueue) {
     return 0;
 }
 
+// the factorisation's four flag words -> host-mapped pinned memory, by a store from the device.  (Until round 5 a 16-byte
+// hipMemcpyAsync: a blit kernel between two barriers -- in the kernel trace the main queue stood idle for 24 us between the last
+// panel launch and the first solve's first kernel, of which the copy itself was 5.)
+// No event behind it either (an event record is a barrier packet with a system-scope release: 11 us in the same trace): the fifth
+// word is the factorisation's sequence number, stored with system-scope release behind the four flags; the host polls it.
+__global__ void k_publish_info(const int *info, int *host, int seq) {
+    if (threadIdx.x == 0) {
+        host[0] = info[0]; host[1] = info[1]; host[2] = info[2]; host[3] = info[3];
+        __hip_atomic_store(host + 4, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// has the flag read-back of factorisation `info_seq` landed?  wait: spin (the stream is polled too: a failed launch must not hang the host)
+static int info_landed(cip_handle *h, bool wait, bool *landed) {
+    volatile int *seqp = h->info_host + 4;
+    *landed = __atomic_load_n(seqp, __ATOMIC_ACQUIRE) == h->info_seq;
+    if (*landed || !wait) return 0;
+    for (long spin = 0;; ++spin) {
+        if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == h->info_seq) { *landed = true; return 0; }
+        if ((spin & 0xfff) == 0xfff) {
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q == hipSuccess) {                                   // everything enqueued has run: the word must be there
+                *landed = __atomic_load_n(seqp, __ATOMIC_ACQUIRE) == h->info_seq;
+                if (*landed) return 0;
+                cip_set_error("LDL': the pivot flags of factorisation %d never arrived", h->info_seq);
+                return CIP_E_HIP;
+            }
+            if (q != hipErrorNotReady) { cip_set_error("hipStreamQuery failed: %s", hipGetErrorString(q)); return CIP_E_HIP; }
+        }
+    }
+}
 // assembly + LDL' + an asynchronous read-back of the pivot flag into pinned host memory; nothing here waits for the GPU
 static int factor_enqueue(cip_handle *h) {
     int rc;
@@ -578,11 +606,16 @@ static int factor_enqueue(cip_handle *h) {
     }
     h->n_factor += 1;
     if (!h->info_host) {
-        CIP_HIP_CHECK(hipHostMalloc((void **)&h->info_host, 4 * sizeof(int), hipHostMallocDefault));
-        memset(h->info_host, 0, 4 * sizeof(int));
+        CIP_HIP_CHECK(hipHostMalloc((void **)&h->info_host, 8 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(h->info_host, 0, 8 * sizeof(int));
     }
-    CIP_HIP_CHECK(hipMemcpyAsync(h->info_host, h->ws.info, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    CIP_HIP_CHECK(hipEventRecord(h->ev_info, h->stream));
+    {
+        int *info_dev = nullptr;
+        CIP_HIP_CHECK(hipHostGetDevicePointer((void **)&info_dev, h->info_host, 0));
+        h->info_seq = (h->info_seq == 0x7fffffff) ? 1 : h->info_seq + 1;
+        hipLaunchKernelGGL(k_publish_info, dim3(1), dim3(64), 0, h->stream, (const int *)h->ws.info, info_dev, h->info_seq);
+        CIP_HIP_CHECK(hipGetLastError());
+    }
     h->info_pending = true;
     h->spec_solves = 0;
     h->factored = true;
@@ -598,12 +631,11 @@ static int factor_resolve(cip_handle *h, bool wait);
 int cip_factor_resolve(cip_handle *h, int wait) { return factor_resolve(h, wait != 0); }
 static int factor_resolve(cip_handle *h, bool wait) {
     if (!h->info_pending) return 0;
-    if (!wait) {
-        const hipError_t q = hipEventQuery(h->ev_info);
-        if (q == hipErrorNotReady) return 0;
-        if (q != hipSuccess) { cip_set_error("hipEventQuery failed: %s", hipGetErrorString(q)); return CIP_E_HIP; }
-    } else {
-        CIP_HIP_CHECK(hipEventSynchronize(h->ev_info));
+    {
+        bool landed = false;
+        const int rc = info_landed(h, wait, &landed);
+        if (rc) return rc;
+        if (!landed) return 0;
     }
     h->info_pending = false;
     // info_host: [0] first bad pivot of any kind (1-based column), [1] bail-out flag of the sweep kernels,
@@ -626,7 +658,7 @@ static int factor_resolve(cip_handle *h, bool wait) {
         h->n_regularized += 1;
         int rc;
         if ((rc = factor_enqueue(h))) return rc;
-        CIP_HIP_CHECK(hipEventSynchronize(h->ev_info));
+        { bool landed = false; if ((rc = info_landed(h, true, &landed))) return rc; }
         h->info_pending = false;
         if (h->info_host[2] == 0) {
             h->pivots_verified = true;

@@ -62,7 +62,7 @@ struct cip_handle {
     // pivot flag of the last factorisation: read back asynchronously into pinned host memory, resolved lazily
     // (api.hip: factor_resolve) so that cip_factor never waits for the GPU
     int *info_host = nullptr;
-    hipEvent_t ev_info = nullptr;
+    int info_seq = 0;                 // sequence number of the last factorisation's flag read-back (info_host[4] == info_seq: landed)
     bool info_pending = false;
     int spec_solves = 0;            // solves enqueued while the flag was still in flight
     // true once a factorisation of this handle has been resolved clean (or the regularised mode is on): until then the

@@ -102,6 +102,7 @@ struct GemmArgs {
     double *Ct; long ldct, sCty, sCtz;   // 128-tile EPI_ACCUM only, optional: the result is also stored transposed, Ct[j + i*ldct]
     const double *Cdiag;         // EPI_LAZYC: the diagonal of Cin
     int force64;                 // plain accumulate form: quarter tiles (k_gemm_nt_64) whatever the tile count
+    int tiny16;                  // batched overwrite form: one 16x16 tile per workgroup, k split over its waves (k_gemm_nt_16_batched; K % 128 == 0)
     // EPI_SYRKQ with few output tiles and a long K (round 4): the k range is cut into `ksplit_n` slices of `ksplit_len` columns, every
     // slice's product goes to its own M x M image in `ksplit_ws`, a second launch adds them up in slice order together with Qin
     double *ksplit_ws; int ksplit_n, ksplit_len;

@@ -201,6 +201,57 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_64_batched(GemmArgs g, CipBa
     gemm_tile_64<EPI_STORE>(g, lds, (long)(blockIdx.x % tm) * SB, (long)(blockIdx.x / tm) * SB);
 }
 
+// The same batched overwrite form with ONE 16x16 tile of C per workgroup, the k range split over its four waves, operands from
+// global memory (L2) straight into the MFMA lanes -- lane l supplies row l % 16, k = l / 16 of its operand tile -- no LDS
+// staging; the partial accumulators of waves 1..3 are added to wave 0's in a fixed order (the form of sdp_large.hip's
+// k_gemm_nt_small).  For the block-inverse doubling (ldlt.hip): a level is a handful of h x h x h products, and a 64x64 tile walks
+// its whole K = h on one CU -- 512 dependent MFMAs per wave at h = 512, 14 us of one CU's MFMA pipe behind a latency-bound
+// k-loop, 19 us per launch on an idle chip -- while here the same product is (h / 16)^2 workgroups with 8 h / 128 MFMAs per
+// wave.  K a multiple of 128, M and N of 16.  Register q of lane l holds C[i0 + l % 16, j0 + l / 16 + 4 q].
+__global__ __launch_bounds__(256) void k_gemm_nt_16_batched(GemmArgs g, CipBatch cb) {
+    __shared__ double red[3][4][64];
+    bool live;
+    const unsigned oz = gemm_batch_prologue(g, cb, live);
+    if (!live) return;
+    gemm_own_batch(g, oz);
+    const int tm = g.M / 16;
+    const long i0 = (long)(blockIdx.x % tm) * 16, j0 = (long)(blockIdx.x / tm) * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int kq = g.K >> 2;
+    const double *a = g.A + i0 + l15 + (long)(wave * kq + l4) * g.lda;
+    const double *b = g.B + j0 + l15 + (long)(wave * kq + l4) * g.ldb;
+    v4d acc0 = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+    for (int k = 0; k < kq; k += 32) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            av[u] = a[(long)(k + 4 * u) * g.lda];
+            bv[u] = b[(long)(k + 4 * u) * g.ldb];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[u], av[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[u + 1], av[u + 1], acc1, 0, 0, 0);
+        }
+    }
+    acc0 += acc1;
+    if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wave - 1][q][lane] = acc0[q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double c = g.alpha * (((acc0[q] + red[0][q][lane]) + red[1][q][lane]) + red[2][q][lane]);
+            const long i = i0 + l15, j = j0 + l4 + 4 * q;
+            g.C[i + j * g.ldc] = c;
+            if (g.Ct) g.Ct[j + i * g.ldct] = c;
+        }
+    }
+}
+
 // Schur formation S = Q + Wt Wt' (lower tiles) in quarter tiles: the long-K (K = m) counterpart of the trailing update
 template <bool GLDS>
 __global__ __launch_bounds__(256, 4) void k_syrkq_64(GemmArgs g, CipBatch cb) {
@@ -334,6 +385,11 @@ int cip_launch_gemm(hipStream_t s, int epi, const GemmArgs &g) {
     const int by = g.by > 0 ? g.by : 1, bz = g.bz > 0 ? g.bz : 1;
     if (by * bz > 1 || (g.overwrite && epi == EPI_ACCUM && g.lower != 1)) {
         if (epi != EPI_ACCUM || g.lower == 1 || (g.lower >= 2 && !g.overwrite)) { cip_set_error("gemm: batching needs the plain accumulate form"); return -1; }
+        if (g.overwrite && g.tiny16 && !g.lower && g.K % 128 == 0) {
+            cip_launch_b(k_gemm_nt_16_batched, dim3((unsigned)((g.M / 16) * (g.N / 16)), by, bz), dim3(256), 0, s, g);
+            CIP_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
         if (g.overwrite) {
             cip_launch_b(k_gemm_nt_64_batched, dim3((unsigned)(4 * tiles), by, bz), dim3(256), 0, s, g);
             CIP_HIP_CHECK(hipGetLastError());

@@ -426,6 +426,18 @@ __global__ __launch_bounds__(256, 4) void k_solve_premul(const double *K, long l
     }
     gemm_tile_64<EPI_STORE>(g, lds, i0, j0);
 }
+// The doubling products of the LAST solve block of a 1024-wide blocking on 16x16 tiles (k_gemm_nt_16_batched; CIP_DOUBLING_TINY=0:
+// never).  That block's preparation is the one piece of a factorisation nothing hides: with the side stream it runs under the first
+// solve's forward sweep, which reaches the block after ~90 us, and its seven dependent launches took 135 us -- a 64x64 tile walks its
+// whole K = h on one CU (512 dependent MFMAs per wave at h = 512: 19 us per launch on an idle chip), the 16x16 form spreads the same
+// product over (h / 16)^2 workgroups.  Same-session, n = 8192: the first solve after a factorisation 0.282 -> 0.244 ms (the second:
+// 0.205).  For every block, or in lock-step batches, the small tiles LOSE (more workgroups beside the panel chain: factor + 0.05 ms;
+// 8 problems of order 2048: 15.2 -> 15.8 ms per pass).  A function of the block's position and the blocking only -- a side-stream
+// group, a whole-matrix preparation (which splits the last block off) and a lock-step batch all produce the same bits.
+static int doubling_tiny(int Bs, int J0, int nbk_all) {
+    static const int on = [] { const char *e = getenv("CIP_DOUBLING_TINY"); return e ? atoi(e) : 1; }();
+    return on && Bs == 1024 && J0 == nbk_all - 1;
+}
 static int build_solve_premul(hipStream_t s, double *K, long ld, const LdltWorkspace &ws, int nbk_all, int J0, int J1) {
     if (!ws.fused) return 0;
     const int Bs = ws.Bs;
@@ -444,6 +456,10 @@ static int build_solve_premul(hipStream_t s, double *K, long ld, const LdltWorks
 static int build_solve_blocks(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws, int J0 = 0, int J1 = -1) {
     const int Bs = ws.Bs;
     if (J1 < 0) J1 = Npad / Bs;
+    if (J1 - J0 > 1 && J1 == Npad / Bs && doubling_tiny(Bs, J1 - 1, Npad / Bs)) {      // the last block goes its own way (see doubling_tiny)
+        const int rc0 = build_solve_blocks(s, K, Npad, ld, ws, J0, J1 - 1);
+        return rc0 ? rc0 : build_solve_blocks(s, K, Npad, ld, ws, J1 - 1, J1);
+    }
     const int nbk = J1 - J0;
     if (nbk <= 0) return 0;
     int rc;
@@ -471,6 +487,7 @@ static int build_solve_blocks(hipStream_t s, double *K, int Npad, long ld, const
         const long pK = 2L * h * (ld + 1);                   // pair stride along the diagonal of K
         GemmArgs g = {};
         g.M = g.N = g.K = h; g.lower = 0; g.overwrite = 1; g.by = nbk; g.bz = P;
+        g.tiny16 = doubling_tiny(Bs, J0, Npad / Bs);
         // Tt = XT11 * L21'
         g.alpha = 1.0;
         g.A = XT0; g.lda = Bs; g.sAy = bs2; g.sAz = pX;
@@ -525,6 +542,8 @@ static LdltSide *side_get(const LdltWorkspace &ws) {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);             // lo = numerically greatest = LOWEST priority: the chain goes first
     bool ok = hipStreamCreateWithPriority(&sd->s2, hipStreamNonBlocking, lo) == hipSuccess;
+    // (round 5: the LAST group -- what the first solve waits for -- on a third stream of the HIGHEST priority was measured and lost:
+    //  the first solve unchanged, 0.246 -> 0.251 ms, and the factorisation 0.08-0.12 ms slower with such a queue in the process)
     for (hipEvent_t &e : sd->fork) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     for (hipEvent_t &e : sd->done) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); cip_ldlt_side_destroy(sd); return nullptr; }
@@ -536,10 +555,11 @@ static int side_fork(LdltSide *sd, hipStream_t s, double *K, int Npad, long ld, 
     if (sd->nfork >= 16) return build_solve_blocks(s, K, Npad, ld, ws, J0, J1);
     const int g = sd->nfork++;
     sd->j0[g] = J0;
+    hipStream_t t = sd->s2;
     CIP_HIP_CHECK(hipEventRecord(sd->fork[g], s));
-    CIP_HIP_CHECK(hipStreamWaitEvent(sd->s2, sd->fork[g], 0));
-    const int rc = build_solve_blocks(sd->s2, K, Npad, ld, ws, J0, J1);
-    CIP_HIP_CHECK(hipEventRecord(sd->done[g], sd->s2));
+    CIP_HIP_CHECK(hipStreamWaitEvent(t, sd->fork[g], 0));
+    const int rc = build_solve_blocks(t, K, Npad, ld, ws, J0, J1);
+    CIP_HIP_CHECK(hipEventRecord(sd->done[g], t));
     return rc;
 }
 // The factorisation's stream waits for the side stream's groups that hold solve blocks <= J (J < 0: all of them).  The
@@ -623,7 +643,15 @@ int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorks
             if (prof && (rc = prof_event(prof, s))) return rc;
         }
     }
-    if (sd && sd->nfork > 0) return side_fork(sd, s, K, Npad, ld, ws, Jdone, Npad / Bs);      // joined by the solves (cip_ldlt_side_join)
+    if (sd && sd->nfork > 0) {
+        // The LAST group -- the solve blocks whose columns the last panels produced -- runs under the first solve's forward sweep,
+        // which waits for it at the last block (cip_ldlt_side_join).  Round 5 measured it on the factorisation's own stream instead
+        // (CIP_SIDE_LAST_MAIN=1: no fork, no join, the group's seven launches alone on the chip: 63 us with the 16x16-tile doubling
+        // products): the first solve 0.245 -> 0.223 ms, the step 0.03 ms SLOWER.  On the side stream by default.
+        static const int last_main = [] { const char *e = getenv("CIP_SIDE_LAST_MAIN"); return e ? atoi(e) : 0; }();
+        if (last_main && Npad / Bs - Jdone == 1) return build_solve_blocks(s, K, Npad, ld, ws, Jdone, Npad / Bs);
+        return side_fork(sd, s, K, Npad, ld, ws, Jdone, Npad / Bs);      // joined by the solves (cip_ldlt_side_join)
+    }
     if (ws.no_prep) return 0;
     return build_solve_blocks(s, K, Npad, ld, ws, Jdone, Npad / Bs);
 }

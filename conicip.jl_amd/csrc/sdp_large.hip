@@ -278,8 +278,13 @@ __device__ __forceinline__ double lg_rsqrt(double x) {
 // G_in V = U diag(sigma): column i ends as sigma_i u_i, all of svd(Lz' Ls) that nestod_sdc uses (src/ConicIP.jl:204-208).
 // EPL: elements of a column per lane (rp == EPL * tpp): 8 up to order 512; 16 at order 1024 (round 4), where 64 lanes hold a column
 template <int NT, int EPL = 8>
-__global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsigned *ctr, int *err) {
+__global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int bflags, unsigned *ctr, int *err) {
     extern __shared__ double sh[];
+    const int b = bflags & 0xff;
+    // stepped form (order 1024): ONE phase of ONE sweep per launch -- step 0 the pairs inside the blocks, step t + 1 round t of the
+    // tournament over blocks -- the launch boundary in place of the grid barrier (see cip_sdp_large_nt)
+    const bool stepped = (bflags & 0x200) != 0;
+    const int step_sweep = (bflags >> 16) & 0x3f, step = (bflags >> 22) & 0x1ff;
     __shared__ int s_rot;
     __shared__ double s_nrm[32];
     const int tid = threadIdx.x;
@@ -339,10 +344,10 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsi
             lg_st(G + i + (long)(c < b ? bp * b + c : bq * b + (c - b)) * rp, t[u]);
         }
     };
-    for (int sweep = 0; sweep < 40; ++sweep) {
+    for (int sweep = stepped ? step_sweep : 0; sweep < (stepped ? step_sweep + 1 : 40); ++sweep) {
         int rotated = 0;
         // ---- pairs inside the blocks
-        {
+        if (!stepped || step == 0) {
             const int bp = 2 * (int)blockIdx.x, bq = bp + 1;
             load(bp, bq);
             const int hb = b / 2, blk = pair / hb, kk = pair % hb;
@@ -356,10 +361,10 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsi
             }
             rotated = s_rot > rotated ? s_rot : rotated;
             store(bp, bq);
-            lg_grid_barrier(bar, nwg, phase, err);
+            if (!stepped) lg_grid_barrier(bar, nwg, phase, err);
         }
         // ---- pairs across blocks
-        for (int t = 0; t < m - 1; ++t) {
+        for (int t = stepped ? (step > 0 ? step - 1 : 0) : 0; t < (stepped ? step : m - 1); ++t) {
             int bp, bq;
             const int k = blockIdx.x;
             if (k == 0) { bp = m - 1; bq = t; }
@@ -412,9 +417,10 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int b, unsi
             }
             rotated = s_rot > rotated ? s_rot : rotated;
             store(bp, bq);
-            lg_grid_barrier(bar, nwg, phase, err);
+            if (!stepped) lg_grid_barrier(bar, nwg, phase, err);
         }
         if (tid == 0 && rotated == 2) atomicAdd(sweepflag + sweep, 1u);
+        if (stepped) break;
         lg_grid_barrier(bar, nwg, phase, err);
         const unsigned any = __hip_atomic_load(sweepflag + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!any || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
@@ -617,8 +623,10 @@ int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out) {
     *out = w;
     return 0;
 }
+void cip_lg_cks_dump(void);
 void cip_sdp_large_destroy(LargeWs *w) {
     if (!w) return;
+    cip_lg_cks_dump();
     if (w->s2) (void)hipStreamDestroy(w->s2);
     if (w->efork) (void)hipEventDestroy(w->efork);
     if (w->ejoin) (void)hipEventDestroy(w->ejoin);
@@ -1254,6 +1262,45 @@ static int lg_warm(void) {
     static const int on = [] { const char *e = getenv("CIP_LG_WARM"); return e ? atoi(e) : 1; }();
     return on;
 }
+// ---- development aid (CIP_LG_CHECKSUM=1): order-independent checksums (integer sums of the bit patterns) of the NT scaling's
+// intermediates, per call and stage, printed when the workspace is destroyed -- two runs of one program must print the same table
+// (tools/sdp640_repeat.py: a difference names the first racy stage)
+__global__ __launch_bounds__(256) void k_lg_checksum(const double *x, long n, unsigned long long *out) {
+    unsigned long long acc = 0;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) acc += (unsigned long long)__double_as_longlong(x[e]);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+__global__ __launch_bounds__(256) void k_lg_sumsq(const double *x, long n, unsigned long long *out) {     // sum of squares as a double in a 64-bit slot (atomic adds: good to rounding)
+    double acc = 0.0;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) acc += x[e] * x[e];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd((double *)out, acc);
+}
+static unsigned long long *g_lg_cks = nullptr;      // LG_CKS_CALLS calls x 16 stages
+#define LG_CKS_CALLS 4096
+static int g_lg_cks_call = 0;
+static int lg_cks_on(void) { static const int on = [] { const char *e = getenv("CIP_LG_CHECKSUM"); return e ? atoi(e) : 0; }(); return on; }
+static void lg_cks(hipStream_t s, int stage, const double *x, long n) {
+    if (!lg_cks_on() || g_lg_cks_call >= LG_CKS_CALLS) return;
+    if (!g_lg_cks) { (void)hipMalloc((void **)&g_lg_cks, LG_CKS_CALLS * 16 * 8); (void)hipMemset(g_lg_cks, 0, LG_CKS_CALLS * 16 * 8); }
+    if (stage >= 12) hipLaunchKernelGGL(k_lg_sumsq, dim3(256), dim3(256), 0, s, x, n, g_lg_cks + g_lg_cks_call * 16 + stage);
+    else hipLaunchKernelGGL(k_lg_checksum, dim3(256), dim3(256), 0, s, x, n, g_lg_cks + g_lg_cks_call * 16 + stage);
+}
+void cip_lg_cks_dump(void) {
+    if (!g_lg_cks) return;
+    static unsigned long long h[LG_CKS_CALLS * 16];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h, g_lg_cks, sizeof(h), hipMemcpyDeviceToHost);
+    for (int c = 0; c < g_lg_cks_call && c < LG_CKS_CALLS; ++c) {
+        fprintf(stderr, "cks call %d:", c);
+        for (int q = 0; q < 12; ++q) fprintf(stderr, " %016llx", h[c * 16 + q]);
+        { double a, b; __builtin_memcpy(&a, &h[c * 16 + 12], 8); __builtin_memcpy(&b, &h[c * 16 + 13], 8); fprintf(stderr, " | |G_in|^2 %.17g |G_out|^2 %.17g rel %.3e", a, b, (b - a) / a); }
+        fprintf(stderr, "\n");
+    }
+    (void)hipMemset(g_lg_cks, 0, LG_CKS_CALLS * 16 * 8);
+    g_lg_cks_call = 0;
+}
 // nestod_sdc for one large cone (index li among the large cones)
 int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, const double *v, const double *sv, double *scal,
                      double *lambda, int *flag) {
@@ -1264,10 +1311,12 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
     hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, sv + cd.off, 1L, 0L, w->Ks, r, rp, 1.0);
     if ((rc = cip_ldlt_factor(s, w->Kz, rp, rp, w->wz))) return rc;                 // Lz (unit) and d_z  (:202-203)
     if ((rc = cip_ldlt_factor(s, w->Ks, rp, rp, w->ws))) return rc;
+    lg_cks(s, 0, w->Kz, n2); lg_cks(s, 1, w->Ks, n2);
     hipLaunchKernelGGL(k_lg_flag, dim3(1), dim3(64), 0, s, w->wz.info, w->ws.info, flag);
     hipLaunchKernelGGL(k_lg_tfac, lg_grid(n2), dim3(256), 0, s, w->Kz, w->wz.dvec, w->Tz, rp);
     hipLaunchKernelGGL(k_lg_tfac, lg_grid(n2), dim3(256), 0, s, w->Ks, w->ws.dvec, w->Ts, rp);
     if ((rc = lg_gemm(s, w->G, 0, w->Tz, 0, w->Ts, 0, rp, 1))) return rc;           // G = Lz' Ls          (:204)
+    lg_cks(s, 2, w->G, n2);
     // Round 5: WARM START of the one-sided Jacobi.  svd(G) = U Sigma V' is needed for U and Sigma only (:204-208), and the
     // Jacobi below may start from G W for ANY orthogonal W: the left singular vectors and the singular values are those of G.
     // Between two interior-point iterations the NT scaling moves little, so with W = the right singular vectors V of the previous
@@ -1289,7 +1338,9 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
         hipLaunchKernelGGL(k_lg_ns, lg_grid(n2), dim3(256), 0, s, w->W2, rp);                                               // 1.5 I - 0.5 V'V (symmetric)
         if ((rc = lg_gemm(s, w->W1, 0, Vw, 0, w->W2, 0, rp, 1))) return rc;                                                 // Vn = V (1.5 I - 0.5 V'V)
         hipLaunchKernelGGL(k_lg_transpose, tg, dim3(256), 0, s, (const double *)w->W1, w->W2, rp, (const double *)nullptr);  // Vn'
+        lg_cks(s, 3, w->W2, n2);
         if ((rc = lg_gemm(s, w->G, 0, w->G0, 0, w->W2, 0, rp, 1))) return rc;                                               // G <- G Vn
+        lg_cks(s, 4, w->G, n2);
     }
     {
         // column blocks of 8 at order 256 (16 workgroups of 256 threads; round 4, with the DPP sums: 4 / 8 / 16 / 32 wide ->
@@ -1302,28 +1353,47 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
         const int nt = rp > 512 ? b * 64 : b * (rp / 8);           // 512 (order 256, b = 16), 256 (b = 8), 1024 (order 512) or 512 (order 1024: 64 lanes x 16 elements per column)
         const size_t shm = (size_t)2 * b * lg_pitch(rp) * sizeof(double);
         CIP_HIP_CHECK(hipMemsetAsync(w->ctr, 0, 1024, s));
+        lg_cks(s, 12, w->G, n2);
         if ((rc = cip_prof_slot_begin(CIP_PROF_JACOBI, s, 0.0))) return rc;
+        // STEPPED form (round 5, second session): one launch per phase -- the pairs inside the blocks, then each round of the
+        // tournament over blocks -- with the launch boundary in place of the grid barrier, the sweep's flag read back by the host.
+        // The persistent form hands the blocks from workgroup to workgroup inside the launch (`sc1` stores, drained, one counter,
+        // `sc1` loads: MI355X_MICROARCH.md lists that hand-off as measured, not guaranteed) and at order 1024 -- 64 workgroups, 129
+        // hand-offs per sweep -- about one NT scaling in 800 came out with other bits: an orthogonally equivalent but different
+        // factor in the best case (|G| preserved to rounding), an iterate off by 1e-3 in the worst; one interior-point run in 60
+        // left the oracle's trajectory (tools/nt1024_repeat.py, tools/sdp640_repeat.py; neither agent-scope fences around the
+        // barrier nor read-modify-write loads of the blocks changed the rate).  Order 512: 1 in 4000; order 256: 0 in 6000.
+        // Stepped: 0 in 4500 at order 1024, 0 of 300 interior-point runs; the NT scaling 43 -> 60 ms at order 640 (ill-conditioned
+        // pair), 30 -> 40 ms at order 1000.  CIP_LG_JACOBI_STEPPED: 1 (default) = orders above 256, 2 = every order, 0 = never.
+        static const int stepped_mode = [] { const char *e = getenv("CIP_LG_JACOBI_STEPPED"); return e ? atoi(e) : 1; }();
+        const bool stepped = stepped_mode == 2 || (stepped_mode == 1 && rp > 256);
+        auto run = [&](auto kern, int nthreads, int bb, size_t lds) -> int {
+            int rc2;
+            if ((rc2 = lg_set_attr((const void *)kern, lds))) return rc2;
+            const int m = rp / bb;
+            if (!stepped) {
+                hipLaunchKernelGGL(kern, dim3(m / 2), dim3(nthreads), lds, s, w->G, rp, bb, w->ctr, (int *)(w->ctr + 128));
+                return 0;
+            }
+            for (int sweep = 0; sweep < 40; ++sweep) {
+                for (int step = 0; step < m; ++step)
+                    hipLaunchKernelGGL(kern, dim3(m / 2), dim3(nthreads), lds, s, w->G, rp, bb | 0x200 | (sweep << 16) | (step << 22), w->ctr, (int *)(w->ctr + 128));
+                unsigned any = 0;
+                CIP_HIP_CHECK(hipMemcpyAsync(&any, w->ctr + 8 + sweep, sizeof(any), hipMemcpyDeviceToHost, s));
+                CIP_HIP_CHECK(hipStreamSynchronize(s));
+                if (!any) break;
+            }
+            return 0;
+        };
         if (rp == 256 && bforce == 116) {                  // A/B form (round 5): 16-column blocks, 16 lanes x 16 elements per column, 4 waves, 8 workgroups -- half the
                                                            // outer rounds, shorter lane sums, and SLOWER: config 4 8.41 against 8.03 ms per iteration
-            const size_t shm16 = (size_t)2 * 16 * lg_pitch(rp) * sizeof(double);
-            if ((rc = lg_set_attr((const void *)k_lg_jacobi<256, 16>, shm16))) return rc;
-            hipLaunchKernelGGL((k_lg_jacobi<256, 16>), dim3(rp / 16 / 2), dim3(256), shm16, s, w->G, rp, 16, w->ctr, (int *)(w->ctr + 128));
-        } else if (rp > 512) {
-            if ((rc = lg_set_attr((const void *)k_lg_jacobi<512, 16>, shm))) return rc;
-            hipLaunchKernelGGL((k_lg_jacobi<512, 16>), dim3(rp / b / 2), dim3(512), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
-        } else if (nt == 128) {
-            if ((rc = lg_set_attr((const void *)k_lg_jacobi<128>, shm))) return rc;
-            hipLaunchKernelGGL(k_lg_jacobi<128>, dim3(rp / b / 2), dim3(128), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
-        } else if (nt == 256) {
-            if ((rc = lg_set_attr((const void *)k_lg_jacobi<256>, shm))) return rc;
-            hipLaunchKernelGGL(k_lg_jacobi<256>, dim3(rp / b / 2), dim3(256), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
-        } else if (nt == 512) {
-            if ((rc = lg_set_attr((const void *)k_lg_jacobi<512>, shm))) return rc;
-            hipLaunchKernelGGL(k_lg_jacobi<512>, dim3(rp / b / 2), dim3(512), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
-        } else {
-            if ((rc = lg_set_attr((const void *)k_lg_jacobi<1024>, shm))) return rc;
-            hipLaunchKernelGGL(k_lg_jacobi<1024>, dim3(rp / b / 2), dim3(1024), shm, s, w->G, rp, b, w->ctr, (int *)(w->ctr + 128));
-        }
+            rc = run(k_lg_jacobi<256, 16>, 256, 16, (size_t)2 * 16 * lg_pitch(rp) * sizeof(double));
+        } else if (rp > 512) rc = run(k_lg_jacobi<512, 16>, 512, b, shm);
+        else if (nt == 128) rc = run(k_lg_jacobi<128>, 128, b, shm);
+        else if (nt == 256) rc = run(k_lg_jacobi<256>, 256, b, shm);
+        else if (nt == 512) rc = run(k_lg_jacobi<512>, 512, b, shm);
+        else rc = run(k_lg_jacobi<1024>, 1024, b, shm);
+        if (rc) return rc;
         if ((rc = cip_prof_slot_end(CIP_PROF_JACOBI, s))) return rc;
     }
     if (getenv("CIP_LG_DEBUG")) {
@@ -1335,11 +1405,14 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
         fprintf(stderr, "[lg] jacobi: %d sweeps with a rotation above cos^2 = 1e-16, %u barriers\n", sweeps, hc[0] / (unsigned)(rp / 16 / 2));
     }
     double *lam = w->vec;
+    lg_cks(s, 5, w->G, n2); lg_cks(s, 13, w->G, n2);
     hipLaunchKernelGGL(k_lg_colnorm, dim3((rp + 3) / 4), dim3(256), 0, s, w->G, lam, rp);
+    lg_cks(s, 6, lam, rp);
     if (keep_v) {                                                                                                           // V = G0' (A_f Sigma^-2) for the next call
         hipLaunchKernelGGL(k_lg_transpose, tg, dim3(256), 0, s, (const double *)w->G, w->W1, rp, (const double *)lam);        // (A_f Sigma^-2)'
         hipLaunchKernelGGL(k_lg_transpose, tg, dim3(256), 0, s, (const double *)w->G0, w->W2, rp, (const double *)nullptr);   // G0'
         if ((rc = lg_gemm(s, Vw, 0, w->W2, 0, w->W1, 0, rp, 1))) return rc;
+        lg_cks(s, 7, Vw, n2);
         w->have_v[li] = 1;
     }
     hipLaunchKernelGGL(k_lg_build, lg_grid(n2), dim3(256), 0, s, w->G, lam, w->wz.dvec, w->Kz, w->M1, w->M2, w->M3, rp);
@@ -1350,6 +1423,8 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
     hipLaunchKernelGGL(k_lg_store, lg_grid(n2 > cd.dim ? n2 : cd.dim), dim3(256), 0, s, w->Tz, w->Ts, R, Ri, w->Rip + LG_NPAD * (size_t)li * n2,
                        lam, lambda ? lambda + cd.off : nullptr, r, rp, cd.dim);
     if (lambda) hipLaunchKernelGGL(k_lg_lambda_diag, lg_grid(r), dim3(256), 0, s, lam, lambda + cd.off, r);
+    lg_cks(s, 8, w->Tz, n2); lg_cks(s, 9, w->Ts, n2);
+    if (lg_cks_on()) g_lg_cks_call += 1;
     CIP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -1,26 +1,20 @@
 #!/bin/bash
-# kernel timeline of the END of one factorisation of the headline step (from the last trailing update on), both streams, from a
-# rocprofv3 kernel trace.   usage: bash tools/tail_trace.sh [VAR=VALUE ...]   (environment of the traced run)
-R=$(cd "$(dirname "$0")/.." && pwd); OUT=$R/gpurun_out/tail_trace; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-tag=$(echo "$*" | tr ' =' '__'); [ -z "$tag" ] && tag=default
-for kv in "$@"; do export "$kv"; done
-rm -rf /tmp/tt_$tag
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tt_$tag -o t -- python3 $R/bench.py --no-cpu-baseline --no-c5 --no-converge --steps 4 --warmup 2 > $OUT/$tag.out 2> $OUT/$tag.err
-f=$(find /tmp/tt_$tag -name "*kernel_trace.csv" | head -1)
-python3 - "$f" <<'PY' | tee $OUT/$tag.txt
+# kernel trace of the END of a factorisation and the first solve behind it (n = 8192): every launch from the third-last panel
+# launch to the end of the first solve4x4, with its queue -- the side stream's last group beside the forward sweep
+R=$(cd "$(dirname "$0")/.." && pwd); cd /tmp; export TMPDIR=/tmp
+rm -rf /tmp/tt
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tt -o t -- python3 $R/tools/step_split.py > /dev/null 2>&1
+f=$(find /tmp/tt -name "*kernel_trace.csv" | head -1)
+python3 - "$f" <<'PY'
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 nm = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "")
-tr = [i for i, r in enumerate(rows) if nm(r).startswith("k_ldlt_trailing")]
-# the 7th trailing update of the last-but-one factorisation of the run
-groups = [tr[i:i + 7] for i in range(0, len(tr) - 6, 7)]
-g = groups[-2]
-lo = g[-1]
-nt = [i for i in range(lo, len(rows)) if nm(rows[i]).startswith("k_nt_scaling") or nm(rows[i]).startswith("k_s4_pre")]
-hi = nt[0] + 40 if nt else min(len(rows), lo + 80)
-t0 = int(rows[lo]["Start_Timestamp"])
-for i in range(lo, hi):
-    r = rows[i]
-    s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
-    print("%9.1f %9.1f %7.1f  q%-3s grid %8s  %s" % (s / 1e3, e / 1e3, (e - s) / 1e3, r.get("Queue_Id", "?"), r["Grid_Size_X"], nm(r)[:40]))
+pan = [i for i, r in enumerate(rows) if nm(r).startswith("k_ldlt_panel")]
+# the last factorisation that is followed by solves: take the last panel launch that has >= 60 kernels behind it
+last = [i for i in pan if i + 80 < len(rows)][-1]
+while last + 1 < len(rows) and last + 1 in pan: last += 1
+t0 = int(rows[last]["End_Timestamp"])
+for r in rows[last - 2:last + 75]:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    print("q%-3s %8.1f -> %8.1f  (%6.1f us)  %s  grid %s" % (r.get("Queue_Id", "?"), (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, nm(r), r.get("Grid_Size", "")))
 PY
