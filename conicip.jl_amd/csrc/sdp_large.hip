@@ -279,7 +279,7 @@ __device__ __forceinline__ double lg_rsqrt(double x) {
 // EPL: elements of a column per lane (rp == EPL * tpp): 8 up to order 512; 16 at order 1024 (round 4), where 64 lanes hold a column
 template <int NT, int EPL = 8>
 __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int bflags, unsigned *ctr, int *err) {
-    extern __shared__ double sh[];
+    extern __shared__ __attribute__((aligned(16))) double sh[];
     const int b = bflags & 0xff;
     // stepped form (order 1024): ONE phase of ONE sweep per launch -- step 0 the pairs inside the blocks, step t + 1 round t of the
     // tournament over blocks -- the launch boundary in place of the grid barrier (see cip_sdp_large_nt)
@@ -316,32 +316,37 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int bflags,
         }
         return (c * c > 1e-16 * (a * bb)) ? 2 : 1;
     };
-    // a block pair is 2 b rp = 16384 doubles whatever (b, rp): 16 per thread.  All 16 coherent loads of a thread are issued
-    // before the first LDS store (one at a time, store after load, each global round trip was exposed: 16 x ~1.5 us per
-    // outer round -- half of a sweep's time)
+    // a block pair is 2 b rp = 16384 doubles whatever (b, rp): 16 per thread.  All loads of a thread are issued before the first
+    // LDS store (one at a time, store after load, each global round trip was exposed: 16 x ~1.5 us per outer round -- half of a
+    // sweep's time).  16-BYTE `sc1` buffer accesses (second session of round 5; until then 8-byte agent-scope atomic loads /
+    // stores, `global_load_dwordx2 sc1`): MI355X_MICROARCH.md's table of hand-offs measured valid with `sc1` loads in place of an
+    // acquire names dword and dwordx4 loads for this shape -- one counter, every workgroup adds, a barrier between the poll and
+    // the loads -- and excludes dwordx2.
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)G, 0, 0x7fffffff, 0x00020000);
     auto load = [&](int bp, int bq) {                      // coherent loads: other workgroups wrote these blocks
-        double t[2 * EPL];
+        v4i_t t[EPL];
 #pragma unroll
-        for (int u = 0; u < 2 * EPL; ++u) {
-            const int e = tid + u * NT, i = e % rp, c = e / rp;
-            t[u] = lg_ld(G + i + (long)(c < b ? bp * b + c : bq * b + (c - b)) * rp);
+        for (int u = 0; u < EPL; ++u) {
+            const int e = 2 * (tid + u * NT), i = e % rp, c = e / rp;
+            t[u] = __builtin_amdgcn_raw_buffer_load_b128(grs, (int)((i + (long)(c < b ? bp * b + c : bq * b + (c - b)) * rp) * 8), 0, 16);
         }
 #pragma unroll
-        for (int u = 0; u < 2 * EPL; ++u) {
-            const int e = tid + u * NT;
-            sh[e % rp + (e / rp) * ld] = t[u];
+        for (int u = 0; u < EPL; ++u) {
+            const int e = 2 * (tid + u * NT);
+            *(v2d *)(sh + e % rp + (e / rp) * ld) = __builtin_bit_cast(v2d, t[u]);
         }
         if (tid == 0) s_rot = 0;
         __syncthreads();
     };
     auto store = [&](int bp, int bq) {
-        double t[2 * EPL];
+        v2d t[EPL];
 #pragma unroll
-        for (int u = 0; u < 2 * EPL; ++u) { const int e = tid + u * NT; t[u] = sh[e % rp + (e / rp) * ld]; }
+        for (int u = 0; u < EPL; ++u) { const int e = 2 * (tid + u * NT); t[u] = *(const v2d *)(sh + e % rp + (e / rp) * ld); }
 #pragma unroll
-        for (int u = 0; u < 2 * EPL; ++u) {
-            const int e = tid + u * NT, i = e % rp, c = e / rp;
-            lg_st(G + i + (long)(c < b ? bp * b + c : bq * b + (c - b)) * rp, t[u]);
+        for (int u = 0; u < EPL; ++u) {
+            const int e = 2 * (tid + u * NT), i = e % rp, c = e / rp;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, t[u]), grs, (int)((i + (long)(c < b ? bp * b + c : bq * b + (c - b)) * rp) * 8), 0, 16);
         }
     };
     for (int sweep = stepped ? step_sweep : 0; sweep < (stepped ? step_sweep + 1 : 40); ++sweep) {

@@ -39,6 +39,15 @@ bash $R/tools/prof_lockstep.sh 8 2048 $OUT/c5b8 > $OUT/c5_b8_profile.txt 2>&1
 cp $OUT/c5b8/b8_kernel_stats.csv $OUT/c5_b8_kernel_stats.csv
 bash $R/tools/lockstep_trace.sh 8 2048 $OUT/lt8 > /dev/null 2>&1; cp $OUT/lt8/b8_timeline.txt $OUT/c5_b8_iter_timeline.txt
 CIP_BENCH_SHARE_GPU=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29751 $R/bench.py --gpus 2 --workload c5 --steps 2 --warmup 1 > $OUT/bench_c5_two_ranks_one_gpu.json 2> /dev/null
+# second session of round 5: where a step's time goes on the GPU timeline (first solve behind a factorisation against the second), the end
+# of a factorisation + first solve as a kernel trace, same-session A/B against the build at the start of the session, and the
+# run-to-run repeatability of a large S cone's NT scaling (persistent against stepped Jacobi)
+python3 $R/tools/step_split.py > $OUT/step_split.txt 2>/dev/null
+bash $R/tools/tail_trace.sh > $OUT/tail_trace.txt 2>/dev/null
+[ -f $R/conicip.jl_amd/build/variants/libcipkkt_base.so ] && bash $R/tools/ab_quick.sh 3 session_start=conicip.jl_amd/build/variants/libcipkkt_base.so final=default > $OUT/ab_session2.txt 2>&1
+{ echo "== order 640 (padded 1024), persistent Jacobi (CIP_LG_JACOBI_STEPPED=0)"; CIP_LG_JACOBI_STEPPED=0 python3 $R/tools/nt1024_repeat.py 640 1500 6 2>/dev/null | tail -4;
+  echo "== order 640, one launch per phase (default)"; python3 $R/tools/nt1024_repeat.py 640 1000 6 2>/dev/null | tail -2;
+  echo "== order 256, persistent (default at this order)"; python3 $R/tools/nt1024_repeat.py 256 3000 6 2>/dev/null | tail -2; } > $OUT/jacobi_repeatability.txt
 python3 $R/tools/config_rooflines.py $OUT > $OUT/rooflines.json
 rm -rf $OUT/stats $OUT/pmc_* $OUT/c4 $OUT/c3 $OUT/c5b8 $OUT/lt8
 ls -la $OUT
