@@ -1110,6 +1110,7 @@ extern "C" int cip_profile_thread_get(double *out3) {
 }
 extern "C" int cip_set_lazy_copy(int on) { return cip_lazy_copy_set(on); }
 extern "C" int cip_set_sdp_lanczos(int on) { return cip_sdp_large_lanczos(on); }
+extern "C" int cip_set_sdp_jacobi_stepped(int mode) { return cip_sdp_large_jacobi_stepped(mode); }
 extern "C" int cip_sdp_lanczos_fallbacks(cip_handle *h, int *count) {
     if (!h || !count) { cip_set_error("bad argument"); return CIP_E_INVALID; }
     int out2[2] = {0, 0};

@@ -250,6 +250,7 @@ int cip_sdp_large_refresh(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li,
 int cip_sdp_large_apply(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, int mode, const double *x, double *out);
 int cip_sdp_large_prod(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *y, double *out);
 int cip_sdp_large_div(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *y, double *out, int *flag);
+int cip_sdp_large_jacobi_stepped(int mode);          // sdp_large.hip: one-sided Jacobi as one launch per phase above order 256 (1), everywhere (2), never (0); < 0 reads; returns the previous setting
 int cip_sdp_large_lanczos(int on);                  // sdp_large.hip: max-step eigenvalue by Lanczos (1), Lanczos + inertia certificate (2), tridiagonalisation (0); < 0 reads; returns the previous setting
 int cip_sdp_large_cert_stats(hipStream_t s, struct LargeWs *w, int *out2);     // {certificates failed -> fallbacks taken, 0}
 int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *d, double scale,

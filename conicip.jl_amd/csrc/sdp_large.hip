@@ -26,6 +26,7 @@
 #include "../../include/cipkkt.h"
 #include <math.h>
 #include <vector>
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -1306,6 +1307,14 @@ void cip_lg_cks_dump(void) {
     (void)hipMemset(g_lg_cks, 0, LG_CKS_CALLS * 16 * 8);
     g_lg_cks_call = 0;
 }
+// 1 (default; CIP_LG_JACOBI_STEPPED): the NT scaling's one-sided Jacobi as one launch per phase at padded orders above 256; 2: at every
+// order; 0: one persistent launch everywhere.  mode < 0 only reads; returns the previous setting
+int cip_sdp_large_jacobi_stepped(int mode) {
+    static std::atomic<int> m{[] { const char *e = getenv("CIP_LG_JACOBI_STEPPED"); const int v = e ? atoi(e) : 1; return (v >= 0 && v <= 2) ? v : 1; }()};
+    const int prev = m.load();
+    if (mode >= 0 && mode <= 2) m.store(mode);
+    return prev;
+}
 // nestod_sdc for one large cone (index li among the large cones)
 int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, const double *v, const double *sv, double *scal,
                      double *lambda, int *flag) {
@@ -1370,7 +1379,7 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
         // barrier nor read-modify-write loads of the blocks changed the rate).  Order 512: 1 in 4000; order 256: 0 in 6000.
         // Stepped: 0 in 4500 at order 1024, 0 of 300 interior-point runs; the NT scaling 43 -> 60 ms at order 640 (ill-conditioned
         // pair), 30 -> 40 ms at order 1000.  CIP_LG_JACOBI_STEPPED: 1 (default) = orders above 256, 2 = every order, 0 = never.
-        static const int stepped_mode = [] { const char *e = getenv("CIP_LG_JACOBI_STEPPED"); return e ? atoi(e) : 1; }();
+        const int stepped_mode = cip_sdp_large_jacobi_stepped(-1);
         const bool stepped = stepped_mode == 2 || (stepped_mode == 1 && rp > 256);
         auto run = [&](auto kern, int nthreads, int bb, size_t lds) -> int {
             int rc2;

@@ -295,6 +295,48 @@ def test_lanczos_inertia_certificate_catches_a_start_vector_without_the_extreme_
     ks.close()
 
 
+@pytest.mark.parametrize("r", [200, 300, 700])
+def test_jacobi_one_launch_per_phase_has_the_persistent_kernels_bits(r):
+    """The NT scaling of a large S cone with its one-sided Jacobi as one launch per phase (default above padded order 256; the
+    persistent kernel's in-launch block hand-off was measured to race at orders 512 / 1024: tools/nt1024_repeat.py) against the
+    persistent kernel: same arithmetic in the same order, so the packed scaling must have the same bits (compared at r = 200, where
+    the persistent form has not been seen to race in 12000 repetitions; at r = 300 / 700 one persistent run in 4000 / 800 differs,
+    so only the stepped form's own reproducibility is asserted there) -- src/ConicIP.jl:196-210."""
+    import cipkkt
+    from cipkkt import _lib as L
+    lib = L.load()
+    k = r * (r + 1) // 2
+    cone_dims = [("S", k)]
+    rng = np.random.default_rng(r)
+    v, s = dev(interior(cone_dims, rng)), dev(interior(cone_dims, rng))
+    lam = torch.zeros(k, dtype=torch.float64, device="cuda")
+    x = dev(rng.standard_normal(k))
+    prev = lib.cip_set_sdp_jacobi_stepped(-1)
+    out = {}
+    try:
+        for mode in ((2, 0, 2) if r <= 256 else (2, 2)):
+            lib.cip_set_sdp_jacobi_stepped(mode)
+            ks = cipkkt.KKTSystem(np.eye(2), np.zeros((k, 2)), None, cone_dims)
+            ks.set_scaling_from_iterate(v, s, lam)
+            F = ks.get_scaling_packed()
+            y = torch.zeros_like(x)
+            ks.apply_F(L.OP_F, x, y)
+            z = torch.zeros_like(x)
+            ks.apply_F(L.OP_FT, y, z)                          # F'F x: invariant under the factor's orthogonal freedom
+            out.setdefault(mode, []).append((F, z.cpu().numpy(), lam.cpu().numpy().copy()))
+            ks.close()
+    finally:
+        lib.cip_set_sdp_jacobi_stepped(prev)
+    (F2a, z2a, l2a), (F2b, z2b, l2b) = out[2]
+    np.testing.assert_array_equal(F2a, F2b)
+    np.testing.assert_array_equal(l2a, l2b)
+    np.testing.assert_array_equal(z2a, z2b)
+    if r <= 256:
+        F0, z0, l0 = out[0][0]
+        np.testing.assert_array_equal(F0, F2a)
+        np.testing.assert_array_equal(z0, z2a)
+
+
 @pytest.mark.parametrize("cone_dims", [[("R", 700)], [("Q", 40), ("R", 9), ("S", 6)], [("S", 200 * 201 // 2)],
                                        [("R", 5), ("S", 150 * 151 // 2), ("S", 10)]])
 def test_maxstep_pair_equals_two_calls(cone_dims):
