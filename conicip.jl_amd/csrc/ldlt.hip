@@ -543,7 +543,8 @@ static LdltSide *side_get(const LdltWorkspace &ws) {
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);             // lo = numerically greatest = LOWEST priority: the chain goes first
     bool ok = hipStreamCreateWithPriority(&sd->s2, hipStreamNonBlocking, lo) == hipSuccess;
     // (round 5: the LAST group -- what the first solve waits for -- on a third stream of the HIGHEST priority was measured and lost:
-    //  the first solve unchanged, 0.246 -> 0.251 ms, and the factorisation 0.08-0.12 ms slower with such a queue in the process)
+    //  the first solve unchanged, 0.246 -> 0.251 ms, and the factorisation 0.08-0.12 ms slower with such a queue in the process; on a
+    //  third stream of DEFAULT priority: first solve 0.249 -> 0.249, factorisation + 0.02 ms)
     for (hipEvent_t &e : sd->fork) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     for (hipEvent_t &e : sd->done) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); cip_ldlt_side_destroy(sd); return nullptr; }
