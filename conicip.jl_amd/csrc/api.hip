@@ -223,7 +223,7 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
         else if (cd.type == CIP_CONE_S) {
             const int r = (int)llround((sqrt(1.0 + 8.0 * cd.dim) - 1.0) / 2.0);     // ord() src/ConicIP.jl:85
             if (r * (r + 1) / 2 != cd.dim) { cip_set_error("S cone %d: %d is not a triangular number", c, cd.dim); return CIP_E_INVALID; }
-            if (r > 1024) { cip_set_error("S cone %d: matrix order %d > 1024 is not supported", c, r); return CIP_E_UNSUPPORTED; }
+            if (r > 2048) { cip_set_error("S cone %d: matrix order %d > 2048 is not supported", c, r); return CIP_E_UNSUPPORTED; }
             cd.r = r; soff += 2 * (size_t)r * r; has_S = true;
             sidx.push_back(c);
             if (r > rmax) rmax = r;

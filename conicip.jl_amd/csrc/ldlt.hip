@@ -177,7 +177,9 @@ int cip_solve_block_max_set(int b) {
 int cip_solve_block(int Npad) {
     int mx = cip_tl_solve_block_max > 0 ? cip_tl_solve_block_max : cip_solve_block_max_set(0);
     if (mx < CIP_NB) mx = CIP_NB;
-    for (int b = 1024; b > CIP_NB; b >>= 1)
+    // (2048: only through the calling thread's override -- the order-2048 workspaces of large S cones want inv(L) of the WHOLE matrix,
+    //  sdp_large.hip; the public knob stops at 1024)
+    for (int b = 2048; b > CIP_NB; b >>= 1)
         if (b <= mx && Npad % b == 0) return b;
     return CIP_NB;
 }

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(LG_T) void k_lg_tridiag(const double *M, int ldm, c
 __global__ __launch_bounds__(LG_T) void k_lg_sturm(const double *dgg, const double *ofg, int r, int want_max, double scale,
                                                     const int *info, double *partial, int item, const int *gate = nullptr) {
     if (gate && !gate[0]) return;
-    __shared__ double dg[1024], of[1024], red[64];
+    __shared__ double dg[2048], of[2048], red[64];
     __shared__ int first;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double INF = __builtin_inf();
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(LG_T) void k_lg_sturm(const double *dgg, const doub
 
 // ------------------------------------------------------------------------------------------ host side
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
-int cip_sdp_large_padded(int r) { return r <= 256 ? 256 : (r <= 512 ? 512 : 1024); }
+int cip_sdp_large_padded(int r) { return r <= 256 ? 256 : (r <= 512 ? 512 : (r <= 1024 ? 1024 : 2048)); }
 
 int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out) {
     LargeWs *w = new LargeWs();
@@ -605,8 +605,13 @@ int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out) {
     w->ncols = ncols;
     const bool cache_mat = ncols > 0 && w->chunk >= ncols && (size_t)nlarge * ncols * m2 <= ((size_t)4 << 30) && !(getenv("CIP_LG_AMAT") && atoi(getenv("CIP_LG_AMAT")) == 0);
     size_t bytes = (cache_mat ? (size_t)nlarge * ncols * m2 : 0) + 8 * m2 + (3 + (size_t)nlarge) * m2 + LG_NPAD * (size_t)nlarge * m2 + al256(12 * (size_t)rp * 8) + 2 * (size_t)w->chunk * m2 + al256(1024) +
-                   2 * al256(cip_ldlt_ws_bytes(rp));
-    CIP_HIP_CHECK(hipMalloc((void **)&w->base, bytes));
+                   0;
+    // the two LDL' workspaces: solve block = the whole padded matrix (X = inv(L_unit) in one piece: the "triangular solves" here are
+    // GEMMs with it), also at order 2048 (the calling thread's solve-block limit for the sizing and the carve)
+    const int tl_saved = cip_tl_solve_block_max;
+    cip_tl_solve_block_max = rp;
+    bytes += 2 * al256(cip_ldlt_ws_bytes(rp));
+    if (hipMalloc((void **)&w->base, bytes) != hipSuccess) { cip_tl_solve_block_max = tl_saved; cip_set_error("large S cone workspace: hipMalloc of %zu bytes failed", bytes); delete w; return -3; }
     char *p = (char *)w->base;
     double **mats[8] = {&w->Kz, &w->Ks, &w->Tz, &w->Ts, &w->G, &w->M1, &w->M2, &w->M3};
     for (auto m : mats) { *m = (double *)p; p += m2; }
@@ -624,6 +629,7 @@ int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out) {
     w->ldl_s = p;
     cip_ldlt_ws_carve(w->ldl_z, rp, &w->wz);
     cip_ldlt_ws_carve(w->ldl_s, rp, &w->ws);
+    cip_tl_solve_block_max = tl_saved;
     w->wz.signs = w->ws.signs = PivotSigns{0, rp, rp};       // a Cholesky in disguise: every pivot must be positive
     w->wz.x_zeroed = &w->xz_z; w->ws.x_zeroed = &w->xz_s;
     *out = w;
@@ -1221,8 +1227,106 @@ __global__ __launch_bounds__(512) void k_lg_lanczos1(const double *M, int ldm, c
     }
 }
 
-static int lg_tridiag(hipStream_t s, LargeWs *w, const double *M, const double *dscale, int r) {
+// ---- Orders above 1024: the slabs of the cooperative kernel no longer fit the LDS of 256 resident workgroups.  The matrix lives in
+// global memory (A, full symmetric storage, both triangles kept up to date) and a Householder step is TWO launches, the launch
+// boundary in place of the grid barrier:
+//   k_tg_symv   every workgroup forms the reflector of column k for itself (x = A[k+1:, k], at most 2047 entries: sigma, alpha, beta, v --
+//               exactly k_lg_tridiag's), workgroup 0 stores v, beta and d_k, e_k; then p_j = beta A22[:, j] . v, one wave per column j
+//   k_tg_rank2  every workgroup forms kk = beta v'p / 2 for itself; A22 -= v w' + w v' with w = p - kk v, one 64 x 64 tile each
+// 2 (r - 1) launches, 8 r^3 bytes in all: ~35 ms at order 2048.  Same reflectors as the other two forms; d and e go to k_lg_sturm.
+__global__ __launch_bounds__(256) void k_tg_init(const double *M, int ldm, const double *dscale, int r, double *A, int lda) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)r * r) return;
+    const int i = (int)(e % r), j = (int)(e / r);
+    double x = 0.5 * (M[i + (long)j * ldm] + M[j + (long)i * ldm]);
+    if (dscale) x *= rsqrt(dscale[i]) * rsqrt(dscale[j]);
+    A[i + (long)j * lda] = x;
+}
+__device__ __forceinline__ double tg_block_sum(double x, double *red) {          // 256 threads; every thread gets the sum
+    x = cip_wave_sum(x);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+// scal: [0] beta, [1] flat (1.0: nothing to do in this column)
+__global__ __launch_bounds__(256) void k_tg_symv(const double *A, int lda, int r, int k, double *vbuf, double *pbuf, double *dg, double *of, double *scal) {
+    __shared__ double red[4];
+    __shared__ double vs[2048];
+    const int tid = threadIdx.x, m = r - k - 1;
+    const double *x = A + (k + 1) + (long)k * lda;
+    double part = 0.0;
+    for (int i = tid; i < m; i += 256) { const double xi = x[i]; vs[i] = xi; part += xi * xi; }
+    const double sigma = tg_block_sum(part, red);
+    const double x0 = vs[0];
+    const bool flat = (m == 1) || !(sigma - x0 * x0 > 0.0);
+    double alpha = x0, beta = 0.0;
+    if (!flat) { alpha = -copysign(sqrt(sigma), x0); beta = 1.0 / (sigma - x0 * alpha); }
+    if (blockIdx.x == 0 && tid == 0) {
+        dg[k] = A[k + (long)k * lda];
+        of[k] = alpha;
+        if (m == 1) { dg[r - 1] = A[(r - 1) + (long)(r - 1) * lda]; of[r - 1] = 0.0; }
+        scal[0] = beta; scal[1] = flat ? 1.0 : 0.0;
+    }
+    if (flat) return;
+    if (tid == 0) vs[0] = x0 - alpha;
+    __syncthreads();
+    if (blockIdx.x == 0) for (int i = tid; i < m; i += 256) vbuf[i] = vs[i];
+    const int lane = tid & 63, j = blockIdx.x * 4 + (tid >> 6);
+    if (j >= m) return;
+    const double *col = A + (k + 1) + (long)(k + 1 + j) * lda;
+    double acc = 0.0;
+    for (int i = lane; i < m; i += 64) acc = fma(col[i], vs[i], acc);
+    acc = cip_wave_sum(acc);
+    if (lane == 0) pbuf[j] = beta * acc;
+}
+__global__ __launch_bounds__(256) void k_tg_rank2(double *A, int lda, int r, int k, const double *vbuf, const double *pbuf, const double *scal) {
+    __shared__ double red[4];
+    __shared__ double vi[64], wi[64], vj[64], wj[64];
+    if (scal[1] != 0.0) return;
+    const int tid = threadIdx.x, m = r - k - 1;
+    const double beta = scal[0];
+    double part = 0.0;
+    for (int i = tid; i < m; i += 256) part += pbuf[i] * vbuf[i];
+    const double kk = 0.5 * beta * tg_block_sum(part, red);
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    if (tid < 64) {
+        const int i = i0 + tid;
+        const double v = i < m ? vbuf[i] : 0.0, p = i < m ? pbuf[i] : 0.0;
+        vi[tid] = v; wi[tid] = p - kk * v;
+    } else if (tid < 128) {
+        const int j = j0 + tid - 64;
+        const double v = j < m ? vbuf[j] : 0.0, p = j < m ? pbuf[j] : 0.0;
+        vj[tid - 64] = v; wj[tid - 64] = p - kk * v;
+    }
+    __syncthreads();
+    const int ti = tid & 63, tq = tid >> 6;
+    if (i0 + ti >= m) return;
+    double *a = A + (k + 1 + i0 + ti) + (long)(k + 1 + j0) * lda;
+    const double v_i = vi[ti], w_i = wi[ti];
+#pragma unroll 4
+    for (int c = tq; c < 64; c += 4)
+        if (j0 + c < m) a[(long)c * lda] -= v_i * wj[c] + w_i * vj[c];
+}
+static int lg_tridiag_stepped(hipStream_t s, LargeWs *w, const double *M, const double *dscale, int r, double *work) {
+    const int rp = w->rp;
+    double *dg = w->vec + 1 * rp, *of = w->vec + 2 * rp, *vbuf = w->vec + 3 * rp, *pbuf = w->vec + 5 * rp, *scal = w->vec + 7 * rp;
+    hipLaunchKernelGGL(k_tg_init, lg_grid((long)r * r), dim3(256), 0, s, M, rp, dscale, r, work, rp);
+    for (int k = 0; k + 1 < r; ++k) {
+        const int m = r - k - 1;
+        hipLaunchKernelGGL(k_tg_symv, dim3((m + 3) / 4), dim3(256), 0, s, (const double *)work, rp, r, k, vbuf, pbuf, dg, of, scal);
+        if (m > 1) hipLaunchKernelGGL(k_tg_rank2, dim3((m + 63) / 64, (m + 63) / 64), dim3(256), 0, s, work, rp, r, k, (const double *)vbuf, (const double *)pbuf, (const double *)scal);
+    }
+    CIP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int lg_tridiag(hipStream_t s, LargeWs *w, const double *M, const double *dscale, int r, double *work = nullptr) {
     int rc;
+    if (r > 1024) {
+        if (!work) { cip_set_error("large S cone: the tridiagonalisation above order 1024 needs a work matrix"); return CIP_E_INVALID; }
+        return lg_tridiag_stepped(s, w, M, dscale, r, work);
+    }
     // CIP_LG_TRIDIAG1=0: the cooperative kernel at every order (A/B runs)
     static const int one_wg = [] { const char *e = getenv("CIP_LG_TRIDIAG1"); return (e && atoi(e) == 0) ? 0 : 1; }();
     if (one_wg && r <= 256) {
@@ -1363,7 +1467,7 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
         // L2 + grid barrier) and their number doubles as the blocks halve), 16 at order 512 (16 workgroups), 8 at order 1024.
         // CIP_LG_JACOBI_B = 4 / 8 / 16 / 32 overrides at order 256.
         static const int bforce = [] { const char *e = getenv("CIP_LG_JACOBI_B"); return e ? atoi(e) : 0; }();
-        const int b = rp > 512 ? 8 : (rp <= 256 ? ((bforce == 32 || bforce == 16 || bforce == 4) ? bforce : 8) : 16);
+        const int b = rp > 1024 ? 4 : rp > 512 ? 8 : (rp <= 256 ? ((bforce == 32 || bforce == 16 || bforce == 4) ? bforce : 8) : 16);       // order 2048: two blocks of 4 columns are a CU's LDS
         const int nt = rp > 512 ? b * 64 : b * (rp / 8);           // 512 (order 256, b = 16), 256 (b = 8), 1024 (order 512) or 512 (order 1024: 64 lanes x 16 elements per column)
         const size_t shm = (size_t)2 * b * lg_pitch(rp) * sizeof(double);
         CIP_HIP_CHECK(hipMemsetAsync(w->ctr, 0, 1024, s));
@@ -1380,7 +1484,7 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
         // Stepped: 0 in 4500 at order 1024, 0 of 300 interior-point runs; the NT scaling 43 -> 60 ms at order 640 (ill-conditioned
         // pair), 30 -> 40 ms at order 1000.  CIP_LG_JACOBI_STEPPED: 1 (default) = orders above 256, 2 = every order, 0 = never.
         const int stepped_mode = cip_sdp_large_jacobi_stepped(-1);
-        const bool stepped = stepped_mode == 2 || (stepped_mode == 1 && rp > 256);
+        const bool stepped = stepped_mode == 2 || (stepped_mode == 1 && rp > 256) || rp > 1024;      // (order 2048: 256 workgroups of 131 KB of LDS each cannot be assumed resident together)
         auto run = [&](auto kern, int nthreads, int bb, size_t lds) -> int {
             int rc2;
             if ((rc2 = lg_set_attr((const void *)kern, lds))) return rc2;
@@ -1402,7 +1506,8 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
         if (rp == 256 && bforce == 116) {                  // A/B form (round 5): 16-column blocks, 16 lanes x 16 elements per column, 4 waves, 8 workgroups -- half the
                                                            // outer rounds, shorter lane sums, and SLOWER: config 4 8.41 against 8.03 ms per iteration
             rc = run(k_lg_jacobi<256, 16>, 256, 16, (size_t)2 * 16 * lg_pitch(rp) * sizeof(double));
-        } else if (rp > 512) rc = run(k_lg_jacobi<512, 16>, 512, b, shm);
+        } else if (rp > 1024) rc = run(k_lg_jacobi<256, 32>, 256, b, shm);
+        else if (rp > 512) rc = run(k_lg_jacobi<512, 16>, 512, b, shm);
         else if (nt == 128) rc = run(k_lg_jacobi<128>, 128, b, shm);
         else if (nt == 256) rc = run(k_lg_jacobi<256>, 256, b, shm);
         else if (nt == 512) rc = run(k_lg_jacobi<512>, 512, b, shm);
@@ -1567,7 +1672,7 @@ int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const d
             if (cert) return lg_certify(s, w, M3, nullptr, r, 0, 1.0, M1, M2, wx, partial, cd.item, side);
             return 0;
         }
-        if ((rc = lg_tridiag(s, w, M3, nullptr, r))) return rc;
+        if ((rc = lg_tridiag(s, w, M3, nullptr, r, M2))) return rc;
         hipLaunchKernelGGL(k_lg_sturm, dim3(1), dim3(LG_T), 0, s, dg, of, r, 0, 1.0, (const int *)nullptr, partial, cd.item);
         CIP_HIP_CHECK(hipGetLastError());
         return 0;
@@ -1589,7 +1694,7 @@ int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const d
         if (cert) return lg_certify(s, w, M3, wx.dvec, r, 1, scale, M1, M2, wx, partial, cd.item, side);
         return 0;
     }
-    if ((rc = lg_tridiag(s, w, M3, wx.dvec, r))) return rc;
+    if ((rc = lg_tridiag(s, w, M3, wx.dvec, r, M2))) return rc;
     hipLaunchKernelGGL(k_lg_sturm, dim3(1), dim3(LG_T), 0, s, dg, of, r, 1, scale, (const int *)wx.info, partial, cd.item);
     CIP_HIP_CHECK(hipGetLastError());
     return 0;

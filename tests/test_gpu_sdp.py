@@ -40,9 +40,9 @@ def interior(cone_dims, rng):
 @pytest.mark.parametrize("cone_dims", [[("S", 6)], [("S", 21)], [("S", 15), ("S", 3)],
                                        [("R", 5), ("Q", 4), ("S", 10)], [("S", 465)], [("S", 2080)], [("S", 5050), ("S", 6)],
                                        [("S", 8256)], [("S", 11325)], [("S", 20100), ("S", 10)], [("S", 32896)], [("S", 45150)],
-                                       [("S", 205120)], [("S", 500500), ("S", 6)]],
+                                       [("S", 205120)], [("S", 500500), ("S", 6)], [("S", 605550), ("S", 3)]],
                          ids=["r3", "r6", "r5+r2", "mixed", "r30", "r64", "r100+r3", "r128", "r150", "r200+r4", "r256", "r300",
-                              "r640", "r1000+r3"])
+                              "r640", "r1000+r3", "r1100+r2"])        # (r1100: padded order 2048, round 5; r = 1600 + 2 passed the same assertions in 7 minutes of oracle time and is not in the suite)
 def test_sdp_cone_ops(cone_dims):
     import cipkkt
     from cipkkt import OP_F, OP_FT, OP_FINV, OP_FINVT
@@ -355,11 +355,12 @@ def test_maxstep_pair_equals_two_calls(cone_dims):
     ks.close()
 
 
-@pytest.mark.parametrize("r,n,p,seed", [(133, 64, 4, 919850), (192, 40, 4, 790518), (256, 24, 0, 639913), (640, 12, 0, 31337)])
+@pytest.mark.parametrize("r,n,p,seed", [(133, 64, 4, 919850), (192, 40, 4, 790518), (256, 24, 0, 639913), (640, 12, 0, 31337), (1100, 8, 0, 4242)])
 def test_large_s_cone_programs_walk_the_oracles_trajectory(r, n, p, seed):
     """Config 4's family on the large-cone path (orders 133..256: Lanczos max-step, the two max-steps of a pair side by side;
     round 4: order 640 on the order-1024 workspaces -- 64 Jacobi workgroups with 16 elements per lane, tridiagonalisation in
-    16-column slabs; the reference has no order limit, src/ConicIP.jl:196-210) against the oracle with the exact block
+    16-column slabs; round 5: order 1100 on the order-2048 workspaces -- Jacobi with 32 elements per lane, one launch per phase, the
+    max-step's tridiagonalisation with the matrix in global memory; the reference has no order limit, src/ConicIP.jl:196-210) against the oracle with the exact block
     elimination: same status, same iteration count, iterates at 1e-8 (tools/fuzz_sdp.py draws more of them)."""
     import cipkkt
     from cipkkt import workloads as W
@@ -519,14 +520,16 @@ def _sdp_problem(r, n=4, extra_small=0):
     return dict(Q=np.eye(n), c=np.ones(n), A=np.zeros((k, n)), b=-vecm_identity(r), cone_dims=[("S", k)], G=None, d=None, kwargs={})
 
 
-def test_s_cone_above_order_1024_is_refused_cleanly():
-    """the reference has no limit on the matrix order (src/ConicIP.jl:196-210); this library stops at 1024.  A larger cone must
+def test_s_cone_above_order_2048_is_refused_cleanly():
+    """the reference has no limit on the matrix order (src/ConicIP.jl:196-210); this library stops at 2048 (1024 until round 5's second
+    session: orders 1025..2048 run the NT scaling's Jacobi with 32 elements per lane, one launch per phase, and the max-step's
+    tridiagonalisation with the matrix in global memory, two launches per column).  A larger cone must
     be REFUSED at level 1 -- CIP_E_UNSUPPORTED, a message naming the cone, no handle -- not mis-handled.  Only the cone table
     is inspected before the refusal (no 4 GB upload of A)."""
     import ctypes as C
     from cipkkt import _lib as L
     lib = L.load()
-    r = 1025
+    r = 2049
     k = r * (r + 1) // 2
     ct = (C.c_int * 1)(L.CONE_S if hasattr(L, "CONE_S") else 2)
     cd = (C.c_int * 1)(k)
@@ -543,7 +546,7 @@ def test_s_cone_above_order_1024_is_refused_cleanly():
     rc = lib.cip_create_ex(C.byref(pr), C.byref(h))
     assert rc == L.E_UNSUPPORTED, rc
     assert not h.value                                     # nothing to destroy
-    assert b"1025" in lib.cip_last_error() and b"1024" in lib.cip_last_error()
+    assert b"2049" in lib.cip_last_error() and b"2048" in lib.cip_last_error()
 
 
 def test_more_than_64_large_s_cones_are_refused_cleanly():
