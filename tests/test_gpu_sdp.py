@@ -40,9 +40,10 @@ def interior(cone_dims, rng):
 @pytest.mark.parametrize("cone_dims", [[("S", 6)], [("S", 21)], [("S", 15), ("S", 3)],
                                        [("R", 5), ("Q", 4), ("S", 10)], [("S", 465)], [("S", 2080)], [("S", 5050), ("S", 6)],
                                        [("S", 8256)], [("S", 11325)], [("S", 20100), ("S", 10)], [("S", 32896)], [("S", 45150)],
-                                       [("S", 205120)], [("S", 500500), ("S", 6)], [("S", 605550), ("S", 3)]],
+                                       [("S", 205120)], [("S", 605550), ("S", 3)]],
                          ids=["r3", "r6", "r5+r2", "mixed", "r30", "r64", "r100+r3", "r128", "r150", "r200+r4", "r256", "r300",
-                              "r640", "r1000+r3", "r1100+r2"])        # (r1100: padded order 2048, round 5; r = 1600 + 2 passed the same assertions in 7 minutes of oracle time and is not in the suite)
+                              "r640", "r1100+r2"])        # (r640: the padded-1024 path; r1100: padded order 2048, round 5.  r = 1000 + 3 (67 s of oracle time, in the suite until
+                                                          #  round 5) and r = 1600 + 2 (7 minutes) pass the same assertions and are left out for the suite's run time)
 def test_sdp_cone_ops(cone_dims):
     import cipkkt
     from cipkkt import OP_F, OP_FT, OP_FINV, OP_FINVT
