@@ -1,6 +1,7 @@
 // C ABI of libcipkkt (see include/cipkkt.h for the contract and the reference lines
 // each entry point replaces).
 #include "cip_handle.h"
+#include <thread>
 #include <stdlib.h>
 #include "../../include/cipkkt.h"
 #include <stdarg.h>
@@ -580,6 +581,7 @@ static int info_landed(cip_handle *h, bool wait, bool *landed) {
     for (long spin = 0;; ++spin) {
         if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == h->info_seq) { *landed = true; return 0; }
         if ((spin & 0xfff) == 0xfff) {
+            std::this_thread::yield();
             const hipError_t q = hipStreamQuery(h->stream);
             if (q == hipSuccess) {                                   // everything enqueued has run: the word must be there
                 *landed = __atomic_load_n(seqp, __ATOMIC_ACQUIRE) == h->info_seq;

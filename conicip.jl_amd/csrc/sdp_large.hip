@@ -608,10 +608,13 @@ int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out) {
                    0;
     // the two LDL' workspaces: solve block = the whole padded matrix (X = inv(L_unit) in one piece: the "triangular solves" here are
     // GEMMs with it), also at order 2048 (the calling thread's solve-block limit for the sizing and the carve)
-    const int tl_saved = cip_tl_solve_block_max;
-    cip_tl_solve_block_max = rp;
+    struct SolveBlockOverride {          // restores the thread's limit on every way out
+        int saved;
+        explicit SolveBlockOverride(int b) : saved(cip_tl_solve_block_max) { cip_tl_solve_block_max = b; }
+        ~SolveBlockOverride() { cip_tl_solve_block_max = saved; }
+    } whole_matrix_block(rp);
     bytes += 2 * al256(cip_ldlt_ws_bytes(rp));
-    if (hipMalloc((void **)&w->base, bytes) != hipSuccess) { cip_tl_solve_block_max = tl_saved; cip_set_error("large S cone workspace: hipMalloc of %zu bytes failed", bytes); delete w; return -3; }
+    if (hipMalloc((void **)&w->base, bytes) != hipSuccess) { cip_set_error("large S cone workspace: hipMalloc of %zu bytes failed", bytes); delete w; return -3; }
     char *p = (char *)w->base;
     double **mats[8] = {&w->Kz, &w->Ks, &w->Tz, &w->Ts, &w->G, &w->M1, &w->M2, &w->M3};
     for (auto m : mats) { *m = (double *)p; p += m2; }
@@ -629,7 +632,6 @@ int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out) {
     w->ldl_s = p;
     cip_ldlt_ws_carve(w->ldl_z, rp, &w->wz);
     cip_ldlt_ws_carve(w->ldl_s, rp, &w->ws);
-    cip_tl_solve_block_max = tl_saved;
     w->wz.signs = w->ws.signs = PivotSigns{0, rp, rp};       // a Cholesky in disguise: every pivot must be positive
     w->wz.x_zeroed = &w->xz_z; w->ws.x_zeroed = &w->xz_s;
     *out = w;
