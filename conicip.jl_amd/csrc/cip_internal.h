@@ -234,11 +234,12 @@ struct ConeSet {
     int ns_small;             // number of S cones below that order, listed in d_sidx_small
     int *d_sidx_small;
     int nlarge;               // the others (at most CIP_MAX_LARGE_S)
-    int large_cone[64];       // their cone indices (CIP_MAX_LARGE_S entries)
+    int large_cone[1024];     // their cone indices (CIP_MAX_LARGE_S entries)
     const ConeDesc *h_cones;  // host copy of the cone table (owned by the handle)
     struct LargeWs *lg;       // workspace of the large path (NULL when nlarge == 0)
 };
-#define CIP_MAX_LARGE_S 64              // round 5: was 8 -- every large cone costs 5 padded matrices (Rinv, Rinv', R, R', V) + its mat(a_i) images when they fit
+#define CIP_MAX_LARGE_S 1024            // rounds 1-4: 8, round 5: 64, then 1024 -- every large cone costs 5 padded matrices (Rinv, Rinv', R, R', V) + its mat(a_i) images when they fit;
+                                        // the cones' scalings are computed one after the other
 #define CIP_LARGE_S_MIN 133
 struct LargeWs;
 int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out);

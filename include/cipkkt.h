@@ -74,7 +74,7 @@ typedef struct cip_handle cip_handle;
 
 /* Problem description for cip_create_ex.  A may be given dense (A != NULL) or
  * in CSR (A == NULL, A_rowptr/A_colind/A_val != NULL, 0-based) -- with any mix of cone types (the rows of S cones are expanded
- * into a dense block on the device; R / Q rows stay CSR).  S cones: matrix order r <= 2048 and at most 64 cones of order >= 133
+ * into a dense block on the device; R / Q rows stay CSR).  S cones: matrix order r <= 2048 and at most 1024 cones of order >= 133
  * (CIP_E_UNSUPPORTED beyond either; the reference has no limit, src/ConicIP.jl:196-210). */
 typedef struct cip_problem {
     int n, m, p;

@@ -550,9 +550,9 @@ def test_s_cone_above_order_2048_is_refused_cleanly():
     assert b"2049" in lib.cip_last_error() and b"2048" in lib.cip_last_error()
 
 
-def test_more_than_64_large_s_cones_are_refused_cleanly():
-    """65 S cones of order 133 (the chip-wide kernels keep one set of padded matrices per large cone, at most 64 -- 8 until
-    round 5): CIP_E_UNSUPPORTED from level 1, no handle; nine (refused until round 5) are accepted AND solved"""
+def test_more_than_1024_large_s_cones_are_refused_cleanly():
+    """1025 S cones of order 133 (the chip-wide kernels keep one set of padded matrices per large cone, at most 1024 -- 8 until
+    round 5, 64 in its first session): CIP_E_UNSUPPORTED from level 1, no handle; nine (refused until round 5) are accepted AND solved"""
     import cipkkt
     from cipkkt import _lib as L
     from cipkkt.workloads import vecm_identity
@@ -565,7 +565,7 @@ def test_more_than_64_large_s_cones_are_refused_cleanly():
         A = rng.standard_normal((count * k, n)) * 0.01
         return np.eye(n), A, [("S", k)] * count
 
-    Q, A, K = build(65)
+    Q, A, K = build(1025)
     with pytest.raises(L.CipError) as ei:
         cipkkt.KKTSystem(Q, A, None, K)
     assert ei.value.code == L.E_UNSUPPORTED and "S cones" in str(ei.value)
