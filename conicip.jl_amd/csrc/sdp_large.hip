@@ -296,6 +296,8 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int bflags,
     const int part = tid % tpp, pair = tid / tpp;
     unsigned phase = 0;
     unsigned *bar = ctr, *sweepflag = ctr + 8;
+    // stepped form: the host enqueues sweeps ahead of reading their flags; a sweep behind one that found nothing to rotate is a no-op
+    if (stepped && step_sweep > 0 && __hip_atomic_load(sweepflag + step_sweep - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     // rotation of LDS columns p, q; returns 0 / 1 (rotated, small) / 2 (rotated, cos^2 >= 1e-16)
     auto rotate = [&](int p, int q) -> int {
         double *gp = sh + p * ld, *gq = sh + q * ld;
@@ -1413,10 +1415,11 @@ void cip_lg_cks_dump(void) {
     (void)hipMemset(g_lg_cks, 0, LG_CKS_CALLS * 16 * 8);
     g_lg_cks_call = 0;
 }
-// 1 (default; CIP_LG_JACOBI_STEPPED): the NT scaling's one-sided Jacobi as one launch per phase at padded orders above 256; 2: at every
-// order; 0: one persistent launch everywhere.  mode < 0 only reads; returns the previous setting
+// 2 (default; CIP_LG_JACOBI_STEPPED): the NT scaling's one-sided Jacobi as one launch per phase at every order; 1: at padded orders above
+// 256 only (order 256 on the persistent kernel: 5 % faster on config 4, and one scaling in 40000 with other bits); 0: one persistent
+// launch wherever all its workgroups can be resident (<= 1024).  mode < 0 only reads; returns the previous setting
 int cip_sdp_large_jacobi_stepped(int mode) {
-    static std::atomic<int> m{[] { const char *e = getenv("CIP_LG_JACOBI_STEPPED"); const int v = e ? atoi(e) : 1; return (v >= 0 && v <= 2) ? v : 1; }()};
+    static std::atomic<int> m{[] { const char *e = getenv("CIP_LG_JACOBI_STEPPED"); const int v = e ? atoi(e) : 2; return (v >= 0 && v <= 2) ? v : 2; }()};
     const int prev = m.load();
     if (mode >= 0 && mode <= 2) m.store(mode);
     return prev;
@@ -1483,8 +1486,11 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
         // factor in the best case (|G| preserved to rounding), an iterate off by 1e-3 in the worst; one interior-point run in 60
         // left the oracle's trajectory (tools/nt1024_repeat.py, tools/sdp640_repeat.py; neither agent-scope fences around the
         // barrier nor read-modify-write loads of the blocks changed the rate).  Order 512: 1 in 4000; order 256: 0 in 6000.
-        // Stepped: 0 in 4500 at order 1024, 0 of 300 interior-point runs; the NT scaling 43 -> 60 ms at order 640 (ill-conditioned
-        // pair), 30 -> 40 ms at order 1000.  CIP_LG_JACOBI_STEPPED: 1 (default) = orders above 256, 2 = every order, 0 = never.
+        // Stepped: 0 in 4500 at order 1024, 0 of 300 interior-point runs; the NT scaling 43 -> 41 ms at order 640 (with the 16-byte
+        // block exchange), 19 -> 16 ms at order 400.  Order 256 (16 workgroups, 512 KB per round) looked clean for 15000 repetitions and
+        // then gave ONE in 25000: the stepped form is the default at every order (config 4: 7.95 -> 8.36 ms per iteration with the
+        // sweep gate below; CIP_LG_JACOBI_STEPPED / cip_set_sdp_jacobi_stepped: 2 (default) = every order, 1 = above 256, 0 = never).
+        const bool jacobi_warm = keep_v && w->have_v[li];
         const int stepped_mode = cip_sdp_large_jacobi_stepped(-1);
         const bool stepped = stepped_mode == 2 || (stepped_mode == 1 && rp > 256) || rp > 1024;      // (order 2048: 256 workgroups of 131 KB of LDS each cannot be assumed resident together)
         auto run = [&](auto kern, int nthreads, int bb, size_t lds) -> int {
@@ -1495,9 +1501,13 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
                 hipLaunchKernelGGL(kern, dim3(m / 2), dim3(nthreads), lds, s, w->G, rp, bb, w->ctr, (int *)(w->ctr + 128));
                 return 0;
             }
+            // the host reads a sweep's flag only from the sweep on that usually is the last but one (warm start: 6-8 sweeps, cold: 9-11):
+            // a sweep enqueued behind the converged one returns at once (the kernel's gate), the read-backs before it are saved
+            const int first_check = jacobi_warm ? 4 : 7;
             for (int sweep = 0; sweep < 40; ++sweep) {
                 for (int step = 0; step < m; ++step)
                     hipLaunchKernelGGL(kern, dim3(m / 2), dim3(nthreads), lds, s, w->G, rp, bb | 0x200 | (sweep << 16) | (step << 22), w->ctr, (int *)(w->ctr + 128));
+                if (sweep < first_check) continue;
                 unsigned any = 0;
                 CIP_HIP_CHECK(hipMemcpyAsync(&any, w->ctr + 8 + sweep, sizeof(any), hipMemcpyDeviceToHost, s));
                 CIP_HIP_CHECK(hipStreamSynchronize(s));

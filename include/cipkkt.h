@@ -292,11 +292,12 @@ int cip_set_lazy_copy(int on);
    3 (self-test): as 2 with the bound on the wrong side of theta, so that every certificate fails and every verdict is the fallback's. */
 int cip_set_sdp_lanczos(int on);
 /* S cones of order >= 133, NT scaling (src/ConicIP.jl:196-210): the one-sided Jacobi of svd(Lz'Ls) as ONE LAUNCH PER PHASE -- the pairs
-   inside the column blocks, then every round of the tournament over blocks, the sweep's flag read back by the host -- at padded orders
-   above 256 (1, default; also CIP_LG_JACOBI_STEPPED), at every order (2), or as one persistent launch whose workgroups hand the blocks
-   to each other inside the launch (0).  Same arithmetic, same bits -- except that the persistent form was measured to come out with
-   other bits about once in 800 scalings at order 1024 and once in 4000 at order 512 (never in 12000 at order 256, which keeps it
-   by default: config 4 is 7 % faster with it).  Process-wide; returns the previous mode (other values: query). */
+   inside the column blocks, then every round of the tournament over blocks, a sweep behind a converged one a no-op, the sweep's flag read
+   back by the host -- at every order (2, default; also CIP_LG_JACOBI_STEPPED), at padded orders above 256 only (1), or as one persistent
+   launch whose workgroups hand the blocks to each other inside the launch (0; orders above 1024 are always stepped).  Same arithmetic,
+   same bits -- except that the persistent form was measured to come out with other bits about once in 800 scalings at order 1024, once
+   in 4000 at order 512 and once in 40000 at order 256 (where it is 5 % faster on config 4: mode 1 for those who prefer that).
+   Process-wide; returns the previous mode (other values: query). */
 int cip_set_sdp_jacobi_stepped(int mode);
 int cip_sdp_lanczos_fallbacks(cip_handle *h, int *count);
 /* HIP-event timing of the LDL' trailing-update launches (bench.py roofline): enable, then read
