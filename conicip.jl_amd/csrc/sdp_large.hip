@@ -1075,25 +1075,36 @@ __global__ __launch_bounds__(512) void k_lg_lanczos1(const double *M, int ldm, c
             LZ_T(3);
             alpha += hb[j];
             double h2 = 0.0;                                   // |h|^2: what this sweep takes out of w
-            if (tid < 256) {
-                double acc0 = 0.0, acc1 = 0.0;
+            {
+                // w -= V h on all 512 threads (round 5, second session): the even-k chain (acc0) on threads 0..255, the odd-k chain and
+                // the vectors beyond the LDS copy (acc1) on threads 256..511 for the same element i, handed over through `zz` (free
+                // outside the convergence test); same two chains, same final acc0 + acc1: same bits as the 256-thread form
+                const int i = tid & 255;
                 const int jl = j < LZ_LDSV ? j : LZ_LDSV - 1;
-                int k = 0;
-                for (; k + 1 <= jl; k += 2) {
-                    const double h0 = hb[k], h1 = hb[k + 1];
-                    acc0 = fma(h0, Vl[k * 256 + (tid ^ ((k & 7) << 3))], acc0);
-                    acc1 = fma(h1, Vl[(k + 1) * 256 + (tid ^ (((k + 1) & 7) << 3))], acc1);
-                    h2 = fma(h0, h0, fma(h1, h1, h2));
-                }
-                if (k <= jl) { const double h0 = hb[k]; acc0 = fma(h0, Vl[k * 256 + (tid ^ ((k & 7) << 3))], acc0); h2 = fma(h0, h0, h2); }
+                if (tid >= 256) {
+                    double acc1 = 0.0;
+                    int k = 0;
+                    for (; k + 1 <= jl; k += 2) acc1 = fma(hb[k + 1], Vl[(k + 1) * 256 + (i ^ (((k + 1) & 7) << 3))], acc1);
 #pragma unroll 8
-                for (int kk = LZ_LDSV; kk <= j; ++kk) {
-                    const double h0 = hb[kk];
-                    acc1 = fma(h0, __builtin_nontemporal_load(Vg + (size_t)(kk - LZ_LDSV) * 256 + tid), acc1);
-                    h2 = fma(h0, h0, h2);
+                    for (int kk = LZ_LDSV; kk <= j; ++kk) acc1 = fma(hb[kk], __builtin_nontemporal_load(Vg + (size_t)(kk - LZ_LDSV) * 256 + i), acc1);
+                    zz[i] = acc1;
                 }
-                wi -= acc0 + acc1;
-                wsv[tid] = wi;
+                double acc0 = 0.0;
+                if (tid < 256) {
+                    int k = 0;
+                    for (; k + 1 <= jl; k += 2) {
+                        const double h0 = hb[k], h1 = hb[k + 1];
+                        acc0 = fma(h0, Vl[k * 256 + (i ^ ((k & 7) << 3))], acc0);
+                        h2 = fma(h0, h0, fma(h1, h1, h2));
+                    }
+                    if (k <= jl) { const double h0 = hb[k]; acc0 = fma(h0, Vl[k * 256 + (i ^ ((k & 7) << 3))], acc0); h2 = fma(h0, h0, h2); }
+                    for (int kk = LZ_LDSV; kk <= j; ++kk) { const double h0 = hb[kk]; h2 = fma(h0, h0, h2); }
+                }
+                __syncthreads();
+                if (tid < 256) {
+                    wi -= acc0 + zz[i];
+                    wsv[tid] = wi;
+                }
             }
             nrm2 = lz_sum256(tid < 256 ? wi * wi : 0.0, red, pass);        // (its barrier also publishes wsv)
             LZ_T(4);
