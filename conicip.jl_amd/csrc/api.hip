@@ -332,8 +332,9 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
         CIP_HIP_CHECK(hipMemcpyAsync(h->cs.d_sidx, h->st_sidx.data(), sizeof(int) * sidx.size(), hipMemcpyHostToDevice, s));
         DMALLOC(h->cs.d_sdpws, sizeof(double) * (size_t)h->cs.sdp_slots * 6 * rmax * rmax);
         DMALLOC(h->cs.d_sdpvec, sizeof(double) * (size_t)h->cs.sdp_slots * 2 * kmax);
-        DMALLOC(h->cs.d_sdpflag, sizeof(int) * 16);               // [0]: an iterate left the cone; [4 + li]: gate of large cone li's general division
-        CIP_HIP_CHECK(hipMemsetAsync(h->cs.d_sdpflag, 0, sizeof(int) * 16, s));
+        const size_t nflag = (size_t)rup(4 + (h->cs.nlarge > 12 ? h->cs.nlarge : 12), 16);   // [0]: an iterate left the cone; [4 + li]: gate of large cone li's general division (li < nlarge <= CIP_MAX_LARGE_S)
+        DMALLOC(h->cs.d_sdpflag, sizeof(int) * nflag);
+        CIP_HIP_CHECK(hipMemsetAsync(h->cs.d_sdpflag, 0, sizeof(int) * nflag, s));
     }
     if (!h->h_cones.empty())
         CIP_HIP_CHECK(hipMemcpyAsync(h->cs.d_cones, h->h_cones.data(), sizeof(ConeDesc) * h->h_cones.size(), hipMemcpyHostToDevice, s));
@@ -391,8 +392,11 @@ static int create_impl(const cip_problem *pr, cip_handle *h, bool final_sync = t
 
     // ---- KKT matrix, workspace, scratch
     DMALLOC(h->K, sizeof(double) * (size_t)h->ldk * h->Npad);
-    DMALLOC(h->ws_base, cip_ldlt_ws_bytes(h->Npad));
-    cip_ldlt_ws_carve(h->ws_base, h->Npad, &h->ws);
+    {
+        const int fz = cip_ldlt_fused_for(h->Npad);             // read ONCE: sizing and carve must agree
+        DMALLOC(h->ws_base, cip_ldlt_ws_bytes(h->Npad, fz));
+        cip_ldlt_ws_carve(h->ws_base, h->Npad, &h->ws, fz);
+    }
     h->ws.x_zeroed = &h->x_zeroed;
     h->ws.side = h->arena ? nullptr : &h->ldlt_side;      // (handles of a lock-step arena factor inside batched launches)
     // pivot signs of the quasi-definite order: Schur route [S G'; G 0] = n positive, p negative; literal 3x3 in the
@@ -1024,13 +1028,13 @@ extern "C" int cip_axpby_dev(cip_handle *h, int len, double alpha, const double 
 // ------------------------------------------------------------------ stand-alone LDL' / GEMM
 extern "C" int cip_ldlt_workspace_bytes(int N, size_t *bytes) {
     if (N <= 0 || N % CIP_NB || !bytes) { cip_set_error("N must be a positive multiple of 128"); return CIP_E_INVALID; }
-    *bytes = cip_ldlt_ws_bytes(N);
+    *bytes = cip_ldlt_ws_bytes(N, -1);                  // room for the one-launch block steps whatever the mode is now or later
     return 0;
 }
 extern "C" int cip_ldlt_factor_dev(void *stream, double *K, int N, int ld, void *workspace, int *info_host) {
     if (!K || !workspace || N <= 0 || N % CIP_NB || ld < N || ld % 2) { cip_set_error("bad argument"); return CIP_E_INVALID; }
     LdltWorkspace ws{};
-    cip_ldlt_ws_carve(workspace, N, &ws);
+    cip_ldlt_ws_carve(workspace, N, &ws, cip_ldlt_fused_for(N));      // (the workspace has room for either mode: cip_ldlt_workspace_bytes)
     int rc = cip_ldlt_factor((hipStream_t)stream, K, N, ld, ws);
     if (rc) return rc;
     if (info_host) {
@@ -1042,7 +1046,7 @@ extern "C" int cip_ldlt_factor_dev(void *stream, double *K, int N, int ld, void 
 extern "C" int cip_ldlt_solve_dev(void *stream, const double *K, int N, int ld, const void *workspace, double *rhs) {
     if (!K || !workspace || !rhs || N <= 0 || N % CIP_NB) { cip_set_error("bad argument"); return CIP_E_INVALID; }
     LdltWorkspace ws{};
-    cip_ldlt_ws_carve((void *)workspace, N, &ws);
+    cip_ldlt_ws_carve((void *)workspace, N, &ws, cip_ldlt_fused_for(N));   // same mode as at the factorisation: cip_set_solve_fused must not change between a factor and its solves
     return cip_ldlt_solve((hipStream_t)stream, K, N, ld, ws, rhs);
 }
 extern "C" int cip_gemm_nt_dev(void *stream, int M, int N, int K, double alpha, const double *A, int lda, const double *B,
@@ -1112,7 +1116,6 @@ extern "C" int cip_profile_thread_get(double *out3) {
 }
 extern "C" int cip_set_lazy_copy(int on) { return cip_lazy_copy_set(on); }
 extern "C" int cip_set_sdp_lanczos(int on) { return cip_sdp_large_lanczos(on); }
-extern "C" int cip_set_sdp_jacobi_stepped(int mode) { return cip_sdp_large_jacobi_stepped(mode); }
 extern "C" int cip_sdp_lanczos_fallbacks(cip_handle *h, int *count) {
     if (!h || !count) { cip_set_error("bad argument"); return CIP_E_INVALID; }
     int out2[2] = {0, 0};

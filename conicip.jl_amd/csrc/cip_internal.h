@@ -183,8 +183,9 @@ int cip_solve_block(int Npad);
 int cip_solve_block_max_set(int b);              // 128 | 256 | 512 | 1024 (0: query); returns the previous limit
 int cip_solve_fused_set(int mode);               // 0 (default): two launches per block step; 1: one (pre-multiplied neighbours) for solve blocks <= 512; 2: always; < 0: query.  Returns the previous mode
 extern thread_local int cip_tl_solve_block_max;  // > 0: this thread's limit for handles it creates
-size_t cip_ldlt_ws_bytes(int Npad);
-void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws);
+int cip_ldlt_fused_for(int Npad);                // does the CURRENT mode (cip_solve_fused_set) ask for the one-launch block steps at this order?
+size_t cip_ldlt_ws_bytes(int Npad, int fused);     // fused: 1 / 0 = with / without MT, PT; < 0: reserve them whenever the order has two solve blocks
+void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws, int fused);   // fused as passed to cip_ldlt_ws_bytes by the same owner (0 / 1)
 int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws);
 int cip_ldlt_solve(hipStream_t s, const double *K, int Npad, long ld, const LdltWorkspace &ws, double *rhs);
 int cip_ldlt_outer_block(void);          // the knob: 0 = automatic
@@ -251,7 +252,6 @@ int cip_sdp_large_refresh(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li,
 int cip_sdp_large_apply(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, int mode, const double *x, double *out);
 int cip_sdp_large_prod(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *y, double *out);
 int cip_sdp_large_div(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *y, double *out, int *flag);
-int cip_sdp_large_jacobi_stepped(int mode);          // sdp_large.hip: one-sided Jacobi as one launch per phase above order 256 (1), everywhere (2), never (0); < 0 reads; returns the previous setting
 int cip_sdp_large_lanczos(int on);                  // sdp_large.hip: max-step eigenvalue by Lanczos (1), Lanczos + inertia certificate (2), tridiagonalisation (0); < 0 reads; returns the previous setting
 int cip_sdp_large_cert_stats(hipStream_t s, struct LargeWs *w, int *out2);     // {certificates failed -> fallbacks taken, 0}
 int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const double *x, const double *d, double scale,

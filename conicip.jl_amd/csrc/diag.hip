@@ -854,6 +854,10 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
                     // (the DS operations of a wave return in order; its own A(kb) stores are in front of them).  The tiles are normally
                     // long done -- if not, wait and load the two tile operands again.
                     const unsigned tf = __hip_atomic_load(tflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // (round 6, advisor) the operand loads below are PLAIN LDS loads and the acquire fence comes behind them: the hardware
+                    // returns a wave's DS operations in order, but nothing kept the COMPILER from hoisting them above the relaxed poll --
+                    // a compiler barrier (no instruction) pins the order the one-round-trip form relies on
+                    asm volatile("" ::: "memory");
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         xa[s] = xm[kb * 256 + (g + 4 * s) * 16 + l15];
@@ -1020,8 +1024,8 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
             // -- two per SIMD, the serial wave alone on the fourth -- are what the serial wave waits for at this barrier from
             // micro-panel 2 on (tools/diag_bench -DDIAG_TIMING -DDIAG_TIMING_END -DDIAG_TIMING_TID=..: a helper with a tile on a SIMD
             // that hosts two tile waves needs 5100 ticks for stores + tile + transposed stores beside the serial wave's 3900).
-            // The whole block's transpose is written by all the waves behind the last micro-panel, under the tail of the launch's
-            // TRSM strips, which follow this workgroup one stage behind.
+            // (The 128 x 128 block's own transpose is not written at all since round 5: the solves read L' from the upper triangle
+            // only OUTSIDE their Bs-wide diagonal blocks.  The upper triangle of the diagonal blocks is UNDEFINED after a factorisation.)
 #ifdef DIAG_TIMING_END
             DIAG_STAMP(kb, 7, tid == DIAG_TIMING_TID);                // (instead of "tiles done": the helper's whole phase, transposed stores included)
 #endif

@@ -206,26 +206,30 @@ static int solve_fused_for(int Npad, int Bs) {
     return mode == 2 || (mode == 1 && Bs <= 512);
 }
 
-size_t cip_ldlt_ws_bytes(int Npad) {
+// Layout: everything whose size depends on (Npad, solve block) only, then -- LAST -- the pre-multiplied neighbour blocks MT / PT of the
+// one-launch block steps.  `fused` is decided ONCE by the owner of the workspace and passed to both functions (round-5 advisor: each
+// used to read the process-wide mode for itself, so a cip_set_solve_fused between the two -- or between handle creation's sizing and
+// its carve -- placed MT / PT beyond the allocation).  fused < 0: by the current mode (cip_ldlt_ws_bytes only: the public sizing
+// call reserves MT / PT whenever the order has two solve blocks, whatever the mode, so that a caller-owned workspace fits every mode).
+int cip_ldlt_fused_for(int Npad) { return solve_fused_for(Npad, cip_solve_block(Npad)); }
+size_t cip_ldlt_ws_bytes(int Npad, int fused) {
     const size_t nblk = Npad / CIP_NB;
     size_t b = 0;
     b += al256((size_t)Npad * wbuf_cols(Npad) * 8);       // Wbuf
     b += al256(nblk * CIP_NB * CIP_NB * 8) * 2;          // Linv, LinvT
     b += al256(nblk * 2048 * 8);                         // Xm
-    {
-        const int Bs = cip_solve_block(Npad);
-        const size_t nbk = Npad / Bs;
-        b += al256(nbk * (size_t)Bs * Bs * 8) * 2;       // X, XT
-        b += al256(nbk * (size_t)(Bs / 2) * (Bs / 2) * 8 + 256);   // Tt
-        b += al256((size_t)Npad * 8);                    // zbuf
-        if (solve_fused_for(Npad, Bs)) b += al256(nbk * (size_t)Bs * Bs * 8) * 2;   // MT, PT
-    }
+    const int Bs = cip_solve_block(Npad);
+    const size_t nbk = Npad / Bs;
+    b += al256(nbk * (size_t)Bs * Bs * 8) * 2;           // X, XT
+    b += al256(nbk * (size_t)(Bs / 2) * (Bs / 2) * 8 + 256);   // Tt
+    b += al256((size_t)Npad * 8);                        // zbuf
     b += al256((size_t)Npad * 8) * 3;                    // dinv, dvec, tmp
     b += al256(64 + 12 * nblk);                          // info (16 ints) + a `ready`, a `stage` and a tile-queue counter per 128-block (fused panel launches)
+    if (fused < 0 ? nbk >= 2 : fused) b += al256(nbk * (size_t)Bs * Bs * 8) * 2;   // MT, PT
     return b;
 }
 
-void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
+void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws, int fused) {
     const size_t nblk = Npad / CIP_NB;
     char *p = (char *)base;
     ws->Wbuf = (double *)p;  p += al256((size_t)Npad * wbuf_cols(Npad) * 8);
@@ -233,23 +237,21 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws) {
     ws->LinvT = (double *)p; p += al256(nblk * CIP_NB * CIP_NB * 8);
     ws->Xm = (double *)p;    p += al256(nblk * 2048 * 8);
     ws->Bs = cip_solve_block(Npad);
-    {
-        const size_t nbk = Npad / ws->Bs;
-        ws->X = (double *)p;     p += al256(nbk * (size_t)ws->Bs * ws->Bs * 8);
-        ws->XT = (double *)p;    p += al256(nbk * (size_t)ws->Bs * ws->Bs * 8);
-        ws->Tt = (double *)p;    p += al256(nbk * (size_t)(ws->Bs / 2) * (ws->Bs / 2) * 8 + 256);
-        ws->zbuf = (double *)p;  p += al256((size_t)Npad * 8);
-        ws->fused = solve_fused_for(Npad, ws->Bs);
-        ws->MT = ws->PT = nullptr;
-        if (ws->fused) {
-            ws->MT = (double *)p;  p += al256(nbk * (size_t)ws->Bs * ws->Bs * 8);
-            ws->PT = (double *)p;  p += al256(nbk * (size_t)ws->Bs * ws->Bs * 8);
-        }
-    }
+    const size_t nbk = Npad / ws->Bs;
+    ws->X = (double *)p;     p += al256(nbk * (size_t)ws->Bs * ws->Bs * 8);
+    ws->XT = (double *)p;    p += al256(nbk * (size_t)ws->Bs * ws->Bs * 8);
+    ws->Tt = (double *)p;    p += al256(nbk * (size_t)(ws->Bs / 2) * (ws->Bs / 2) * 8 + 256);
+    ws->zbuf = (double *)p;  p += al256((size_t)Npad * 8);
     ws->dinv = (double *)p;  p += al256((size_t)Npad * 8);
     ws->dvec = (double *)p;  p += al256((size_t)Npad * 8);
     ws->tmp = (double *)p;   p += al256((size_t)Npad * 8);
     ws->info = (int *)p;     p += al256(64 + 12 * nblk);
+    ws->fused = (fused != 0 && nbk >= 2) ? 1 : 0;
+    ws->MT = ws->PT = nullptr;
+    if (ws->fused) {
+        ws->MT = (double *)p;  p += al256(nbk * (size_t)ws->Bs * ws->Bs * 8);
+        ws->PT = (double *)p;  p += al256(nbk * (size_t)ws->Bs * ws->Bs * 8);
+    }
     ws->prof = nullptr;
     ws->lazyC = nullptr; ws->lazy_ld = 0; ws->lazy_diag = nullptr;
     ws->signs = PivotSigns{-1, 0, 0};

@@ -29,6 +29,8 @@
 #include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <thread>
 
 #define LG_T 1024
 #define LG_SQRT2 1.4142135623730951
@@ -63,6 +65,9 @@ struct LargeWs {
     double *Vw = nullptr;          // nlarge x rp x rp
     double *G0 = nullptr, *W1 = nullptr, *W2 = nullptr;
     int have_v[CIP_MAX_LARGE_S] = {};
+    unsigned long long *vstate = nullptr;   // device, 2 words per large cone: [0] = 1: the stored V may be used; [1]: max |V'V - I| (bit pattern) of the current call
+    int *hflag = nullptr, *hflag_dev = nullptr;   // host-mapped: {sweep flag, Cholesky flags, sequence number} of the Jacobi's read-backs
+    int hseq = 0;
     void *ldl_z = nullptr, *ldl_s = nullptr;
     LdltWorkspace wz, ws;
     int xz_z = 0, xz_s = 0;        // the upper triangles of their block inverses have been zeroed (they stay zero)
@@ -266,38 +271,35 @@ __device__ __forceinline__ double lg_rsqrt(double x) {
     r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
     return r;
 }
-// One persistent launch, nbk / 2 workgroups, every column pair rotated exactly once per sweep (cyclic Jacobi):
-//   intra-block phase   workgroup k holds blocks 2k, 2k+1 in LDS: b - 1 rounds of the round-robin tournament inside
+// nbk / 2 workgroups, every column pair rotated exactly once per sweep (cyclic Jacobi), ONE PHASE PER LAUNCH:
+//   step 0              workgroup k holds blocks 2k, 2k+1 in LDS: b - 1 rounds of the round-robin tournament inside
 //                       each block (b / 2 + b / 2 disjoint pairs per round)
-//   nbk - 1 outer rounds of the tournament over blocks: the workgroup holds its block pair (I, J) and rotates the
-//                       b x b cross pairs in b rounds of b disjoint pairs (p in I with p + it in J)
-// with a grid barrier after every phase (the blocks travel through global memory with coherent accesses): 255 rotation
-// rounds per sweep at r = 256 -- the depth of the plain parallel ordering -- where a full inner sweep per block pair
-// cost 441 (first version: 12.7 ms; this one: see DESIGN.md).  rp / 8 lanes per pair, both columns in registers between
-// the dot products and the rotation.  Ends after the first sweep whose largest rotation had cos^2 < 1e-16 (the next
-// sweep would find nothing above the 1e-30 threshold: quadratic convergence), or after a sweep without any rotation.
+//   step t + 1          round t of the tournament over blocks (nbk - 1 rounds): the workgroup holds its block pair (I, J) and
+//                       rotates the b x b cross pairs in b rounds of b disjoint pairs (p in I with p + it in J)
+// The launch boundary orders the phases: 255 rotation rounds per sweep at r = 256 -- the depth of the plain parallel ordering.
+// (Rounds 3-5 also had ONE persistent launch per NT scaling with a grid barrier per phase and the blocks handed from workgroup to
+//  workgroup through `sc1` stores + a counter: about one scaling in 800 / 4000 / 40000 at order 1024 / 512 / 256 came out with other
+//  bits and the cause was never found -- DESIGN_LOG.md, round 5.  Round 6 removed that form and its switch: a library must not offer
+//  a mode whose documented effect is other bits once in a while.)
+// rp / 8 lanes per pair, both columns in registers between the dot products and the rotation.  A sweep behind one that found no
+// rotation with cos^2 >= 1e-16 returns at once (the next sweep would find nothing above the 1e-30 threshold: quadratic convergence).
 // G_in V = U diag(sigma): column i ends as sigma_i u_i, all of svd(Lz' Ls) that nestod_sdc uses (src/ConicIP.jl:204-208).
 // EPL: elements of a column per lane (rp == EPL * tpp): 8 up to order 512; 16 at order 1024 (round 4), where 64 lanes hold a column
 template <int NT, int EPL = 8>
-__global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int bflags, unsigned *ctr, int *err) {
+__global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int bflags, unsigned *ctr) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int b = bflags & 0xff;
-    // stepped form (order 1024): ONE phase of ONE sweep per launch -- step 0 the pairs inside the blocks, step t + 1 round t of the
-    // tournament over blocks -- the launch boundary in place of the grid barrier (see cip_sdp_large_nt)
-    const bool stepped = (bflags & 0x200) != 0;
     const int step_sweep = (bflags >> 16) & 0x3f, step = (bflags >> 22) & 0x1ff;
     __shared__ int s_rot;
     __shared__ double s_nrm[32];
     const int tid = threadIdx.x;
-    const int nbk = rp / b, m = nbk, nwg = nbk / 2;
+    const int nbk = rp / b, m = nbk;
     const int ld = lg_pitch(rp);
-    const int nc = 2 * b;                                  // columns in LDS
     const int tpp = NT / b;                              // lanes per column pair (32 or 64); rp == EPL * tpp
     const int part = tid % tpp, pair = tid / tpp;
-    unsigned phase = 0;
-    unsigned *bar = ctr, *sweepflag = ctr + 8;
-    // stepped form: the host enqueues sweeps ahead of reading their flags; a sweep behind one that found nothing to rotate is a no-op
-    if (stepped && step_sweep > 0 && __hip_atomic_load(sweepflag + step_sweep - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    unsigned *sweepflag = ctr + 8;
+    // the host enqueues sweeps ahead of reading their flags; a sweep behind one that found nothing to rotate is a no-op
+    if (step_sweep > 0 && __hip_atomic_load(sweepflag + step_sweep - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     // rotation of LDS columns p, q; returns 0 / 1 (rotated, small) / 2 (rotated, cos^2 >= 1e-16)
     auto rotate = [&](int p, int q) -> int {
         double *gp = sh + p * ld, *gq = sh + q * ld;
@@ -321,10 +323,9 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int bflags,
     };
     // a block pair is 2 b rp = 16384 doubles whatever (b, rp): 16 per thread.  All loads of a thread are issued before the first
     // LDS store (one at a time, store after load, each global round trip was exposed: 16 x ~1.5 us per outer round -- half of a
-    // sweep's time).  16-BYTE `sc1` buffer accesses (second session of round 5; until then 8-byte agent-scope atomic loads /
-    // stores, `global_load_dwordx2 sc1`): MI355X_MICROARCH.md's table of hand-offs measured valid with `sc1` loads in place of an
-    // acquire names dword and dwordx4 loads for this shape -- one counter, every workgroup adds, a barrier between the poll and
-    // the loads -- and excludes dwordx2.
+    // sweep's time).  16-byte buffer accesses with the `sc1` policy bit: a relic of the in-launch block exchange (the blocks now
+    // change hands across a launch boundary, where plain accesses would do); kept because the one-launch-per-phase form was
+    // measured, repeated 11 500 times and pinned bit for bit with exactly these instructions.
     typedef int v4i_t __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)G, 0, 0x7fffffff, 0x00020000);
     auto load = [&](int bp, int bq) {                      // coherent loads: other workgroups wrote these blocks
@@ -352,87 +353,79 @@ __global__ __launch_bounds__(NT) void k_lg_jacobi(double *G, int rp, int bflags,
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, t[u]), grs, (int)((i + (long)(c < b ? bp * b + c : bq * b + (c - b)) * rp) * 8), 0, 16);
         }
     };
-    for (int sweep = stepped ? step_sweep : 0; sweep < (stepped ? step_sweep + 1 : 40); ++sweep) {
-        int rotated = 0;
+    int rotated = 0;
+    if (step == 0) {
         // ---- pairs inside the blocks
-        if (!stepped || step == 0) {
-            const int bp = 2 * (int)blockIdx.x, bq = bp + 1;
-            load(bp, bq);
-            const int hb = b / 2, blk = pair / hb, kk = pair % hb;
-            for (int it = 0; it < b - 1; ++it) {
-                int p, q;
-                if (kk == 0) { p = b - 1; q = it; }
-                else { p = (it + kk) % (b - 1); q = (it - kk + (b - 1)) % (b - 1); }
-                const int rr = rotate(blk * b + p, blk * b + q);
-                if (rr && part == 0) atomicMax(&s_rot, rr);
+        const int bp = 2 * (int)blockIdx.x, bq = bp + 1;
+        load(bp, bq);
+        const int hb = b / 2, blk = pair / hb, kk = pair % hb;
+        for (int it = 0; it < b - 1; ++it) {
+            int p, q;
+            if (kk == 0) { p = b - 1; q = it; }
+            else { p = (it + kk) % (b - 1); q = (it - kk + (b - 1)) % (b - 1); }
+            const int rr = rotate(blk * b + p, blk * b + q);
+            if (rr && part == 0) atomicMax(&s_rot, rr);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        rotated = s_rot > rotated ? s_rot : rotated;
+        store(bp, bq);
+    } else {
+        // ---- pairs across blocks: round t = step - 1 of the tournament
+        const int t = step - 1;
+        int bp, bq;
+        const int k = blockIdx.x;
+        if (k == 0) { bp = m - 1; bq = t; }
+        else { bp = (t + k) % (m - 1); bq = (t - k + (m - 1)) % (m - 1); }
+        load(bp, bq);
+        {
+            // column p = `pair` of block I stays with this lane group for all b rounds: it lives in registers, its
+            // squared norm `a` and the partners' (s_nrm, in LDS) follow the rotations (a' = a - t c, b' = b + t c)
+            // instead of being re-summed -- a round is then one dot product, 8 LDS loads and 8 stores per lane
+            double *gp = sh + pair * ld;
+            double xv[EPL], a = 0.0;
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) { xv[u] = gp[part + u * tpp]; a += xv[u] * xv[u]; }
+            {
+                double *gq0 = sh + (b + pair) * ld;
+                double bq2 = 0.0;
+#pragma unroll
+                for (int u = 0; u < EPL; ++u) { const double y = gq0[part + u * tpp]; bq2 += y * y; }
+                a = lg_sum_group(a, tpp); bq2 = lg_sum_group(bq2, tpp);
+                if (part == 0) s_nrm[pair] = bq2;
+            }
+            __syncthreads();
+            for (int it = 0; it < b; ++it) {
+                const int qi = (pair + it) % b;
+                double *gq = sh + (b + qi) * ld;
+                double yv[EPL], c = 0.0;
+#pragma unroll
+                for (int u = 0; u < EPL; ++u) { yv[u] = gq[part + u * tpp]; c += xv[u] * yv[u]; }
+                c = lg_sum_group(c, tpp);
+                const double bb = s_nrm[qi];
+                if (c * c > 1e-30 * (a * bb) && c != 0.0) {
+                    const double zeta = (bb - a) * 0.5 * lg_rcp(c);
+                    const double h2 = 1.0 + zeta * zeta;
+                    const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * lg_rcp(fabs(zeta) + h2 * lg_rsqrt(h2));
+                    const double cs = lg_rsqrt(1.0 + tt * tt), sn = cs * tt;
+#pragma unroll
+                    for (int u = 0; u < EPL; ++u) {
+                        const double x = xv[u];
+                        xv[u] = cs * x - sn * yv[u];
+                        gq[part + u * tpp] = sn * x + cs * yv[u];
+                    }
+                    if (part == 0) { s_nrm[qi] = bb + tt * c; atomicMax(&s_rot, (c * c > 1e-16 * (a * bb)) ? 2 : 1); }
+                    a -= tt * c;
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
-            rotated = s_rot > rotated ? s_rot : rotated;
-            store(bp, bq);
-            if (!stepped) lg_grid_barrier(bar, nwg, phase, err);
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) gp[part + u * tpp] = xv[u];
+            __syncthreads();
         }
-        // ---- pairs across blocks
-        for (int t = stepped ? (step > 0 ? step - 1 : 0) : 0; t < (stepped ? step : m - 1); ++t) {
-            int bp, bq;
-            const int k = blockIdx.x;
-            if (k == 0) { bp = m - 1; bq = t; }
-            else { bp = (t + k) % (m - 1); bq = (t - k + (m - 1)) % (m - 1); }
-            load(bp, bq);
-            {
-                // column p = `pair` of block I stays with this lane group for all b rounds: it lives in registers, its
-                // squared norm `a` and the partners' (s_nrm, in LDS) follow the rotations (a' = a - t c, b' = b + t c)
-                // instead of being re-summed -- a round is then one dot product, 8 LDS loads and 8 stores per lane
-                double *gp = sh + pair * ld;
-                double xv[EPL], a = 0.0;
-#pragma unroll
-                for (int u = 0; u < EPL; ++u) { xv[u] = gp[part + u * tpp]; a += xv[u] * xv[u]; }
-                {
-                    double *gq0 = sh + (b + pair) * ld;
-                    double bq2 = 0.0;
-#pragma unroll
-                    for (int u = 0; u < EPL; ++u) { const double y = gq0[part + u * tpp]; bq2 += y * y; }
-                    a = lg_sum_group(a, tpp); bq2 = lg_sum_group(bq2, tpp);
-                    if (part == 0) s_nrm[pair] = bq2;
-                }
-                __syncthreads();
-                for (int it = 0; it < b; ++it) {
-                    const int qi = (pair + it) % b;
-                    double *gq = sh + (b + qi) * ld;
-                    double yv[EPL], c = 0.0;
-#pragma unroll
-                    for (int u = 0; u < EPL; ++u) { yv[u] = gq[part + u * tpp]; c += xv[u] * yv[u]; }
-                    c = lg_sum_group(c, tpp);
-                    const double bb = s_nrm[qi];
-                    if (c * c > 1e-30 * (a * bb) && c != 0.0) {
-                        const double zeta = (bb - a) * 0.5 * lg_rcp(c);
-                        const double h2 = 1.0 + zeta * zeta;
-                        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * lg_rcp(fabs(zeta) + h2 * lg_rsqrt(h2));
-                        const double cs = lg_rsqrt(1.0 + tt * tt), sn = cs * tt;
-#pragma unroll
-                        for (int u = 0; u < EPL; ++u) {
-                            const double x = xv[u];
-                            xv[u] = cs * x - sn * yv[u];
-                            gq[part + u * tpp] = sn * x + cs * yv[u];
-                        }
-                        if (part == 0) { s_nrm[qi] = bb + tt * c; atomicMax(&s_rot, (c * c > 1e-16 * (a * bb)) ? 2 : 1); }
-                        a -= tt * c;
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                }
-#pragma unroll
-                for (int u = 0; u < EPL; ++u) gp[part + u * tpp] = xv[u];
-                __syncthreads();
-            }
-            rotated = s_rot > rotated ? s_rot : rotated;
-            store(bp, bq);
-            if (!stepped) lg_grid_barrier(bar, nwg, phase, err);
-        }
-        if (tid == 0 && rotated == 2) atomicAdd(sweepflag + sweep, 1u);
-        if (stepped) break;
-        lg_grid_barrier(bar, nwg, phase, err);
-        const unsigned any = __hip_atomic_load(sweepflag + sweep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!any || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        rotated = s_rot > rotated ? s_rot : rotated;
+        store(bp, bq);
     }
+    if (tid == 0 && rotated == 2) atomicAdd(sweepflag + step_sweep, 1u);
 }
 
 // ------------------------------------------------------------------------------------------ cooperative tridiagonalisation
@@ -607,7 +600,7 @@ int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out) {
     w->ncols = ncols;
     const bool cache_mat = ncols > 0 && w->chunk >= ncols && (size_t)nlarge * ncols * m2 <= ((size_t)4 << 30) && !(getenv("CIP_LG_AMAT") && atoi(getenv("CIP_LG_AMAT")) == 0);
     size_t bytes = (cache_mat ? (size_t)nlarge * ncols * m2 : 0) + 8 * m2 + (3 + (size_t)nlarge) * m2 + LG_NPAD * (size_t)nlarge * m2 + al256(12 * (size_t)rp * 8) + 2 * (size_t)w->chunk * m2 + al256(1024) +
-                   0;
+                   al256(16 * (size_t)nlarge);
     // the two LDL' workspaces: solve block = the whole padded matrix (X = inv(L_unit) in one piece: the "triangular solves" here are
     // GEMMs with it), also at order 2048 (the calling thread's solve-block limit for the sizing and the carve)
     struct SolveBlockOverride {          // restores the thread's limit on every way out
@@ -615,7 +608,7 @@ int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out) {
         explicit SolveBlockOverride(int b) : saved(cip_tl_solve_block_max) { cip_tl_solve_block_max = b; }
         ~SolveBlockOverride() { cip_tl_solve_block_max = saved; }
     } whole_matrix_block(rp);
-    bytes += 2 * al256(cip_ldlt_ws_bytes(rp));
+    bytes += 2 * al256(cip_ldlt_ws_bytes(rp, 0));
     if (hipMalloc((void **)&w->base, bytes) != hipSuccess) { cip_set_error("large S cone workspace: hipMalloc of %zu bytes failed", bytes); delete w; return -3; }
     char *p = (char *)w->base;
     double **mats[8] = {&w->Kz, &w->Ks, &w->Tz, &w->Ts, &w->G, &w->M1, &w->M2, &w->M3};
@@ -629,11 +622,18 @@ int cip_sdp_large_create(int rmax_large, int nlarge, int ncols, LargeWs **out) {
     if (cache_mat) { w->amat = (double *)p; p += (size_t)nlarge * ncols * m2; }
     w->ctr = (unsigned *)p; p += al256(1024);
     CIP_HIP_CHECK(hipMemset(w->ctr, 0, 1024));
+    w->vstate = (unsigned long long *)p; p += al256(16 * (size_t)nlarge);
+    CIP_HIP_CHECK(hipMemset(w->vstate, 0, 16 * (size_t)nlarge));
+    if (hipHostMalloc((void **)&w->hflag, 8 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&w->hflag_dev, w->hflag, 0) != hipSuccess) {
+        cip_set_error("large S cone workspace: host-mapped flag words"); if (w->hflag) (void)hipHostFree(w->hflag); (void)hipFree(w->base); delete w; return -3;
+    }
+    memset(w->hflag, 0, 8 * sizeof(int));
     CIP_HIP_CHECK(hipMemset(w->vec, 0, 12 * (size_t)rp * 8));
-    w->ldl_z = p; p += al256(cip_ldlt_ws_bytes(rp));
+    w->ldl_z = p; p += al256(cip_ldlt_ws_bytes(rp, 0));
     w->ldl_s = p;
-    cip_ldlt_ws_carve(w->ldl_z, rp, &w->wz);
-    cip_ldlt_ws_carve(w->ldl_s, rp, &w->ws);
+    cip_ldlt_ws_carve(w->ldl_z, rp, &w->wz, 0);
+    cip_ldlt_ws_carve(w->ldl_s, rp, &w->ws, 0);
     w->wz.signs = w->ws.signs = PivotSigns{0, rp, rp};       // a Cholesky in disguise: every pivot must be positive
     w->wz.x_zeroed = &w->xz_z; w->ws.x_zeroed = &w->xz_s;
     *out = w;
@@ -643,6 +643,7 @@ void cip_lg_cks_dump(void);
 void cip_sdp_large_destroy(LargeWs *w) {
     if (!w) return;
     cip_lg_cks_dump();
+    if (w->hflag) (void)hipHostFree(w->hflag);
     if (w->s2) (void)hipStreamDestroy(w->s2);
     if (w->efork) (void)hipEventDestroy(w->efork);
     if (w->ejoin) (void)hipEventDestroy(w->ejoin);
@@ -1378,10 +1379,48 @@ __global__ __launch_bounds__(256) void k_lg_transpose(const double *src, double 
     }
 }
 // M <- 1.5 I - 0.5 M   (the Newton-Schulz factor of V <- V (3 I - V'V) / 2)
-__global__ __launch_bounds__(256) void k_lg_ns(double *M, int rp) {
+// M = V'V  ->  1.5 I - 0.5 M (the Newton-Schulz factor); vst[1] = max |V'V - I| as the bit pattern of a non-negative double
+// (monotone for finite values; NaN / inf compare as larger than every finite tolerance): what the gate below looks at
+__global__ __launch_bounds__(256) void k_lg_ns(double *M, int rp, unsigned long long *vst) {
+    __shared__ unsigned long long smax;
+    if (threadIdx.x == 0) smax = 0ull;
+    __syncthreads();
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long)rp * rp) return;
-    M[e] = ((e % rp) == (e / rp) ? 1.5 : 0.0) - 0.5 * M[e];
+    if (e < (long)rp * rp) {
+        const double d = ((e % rp) == (e / rp)) ? 1.0 : 0.0, mv = M[e];
+        M[e] = 1.5 * d - 0.5 * mv;
+        atomicMax(&smax, (unsigned long long)__double_as_longlong(fabs(mv - d)));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && smax) atomicMax(vst + 1, smax);
+}
+// Round 6 (advisor): the warm start must not be taken from a V that is not a (near-)orthogonal matrix -- the previous scaling of
+// this cone came from an iterate outside the cone (sqrt of a negative pivot: G, lam, V all NaN), or from a G so ill-conditioned
+// that V = G'A_f Sigma^-2 is orthogonal to less than what ONE Newton-Schulz step repairs to rounding (e <= 1e-6 -> 4e-13).  Decided
+// on the device, no read-back: vst[0] = 1 when the previous call ended with clean Cholesky flags and finite positive singular
+// values (k_lg_vok), vst[1] from k_lg_ns; otherwise G <- G0, i.e. exactly the cold start.
+#define LG_WARM_TOL 1e-6
+__global__ __launch_bounds__(256) void k_lg_warm_gate(double *G, const double *G0, long n2, const unsigned long long *vst) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n2) return;
+    if (vst[0] != 1ull || vst[1] > (unsigned long long)__double_as_longlong(LG_WARM_TOL)) G[e] = G0[e];
+}
+__global__ __launch_bounds__(256) void k_lg_vok(const double *lam, int rp, const int *info_a, const int *info_b, unsigned long long *vst) {
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = (info_a[0] != 0 || info_b[0] != 0) ? 1 : 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < rp; j += 256) { const double l = lam[j]; if (!(l > 0.0 && l < 1.7e308)) bad = 1; }
+    __syncthreads();
+    if (threadIdx.x == 0) { vst[0] = bad ? 0ull : 1ull; vst[1] = 0ull; }
+}
+// a sweep's flag and the two Cholesky flags -> host-mapped memory, the sequence word behind them with system-scope release (the
+// pattern of api.hip: k_publish_info): the host polls the word instead of a 4-byte copy + stream synchronisation per checked sweep
+__global__ void k_lg_pubflag(const unsigned *sweepflag, const int *info_a, const int *info_b, int *host, int seq) {
+    if (threadIdx.x == 0) {
+        host[0] = (int)(*sweepflag != 0u);
+        host[1] = (info_a[0] != 0 || info_b[0] != 0) ? 1 : 0;
+        __hip_atomic_store(host + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 static int lg_warm(void) {
     static const int on = [] { const char *e = getenv("CIP_LG_WARM"); return e ? atoi(e) : 1; }();
@@ -1426,15 +1465,6 @@ void cip_lg_cks_dump(void) {
     (void)hipMemset(g_lg_cks, 0, LG_CKS_CALLS * 16 * 8);
     g_lg_cks_call = 0;
 }
-// 2 (default; CIP_LG_JACOBI_STEPPED): the NT scaling's one-sided Jacobi as one launch per phase at every order; 1: at padded orders above
-// 256 only (order 256 on the persistent kernel: 5 % faster on config 4, and one scaling in 40000 with other bits); 0: one persistent
-// launch wherever all its workgroups can be resident (<= 1024).  mode < 0 only reads; returns the previous setting
-int cip_sdp_large_jacobi_stepped(int mode) {
-    static std::atomic<int> m{[] { const char *e = getenv("CIP_LG_JACOBI_STEPPED"); const int v = e ? atoi(e) : 2; return (v >= 0 && v <= 2) ? v : 2; }()};
-    const int prev = m.load();
-    if (mode >= 0 && mode <= 2) m.store(mode);
-    return prev;
-}
 // nestod_sdc for one large cone (index li among the large cones)
 int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, const double *v, const double *sv, double *scal,
                      double *lambda, int *flag) {
@@ -1464,23 +1494,27 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
     // did before.  CIP_LG_WARM=0 switches it off.
     const dim3 tg(rp / 32, rp / 32);
     double *Vw = w->Vw + (size_t)li * n2;
+    unsigned long long *vst = w->vstate + 2 * (size_t)li;
     const bool keep_v = lg_warm() != 0;
+    const bool jacobi_warm = keep_v && w->have_v[li];
     if (keep_v) CIP_HIP_CHECK(hipMemcpyAsync(w->G0, w->G, sizeof(double) * n2, hipMemcpyDeviceToDevice, s));
-    if (keep_v && w->have_v[li]) {
+    if (jacobi_warm) {
         hipLaunchKernelGGL(k_lg_transpose, tg, dim3(256), 0, s, (const double *)Vw, w->W1, rp, (const double *)nullptr);      // V'
         if ((rc = lg_gemm(s, w->W2, 0, w->W1, 0, w->W1, 0, rp, 1))) return rc;                                              // V'V
-        hipLaunchKernelGGL(k_lg_ns, lg_grid(n2), dim3(256), 0, s, w->W2, rp);                                               // 1.5 I - 0.5 V'V (symmetric)
+        hipLaunchKernelGGL(k_lg_ns, lg_grid(n2), dim3(256), 0, s, w->W2, rp, vst);                                          // 1.5 I - 0.5 V'V (symmetric); max |V'V - I|
         if ((rc = lg_gemm(s, w->W1, 0, Vw, 0, w->W2, 0, rp, 1))) return rc;                                                 // Vn = V (1.5 I - 0.5 V'V)
         hipLaunchKernelGGL(k_lg_transpose, tg, dim3(256), 0, s, (const double *)w->W1, w->W2, rp, (const double *)nullptr);  // Vn'
         lg_cks(s, 3, w->W2, n2);
         if ((rc = lg_gemm(s, w->G, 0, w->G0, 0, w->W2, 0, rp, 1))) return rc;                                               // G <- G Vn
+        hipLaunchKernelGGL(k_lg_warm_gate, lg_grid(n2), dim3(256), 0, s, w->G, (const double *)w->G0, n2, (const unsigned long long *)vst);   // ... unless V is not fit for it: G <- G0 (cold)
         lg_cks(s, 4, w->G, n2);
     }
+    bool left_cone = false;                                 // either Cholesky met a non-positive pivot (read back with the sweep flags)
     {
         // column blocks of 8 at order 256 (16 workgroups of 256 threads; round 4, with the DPP sums: 4 / 8 / 16 / 32 wide ->
         // 3.95 / 3.11 / 3.25 / 4.48 ms per NT scaling -- a rotation round is bound by the hand-over between the wave's lane groups
         // (LDS + workgroup barrier: fewer waves per workgroup, shorter rounds), an outer round costs ~3 us (block exchange through
-        // L2 + grid barrier) and their number doubles as the blocks halve), 16 at order 512 (16 workgroups), 8 at order 1024.
+        // L2 + launch boundary) and their number doubles as the blocks halve), 16 at order 512 (16 workgroups), 8 at order 1024.
         // CIP_LG_JACOBI_B = 4 / 8 / 16 / 32 overrides at order 256.
         static const int bforce = [] { const char *e = getenv("CIP_LG_JACOBI_B"); return e ? atoi(e) : 0; }();
         const int b = rp > 1024 ? 4 : rp > 512 ? 8 : (rp <= 256 ? ((bforce == 32 || bforce == 16 || bforce == 4) ? bforce : 8) : 16);       // order 2048: two blocks of 4 columns are a CU's LDS
@@ -1489,40 +1523,35 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
         CIP_HIP_CHECK(hipMemsetAsync(w->ctr, 0, 1024, s));
         lg_cks(s, 12, w->G, n2);
         if ((rc = cip_prof_slot_begin(CIP_PROF_JACOBI, s, 0.0))) return rc;
-        // STEPPED form (round 5, second session): one launch per phase -- the pairs inside the blocks, then each round of the
-        // tournament over blocks -- with the launch boundary in place of the grid barrier, the sweep's flag read back by the host.
-        // The persistent form hands the blocks from workgroup to workgroup inside the launch (`sc1` stores, drained, one counter,
-        // `sc1` loads: MI355X_MICROARCH.md lists that hand-off as measured, not guaranteed) and at order 1024 -- 64 workgroups, 129
-        // hand-offs per sweep -- about one NT scaling in 800 came out with other bits: an orthogonally equivalent but different
-        // factor in the best case (|G| preserved to rounding), an iterate off by 1e-3 in the worst; one interior-point run in 60
-        // left the oracle's trajectory (tools/nt1024_repeat.py, tools/sdp640_repeat.py; neither agent-scope fences around the
-        // barrier nor read-modify-write loads of the blocks changed the rate).  Order 512: 1 in 4000; order 256: 0 in 6000.
-        // Stepped: 0 in 4500 at order 1024, 0 of 300 interior-point runs; the NT scaling 43 -> 41 ms at order 640 (with the 16-byte
-        // block exchange), 19 -> 16 ms at order 400.  Order 256 (16 workgroups, 512 KB per round) looked clean for 15000 repetitions and
-        // then gave ONE in 25000: the stepped form is the default at every order (config 4: 7.95 -> 8.36 ms per iteration with the
-        // sweep gate below; CIP_LG_JACOBI_STEPPED / cip_set_sdp_jacobi_stepped: 2 (default) = every order, 1 = above 256, 0 = never).
-        const bool jacobi_warm = keep_v && w->have_v[li];
-        const int stepped_mode = cip_sdp_large_jacobi_stepped(-1);
-        const bool stepped = stepped_mode == 2 || (stepped_mode == 1 && rp > 256) || rp > 1024;      // (order 2048: 256 workgroups of 131 KB of LDS each cannot be assumed resident together)
+        // ONE LAUNCH PER PHASE (round 5, second session; the only form since round 6): the pairs inside the blocks, then each round of
+        // the tournament over blocks, the launch boundary in place of a grid barrier.  0 differing results in 11 500 repeated scalings
+        // at orders 256 ... 1024 and in 40 000 at order 256 (profiles/r5/jacobi_repeatability.txt).  The host enqueues whole sweeps; a
+        // sweep behind a converged one is a no-op (the kernel's gate), so the sweep flags are read only from the sweep on that is
+        // usually the last but one (warm start: 6-8 sweeps, cold: 9-11) -- through host-mapped memory (k_lg_pubflag: a one-wave kernel
+        // and a polled word; until round 6 a 4-byte copy + stream synchronisation per checked sweep).
+        bool converged = false;
         auto run = [&](auto kern, int nthreads, int bb, size_t lds) -> int {
             int rc2;
             if ((rc2 = lg_set_attr((const void *)kern, lds))) return rc2;
             const int m = rp / bb;
-            if (!stepped) {
-                hipLaunchKernelGGL(kern, dim3(m / 2), dim3(nthreads), lds, s, w->G, rp, bb, w->ctr, (int *)(w->ctr + 128));
-                return 0;
-            }
-            // the host reads a sweep's flag only from the sweep on that usually is the last but one (warm start: 6-8 sweeps, cold: 9-11):
-            // a sweep enqueued behind the converged one returns at once (the kernel's gate), the read-backs before it are saved
             const int first_check = jacobi_warm ? 4 : 7;
             for (int sweep = 0; sweep < 40; ++sweep) {
                 for (int step = 0; step < m; ++step)
-                    hipLaunchKernelGGL(kern, dim3(m / 2), dim3(nthreads), lds, s, w->G, rp, bb | 0x200 | (sweep << 16) | (step << 22), w->ctr, (int *)(w->ctr + 128));
+                    hipLaunchKernelGGL(kern, dim3(m / 2), dim3(nthreads), lds, s, w->G, rp, bb | (sweep << 16) | (step << 22), w->ctr);
                 if (sweep < first_check) continue;
-                unsigned any = 0;
-                CIP_HIP_CHECK(hipMemcpyAsync(&any, w->ctr + 8 + sweep, sizeof(any), hipMemcpyDeviceToHost, s));
-                CIP_HIP_CHECK(hipStreamSynchronize(s));
-                if (!any) break;
+                w->hseq = (w->hseq == 0x7fffffff) ? 1 : w->hseq + 1;
+                hipLaunchKernelGGL(k_lg_pubflag, dim3(1), dim3(64), 0, s, (const unsigned *)(w->ctr + 8 + sweep), (const int *)w->wz.info, (const int *)w->ws.info, w->hflag_dev, w->hseq);
+                CIP_HIP_CHECK(hipGetLastError());
+                volatile int *seqp = w->hflag + 2;
+                for (long spin = 0; __atomic_load_n(seqp, __ATOMIC_ACQUIRE) != w->hseq; ++spin) {
+                    if ((spin & 0xfff) != 0xfff) continue;
+                    std::this_thread::yield();
+                    const hipError_t q = hipStreamQuery(s);              // (a failed launch must not hang the host)
+                    if (q == hipSuccess && __atomic_load_n(seqp, __ATOMIC_ACQUIRE) != w->hseq) { cip_set_error("NT scaling of an S cone: the Jacobi's sweep flag never arrived"); return CIP_E_HIP; }
+                    if (q != hipSuccess && q != hipErrorNotReady) { cip_set_error("hipStreamQuery failed: %s", hipGetErrorString(q)); return CIP_E_HIP; }
+                }
+                left_cone = w->hflag[1] != 0;
+                if (!w->hflag[0]) { converged = true; break; }
             }
             return 0;
         };
@@ -1535,8 +1564,15 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
         else if (nt == 256) rc = run(k_lg_jacobi<256>, 256, b, shm);
         else if (nt == 512) rc = run(k_lg_jacobi<512>, 512, b, shm);
         else rc = run(k_lg_jacobi<1024>, 1024, b, shm);
+        const int rce = cip_prof_slot_end(CIP_PROF_JACOBI, s);      // (also on the error paths: an unpaired event would mis-pair every later collect)
         if (rc) return rc;
-        if ((rc = cip_prof_slot_end(CIP_PROF_JACOBI, s))) return rc;
+        if (rce) return rce;
+        if (!converged) {
+            // (never seen: the cyclic one-sided Jacobi converges quadratically; a scaling built on unconverged columns would be silently wrong)
+            w->have_v[li] = 0;
+            cip_set_error("NT scaling of an S cone of order %d: the one-sided Jacobi still rotated after 40 sweeps", r);
+            return CIP_E_SINGULAR;
+        }
     }
     if (getenv("CIP_LG_DEBUG")) {
         unsigned hc[64];
@@ -1544,7 +1580,7 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
         CIP_HIP_CHECK(hipStreamSynchronize(s));
         int sweeps = 0;
         for (int q = 8; q < 48; ++q) if (hc[q]) ++sweeps;
-        fprintf(stderr, "[lg] jacobi: %d sweeps with a rotation above cos^2 = 1e-16, %u barriers\n", sweeps, hc[0] / (unsigned)(rp / 16 / 2));
+        fprintf(stderr, "[lg] jacobi: %d sweeps with a rotation above cos^2 = 1e-16%s\n", sweeps, left_cone ? " (iterate outside the cone)" : "");
     }
     double *lam = w->vec;
     lg_cks(s, 5, w->G, n2); lg_cks(s, 13, w->G, n2);
@@ -1555,7 +1591,11 @@ int cip_sdp_large_nt(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li, cons
         hipLaunchKernelGGL(k_lg_transpose, tg, dim3(256), 0, s, (const double *)w->G0, w->W2, rp, (const double *)nullptr);   // G0'
         if ((rc = lg_gemm(s, Vw, 0, w->W2, 0, w->W1, 0, rp, 1))) return rc;
         lg_cks(s, 7, Vw, n2);
-        w->have_v[li] = 1;
+        // fit for the next call's warm start?  The host knows the Cholesky flags from the sweep read-back (an iterate outside the
+        // cone leaves NaN in G, lam and V: round 5 kept such a V, and the next scaling of a perfectly interior iterate came out NaN
+        // with a clean flag); the device-side word also covers non-finite / non-positive singular values (k_lg_warm_gate reads it)
+        hipLaunchKernelGGL(k_lg_vok, dim3(1), dim3(256), 0, s, (const double *)lam, rp, (const int *)w->wz.info, (const int *)w->ws.info, vst);
+        w->have_v[li] = left_cone ? 0 : 1;
     }
     hipLaunchKernelGGL(k_lg_build, lg_grid(n2), dim3(256), 0, s, w->G, lam, w->wz.dvec, w->Kz, w->M1, w->M2, w->M3, rp);
     const double *XTz = (w->wz.Bs == CIP_NB) ? w->wz.LinvT : w->wz.XT;             // inv(Lz_unit)' (one block = the matrix)

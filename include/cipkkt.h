@@ -238,7 +238,11 @@ int cip_conicip_many(cip_handle *const *handles, int count, const double *const 
 
 /* ---- dense symmetric LDL' building blocks (device pointers), usable on their own.
  * K is N x N column-major with leading dimension ld; only the lower triangle is
- * referenced.  N and ld must be multiples of 128 (pad with an identity block). */
+ * referenced.  N and ld must be multiples of 128 (pad with an identity block).
+ * After a factorisation K holds L strictly below the diagonal, D on it and L' above it OUTSIDE the 128 x 128 diagonal blocks;
+ * the upper triangle of the diagonal blocks is undefined.  The workspace size covers either mode of cip_set_solve_fused; the
+ * mode in force at cip_ldlt_factor_dev must still be in force at its cip_ldlt_solve_dev calls, and the solve-block limit
+ * (cip_set_solve_block_max) must not change between the sizing call, the factorisation and its solves. */
 int cip_ldlt_workspace_bytes(int N, size_t *bytes);
 int cip_ldlt_factor_dev(void *hip_stream, double *K, int N, int ld, void *workspace, int *info_host);
 int cip_ldlt_solve_dev(void *hip_stream, const double *K, int N, int ld, const void *workspace, double *rhs);
@@ -291,14 +295,10 @@ int cip_set_lazy_copy(int on);
    (0.09 ms per iteration of config 4, 1 %; also CIP_LG_LANCZOS=2).  cip_sdp_lanczos_fallbacks: how often that happened on this handle.
    3 (self-test): as 2 with the bound on the wrong side of theta, so that every certificate fails and every verdict is the fallback's. */
 int cip_set_sdp_lanczos(int on);
-/* S cones of order >= 133, NT scaling (src/ConicIP.jl:196-210): the one-sided Jacobi of svd(Lz'Ls) as ONE LAUNCH PER PHASE -- the pairs
-   inside the column blocks, then every round of the tournament over blocks, a sweep behind a converged one a no-op, the sweep's flag read
-   back by the host -- at every order (2, default; also CIP_LG_JACOBI_STEPPED), at padded orders above 256 only (1), or as one persistent
-   launch whose workgroups hand the blocks to each other inside the launch (0; orders above 1024 are always stepped).  Same arithmetic,
-   same bits -- except that the persistent form was measured to come out with other bits about once in 800 scalings at order 1024, once
-   in 4000 at order 512 and once in 40000 at order 256 (where it is 5 % faster on config 4: mode 1 for those who prefer that).
-   Process-wide; returns the previous mode (other values: query). */
-int cip_set_sdp_jacobi_stepped(int mode);
+/* (S cones of order >= 133, NT scaling, src/ConicIP.jl:196-210: the one-sided Jacobi of svd(Lz'Ls) runs as one launch per phase.  Rounds
+   3-5 also offered one persistent launch with in-launch block hand-offs behind cip_set_sdp_jacobi_stepped; that form was measured to
+   come out with other bits about once in 800 / 4000 / 40000 scalings at order 1024 / 512 / 256, the cause was never found, and round 6
+   REMOVED it together with its switch: no public knob of this library documents nondeterminism.) */
 int cip_sdp_lanczos_fallbacks(cip_handle *h, int *count);
 /* HIP-event timing of the LDL' trailing-update launches (bench.py roofline): enable, then read
  * out3 = [launches, total ms, total algorithmic flops (r(r+1)K per launch)].  enabled = 1: every launch of every factorisation;

@@ -296,46 +296,88 @@ def test_lanczos_inertia_certificate_catches_a_start_vector_without_the_extreme_
     ks.close()
 
 
-@pytest.mark.parametrize("r", [200, 300, 700])
-def test_jacobi_one_launch_per_phase_has_the_persistent_kernels_bits(r):
-    """The NT scaling of a large S cone with its one-sided Jacobi as one launch per phase (default above padded order 256; the
-    persistent kernel's in-launch block hand-off was measured to race at orders 512 / 1024: tools/nt1024_repeat.py) against the
-    persistent kernel: same arithmetic in the same order, so the packed scaling must have the same bits (compared at r = 200, where
-    the persistent form has not been seen to race in 12000 repetitions; at r = 300 / 700 one persistent run in 4000 / 800 differs,
-    so only the stepped form's own reproducibility is asserted there) -- src/ConicIP.jl:196-210."""
-    import cipkkt
+def _nt_products(ks, v, s, x, k):
+    """set the scaling from (v, s) and return (packed scaling, F'F x, lambda): F'F x and lambda are invariant under the orthogonal
+    freedom of the factor R (src/ConicIP.jl:37-40, :69, :735)"""
     from cipkkt import _lib as L
-    lib = L.load()
+    lam = torch.zeros(k, dtype=torch.float64, device="cuda")
+    ks.set_scaling_from_iterate(v, s, lam)
+    F = ks.get_scaling_packed()
+    y = torch.zeros_like(x)
+    ks.apply_F(L.OP_F, x, y)
+    z = torch.zeros_like(x)
+    ks.apply_F(L.OP_FT, y, z)
+    return F, z.cpu().numpy(), lam.cpu().numpy().copy()
+
+
+@pytest.mark.parametrize("r", [200, 300, 700])
+def test_large_s_cone_nt_scaling_is_reproducible_and_has_the_oracles_invariants(r):
+    """The NT scaling of a large S cone (one-sided Jacobi, one launch per phase -- the only form since round 6: the persistent
+    kernel with in-launch block hand-offs, measured to come out with other bits once in 800 ... 40000 scalings, and its switch are
+    gone) twice from the same iterate on two fresh handles: same bits.  And against the oracle's nestod_sdc on the quantities that
+    do not depend on the factor's orthogonal freedom: lambda (the singular values, as vecm of a diagonal matrix) and F'F x
+    -- src/ConicIP.jl:196-210, :37-40."""
+    import cipkkt
     k = r * (r + 1) // 2
     cone_dims = [("S", k)]
     rng = np.random.default_rng(r)
-    v, s = dev(interior(cone_dims, rng)), dev(interior(cone_dims, rng))
-    lam = torch.zeros(k, dtype=torch.float64, device="cuda")
+    vh, sh = interior(cone_dims, rng), interior(cone_dims, rng)
+    v, s = dev(vh), dev(sh)
+    xh = rng.standard_normal(k)
+    x = dev(xh)
+    out = []
+    for rep in range(2):
+        ks = cipkkt.KKTSystem(np.eye(2), np.zeros((k, 2)), None, cone_dims)
+        out.append(_nt_products(ks, v, s, x, k))
+        ks.close()
+    (Fa, za, la), (Fb, zb, lb) = out
+    np.testing.assert_array_equal(Fa, Fb)
+    np.testing.assert_array_equal(la, lb)
+    np.testing.assert_array_equal(za, zb)
+    R = oc.nestod_sdc(vh, sh)                                  # F x = vecm(R' mat(x) R), F'F x = vecm(P mat(x) P), P = R R'
+    lam_o = oc.vecm(R.T @ oc.mat(vh) @ R)
+    Pm = R @ R.T
+    ftf_o = oc.vecm(Pm @ oc.mat(xh) @ Pm)
+    # lambda = vecm(diag(sigma)): the oracle's singular values come out in LAPACK's order, the Jacobi's in column order -> compare sorted
+    dg = np.array([oc_vidx(i, r) for i in range(r)])
+    np.testing.assert_allclose(np.sort(la[dg]), np.sort(np.asarray(lam_o)[dg]), rtol=1e-10)
+    np.testing.assert_allclose(za, ftf_o, rtol=1e-9, atol=1e-9 * np.abs(ftf_o).max())
+    off = np.ones(k, dtype=bool); off[dg] = False
+    assert np.abs(la[off]).max() <= 1e-10 * np.abs(la[dg]).max()
+
+
+def oc_vidx(i, r):
+    """index of the diagonal entry (i, i) in the vecm layout (upper triangle by rows: src/ConicIP.jl:101-104)"""
+    return i * r - i * (i - 1) // 2
+
+
+def test_warm_start_of_the_jacobi_is_not_taken_from_a_scaling_that_left_the_cone():
+    """Round-5 advisor finding: cip_set_scaling_from_iterate on an iterate OUTSIDE the cone (a Cholesky pivot <= 0) left NaN in the
+    stored right singular vectors, and the next scaling of a perfectly interior iterate on the same handle was warm-started from
+    them: NaN out, clean flag.  Now the warm start is dropped on the host when the Cholesky flags are raised and gated on the device
+    (clean flags, finite positive singular values, |V'V - I| <= 1e-6: sdp_large.hip k_lg_warm_gate): the scaling behind a flagged one
+    has exactly the bits of a cold run on a fresh handle -- src/ConicIP.jl:196-210."""
+    import cipkkt
+    r = 150
+    k = r * (r + 1) // 2
+    cone_dims = [("S", k)]
+    rng = np.random.default_rng(77)
+    vh, sh = interior(cone_dims, rng), interior(cone_dims, rng)
     x = dev(rng.standard_normal(k))
-    prev = lib.cip_set_sdp_jacobi_stepped(-1)
-    out = {}
-    try:
-        for mode in ((2, 0, 2) if r <= 256 else (2, 2)):
-            lib.cip_set_sdp_jacobi_stepped(mode)
-            ks = cipkkt.KKTSystem(np.eye(2), np.zeros((k, 2)), None, cone_dims)
-            ks.set_scaling_from_iterate(v, s, lam)
-            F = ks.get_scaling_packed()
-            y = torch.zeros_like(x)
-            ks.apply_F(L.OP_F, x, y)
-            z = torch.zeros_like(x)
-            ks.apply_F(L.OP_FT, y, z)                          # F'F x: invariant under the factor's orthogonal freedom
-            out.setdefault(mode, []).append((F, z.cpu().numpy(), lam.cpu().numpy().copy()))
-            ks.close()
-    finally:
-        lib.cip_set_sdp_jacobi_stepped(prev)
-    (F2a, z2a, l2a), (F2b, z2b, l2b) = out[2]
-    np.testing.assert_array_equal(F2a, F2b)
-    np.testing.assert_array_equal(l2a, l2b)
-    np.testing.assert_array_equal(z2a, z2b)
-    if r <= 256:
-        F0, z0, l0 = out[0][0]
-        np.testing.assert_array_equal(F0, F2a)
-        np.testing.assert_array_equal(z0, z2a)
+    bad = vh.copy()
+    bad[[oc_vidx(i, r) for i in range(r)]] -= 50.0           # far outside the cone
+    ks = cipkkt.KKTSystem(np.eye(2), np.zeros((k, 2)), None, cone_dims)
+    _nt_products(ks, dev(vh), dev(sh), x, k)                  # a valid scaling: V stored
+    lam = torch.zeros(k, dtype=torch.float64, device="cuda")
+    ks.set_scaling_from_iterate(dev(bad), dev(sh), lam)       # flagged: must not poison what follows
+    got = _nt_products(ks, dev(vh), dev(sh), x, k)
+    ks.close()
+    fresh = cipkkt.KKTSystem(np.eye(2), np.zeros((k, 2)), None, cone_dims)
+    ref = _nt_products(fresh, dev(vh), dev(sh), x, k)
+    fresh.close()
+    for g, f in zip(got, ref):
+        assert np.all(np.isfinite(g))
+        np.testing.assert_array_equal(g, f)
 
 
 @pytest.mark.parametrize("cone_dims", [[("R", 700)], [("Q", 40), ("R", 9), ("S", 6)], [("S", 200 * 201 // 2)],
@@ -552,7 +594,7 @@ def test_s_cone_above_order_2048_is_refused_cleanly():
 
 def test_more_than_1024_large_s_cones_are_refused_cleanly():
     """1025 S cones of order 133 (the chip-wide kernels keep one set of padded matrices per large cone, at most 1024 -- 8 until
-    round 5, 64 in its first session): CIP_E_UNSUPPORTED from level 1, no handle; nine (refused until round 5) are accepted AND solved"""
+    round 5, 64 in its first session): CIP_E_UNSUPPORTED from level 1, no handle; fourteen (refused until round 5) are accepted AND solved"""
     import cipkkt
     from cipkkt import _lib as L
     from cipkkt.workloads import vecm_identity
@@ -569,15 +611,23 @@ def test_more_than_1024_large_s_cones_are_refused_cleanly():
     with pytest.raises(L.CipError) as ei:
         cipkkt.KKTSystem(Q, A, None, K)
     assert ei.value.code == L.E_UNSUPPORTED and "S cones" in str(ei.value)
-    Q, A, K = build(9)
-    b = -np.concatenate([vecm_identity(r)] * 9)
-    sol = cipkkt.conicIP(Q, np.array([1.0, -0.5, 0.25]), A, b, K, optTol=1e-6)
+    # 14 large cones: more than the 12 per-cone division gates a 16-int flag buffer had room for (round 5's buffer: cones 13.. wrote
+    # their gates past the allocation); the whole loop -- NT scaling, division by lambda in every solve4x4, max-steps -- against the oracle
+    ncone = 14
+    Q, A, K = build(ncone)
+    b = -np.concatenate([vecm_identity(r)] * ncone)
+    c = np.array([1.0, -0.5, 0.25])
+    sol = cipkkt.conicIP(Q, c, A, b, K, optTol=1e-6)
     assert sol.status == "Optimal", sol.status
-    # optimality of the 9-cone program: dual residual Q y - c - A'v = 0, complementarity v's = 0 (s = A y - b)
+    # optimality of the program: dual residual Q y - c - A'v = 0, complementarity v's = 0 (s = A y - b)
     y, v = sol.y, sol.v
     sres = A @ y - b
-    assert np.linalg.norm(Q @ y - np.array([1.0, -0.5, 0.25]) - A.T @ v) <= 1e-5 * (1 + np.linalg.norm(v))
+    assert np.linalg.norm(Q @ y - c - A.T @ v) <= 1e-5 * (1 + np.linalg.norm(v))
     assert abs(v @ sres) <= 1e-4 * (1 + abs(sol.pobj))
+    from oracle import kktsolvers as ok
+    ref = oracle_conicIP(Q, c, A, b, K, None, None, optTol=1e-6, kktsolver=ok.kktsolver_schur_exact)
+    assert ref.status == "Optimal" and sol.Iter == ref.Iter, (sol.Iter, ref.Iter)
+    np.testing.assert_allclose(sol.y, ref.y, rtol=1e-7, atol=1e-8)
 
 
 def test_lockstep_refusal_of_large_s_cones_writes_nothing_and_mixed_routes_them():
