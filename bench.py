@@ -55,7 +55,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X vendor fp64 matrix peak (dense); see 
 # (GRBM_GUI_ACTIVE / 8 / duration of profiles/r3/final_pmc_mfma.csv: 2.117 GHz, 2.17 in round 2; tools/mfma_peak.hip measures 77.6 at 2.37 GHz unloaded)
 FP64_MFMA_CLOCK_LIMITED_TFLOPS = 256 * 4 * 32 * 2.12e9 / 1e12
 HBM_PEAK_GBS = 8000.0
-PMC_ROUNDS = ("r4", "r3", "r2", "r1")
+PMC_ROUNDS = ("r6", "r5", "r4", "r3", "r2", "r1")   # newest first: the replay fallback of roofline.traffic uses the latest committed passes
 
 
 def pmc_dir():
@@ -493,6 +493,67 @@ def secondary_config(name, lib, device):
     return out
 
 
+def full3x3_headline(Q, c_host, A, b, cone_dims, device, n):
+    """The literal 3x3 route (src/kktsolvers.jl:254-257: the whole KKT matrix [-F'F -A 0; -A' Q G'; 0 G 0], N = m + n + p = 2n) on the
+    headline workload, after the timed region: the native loop to convergence (iterations = the Schur route's = the oracle's), one
+    timed factorisation (assembly + LDL' of order 2n, solve preparation joined) and HIP events around its trailing-update launches."""
+    import cipkkt
+    ks = cipkkt.KKTSystem(Q, A, None, cone_dims, route="full3x3", device=device)
+    try:
+        cipkkt.conicIP(Q, c_host, A, b, cone_dims, optTol=1e-6, system=ks, kktsolver="full3x3")                    # warm-up
+        sol = cipkkt.conicIP(Q, c_host, A, b, cone_dims, optTol=1e-6, system=ks, kktsolver="full3x3")
+        N = ks.N
+        ks.profile_trailing(1)
+        ks.set_timing(True)
+        ks.factor()
+        st = ks.stats()
+        ks.set_timing(False)
+        prof = ks.profile_get()
+        ks.profile_trailing(False)
+        fl = N ** 3 / 3.0
+        out = {"workload": "headline QP through CIP_ROUTE_FULL3X3: LDL' of the literal 3x3 KKT matrix, order N = %d" % N,
+               "kkt_order": N, "status": sol.status, "iters": sol.Iter, "n_factor": sol.n_factor, "n_solve": sol.n_solve,
+               "wall_s": sol.wall_s, "ms_per_iter": 1e3 * sol.wall_s / max(1, sol.Iter),
+               "ms_assemble": st["ms_assemble"], "ms_ldlt_factor": st["ms_ldlt"],
+               "ldlt_tflops_whole_factor": fl / (st["ms_ldlt"] * 1e-3) / 1e12 if st["ms_ldlt"] > 0 else None,
+               "algorithmic_flops_per_factor": fl}
+        if prof["ms"] > 0:
+            ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
+            out["roofline_trailing"] = {"bound": "mfma", "kernel": "LDL' trailing update k_ldlt_trailing_64 (K = outer block) at order %d" % N,
+                                        "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                                        "launches": prof["launches"], "avg_launch_ms": prof["ms"] / max(1.0, prof["launches"]),
+                                        "algorithmic_flops_per_launch": prof["flops"] / max(1.0, prof["launches"]), "traffic": None}
+        fx = fixture_iters("c2_n%d_seed1234" % n)
+        if fx is not None and "Iter" in fx:
+            out["iters_cpu"] = fx["Iter"]
+        return out
+    finally:
+        ks.close()
+
+
+def c5_shard_passes(device, in_flight, full=None):
+    """Config 5 as the 8 / 4 / 2 / 1-GPU job would hand it to RANK 0: lock-step passes over rank 0's shard of 64 / G problems
+    (problem i -> rank i mod G), on this one GPU, after the timed region.  ms per pass of the shard is what the G-GPU job's slowest-
+    rank time is made of (plus the imbalance between the ranks' shards, which one GPU cannot show): a projection of the 1 -> 8 curve
+    from driver-observed numbers when no 8-GPU node is available, NOT a scaling measurement."""
+    from cipkkt.batch import run_config5
+    out = {}
+    for G in (8, 4, 2, 1):
+        if G == 1 and full is not None:
+            out["64"] = {"gpus_of_the_job": 1, "problems": 64, "ms_per_pass": full["ms_per_pass"], "n_factor": full["n_factor"],
+                         "iters": full["iters"], "n_optimal": full["n_optimal"]}
+            continue
+        stats, el = run_config5(0, G, None, device, 3, 1, count=64, n=2048, seed=4000, in_flight=in_flight)
+        out[str(64 // G)] = {"gpus_of_the_job": G, "problems": stats["n_problems"], "ms_per_pass": el / 3 * 1e3,
+                             "n_factor": stats["n_factor"], "iters": stats["iters"], "n_optimal": stats["n_optimal"]}
+    if "64" in out and "8" in out:
+        out["projected_speedup_8_gpus"] = out["64"]["ms_per_pass"] / out["8"]["ms_per_pass"]
+        out["note"] = ("rank 0's shard of the G-GPU job (problems 0, G, 2G, ...) in lock-step on ONE GPU, 3 passes after 1 warm-up; "
+                       "projected_speedup_8_gpus = ms(64 problems) / ms(8 problems): the other ranks' shards differ in iteration "
+                       "counts, so the real curve is the driver's SCALE record")
+    return out
+
+
 def c5_cpu_baseline(seed=4000, n=2048):
     """Bounded CPU leg of the batch workload: problem 0 of config 5 (n = 2048) through the oracle's conicIP with
     pivot(kktsolver_2x2) (src/kktsolvers.jl:281-349) on the host cores -- a few seconds."""
@@ -615,10 +676,16 @@ def main():
         # ... then the sharded passes
         c5 = config5(args.steps, args.warmup, dist_=dist)
         ranks_seen = 1
+        shard_sizes = [64]
         if dist is not None:
             one = torch.ones(1, dtype=torch.float64, device=reduce_device)
             dist.all_reduce(one, op=dist.ReduceOp.SUM)
             ranks_seen = int(round(float(one.item())))
+            from cipkkt.batch import shard_indices
+            sz = torch.zeros(world, dtype=torch.float64, device=reduce_device)       # the shard map as the ranks themselves see it
+            sz[rank] = len(shard_indices(64, rank, world))
+            dist.all_reduce(sz, op=dist.ReduceOp.SUM)
+            shard_sizes = [int(round(x)) for x in sz.cpu().tolist()]
         if rank == 0:
             # roofline of THIS workload's dominant MFMA kernel: one more (untimed) pass of rank 0's shard with HIP events
             # around every trailing-update launch of the lock-step factorisations (launch = all live problems of the shard)
@@ -654,7 +721,7 @@ def main():
                                           "step = one pass over the batch" % world,
                               "parallelism": ("problem-per-GPU x%d, lock-step batch per GPU" % world) if args.batch_mode == "lockstep"
                                              else "problem-per-GPU x%d, %d in flight per GPU" % (world, args.in_flight)},
-                   "ranks_seen": ranks_seen, "ranks_share_one_gpu": share_gpu,
+                   "ranks_seen": ranks_seen, "ranks_share_one_gpu": share_gpu, "shard_sizes": shard_sizes,
                    "batch": c5, "roofline": roof}
             if c5_one is not None:
                 out["c5_single_gpu"] = c5_one
@@ -766,15 +833,25 @@ def main():
         pb = plugin_boundary(ks, v_mid, s_mid, lam, spf)
     ks.close()
     c5_single = None
+    c5_shards = None
     if world == 1 and not args.no_c5 and n == 8192 and args.route == "schur":
         c5_single = config5(2, 1)                     # single-GPU config-5 figure, for cross-checking a SCALE run
+        if rank == 0 and not os.environ.get("CIP_BENCH_PMC_CHILD") and args.batch_mode == "lockstep":
+            try:
+                c5_shards = c5_shard_passes(device, args.in_flight, full=c5_single)
+            except Exception as e:                   # a side figure never takes the bench line down
+                c5_shards = {"error": repr(e)}
     Qh = Q.cpu().numpy() if (rank == 0 and not args.no_cpu_baseline) else None
     secondary = None
     if (world == 1 and rank == 0 and not args.no_secondary and n == 8192 and args.route == "schur"
             and not os.environ.get("CIP_BENCH_PMC_CHILD")):
+        secondary = {}
+        try:                                         # the literal 3x3 route on the headline workload (needs Q: before it is dropped)
+            secondary["full3x3"] = full3x3_headline(Q, c_host, A, b, cone_dims, device, n)
+        except Exception as e:
+            secondary["full3x3"] = {"error": repr(e)}
         del Q
         torch.cuda.empty_cache()
-        secondary = {}
         for name in ("c3", "c4"):
             try:
                 secondary[name] = secondary_config(name, lib, device)
@@ -848,6 +925,8 @@ def main():
         out["config"]["rng"] = "SplitMix64 + Box-Muller (cipkkt/workloads.py), generated in HBM"
         if c5_single is not None:
             out["c5_single_gpu"] = c5_single
+        if c5_shards is not None:
+            out["c5_shards"] = c5_shards
         if not args.no_cpu_baseline:
             cb = cpu_baseline(Qh, n, spf)
             out["cpu_baseline"] = cb

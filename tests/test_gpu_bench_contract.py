@@ -128,3 +128,53 @@ def test_default_line_carries_the_round5_objects():
     cb = d["cpu_baseline"]
     assert cb["strong_cpu_variant"] in cb["strong_cpu_variants"] and "potrf" in cb["strong_cpu_variants"]
     assert cb["strong_cpu_value"] > 0
+
+
+def test_eight_ranks_on_one_gpu():
+    """World size 8 -- the size the north-star's batched configuration is quoted at -- without an 8-GPU node: eight ranks of
+    `bench.py --gpus 8 --workload c5` on cuda:0 (CIP_BENCH_SHARE_GPU=1, process group on gloo), launched by torch.distributed.run
+    as the driver launches the real thing.  Every rank generates and solves its own shard (problem i -> rank i mod 8: 8 x 8), the
+    SUM / MAX reductions run over eight ranks: all 64 problems Optimal, the iteration and factorisation totals are the one-GPU run's
+    and the oracle's.  Not a scaling measurement: the ranks share the chip."""
+    env = dict(os.environ, CIP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29737", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "8", "--workload", "c5", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=1800, cwd=ROOT, env=env)
+    d = _json_line(r)                                       # exactly one line: ranks 1..7 print nothing
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["ranks_share_one_gpu"] is True
+    assert d["shard_sizes"] == [8] * 8
+    assert d["batch"]["n_problems"] == 64 and d["batch"]["n_optimal"] == 64
+    assert d["batch"]["iters"] == 563 and d["iters_gpu"] == d["iters_cpu"] == 563
+    assert d["batch"]["n_factor"] == 627
+    assert d["c5_single_gpu"]["n_problems"] == 64 and d["c5_single_gpu"]["n_factor"] == 627
+    lo, hi = d["batch"]["rank_busy_ms_min"], d["batch"]["rank_busy_ms_max"]
+    assert 0 < lo <= hi <= d["ms_per_step"] * 1.001 + 1.0
+    assert abs(d["value"] - d["batch"]["n_factor"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_headline_size_line_carries_the_literal_3x3_route_and_the_shard_passes():
+    """Round-5 review: what is claimed must be in the driver-timed line.  At the headline size (no CPU legs, no PMC children: those
+    are the driver's own run) the default line carries `secondary.full3x3` -- the literal 3x3 route of src/kktsolvers.jl:254-257 at
+    N = 16384: ms per factorisation, whole-factor and trailing-update TFLOP/s, the iteration count of the Schur route and the oracle
+    -- and `c5_shards`: lock-step passes over rank 0's shard of the 8 / 4 / 2 / 1-GPU job (8 / 16 / 32 / 64 problems)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-plugin-boundary"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    d = _json_line(r)
+    f3 = d["secondary"]["full3x3"]
+    assert f3["kkt_order"] == 16384 and f3["status"] == "Optimal"
+    assert f3["iters"] == d["converge"]["iters"] == f3["iters_cpu"] == d["iters_cpu"]
+    assert f3["ms_ldlt_factor"] > 0 and 0 < f3["ldlt_tflops_whole_factor"] < 78.6
+    rt = f3["roofline_trailing"]
+    assert rt["bound"] == "mfma" and 0 < rt["frac"] < 1 and rt["launches"] > 0
+    # recompute: the events' flops are the trailing updates' share of N^3 / 3
+    assert rt["algorithmic_flops_per_launch"] * rt["launches"] < f3["algorithmic_flops_per_factor"]
+    sh = d["c5_shards"]
+    assert [sh[k]["problems"] for k in ("8", "16", "32", "64")] == [8, 16, 32, 64]
+    assert all(sh[k]["n_optimal"] == sh[k]["problems"] and sh[k]["ms_per_pass"] > 0 for k in ("8", "16", "32", "64"))
+    assert sh["64"]["n_factor"] == 627 and sh["8"]["ms_per_pass"] < sh["64"]["ms_per_pass"]
+    assert abs(sh["projected_speedup_8_gpus"] - sh["64"]["ms_per_pass"] / sh["8"]["ms_per_pass"]) < 1e-9
+    for name in ("c3", "c4"):
+        assert d["secondary"][name]["status"] == "Optimal" and d["secondary"][name]["iters"] == d["secondary"][name]["iters_cpu"]

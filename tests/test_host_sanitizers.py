@@ -26,3 +26,44 @@ def test_host_side_is_clean_under_asan_and_ubsan():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.asan_host(verbose=False) == 0
+
+
+# ---------------------------------------------------------------- round 6: the PRODUCT's own host code (round-5 review, weak 7)
+def _have_hostsan_toolchain():
+    rt = "/opt/rocm/lib/llvm/lib/clang"
+    return os.path.exists("/opt/rocm/bin/hipcc") and os.path.isdir(rt) and any(
+        os.path.exists(os.path.join(rt, v, "lib", "linux", "libclang_rt.asan-x86_64.a")) for v in os.listdir(rt))
+
+
+def _hostsan(kind):
+    spec = importlib.util.spec_from_file_location("cip_build_hostsan", os.path.join(ROOT, "tests", "hostsan", "build_hostsan.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.run(kind, verbose=False, threads=3)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-6000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr and "ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
+    import re
+    m = re.search(r"drive: (\d+) launches \((\d+) emulated\), (\d+) device allocations / (\d+) bytes still live", r.stdout)
+    assert m, r.stdout[-1500:]
+    launches, emulated, live, live_bytes = map(int, m.groups())
+    # tens of thousands of launch sequences went through the host code; what is still allocated at the end of main() is the main
+    # thread's own 4-KB host scratch (a thread_local, returned at thread exit) and nothing else: no handle, arena or pool leaked
+    assert launches > 10000 and emulated > 100 and live <= 1 and live_bytes <= 4096, (launches, emulated, live, live_bytes)
+
+
+@pytest.mark.skipif(not _have_hostsan_toolchain(), reason="hipcc / clang sanitizer runtimes not available")
+def test_product_host_control_plane_is_clean_under_asan_and_ubsan():
+    """conicip.jl_amd/csrc/*.hip compiled host-only (`hipcc --cuda-host-only`) with -fsanitize=address,undefined, linked against the
+    fake HIP runtime of tests/hostsan/fake_hip.cpp ("device" memory = host memory that reads zero, launches = no-ops) and driven
+    through the C ABI by tests/hostsan/drive.cpp: plugin levels (dense / CSR A, p = 0 / > 0, both routes, a chip-wide S cone), the native
+    loop, cip_conicip_mixed with lock-step groups of 64 and ONE, mixed nnz, a bin of one, the thread pool, a batch refused at level 1,
+    the stand-alone LDL' with a caller-owned workspace of exactly the advertised size in both solve modes, three concurrent callers.
+    No sanitizer report, no leaked "device" allocation."""
+    _hostsan("asan")
+
+
+@pytest.mark.skipif(not _have_hostsan_toolchain(), reason="hipcc / clang sanitizer runtimes not available")
+def test_product_host_control_plane_is_clean_under_tsan():
+    """the same build and driver under -fsanitize=thread: the thread pools of the batch entry points, the thread-local batch contexts,
+    the cached lock-step arena and the process-wide knobs under three concurrent callers"""
+    _hostsan("tsan")
