@@ -691,6 +691,7 @@ def main():
             # around every trailing-update launch of the lock-step factorisations (launch = all live problems of the shard)
             roof = None
             if args.batch_mode == "lockstep":
+                prev_split = lib.cip_set_lockstep_split(1)      # the event profile belongs to the calling thread: one group after the other
                 lib.cip_profile_trailing_thread(1)
                 from cipkkt.batch import solve_batch
                 from cipkkt.workloads import c5_batch
@@ -702,6 +703,7 @@ def main():
                 o3 = (cipkkt._lib.C.c_double * 3)()
                 cipkkt._lib.check(lib.cip_profile_thread_get(o3))
                 lib.cip_profile_trailing_thread(0)
+                lib.cip_set_lockstep_split(prev_split)
                 if o3[1] > 0:
                     ach = o3[2] / (o3[1] * 1e-3) / 1e12
                     roof = {"bound": "mfma", "kernel": "LDL' trailing update of the lock-step batch: k_ldlt_trailing_64, "

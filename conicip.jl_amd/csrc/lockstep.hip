@@ -26,7 +26,10 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 using namespace cipdrv;
@@ -44,6 +47,9 @@ struct BatchScope {           // activates the batch context for the calling thr
 // the four pivot-flag words of a factorisation into slots 32..35 of the problem's row of the gather buffer (slots 0..31
 // carry the dot products: the flags come back with the same device-to-host copy)
 #define INFO_SLOT 32
+#ifndef CIP_LOCKSTEP_SPLIT_DEFAULT
+#define CIP_LOCKSTEP_SPLIT_DEFAULT 1        // (round 6: set by measurement, see cip_conicip_lockstep)
+#endif
 #define STEP_SLOT 40            // deferred max-step minima (cones.hip: cip_cones_maxstep with a defer slot)
 __global__ void k_gather_info(const int *info, double *gather, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
@@ -529,6 +535,21 @@ static int lockstep_group(int B, int call_count, const cip_problem *probs, const
     return 0;
 }
 
+// groups of a large lock-step call that run side by side (see cip_conicip_lockstep); k < 1 only reads; returns the previous value
+static std::atomic<int> g_lockstep_split{-1};
+int cip_lockstep_split_set(int k) {
+    if (g_lockstep_split.load() < 0) {
+        const char *e = getenv("CIP_LOCKSTEP_SPLIT");
+        int v = -1, want = e ? atoi(e) : CIP_LOCKSTEP_SPLIT_DEFAULT;
+        want = want < 1 ? 1 : (want > 8 ? 8 : want);
+        g_lockstep_split.compare_exchange_strong(v, want);
+    }
+    const int prev = g_lockstep_split.load();
+    if (k >= 1 && k <= 8) g_lockstep_split.store(k);
+    return prev;
+}
+extern "C" int cip_set_lockstep_split(int k) { return cip_lockstep_split_set(k); }
+
 // Problems in, solutions out, in lock-step groups of up to 64.  CIP_E_UNSUPPORTED (nothing written): the problems differ
 // in shape or hold S cones -- use cip_conicip_problems.
 extern "C" int cip_conicip_lockstep(int count, const cip_problem *probs, const double *const *c, const double *const *b,
@@ -546,12 +567,46 @@ extern "C" int cip_conicip_lockstep(int count, const cip_problem *probs, const d
         }
     if (cip_tl_builder) { cip_set_error("lock-step batch inside a graph recording"); return CIP_E_INVALID; }
     if (!g_stats_accumulate) g_last_stats[0] = g_last_stats[1] = g_last_stats[2] = 0;
-    for (int g0 = 0; g0 < count; g0 += CIP_BATCH_MAX) {
-        const int B = (count - g0 < CIP_BATCH_MAX) ? (count - g0) : CIP_BATCH_MAX;
-        const int rc = lockstep_group(B, count, probs + g0, c + g0, b ? b + g0 : nullptr, d ? d + g0 : nullptr, opt, y + g0,
-                                      w ? w + g0 : nullptr, v ? v + g0 : nullptr, res + g0);
-        if (rc) return rc;
-    }
+    auto range = [&](int i0, int i1) -> int {                // groups of up to 64 over [i0, i1), one after the other, on the calling thread
+        for (int g0 = i0; g0 < i1; g0 += CIP_BATCH_MAX) {
+            const int B = (i1 - g0 < CIP_BATCH_MAX) ? (i1 - g0) : CIP_BATCH_MAX;
+            const int rc = lockstep_group(B, count, probs + g0, c + g0, b ? b + g0 : nullptr, d ? d + g0 : nullptr, opt, y + g0,
+                                          w ? w + g0 : nullptr, v ? v + g0 : nullptr, res + g0);
+            if (rc) return rc;
+        }
+        return 0;
+    };
+    // Round 6: a large call as TWO (CIP_LOCKSTEP_SPLIT = k: k) lock-step groups side by side, each driven by its own host thread on its
+    // own stream.  A group's loop alternates latency-bound launch chains (the panel chain, the triangular sweeps: most of the chip idle)
+    // with throughput-bound ones (trailing updates, symv) and three host round trips per iteration; two groups fill each other's
+    // gaps.  Measured first with two PROCESSES sharing one GPU (round 5: 64 problems of order 2048, 8819 against 7971 KKT solves/s for
+    // one rank); this is the same overlap inside one process.  Per problem nothing changes: the solve block follows the size of the
+    // whole call, every kernel is the group-size-independent code the bit-identity tests pin (tests/test_gpu_lockstep.py).
+    // Only for calls of at least 2 x 16 problems: below that a group is latency-bound as a whole and gains nothing from a partner.
+    int nsplit = cip_lockstep_split_set(0);
+    while (nsplit > 1 && count / nsplit < 16) --nsplit;
+    if (nsplit <= 1) return range(0, count);
+    int device = 0;
+    CIP_HIP_CHECK(hipGetDevice(&device));
+    std::vector<int> rcs(nsplit, 0);
+    std::vector<std::string> errs(nsplit);
+    std::vector<int> st(3 * (size_t)nsplit, 0);
+    std::vector<std::thread> th;
+    const int per = (count + nsplit - 1) / nsplit;
+    for (int t = 0; t < nsplit; ++t)
+        th.emplace_back([&, t] {
+            (void)hipSetDevice(device);
+            g_last_stats[0] = g_last_stats[1] = g_last_stats[2] = 0;
+            const int i0 = t * per, i1 = (t + 1) * per < count ? (t + 1) * per : count;
+            rcs[t] = i0 < i1 ? range(i0, i1) : 0;
+            if (rcs[t]) errs[t] = cip_last_error();
+            for (int q = 0; q < 3; ++q) st[3 * t + q] = g_last_stats[q];
+        });
+    for (auto &x : th) x.join();
+    for (int t = 0; t < nsplit; ++t)
+        for (int q = 0; q < 3; ++q) g_last_stats[q] += st[3 * t + q];
+    for (int t = 0; t < nsplit; ++t)
+        if (rcs[t]) { cip_set_error("%s", errs[t].c_str()); return rcs[t]; }
     return 0;
 }
 

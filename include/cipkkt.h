@@ -232,6 +232,12 @@ int cip_conicip_mixed(int count, const cip_problem *probs, const double *const *
 int cip_release_cached_memory(void);
 /* diagnostics of the calling thread's last cip_conicip_lockstep: {groups, problems, problems that left their group} */
 int cip_lockstep_stats(int *out3);
+/* a lock-step call of at least 2 x 16 problems of one shape runs as k groups SIDE BY SIDE, each on its own host thread and stream (the
+ * groups fill each other's launch-latency gaps; per problem nothing changes: same kernels, same solve block, same bits).  k = 1: one
+ * group after the other (the form up to round 5).  Also CIP_LOCKSTEP_SPLIT.  Process-wide; returns the previous value (k < 1: query).
+ * With k > 1 a call that cip_conicip_lockstep refuses with CIP_E_UNSUPPORTED for a slab-layout reason found inside a group (CSR arrays
+ * in device memory with differing numbers of non-zeros) may already have written other groups' results. */
+int cip_set_lockstep_split(int k);
 int cip_conicip_many(cip_handle *const *handles, int count, const double *const *c, const double *const *bvec,
                      const double *const *d, const cip_options *opt, double *const *y, double *const *w,
                      double *const *v, cip_result *res, int in_flight);

@@ -214,3 +214,41 @@ def test_moi_patch_applies_to_the_reference(tmp_path):
     out = (work / "MOI_wrapper.jl").read_text()
     assert "kktsolver = dest.kktsolver" in out and 'attr.name == "kktsolver"' in out and "kktsolver::Any" in out
     assert "dest.sol = dest.solve(Q, c_int, A, b, cone_dims, G, d;" in out and "solve::Any" in out
+
+
+REF_SRC = "/root/reference/src"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_SRC, "ConicIP.jl")), reason="reference tree not present (GPU box)")
+def test_every_conicip_identifier_the_julia_shim_uses_exists_in_the_reference():
+    """integration/ConicIPHIP cannot be executed here (no julia in the image): a second static check beside the ccall / struct
+    ones -- every name the shim takes from ConicIP is defined in the reference where the shim's comments say: `Block` with a
+    `Blocks` vector (src/blockmatrices.jl:35-41), `VecCongurance` with its `R` (src/ConicIP.jl:35), `ord` (:85), `Solution` with
+    the eleven fields the shim fills positionally (:384-398), `imcols` / `preprocess_conicIP` (src/preprocessor.jl), `pivot` and
+    `kktsolver_2x2` (src/kktsolvers.jl), the keyword names and defaults of `conicIP` (src/ConicIP.jl:498-509)."""
+    rd = lambda f: open(os.path.join(REF_SRC, f), encoding="utf-8").read()
+    core, blocks, pre, kkt = rd("ConicIP.jl"), rd("blockmatrices.jl"), rd("preprocessor.jl"), rd("kktsolvers.jl")
+    shim = open(os.path.join(ROOT, "integration", "ConicIPHIP", "src", "ConicIPHIP.jl"), encoding="utf-8").read()
+    assert re.search(r"mutable struct Block\b", blocks) and re.search(r"Blocks::Vector\{BlockElem\}", blocks)
+    assert re.search(r"mutable struct VecCongurance; R :: Matrix; end", core)
+    assert re.search(r"^ord\(x\) = ", core, re.M)
+    m = re.search(r"mutable struct Solution\n(.*?)\nend", core, re.S)
+    fields = re.findall(r"^\s*(\w+)\s*::", m.group(1), re.M)
+    assert fields == ["y", "w", "v", "status", "Iter", "Mu", "prFeas", "duFeas", "muFeas", "pobj", "dobj"]
+    # the shim builds Solution positionally with exactly these eleven values, in this order
+    call = re.search(r"ConicIP\.Solution\(y, w, v, _STATUS\[r\.status \+ 1\], Int\(r\.iter\), r\.mu, r\.prFeas, r\.duFeas, r\.muFeas, r\.pobj, r\.dobj\)", shim)
+    assert call, "the shim's Solution constructor call changed: re-check it against src/ConicIP.jl:384-398"
+    assert re.search(r"^function imcols\(A, b", pre, re.M) and re.search(r"^function preprocess_conicIP\(Q, c", pre, re.M)
+    assert re.search(r"^function pivot", kkt, re.M) or re.search(r"^pivot\(", kkt, re.M) or "pivotgen" in kkt
+    assert re.search(r"function kktsolver_2x2", kkt)
+    # every `ConicIP.<name>` of the shim is a name the reference defines somewhere in src/
+    everything = core + blocks + pre + kkt + rd("MOI_wrapper.jl")
+    for name in sorted(set(re.findall(r"ConicIP\.(\w+)", shim))):
+        if name in ("jl",):                                   # "ConicIP.jl:123" in comments
+            continue
+        assert re.search(r"\b%s\b" % re.escape(name), everything), "ConicIP.%s is not a name of the reference" % name
+    # keyword names and defaults of conicIP the shim repeats (src/ConicIP.jl:498-509)
+    sig = core[core.index("function conicIP("):core.index("function conicIP(") + 1500]
+    for kw, default in (("optTol", "1e-6"), ("DTB", "0.01"), ("maxRefinementSteps", "3"), ("maxIters", "100")):
+        assert re.search(r"%s\s*=\s*%s" % (kw, re.escape(default)), sig), kw
+        assert re.search(r"%s\s*=\s*%s" % (kw, re.escape(default)), shim), kw
