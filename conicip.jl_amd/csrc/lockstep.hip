@@ -47,8 +47,11 @@ struct BatchScope {           // activates the batch context for the calling thr
 // the four pivot-flag words of a factorisation into slots 32..35 of the problem's row of the gather buffer (slots 0..31
 // carry the dot products: the flags come back with the same device-to-host copy)
 #define INFO_SLOT 32
+#ifndef CIP_LOCKSTEP_SPLIT_MIN_DEFAULT
+#define CIP_LOCKSTEP_SPLIT_MIN_DEFAULT 8    // smallest group a split may produce (2 x 4 problems side by side LOSE: 15.3 -> 16 ms per pass)
+#endif
 #ifndef CIP_LOCKSTEP_SPLIT_DEFAULT
-#define CIP_LOCKSTEP_SPLIT_DEFAULT 1        // (round 6: set by measurement, see cip_conicip_lockstep)
+#define CIP_LOCKSTEP_SPLIT_DEFAULT 2        // (round 6, measured: see cip_conicip_lockstep)
 #endif
 #define STEP_SLOT 40            // deferred max-step minima (cones.hip: cip_cones_maxstep with a defer slot)
 __global__ void k_gather_info(const int *info, double *gather, CipBatch cb) {
@@ -582,9 +585,13 @@ extern "C" int cip_conicip_lockstep(int count, const cip_problem *probs, const d
     // gaps.  Measured first with two PROCESSES sharing one GPU (round 5: 64 problems of order 2048, 8819 against 7971 KKT solves/s for
     // one rank); this is the same overlap inside one process.  Per problem nothing changes: the solve block follows the size of the
     // whole call, every kernel is the group-size-independent code the bit-identity tests pin (tests/test_gpu_lockstep.py).
-    // Only for calls of at least 2 x 16 problems: below that a group is latency-bound as a whole and gains nothing from a partner.
+    // Measured (profiles/r6/lockstep_split.txt, problems of order 2048, ms per pass, one group -> two side by side): 64 problems 77.3-79.4 ->
+    // 72.4-74.4 (8000 -> 8500-8650 KKT solves/s), 32: 44.9 -> 40.4-41.5, 24: 32.5 -> 30.8-31.7, 16: 25.2 -> 23.7-24.4; 8 problems as
+    // 2 x 4 LOSE (15.3 -> 15.5-16.9: each panel launch owns whole CUs -- 160 KB of LDS per workgroup -- and two latency-bound chains only
+    // get in each other's way), as do three or four groups (64 as 4 x 16: 77.2-78.8).  Hence: two groups, none smaller than 8.
     int nsplit = cip_lockstep_split_set(0);
-    while (nsplit > 1 && count / nsplit < 16) --nsplit;
+    static const int split_min = [] { const char *e = getenv("CIP_LOCKSTEP_SPLIT_MIN"); const int k = e ? atoi(e) : CIP_LOCKSTEP_SPLIT_MIN_DEFAULT; return k < 1 ? 1 : k; }();
+    while (nsplit > 1 && count / nsplit < split_min) --nsplit;
     if (nsplit <= 1) return range(0, count);
     int device = 0;
     CIP_HIP_CHECK(hipGetDevice(&device));

@@ -232,7 +232,7 @@ int cip_conicip_mixed(int count, const cip_problem *probs, const double *const *
 int cip_release_cached_memory(void);
 /* diagnostics of the calling thread's last cip_conicip_lockstep: {groups, problems, problems that left their group} */
 int cip_lockstep_stats(int *out3);
-/* a lock-step call of at least 2 x 16 problems of one shape runs as k groups SIDE BY SIDE, each on its own host thread and stream (the
+/* a lock-step call of at least 2 x 8 problems of one shape runs as k groups (default 2) SIDE BY SIDE, each on its own host thread and stream (the
  * groups fill each other's launch-latency gaps; per problem nothing changes: same kernels, same solve block, same bits).  k = 1: one
  * group after the other (the form up to round 5).  Also CIP_LOCKSTEP_SPLIT.  Process-wide; returns the previous value (k < 1: query).
  * With k > 1 a call that cip_conicip_lockstep refuses with CIP_E_UNSUPPORTED for a slab-layout reason found inside a group (CSR arrays
