@@ -140,6 +140,33 @@ def test_more_than_64_problems_two_groups():
     _assert_identical(lock, one)
 
 
+@pytest.mark.parametrize("count", [16, 40, 70])
+def test_two_groups_side_by_side_equal_one_group_after_the_other(count):
+    """Round 6: a lock-step call of at least 2 x 8 problems runs as TWO groups side by side, each on its own host thread and stream
+    (cip_set_lockstep_split, default 2; lockstep.hip).  Per problem nothing may change -- same kernels, the solve block chosen from the
+    size of the whole call -- so the results must equal those of one group after the other bit for bit, and the statistics must add
+    up over the groups (70 problems: 2 x 35 side by side against 64 + 6 one after the other)."""
+    import ctypes as C
+    from cipkkt import _lib as L
+    lib = L.load()
+    prs = [_as_problem(P.random_mixed(n=24, nq=2, kq=5, p=3, seed=4200 + seed)) for seed in range(count)]
+    prev = lib.cip_set_lockstep_split(1)
+    try:
+        one = _solve(prs, "lockstep")
+        st1 = (C.c_int * 3)()
+        lib.cip_lockstep_stats(st1)
+        lib.cip_set_lockstep_split(2)
+        two = _solve(prs, "lockstep")
+        st2 = (C.c_int * 3)()
+        lib.cip_lockstep_stats(st2)
+    finally:
+        lib.cip_set_lockstep_split(prev)
+    _assert_identical(two, one)
+    assert all(s.status == "Optimal" for s in two)
+    assert st1[1] == st2[1] == count and st1[2] == st2[2]
+    assert st1[0] == (count + 63) // 64 and st2[0] == 2
+
+
 @pytest.mark.parametrize("count", [1, 2, 65])
 def test_groups_of_one_problem(count):
     """a lock-step call of ONE problem, and 65 problems = a full group + a tail group of one (round-4 advisor finding: the
