@@ -646,6 +646,25 @@ static int factor_resolve(cip_handle *h, bool wait) {
     h->info_pending = false;
     // info_host: [0] first bad pivot of any kind (1-based column), [1] bail-out flag of the sweep kernels,
     //            [2] first zero / non-finite pivot
+    if (h->info_host[3] != 0 && h->info_host[1] == 0 && !h->ws.unfused) {
+        // An in-launch wait of the fused panel chain gave up.  Its waits are for workgroups of the same launch and end within
+        // microseconds when the launch has the GPU's attention; on a GPU SHARED WITH OTHER PROCESSES the hardware scheduler can take
+        // a launch's workgroups off the chip for longer than the bound (seen with eight processes on one MI355X: round 6).  The
+        // three-launch chain has no in-launch wait and produces the same bits: this handle keeps it from now on, and the
+        // factorisation is redone (assembly included: K holds a partial factor).
+        const int spec0 = h->spec_solves;
+        h->ws.unfused = 1;
+        h->n_chain_fallbacks += 1;
+        int rc;
+        if ((rc = factor_enqueue(h))) return rc;
+        { bool landed = false; if ((rc = info_landed(h, true, &landed))) return rc; }
+        h->info_pending = false;
+        if (spec0 > 0) {
+            cip_set_error("LDL': %d solve(s) were enqueued on a factorisation whose panel chain gave up an in-launch wait; the handle has "
+                          "switched to the three-launch chain -- repeat them", spec0);
+            return CIP_E_SINGULAR;
+        }
+    }
     if (h->info_host[3] != 0 || h->info_host[1] != 0) {
         cip_set_error("LDL': in-launch wait of the panel chain gave up (%d)", h->info_host[3]);
         h->factored = false;
@@ -1116,6 +1135,7 @@ extern "C" int cip_profile_thread_get(double *out3) {
 }
 extern "C" int cip_set_lazy_copy(int on) { return cip_lazy_copy_set(on); }
 extern "C" int cip_set_sdp_lanczos(int on) { return cip_sdp_large_lanczos(on); }
+extern "C" int cip_debug_chain_giveup(int n) { return cip_debug_chain_giveup_set(n); }
 extern "C" int cip_sdp_lanczos_fallbacks(cip_handle *h, int *count) {
     if (!h || !count) { cip_set_error("bad argument"); return CIP_E_INVALID; }
     int out2[2] = {0, 0};

@@ -58,6 +58,7 @@ struct cip_handle {
     double reg_rel = 0.0;
     bool auto_reg = true;
     int n_regularized = 0;
+    int n_chain_fallbacks = 0;     // factorisations redone with the three-launch chain after an in-launch wait of the fused one gave up
     int x_zeroed = 0;               // block-inverse storage zero-initialised
     // pivot flag of the last factorisation: read back asynchronously into pinned host memory, resolved lazily
     // (api.hip: factor_resolve) so that cip_factor never waits for the GPU

@@ -172,12 +172,14 @@ struct LdltWorkspace {        // carved out of one device allocation
     // keeps the side stream / events, created on first use (NULL: always behind the factorisation, on its own stream)
     struct LdltSide **side;
     int no_prep;              // 1: the factor only (no block inverses for solves) -- inertia checks (sdp_large.hip)
+    int unfused;              // 1: three launches per panel whatever the process-wide chain form (no in-launch wait: set after one gave up, api.hip)
 };
 struct LdltSide;
 void cip_ldlt_side_destroy(struct LdltSide *sd);
 int cip_ldlt_side_join(hipStream_t s, const struct LdltWorkspace &ws, int J);   // ldlt.hip: wait for the side stream's solve preparation (J < 0: all of it)
 int cip_kernels_init(void);                // diag.hip: one-time kernel attributes (before any hipGraph capture)
 int cip_ldlt_set_side_prep(int on);       // 1 (default): solve preparation beside the last outer block's panel chain; returns the previous setting
+int cip_debug_chain_giveup_set(int n);    // test hook: the next n fused-chain factorisations report an in-launch wait that gave up; returns the previous count
 int cip_ldlt_set_fused_chain(int on);     // 1 (default): diag + previous in-block update in one launch; returns the previous setting
 int cip_solve_block(int Npad);
 int cip_solve_block_max_set(int b);              // 128 | 256 | 512 | 1024 (0: query); returns the previous limit

@@ -258,6 +258,7 @@ void cip_ldlt_ws_carve(void *base, int Npad, LdltWorkspace *ws, int fused) {
     ws->x_zeroed = nullptr;
     ws->side = nullptr;
     ws->no_prep = 0;
+    ws->unfused = 0;
 }
 
 // diag.hip
@@ -324,7 +325,7 @@ static int factor_outer_panels(hipStream_t s, double *K, int Npad, long ld, cons
             return 4 * cus;
         }();
         const bool small_group = cip_in_batch() && g_fuse_diag == 3 && cip_tl_bz.B <= lsmax && (long)cip_tl_bz.B * (10 + Npad / 64) <= lscus;
-        const bool fuse = g_fuse_diag && (!cip_in_batch() || small_group);
+        const bool fuse = g_fuse_diag && !ws.unfused && (!cip_in_batch() || small_group);
         if (fuse && g_fuse_diag == 3) {
             const bool upd = t > 0 && rest_of_block_args(K, Npad, ld, Wb, C0, wblk, t - 1, gu);
             unsigned *ctr = (unsigned *)(ws.info + 16);
@@ -582,7 +583,25 @@ int cip_ldlt_side_join(hipStream_t s, const LdltWorkspace &ws, int J) {
     return 0;
 }
 
+// test hook (cip_debug_chain_giveup): the next `n` factorisations on a fused panel chain report that an in-launch wait gave up (info[3]),
+// as a GPU shared with other processes can make them do -- so that the fall-back to the three-launch chain can be tested on one process
+static std::atomic<int> g_debug_giveup{0};
+int cip_debug_chain_giveup_set(int n) { const int prev = g_debug_giveup.load(); if (n >= 0) g_debug_giveup.store(n); return prev; }
+__global__ void k_debug_set_word(int *p, int v, CipBatch cb) {
+    CIP_BATCH_GUARD(cb);
+    CIP_BO1(cb, p);
+    if (threadIdx.x == 0) *p = v;
+}
+static int ldlt_factor_body(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws);
 int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws) {
+    const int rc = ldlt_factor_body(s, K, Npad, ld, ws);
+    if (rc == 0 && !ws.unfused && !cip_tl_builder && g_debug_giveup.load() > 0 && g_debug_giveup.fetch_sub(1) > 0) {
+        cip_launch_b(k_debug_set_word, dim3(1), dim3(64), 0, s, ws.info + 3, -9);
+        CIP_HIP_CHECK(hipGetLastError());
+    }
+    return rc;
+}
+static int ldlt_factor_body(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws) {
     if (Npad % CIP_NB) { cip_set_error("ldlt: N must be a multiple of 128"); return -1; }
     int rc;
     // [0] bad pivot, [1] sweep bail-out, [2] dead pivot, [3] fused-launch wait timed out; from word 16: `ready` counters

@@ -300,8 +300,12 @@ static int lockstep_group(int B, int call_count, const cip_problem *probs, const
         for (int z = 0; z < B; ++z) {
             if (!((fmask >> z) & 1ull)) continue;
             const double *gi = G.gather_host + (size_t)z * CIP_GATHER + INFO_SLOT;
-            if (gi[1] != 0.0 || gi[3] != 0.0) { cip_set_error("LDL': in-launch scheduler gave up waiting (problem %d)", z); return CIP_E_HIP; }
-            if (gi[0] != 0.0) { ejected[z] = 1; active &= ~(1ull << z); }
+            if (gi[1] != 0.0) { cip_set_error("LDL': a triangular sweep bailed out (problem %d)", z); return CIP_E_HIP; }
+            // gi[3]: an in-launch wait of the fused panel launch gave up -- a GPU shared with other processes can keep a launch's
+            // workgroups off the chip for longer than the bound.  The problem leaves the group like one with a bad pivot and is
+            // solved alone afterwards, on the three-launch chain (no in-launch wait, same bits)
+            if (gi[3] != 0.0) { G.h[z]->ws.unfused = 1; G.h[z]->n_chain_fallbacks += 1; h->ws.unfused = 1; }      // (h: the group's launches follow problem 0's workspace -- three launches per panel from here on)
+            if (gi[0] != 0.0 || gi[3] != 0.0) { ejected[z] = 1; active &= ~(1ull << z); }
         }
         return 0;
     };

@@ -284,6 +284,12 @@ int cip_lockstep_solve_block_for(int B);
  * micro-panel through a stage counter; 1 = diagonal kernel + previous panel's update in one launch, TRSM in its own;
  * 0 = three launches per panel.  Same factor bit for bit.  Process-wide; returns the previous setting (other values: query). */
 int cip_set_ldlt_fused_chain(int on);
+/* The fused panel chain waits INSIDE a launch for workgroups of the same launch (bounded: ~1 s, then the factorisation reports that the
+ * wait gave up).  On a GPU shared with other processes the hardware scheduler can keep a launch's workgroups apart for longer than that
+ * (seen with eight processes on one MI355X).  The library then redoes the factorisation with the three-launch chain -- no in-launch wait,
+ * same bits -- and keeps that chain for the handle; a problem of a lock-step group leaves the group and is solved alone.  TEST HOOK: the
+ * next n fused-chain factorisations of the process report such a give-up (n < 0: query); returns the previous count. */
+int cip_debug_chain_giveup(int n);
 /* solve preparation (block inverses for the triangular sweeps, mirror image of L) of every solve block whose columns are final,
  * on a side stream beside the last panels of the factorisation instead of behind it (also CIP_SIDE_PREP; CIP_SIDE_PREP_FROM =
  * columns before the end from which it forks, default 2048).  1 (default) on, 0 off.  Same bits.  Returns the previous setting. */

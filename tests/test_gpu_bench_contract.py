@@ -39,6 +39,8 @@ def test_bench_line_has_the_contract_fields():
 
 
 def _json_line(r):
+    if r.returncode != 0:                                   # (in full: pytest abbreviates long assertion operands)
+        print("---- stdout tail\n" + r.stdout[-3000:] + "\n---- stderr tail\n" + r.stderr[-12000:])
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]

@@ -223,3 +223,45 @@ def test_side_stream_solve_preparation_bitwise(n):
     finally:
         ks.lib.cip_set_ldlt_side_prep(prev)
         ks.close()
+
+
+# ---------------------------------------------------------------- round 6: an in-launch wait that gives up (a GPU shared with other processes)
+def test_a_fused_chain_that_gives_up_falls_back_to_the_three_launch_chain():
+    """The fused panel chain waits inside a launch for workgroups of the same launch; the wait is bounded (~1 s) and then the
+    factorisation reports that it gave up.  With eight processes on one MI355X the hardware scheduler was seen to keep a launch's
+    workgroups apart for longer than that (tests/test_gpu_bench_contract.py::test_eight_ranks_on_one_gpu, round 6).  The library
+    then redoes the factorisation with the three-launch chain (no in-launch wait, same bits) and keeps it for the handle; a problem
+    of a lock-step group leaves the group and is solved alone.  cip_debug_chain_giveup(n) makes the next n fused factorisations
+    report such a give-up: the solve must come out exactly as without it -- one problem, and a lock-step group."""
+    import cipkkt
+    from cipkkt import _lib as L
+    from cipkkt.batch import _solve_problems_native
+    from cipkkt.workloads import c5_batch
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    prs = c5_batch(count=6, n=640, seed=5100, device=dev)
+    pr = prs[0]
+    ref = cipkkt.conicIP(pr["Q"], pr["c"], pr["A"], pr["b"], pr["cone_dims"], optTol=1e-6)
+    assert ref.status == "Optimal"
+    lib.cip_debug_chain_giveup(1)
+    try:
+        got = cipkkt.conicIP(pr["Q"], pr["c"], pr["A"], pr["b"], pr["cone_dims"], optTol=1e-6)
+        assert lib.cip_debug_chain_giveup(-1) == 0                       # the hook fired
+    finally:
+        lib.cip_debug_chain_giveup(0)
+    assert (got.status, got.Iter, got.n_solve) == (ref.status, ref.Iter, ref.n_solve)
+    assert np.array_equal(got.y, ref.y) and np.array_equal(got.v, ref.v)
+    # a lock-step group: the first factorisation of the group gives up for every problem -> all leave the group, solved alone
+    one = _solve_problems_native(prs, dev, 1, "lockstep")
+    lib.cip_debug_chain_giveup(1)
+    try:
+        two = _solve_problems_native(prs, dev, 1, "lockstep")
+        assert lib.cip_debug_chain_giveup(-1) == 0
+    finally:
+        lib.cip_debug_chain_giveup(0)
+    st = (C.c_int * 3)()
+    lib.cip_lockstep_stats(st)
+    assert st[1] == 6 and st[2] == 6, list(st)                             # six problems, six left their group
+    for a, b in zip(two, one):
+        assert (a.status, a.Iter) == (b.status, b.Iter) and a.status == "Optimal"
+        assert np.allclose(a.y, b.y, rtol=1e-9, atol=1e-12)                # (alone: another solve block than in the group -> rounding)
