@@ -23,6 +23,26 @@ __global__ __launch_bounds__(256) void k_gemv_t(int rows, int cols, double alpha
     int i = lane * 2;
     // rows even and 16-byte aligned columns are the common case (padded leading dimensions)
     if (((lda & 1) == 0) && ((((uintptr_t)A) & 15) == 0) && ((((uintptr_t)x) & 15) == 0)) {
+        // (round 6) 1024 rows per trip, EIGHT 16-byte loads of the matrix in flight per lane: the block steps of the triangular sweeps are
+        // column dots over exactly 1024 rows (the solve block), i.e. two dependent memory round trips per wave with four loads in flight --
+        // and those launches are latency-bound (a 58-MB step at 3.6 TB/s, an 8-MB one in 4.6 us).  Same fused multiply-adds on the same
+        // accumulators in the same order as two trips of the 512-row loop below: same bits.  solve4x4 at n = 8192 0.203 -> 0.199 ms.
+        // (NOT kept: skipping the 128-row pieces of the triangular block inverses that are exact zeros -- half the bytes of every
+        //  block product, same bits -- made the predicated loads issue one behind the other: 0.199 -> 0.220 ms.)
+        for (; i + 897 < rows; i += 1024) {
+            v2d av[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[u] = *(const v2d *)(a + i + 128 * u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = *(const v2d *)(x + i + 128 * u);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                s0 = fma(av[4 * h].x, xv[4 * h].x, s0); s1 = fma(av[4 * h].y, xv[4 * h].y, s1);
+                s2 = fma(av[4 * h + 1].x, xv[4 * h + 1].x, s2); s3 = fma(av[4 * h + 1].y, xv[4 * h + 1].y, s3);
+                s0 = fma(av[4 * h + 2].x, xv[4 * h + 2].x, s0); s1 = fma(av[4 * h + 2].y, xv[4 * h + 2].y, s1);
+                s2 = fma(av[4 * h + 3].x, xv[4 * h + 3].x, s2); s3 = fma(av[4 * h + 3].y, xv[4 * h + 3].y, s3);
+            }
+        }
         for (; i + 385 < rows; i += 512) {
             const v2d a0 = *(const v2d *)(a + i), a1 = *(const v2d *)(a + i + 128), a2 = *(const v2d *)(a + i + 256),
                       a3 = *(const v2d *)(a + i + 384);
