@@ -919,7 +919,8 @@ __global__ __launch_bounds__(512) void k_lg_tridiag1(const double *M, int ldm, c
 }
 
 // ---- The max-step needs ONE eigenvalue -- the largest (or smallest) -- of its symmetric r x r matrix, not the tridiagonal
-// form: Lanczos with full reorthogonalisation, the matrix in registers as in k_lg_tridiag1 (same load, same p = A v), and the
+// form: Lanczos (round 6: the plain three-term recurrence by default, the Gram-Schmidt sweeps below behind CIP_LG_LANCZOS_REORTH=1:
+// lz_reorth), the matrix in registers as in k_lg_tridiag1 (same load, same p = A v), and the
 // verdict of maxstep_sdc (src/ConicIP.jl:272-303) in the same launch (round 3; replaces k_lg_tridiag1 + k_lg_sturm for
 // r <= 256: 1.15 + 0.28 ms per max-step, six max-steps per iteration, half of config 4's time).
 //   v_1 fixed (every component non-zero inside the r x r block, zero in the padding: the padded rows never enter);
@@ -951,7 +952,7 @@ __device__ __forceinline__ double lz_sum256(double x, double *red, int slot) {  
     return (red[slot * 4] + red[slot * 4 + 1]) + (red[slot * 4 + 2] + red[slot * 4 + 3]);
 }
 __global__ __launch_bounds__(512) void k_lg_lanczos1(const double *M, int ldm, const double *dscale, int r, int want_max, double scale,
-                                                      const int *info, double *partial, int item, double *Vg, int *stat, double *cert, double cert_tol) {
+                                                      const int *info, double *partial, int item, double *Vg, int *stat, double *cert, double cert_tol, int reorth) {
     extern __shared__ double sh[];
     double *rowp = sh, *colp = sh + 256;                      // p = A v: row sums [i], column sums per wave [wave][j]
     double *vs = colp + 8 * 256, *wsv = vs + 256, *al = wsv + 256, *be = al + 256, *hb = be + 256, *zz = hb + 256;
@@ -1048,7 +1049,8 @@ __global__ __launch_bounds__(512) void k_lg_lanczos1(const double *M, int ldm, c
         // ---- then w orthogonal to v_0 .. v_j by classical Gram-Schmidt: what it finds is rounding noise while the basis is
         // orthogonal; a second sweep when the first one took out a sizeable part of w ("twice is enough")
         double nrm2 = 0.0;
-        for (int pass = 0; pass < 2; ++pass) {
+        if (!reorth) nrm2 = lz_sum256(tid < 256 ? wi * wi : 0.0, red, 0);       // plain three-term Lanczos (the default since round 6: see lz_reorth)
+        for (int pass = 0; pass < (reorth ? 2 : 0); ++pass) {
             {                                                  // h_k = v_k'w: eight threads per vector
                 const int k = tid >> 3, l8 = tid & 7;
                 double h = 0.0;
@@ -1621,6 +1623,17 @@ int cip_sdp_large_refresh(hipStream_t s, LargeWs *w, const ConeDesc &cd, int li,
     return 0;
 }
 
+// Round 6: the max-step's Lanczos WITHOUT the Gram-Schmidt sweeps by default (CIP_LG_LANCZOS_REORTH=1 restores them).  The recurrence
+// stops at the FIRST convergence of the extreme Ritz value, and a Lanczos basis loses its orthogonality only when a Ritz value
+// converges (Paige): up to the stop the plain three-term recurrence is the reorthogonalised one to working precision, unless the
+// other end of the spectrum converges first -- then the wanted end takes more steps (config 4's max-steps: the longest runs 144-151 ->
+// 176-183 steps, the typical 40-47 unchanged).  What the returned value claims is checked by the inertia certificate either way.
+// Measured: config 4 8.17-8.22 -> 7.88-8.00 ms per iteration; tests/test_gpu_sdp.py (LAPACK on hard spectra, the certificate's
+// self-test, five trajectories) green in both modes.
+static int lz_reorth(void) {
+    static const int on = [] { const char *e = getenv("CIP_LG_LANCZOS_REORTH"); return e ? atoi(e) : 0; }();
+    return on;
+}
 // 2 (default; CIP_LG_LANCZOS changes it): the max-step's extreme eigenvalue by k_lg_lanczos1 at orders <= 256 + the inertia certificate
 // (lg_certify); 1: Lanczos alone; 3: certificate self-test; 0: full
 // tridiagonalisation + Sturm multisection at every order (A/B runs, tests).  on < 0 only reads; returns the previous setting
@@ -1730,7 +1743,7 @@ int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const d
         hipLaunchKernelGGL(k_lg_mat, lg_grid(n2), dim3(256), 0, s, x + cd.off, 1L, 0L, M3, r, rp, 0.0);
         if (lz) {
             hipLaunchKernelGGL(k_lg_lanczos1, dim3(1), dim3(512), LZ_LDS_DOUBLES * sizeof(double), s, M3, rp, (const double *)nullptr, r, 0,
-                               1.0, (const int *)nullptr, partial, cd.item, M1, stat, cert, cert_tol);
+                               1.0, (const int *)nullptr, partial, cd.item, M1, stat, cert, cert_tol, lz_reorth());
             CIP_HIP_CHECK(hipGetLastError());
             if (cert) return lg_certify(s, w, M3, nullptr, r, 0, 1.0, M1, M2, wx, partial, cd.item, side);
             return 0;
@@ -1752,7 +1765,7 @@ int cip_sdp_large_maxstep(hipStream_t s, LargeWs *w, const ConeDesc &cd, const d
     if ((rc = lg_gemm(s, M3, 0, M2, 0, Xi, 0, rp, 1))) return rc;             // inv(L) D inv(L)'
     if (lz) {                                                                       // ... scaled by d^-1/2 on both sides
         hipLaunchKernelGGL(k_lg_lanczos1, dim3(1), dim3(512), LZ_LDS_DOUBLES * sizeof(double), s, M3, rp, (const double *)wx.dvec, r, 1,
-                           scale, (const int *)wx.info, partial, cd.item, M1, stat, cert, cert_tol);
+                           scale, (const int *)wx.info, partial, cd.item, M1, stat, cert, cert_tol, lz_reorth());
         CIP_HIP_CHECK(hipGetLastError());
         if (cert) return lg_certify(s, w, M3, wx.dvec, r, 1, scale, M1, M2, wx, partial, cd.item, side);
         return 0;
