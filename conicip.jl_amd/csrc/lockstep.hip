@@ -261,19 +261,6 @@ static int lockstep_group(int B, int call_count, const cip_problem *probs, const
 #define CK(x) do { if ((rc = (x)) != 0) return rc; } while (0)
     auto axpby = [&](int len, double alpha, const double *x, double beta, double *yy) { return len > 0 ? cip_axpby(s, len, alpha, x, beta, yy) : 0; };
     auto copy = [&](int len, const double *x, double *yy) { return axpby(len, 1.0, x, 0.0, yy); };
-    auto kkt_apply = [&](const Vec4 &x, Vec4 &out, const double *Qx) {
-        int ee = Qx ? copy(n, Qx, out.y) : cip_gemv_dev(h, CIP_MAT_Q, 0, 1.0, x.y, 0.0, out.y);
-        if (p > 0) {
-            ee |= cip_gemv_dev(h, CIP_MAT_G, 1, 1.0, x.w, 1.0, out.y);
-            ee |= cip_gemv_dev(h, CIP_MAT_G, 0, 1.0, x.y, 0.0, out.w);
-        }
-        if (m > 0) {
-            ee |= cip_gemv_dev(h, CIP_MAT_A, 1, -1.0, x.v, 1.0, out.y);
-            ee |= cip_gemv_dev(h, CIP_MAT_A, 0, 1.0, x.y, 0.0, out.v);
-            ee |= axpby(m, -1.0, x.s, 1.0, out.v);
-        }
-        return ee;
-    };
     // assembly + LDL' of every problem of the current mask; the pivot flags come back with the next read-back
     auto factor = [&]() -> int {
         int e2;
