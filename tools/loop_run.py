@@ -22,5 +22,7 @@ for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     sol = cipkkt.conicIP(Q, c, A, b, K, G, d, system=ks, **kw)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print("%s: %s, %d iterations, %d factorisations, %d solves, %.4f s -> %.3f ms per iteration" % (which, sol.status, sol.Iter, sol.n_factor, sol.n_solve, dt, dt / sol.Iter * 1e3), flush=True)
+    import hashlib
+    hv = hashlib.sha1(b"".join(torch.as_tensor(t).cpu().numpy().tobytes() for t in (sol.y, sol.w, sol.v) if t is not None)).hexdigest()[:12]
+    print("%s: %s, %d iterations, %d factorisations, %d solves, %.4f s -> %.3f ms per iteration   sha1(y,w,v) %s" % (which, sol.status, sol.Iter, sol.n_factor, sol.n_solve, dt, dt / sol.Iter * 1e3, hv), flush=True)
 ks.close()
