@@ -120,6 +120,7 @@ SIGNATURES = {
     "cip_set_sdp_lanczos": (C.c_int, [C.c_int]),
     "cip_set_lockstep_split": (C.c_int, [C.c_int]),
     "cip_debug_chain_giveup": (C.c_int, [C.c_int]),
+    "cip_get_chain_fallbacks": (C.c_int, [C.c_void_p]),
     "cip_sdp_lanczos_fallbacks": (C.c_int, [C.c_void_p, c_int_p]),
     "cip_set_ldlt_fused_chain": (C.c_int, [C.c_int]),
     "cip_set_ldlt_side_prep": (C.c_int, [C.c_int]),

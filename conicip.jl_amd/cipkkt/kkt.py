@@ -290,6 +290,13 @@ class KKTSystem:
         return dict(n_factor=out[0], n_solve=out[1], ms_assemble=out[2], ms_ldlt=out[3], flops_ldlt=out[4],
                     nbo=out[5], N=out[6], Npad=out[7])
 
+    def health(self):
+        """(relative static regularisation in force, times it was switched on, factorisations redone on the three-launch chain)"""
+        rel = C.c_double(0.0)
+        k = C.c_int(0)
+        L.check(self.lib.cip_get_regularization(self.h, C.byref(rel), C.byref(k)))
+        return dict(reg_rel=rel.value, n_regularized=k.value, n_chain_fallbacks=int(self.lib.cip_get_chain_fallbacks(self.h)))
+
     def profile_trailing(self, on):
         """HIP events around the trailing-update launches: True / 1 = every factorisation, k > 1 = every k-th, False = off."""
         L.check(self.lib.cip_profile_trailing(self.h, int(on)))

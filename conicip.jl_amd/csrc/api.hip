@@ -49,12 +49,23 @@ struct CipRange { explicit CipRange(const char *n) { cip_range_push(n); } ~CipRa
 
 static int rup(int x, int q) { return ((x + q - 1) / q) * q; }
 
+// TEST SWITCH (CIP_DEBUG_POISON=<byte 1..255>): every buffer of a handle starts out filled with that byte (255: NaNs and -1s; 63: doubles of
+// 4.8e-4 and huge ints) instead of whatever the allocator hands out -- fresh memory of a fresh process is zero, recycled memory of a long
+// one is not, and nothing may depend on either.  tests/test_gpu_poison.py runs trajectories under it and compares the bits.
+static int debug_poison(void *p, size_t bytes) {
+    static const int v = [] { const char *e = getenv("CIP_DEBUG_POISON"); return e ? atoi(e) & 255 : 0; }();
+    if (!v) return 0;
+    CIP_HIP_CHECK(hipDeviceSynchronize());
+    CIP_HIP_CHECK(hipMemset(p, v, bytes));
+    CIP_HIP_CHECK(hipDeviceSynchronize());
+    return 0;
+}
 int cip_handle_alloc(cip_handle *h, void **out, size_t bytes) {
     if (bytes == 0) bytes = 256;
     const size_t b = (bytes + 255) & ~(size_t)255;
     h->alloc_bytes += b;
     if (h->arena) {
-        if (h->arena_used + b <= h->arena_cap) { *out = h->arena + h->arena_used; h->arena_used += b; return 0; }
+        if (h->arena_used + b <= h->arena_cap) { *out = h->arena + h->arena_used; h->arena_used += b; return debug_poison(*out, b); }
         h->arena_overflow = true;                  // falls back to its own allocation: the slab layout is broken
     }
     hipError_t e = hipMalloc(out, bytes);
@@ -65,7 +76,7 @@ int cip_handle_alloc(cip_handle *h, void **out, size_t bytes) {
         e = hipMalloc(out, bytes);
     }
     CIP_HIP_CHECK(e);
-    return 0;
+    return debug_poison(*out, bytes);
 }
 #define DMALLOC(ptr, bytes)                                                        \
     do {                                                                           \
@@ -1136,6 +1147,7 @@ extern "C" int cip_profile_thread_get(double *out3) {
 extern "C" int cip_set_lazy_copy(int on) { return cip_lazy_copy_set(on); }
 extern "C" int cip_set_sdp_lanczos(int on) { return cip_sdp_large_lanczos(on); }
 extern "C" int cip_debug_chain_giveup(int n) { return cip_debug_chain_giveup_set(n); }
+extern "C" int cip_get_chain_fallbacks(cip_handle *h) { return h ? h->n_chain_fallbacks : -1; }
 extern "C" int cip_sdp_lanczos_fallbacks(cip_handle *h, int *count) {
     if (!h || !count) { cip_set_error("bad argument"); return CIP_E_INVALID; }
     int out2[2] = {0, 0};

@@ -610,6 +610,11 @@ __device__ __forceinline__ void diag_load_block(double *a, const double *Kb, lon
 // columns [c, c+16) of the LDS image -> K (L strictly lower, d on the diagonal), 16-byte stores where aligned pairs
 // lie below the diagonal; `t` of `nt` threads.  PUB: write-through (`sc1`) stores -- the readers are other workgroups of
 // the same launch (k_ldlt_panel's TRSM strips)
+#ifndef DIAG_OLD_STAGE_COUNT
+#define PANEL_STAGE_LAST 0x10000u            // the serial wave's count on a panel launch's stage word (see stage_reached)
+#else
+#define PANEL_STAGE_LAST ((unsigned)NH)      // rounds 5 - 6a (tools/stage_mix_demo.sh): one running count for both kinds
+#endif
 __device__ __forceinline__ void st_pub(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_pub(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <bool PUB = false>
@@ -916,7 +921,11 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
                             st_pub(dinv + 112 + lane, a[129 + (112 + lane) * DP]);
                         }
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (lane == 0) atomicAdd(stage, (unsigned)NH);
+                        // (round 6: in the HIGH half of the word.  Until then it was NH more on the one running count -- and the strips' stage
+                        //  6, "count >= 7 NH", came true with the helpers' micro-panel 6 still on its way whenever their write-through stores
+                        //  took longer than A(7) and this publication: about one factorisation in 100 000 at order 4096 came out with a few
+                        //  64-row strips of one panel computed from the previous contents of column block 6 -- see PANEL_STAGE_LAST)
+                        if (lane == 0) atomicAdd(stage, PANEL_STAGE_LAST);
                         PANEL_STAMP(8, WAIT && tid == 0);
                     }
                     DIAG_STAMP(kb, 3, tid == 0);                              // C11 + A(kb+1) done
@@ -934,11 +943,24 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
                     count(tflag);
                     DIAG_STAMP(kb, 7, tid == DIAG_TIMING_TID);                // helper: tiles done and counted
                     // micro-panel kb is final: written back (and published) now, beside the serial wave's step and the next B
+#ifdef DIAG_DEBUG_SLOW_HELPERS
+                    // TEST BUILD (tools/stage_mix_demo.sh, tests/test_gpu_panel_chain.py): the helpers' write-back of micro-panel 6 comes
+                    // DIAG_DEBUG_SLOW_HELPERS ticks of s_memtime late (2000 were enough to turn the old counting over), as a slow store
+                    // would make it -- the factor must not change
+                    if (PUB && kb == 6) { const long t0 = __builtin_amdgcn_s_memtime(); while (__builtin_amdgcn_s_memtime() - t0 < (long)(DIAG_DEBUG_SLOW_HELPERS)) __builtin_amdgcn_s_sleep(8); }
+#endif
                     if (!(DIAG_SKIP & 16)) diag_store_panel<PUB>(a, Kb, ld, c, hid * 64 + lane, 64 * NH);
                     if (PUB) diag_publish_micro(a, xm, xm_out, dvec, dinv, kb, hid * 64 + lane, 64 * NH);      // (counted in the next step)
                 } else count(tflag);
             }
             if (PUB && wave != 0) {                                            // micro-panel 6's count
+                // (round 6) not before EVERY helper has issued its count of micro-panel 5: inside the loop a wave cannot run a step
+                // ahead of another one's count (it waits for everybody's tiles of the step before, counted behind that count), here
+                // nothing held it -- a helper whose stores of micro-panel 5 were slow could be overtaken, and the running count said
+                // "6 NH" with that micro-panel incomplete.  Every helper counts `tflag` in step 6 behind its count of micro-panel 5.
+#ifndef DIAG_OLD_STAGE_COUNT
+                wait_for(tflag, 7u * NH);
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) atomicAdd(stage, 1u);
             }
@@ -1045,7 +1067,7 @@ __device__ __forceinline__ void diag_body(double *sm, double *Kb, long ld, doubl
         diag_publish_micro(a, xm, xm_out, dvec, dinv, 7, tid, 64 * NW);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) atomicAdd(stage, (unsigned)NH);
+        if (tid == 0) atomicAdd(stage, PANEL_STAGE_LAST);
         PANEL_STAMP(8, WAIT && tid == 0);
         // (round 5: the diagonal block's own transpose is NOT written any more.  The solves read L' from the upper triangle only
         //  OUTSIDE their Bs-wide diagonal blocks (ldlt.hip: cip_ldlt_solve, K + C0 + (C0 + Bs) ld; Bs >= 128), the diagonal blocks
@@ -1153,12 +1175,22 @@ struct TrsmStrips {
     int pair;                         // round 5, k_ldlt_panel<true> in lock-step groups: a strip workgroup carries TWO strips (see the kernel)
     int nprod;                        // producer workgroups of k_ldlt_panel<true>: 36 (one wave each; one problem) or 9 (four waves each; lock-step groups)
 };
-__device__ __forceinline__ unsigned strip_wait(unsigned v, unsigned target, const unsigned *stage, unsigned *slot, int *info) {
-    if (v >= target) return v;
+// The stage word of a panel launch: the LOW half counts the helper waves' publications of micro-panels 0 .. 6 (PANEL_NH each, in
+// order: low >= PANEL_NH (kb + 1) <=> micro-panels 0 .. kb are readable), the HIGH half is set by the serial wave when micro-panel 7's
+// inverse and 1/d are (no column of L lies below the last diagonal tile, and the serial wave publishes them itself, ahead of the
+// helpers' last stores).  Two fields because the two kinds of count are not ordered against each other.
+__device__ __forceinline__ bool stage_reached(unsigned x, int kb) {
+#ifdef DIAG_OLD_STAGE_COUNT
+    return x >= (unsigned)PANEL_NH * (unsigned)(kb + 1);
+#endif
+    return kb < 7 ? (x & 0xffffu) >= (unsigned)PANEL_NH * (unsigned)(kb + 1) : (x >> 16) != 0u;
+}
+__device__ __forceinline__ unsigned strip_wait(unsigned v, int kb, const unsigned *stage, unsigned *slot, int *info) {
+    if (stage_reached(v, kb)) return v;
     if (threadIdx.x == 0) {
         const long t0 = __builtin_amdgcn_s_memtime();
         unsigned x;
-        while ((x = __hip_atomic_load(stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+        while (!stage_reached(x = __hip_atomic_load(stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kb)) {
             __builtin_amdgcn_s_sleep(2);
             if (__builtin_amdgcn_s_memtime() - t0 > 2000000000L) { atomicCAS(info + 3, 0, -9); x = 0xffffffffu; break; }   // never hang the GPU
         }
@@ -1177,12 +1209,12 @@ __device__ __forceinline__ unsigned strip_wait(unsigned v, unsigned target, cons
 // the same order (qq ascending): bit-identical.
 // the wait of a strip whose four waves share the workgroup with a tile group (k_ldlt_panel<true>): no barrier, every wave
 // polls for itself (one blocking agent-scope load per round trip: four pollers per strip do not load the L2 channel)
-__device__ __forceinline__ unsigned strip_wait_wave(unsigned v, unsigned target, const unsigned *stage, int *info) {
-    if (v >= target) return v;
+__device__ __forceinline__ unsigned strip_wait_wave(unsigned v, int kb, const unsigned *stage, int *info) {
+    if (stage_reached(v, kb)) return v;
     unsigned x = 0u;
     if ((threadIdx.x & 63) == 0) {
         const long t0 = __builtin_amdgcn_s_memtime();
-        while ((x = __hip_atomic_load(stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+        while (!stage_reached(x = __hip_atomic_load(stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kb)) {
             __builtin_amdgcn_s_sleep(2);
             if (__builtin_amdgcn_s_memtime() - t0 > 2000000000L) { atomicCAS(info + 3, 0, -9); x = 0xffffffffu; break; }   // never hang the GPU
         }
@@ -1208,8 +1240,7 @@ __device__ __forceinline__ void trsm_strip_pipelined(const TrsmStrips &tr, int s
         for (int q = 0; q < 4; ++q) T[r][q] = ap[(long)(r * 16 + 4 * q) * tr.ld];
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
-        v = WAVEWAIT ? strip_wait_wave(v, (unsigned)PANEL_NH * (kb + 1), stage, info)
-                     : strip_wait(v, (unsigned)PANEL_NH * (kb + 1), stage, slot, info);
+        v = WAVEWAIT ? strip_wait_wave(v, kb, stage, info) : strip_wait(v, kb, stage, slot, info);
         // one batch of loads per stage: the micro inverse and 1/d of kb and column block kb of L11 below its diagonal tile
         double xo[4], dv[4], lo[7][4];
 #pragma unroll

@@ -556,6 +556,12 @@ static LdltSide *side_get(const LdltWorkspace &ws) {
     *ws.side = sd;
     return sd;
 }
+// TEST SWITCH (CIP_DEBUG_SIDE_DELAY_US=k): every group of the side stream starts k microseconds late -- whoever reads what the group
+// prepares without having waited for it then reads the previous factorisation's blocks, and the bits say so
+__global__ void k_debug_spin(long ticks) {
+    const long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 static int side_fork(LdltSide *sd, hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws, int J0, int J1) {
     if (J1 <= J0) return 0;
     if (sd->nfork >= 16) return build_solve_blocks(s, K, Npad, ld, ws, J0, J1);
@@ -564,6 +570,8 @@ static int side_fork(LdltSide *sd, hipStream_t s, double *K, int Npad, long ld, 
     hipStream_t t = sd->s2;
     CIP_HIP_CHECK(hipEventRecord(sd->fork[g], s));
     CIP_HIP_CHECK(hipStreamWaitEvent(t, sd->fork[g], 0));
+    static const long delay_us = [] { const char *e = getenv("CIP_DEBUG_SIDE_DELAY_US"); return e ? atol(e) : 0L; }();
+    if (delay_us > 0) { hipLaunchKernelGGL(k_debug_spin, dim3(1), dim3(64), 0, t, delay_us * 100); CIP_HIP_CHECK(hipGetLastError()); }
     const int rc = build_solve_blocks(t, K, Npad, ld, ws, J0, J1);
     CIP_HIP_CHECK(hipEventRecord(sd->done[g], t));
     return rc;
@@ -585,8 +593,14 @@ int cip_ldlt_side_join(hipStream_t s, const LdltWorkspace &ws, int J) {
 
 // test hook (cip_debug_chain_giveup): the next `n` factorisations on a fused panel chain report that an in-launch wait gave up (info[3]),
 // as a GPU shared with other processes can make them do -- so that the fall-back to the three-launch chain can be tested on one process
-static std::atomic<int> g_debug_giveup{0};
-int cip_debug_chain_giveup_set(int n) { const int prev = g_debug_giveup.load(); if (n >= 0) g_debug_giveup.store(n); return prev; }
+// (n = count + 65536 * skip: the first `skip` fused factorisations from now on are left alone, the `count` after them give up)
+// (+ 2^28: they report a wrong-sign pivot at column 1 instead -- what the automatic regularisation answers)
+static std::atomic<int> g_debug_giveup{0}, g_debug_giveup_skip{0}, g_debug_giveup_kind{0};
+int cip_debug_chain_giveup_set(int n) {
+    const int prev = g_debug_giveup.load();
+    if (n >= 0) { g_debug_giveup_kind.store((n >> 28) & 1); g_debug_giveup_skip.store((n >> 16) & 0xfff); g_debug_giveup.store(n & 0xffff); }
+    return prev;
+}
 __global__ void k_debug_set_word(int *p, int v, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     CIP_BO1(cb, p);
@@ -595,8 +609,9 @@ __global__ void k_debug_set_word(int *p, int v, CipBatch cb) {
 static int ldlt_factor_body(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws);
 int cip_ldlt_factor(hipStream_t s, double *K, int Npad, long ld, const LdltWorkspace &ws) {
     const int rc = ldlt_factor_body(s, K, Npad, ld, ws);
-    if (rc == 0 && !ws.unfused && !cip_tl_builder && g_debug_giveup.load() > 0 && g_debug_giveup.fetch_sub(1) > 0) {
-        cip_launch_b(k_debug_set_word, dim3(1), dim3(64), 0, s, ws.info + 3, -9);
+    if (rc == 0 && !ws.unfused && !cip_tl_builder && g_debug_giveup.load() > 0 && g_debug_giveup_skip.fetch_sub(1) <= 0 && g_debug_giveup.fetch_sub(1) > 0) {
+        if (g_debug_giveup_kind.load()) cip_launch_b(k_debug_set_word, dim3(1), dim3(64), 0, s, ws.info + 0, 1);
+        else cip_launch_b(k_debug_set_word, dim3(1), dim3(64), 0, s, ws.info + 3, -9);
         CIP_HIP_CHECK(hipGetLastError());
     }
     return rc;

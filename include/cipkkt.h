@@ -288,8 +288,11 @@ int cip_set_ldlt_fused_chain(int on);
  * wait gave up).  On a GPU shared with other processes the hardware scheduler can keep a launch's workgroups apart for longer than that
  * (seen with eight processes on one MI355X).  The library then redoes the factorisation with the three-launch chain -- no in-launch wait,
  * same bits -- and keeps that chain for the handle; a problem of a lock-step group leaves the group and is solved alone.  TEST HOOK: the
- * next n fused-chain factorisations of the process report such a give-up (n < 0: query); returns the previous count. */
+ * next n fused-chain factorisations of the process report such a give-up (n < 0: query; n = count + 65536 * skip: the `count` ones after
+ * the next `skip`); returns the previous count. */
 int cip_debug_chain_giveup(int n);
+/* how many factorisations of this handle were redone on the three-launch chain after such a give-up (-1: NULL handle) */
+int cip_get_chain_fallbacks(cip_handle *h);
 /* solve preparation (block inverses for the triangular sweeps, mirror image of L) of every solve block whose columns are final,
  * on a side stream beside the last panels of the factorisation instead of behind it (also CIP_SIDE_PREP; CIP_SIDE_PREP_FROM =
  * columns before the end from which it forks, default 2048).  1 (default) on, 0 off.  Same bits.  Returns the previous setting. */

@@ -3,6 +3,7 @@ product driver (HIP KKT path) against the oracle's restatement of conicIP on the
 reference's own known-answer problems (test/runtests.jl) -- same status, same
 iteration count, iterates equal to 1e-6 relative (the tolerance the north-star asks
 to be stated), and the analytic answers the reference asserts."""
+import os
 import numpy as np
 import pytest
 
@@ -101,15 +102,30 @@ def test_dense_qp_2048_properties():
     import scipy.sparse as sp
     A = sp.identity(n, format="csr")
     b = np.zeros(n)
-    s1 = cipkkt.conicIP(Q, c, A, b, [("R", n)], optTol=1e-6)
+    K = [("R", n)]
+    k1 = cipkkt.KKTSystem(Q, A, None, K, route="schur")
+    s1 = cipkkt.conicIP(Q, c, A, b, K, optTol=1e-6, system=k1)
+    h1 = k1.health(); k1.close()
     assert s1.status == "Optimal"
     y, v = s1.y, s1.v
     assert np.linalg.norm(Q @ y - c - v) / (1 + np.linalg.norm(c)) < 1e-6      # stationarity
     assert y.min() > -1e-6 and v.min() > -1e-9                                # primal / dual feasibility
     assert abs(y @ v) / n < 1e-5                                              # complementarity
-    s2 = cipkkt.conicIP(Q, c, A, b, [("R", n)], optTol=1e-6, kktsolver="full3x3")
+    k2 = cipkkt.KKTSystem(Q, A, None, K, route="full3x3")
+    s2 = cipkkt.conicIP(Q, c, A, b, K, optTol=1e-6, system=k2)
+    h2 = k2.health(); k2.close()
     assert s2.status == "Optimal" and s2.Iter == s1.Iter
-    assert np.linalg.norm(s1.y - s2.y) / (1 + np.linalg.norm(s1.y)) < 1e-6
+    dev = np.linalg.norm(s1.y - s2.y) / (1 + np.linalg.norm(s1.y))
+    # the two routes factor different matrices (order 2048 and 4096) and still end within 1e-15 of each other on this problem;
+    # 1e-6 is the bound the optimality tolerance gives.  What is printed when it fails says which of the two left its usual path.
+    import hashlib
+    diag = "schur: sha1 %s health %s\nfull3x3: sha1 %s health %s\n" % (
+        hashlib.sha1(s1.y.tobytes() + s1.v.tobytes()).hexdigest()[:12], h1, hashlib.sha1(s2.y.tobytes() + s2.v.tobytes()).hexdigest()[:12], h2)
+    diag += "\n".join("it %d  mu %.17g / %.17g  pobj %.17g / %.17g  alpha %s / %s" % (a["Iter"], a["mu"], b_["mu"], a["pobj"], b_["pobj"], a.get("alpha"), b_.get("alpha"))
+                      for a, b_ in zip(s1.trace, s2.trace))
+    if os.environ.get("CIP_TEST_DUMP") and dev > 1e-12:
+        with open(os.environ["CIP_TEST_DUMP"], "a") as f: f.write("deviation %.3e\n%s\n\n" % (dev, diag))
+    assert dev < 1e-6, diag
 
 
 @pytest.mark.parametrize("name", ["sphere", "combined", "simplex", "soc_direct", "lp_doc", "psd_projection",
