@@ -190,12 +190,17 @@ int cip_spmv_csr(hipStream_t s, int rows, const int *rowptr, const int *colind, 
 // ---- multi-dot: stage 1 = (count x DOT_NB) partial sums, stage 2 = one block per dot
 #define DOT_NB 32
 struct DotPtrs { const double *x; const double *y; int len; int pad; };
+#define DOT_MAX 32
+// The pointer table travels BY VALUE in the kernel arguments (768 bytes; round 6, second session): until then every call
+// uploaded it from the caller's stack with a hipMemcpyAsync -- a staged copy and a blit kernel in front of every dot-product group,
+// three to four per interior-point iteration.
+struct DotTable { DotPtrs p[DOT_MAX]; };
 
 // In a batch the pointer table is problem 0's (shared): the vectors it names and the partial sums are shifted.
-__global__ __launch_bounds__(256) void k_dots1(const DotPtrs *p, double *partial, CipBatch cb) {
+__global__ __launch_bounds__(256) void k_dots1(const DotTable tab, double *partial, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     __shared__ double sh[4];
-    DotPtrs d = p[blockIdx.y];
+    DotPtrs d = tab.p[blockIdx.y];
     CIP_BO3(cb, d.x, d.y, partial);
     double s = 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < d.len; i += (long)DOT_NB * 256) s += d.x[i] * d.y[i];
@@ -222,11 +227,11 @@ __global__ __launch_bounds__(64) void k_dots2(const double *partial, double *out
 // launch (~4 us) less per dot-product group, three or four groups per interior-point iteration -- and NOT faster: the in-launch
 // hand-off (write-through store, wait, atomic, coherent re-load) costs what the launch boundary does (8 / 64 problems of order 2048
 // in lock-step: 16.7 / 79.8 ms per pass against 15.9 / 78.3 with two launches).  Off by default; CIP_DOTS_FUSED=1 selects it.
-__global__ __launch_bounds__(256) void k_dots(const DotPtrs *p, double *partial, unsigned *cnt, double *out, double *gather, CipBatch cb) {
+__global__ __launch_bounds__(256) void k_dots(const DotTable tab, double *partial, unsigned *cnt, double *out, double *gather, CipBatch cb) {
     CIP_BATCH_GUARD(cb);
     __shared__ double sh[4];
     __shared__ unsigned last;
-    DotPtrs d = p[blockIdx.y];
+    DotPtrs d = tab.p[blockIdx.y];
     CIP_BO3(cb, d.x, d.y, partial);
     CIP_BO2(cb, cnt, out);
     double s = 0;
@@ -255,16 +260,13 @@ __global__ __launch_bounds__(256) void k_dots(const DotPtrs *p, double *partial,
     }
 }
 
-#define DOT_MAX 32
 int cip_dots(hipStream_t s, int count, const double *const *x_host, const double *const *y_host, const int *len_host,
              double *scratch_dev, void *ptrs_dev, double *out_host) {
     if (count <= 0) return 0;
     if (count > DOT_MAX) { cip_set_error("dots: count > %d", DOT_MAX); return -1; }
-    DotPtrs hp[DOT_MAX];
-    for (int i = 0; i < count; ++i) { hp[i].x = x_host[i]; hp[i].y = y_host[i]; hp[i].len = len_host[i]; hp[i].pad = 0; }
-    CIP_HIP_CHECK(hipMemcpyAsync(ptrs_dev, hp, sizeof(DotPtrs) * count, hipMemcpyHostToDevice, s));
-    // hp lives on this stack frame: the copy above must have consumed it before we return -> we
-    // synchronise below anyway (the result comes back to the host).
+    DotTable tab = {};
+    for (int i = 0; i < count; ++i) { tab.p[i].x = x_host[i]; tab.p[i].y = y_host[i]; tab.p[i].len = len_host[i]; tab.p[i].pad = 0; }
+    (void)ptrs_dev;                                  // (the device copy of the table: unused since the table is a kernel argument)
     double *partial = scratch_dev;
     double *out = scratch_dev + DOT_MAX * DOT_NB;
     const CipBatchCtx &bc = cip_tl_bz;
@@ -275,10 +277,10 @@ int cip_dots(hipStream_t s, int count, const double *const *x_host, const double
     static const int fused = [] { const char *e = getenv("CIP_DOTS_FUSED"); return e ? atoi(e) : 0; }();
     if (fused) {
         unsigned *cnt = (unsigned *)(scratch_dev + DOT_MAX * DOT_NB + DOT_MAX);         // zeroed when the scratch was allocated; every call leaves it zero
-        cip_launch_b(k_dots, dim3(DOT_NB, count), dim3(256), 0, s, (const DotPtrs *)ptrs_dev, partial, cnt, direct ? hs.dev : out,
+        cip_launch_b(k_dots, dim3(DOT_NB, count), dim3(256), 0, s, tab, partial, cnt, direct ? hs.dev : out,
                      bc.B > 1 ? bc.gather_dev : (double *)nullptr);
     } else {
-        cip_launch_b(k_dots1, dim3(DOT_NB, count), dim3(256), 0, s, (const DotPtrs *)ptrs_dev, partial);
+        cip_launch_b(k_dots1, dim3(DOT_NB, count), dim3(256), 0, s, tab, partial);
         cip_launch_b(k_dots2, dim3(count), dim3(64), 0, s, (const double *)partial, direct ? hs.dev : out, bc.B > 1 ? bc.gather_dev : (double *)nullptr);
     }
     CIP_HIP_CHECK(hipGetLastError());

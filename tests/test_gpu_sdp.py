@@ -310,7 +310,7 @@ def _nt_products(ks, v, s, x, k):
     return F, z.cpu().numpy(), lam.cpu().numpy().copy()
 
 
-@pytest.mark.parametrize("r", [200, 300, 700])
+@pytest.mark.parametrize("r", [200, 300, 700, 2048])        # (2048: the largest order the library takes -- include/cipkkt.h)
 def test_large_s_cone_nt_scaling_is_reproducible_and_has_the_oracles_invariants(r):
     """The NT scaling of a large S cone (one-sided Jacobi, one launch per phase -- the only form since round 6: the persistent
     kernel with in-launch block hand-offs, measured to come out with other bits once in 800 ... 40000 scalings, and its switch are
