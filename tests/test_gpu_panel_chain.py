@@ -305,3 +305,25 @@ def test_late_helper_stores_of_the_diagonal_kernel_do_not_change_the_factor(tmp_
         return [l for l in r.stdout.splitlines() if l.startswith("BITS ")][-1]
     for n in (1024, 2048):
         assert bits(lib, n) == bits(None, n), n
+
+
+@pytest.mark.parametrize("env", [{"CIP_DEBUG_POISON": "63"}, {"CIP_DEBUG_POISON": "255"}, {"CIP_DEBUG_SIDE_DELAY_US": "3000"}],
+                         ids=["buffers start as 0x3f", "buffers start as NaN", "side stream 3 ms late"])
+def test_bits_do_not_depend_on_what_fresh_memory_holds_or_on_when_the_side_stream_runs(env):
+    """The library's debug switches of round 6 as a regression test: every buffer of a handle filled with a byte pattern at creation
+    (fresh memory of a fresh process is zero, recycled memory of a long-lived one is not), and every group of the solve preparation's
+    side stream started late (whoever reads a group's blocks without having waited for it reads the previous factorisation's) --
+    factor + solve of three scalings on both routes must come out with the plain run's bits."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def bits(extra):
+        e = dict(os.environ)
+        for k in ("CIPKKT_LIB", "CIP_DEBUG_POISON", "CIP_DEBUG_SIDE_DELAY_US"):
+            e.pop(k, None)
+        e.update(extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_chain_bits.py"), "2048", "3"], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [l for l in r.stdout.splitlines() if l.startswith("BITS ")][-1]
+    assert bits(env) == bits({})
