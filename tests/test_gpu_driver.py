@@ -116,8 +116,10 @@ def test_dense_qp_2048_properties():
     h2 = k2.health(); k2.close()
     assert s2.status == "Optimal" and s2.Iter == s1.Iter
     dev = np.linalg.norm(s1.y - s2.y) / (1 + np.linalg.norm(s1.y))
-    # the two routes factor different matrices (order 2048 and 4096) and still end within 1e-15 of each other on this problem;
-    # 1e-6 is the bound the optimality tolerance gives.  What is printed when it fails says which of the two left its usual path.
+    # the two routes factor different matrices (order 2048 and 4096) and still end within 1e-15 of each other on this problem
+    # (every Newton step is refined against the same operator); the optimality tolerance alone would allow 1e-6 -- which is what
+    # round 6 saw once in ~40 suite runs, a factorisation with a few stale strips (diag.hip: PANEL_STAGE_LAST).  1e-9 keeps such a
+    # run from passing.  What is printed when it fails says which of the two routes left its usual path, and at which iteration.
     import hashlib
     diag = "schur: sha1 %s health %s\nfull3x3: sha1 %s health %s\n" % (
         hashlib.sha1(s1.y.tobytes() + s1.v.tobytes()).hexdigest()[:12], h1, hashlib.sha1(s2.y.tobytes() + s2.v.tobytes()).hexdigest()[:12], h2)
@@ -125,7 +127,7 @@ def test_dense_qp_2048_properties():
                       for a, b_ in zip(s1.trace, s2.trace))
     if os.environ.get("CIP_TEST_DUMP") and dev > 1e-12:
         with open(os.environ["CIP_TEST_DUMP"], "a") as f: f.write("deviation %.3e\n%s\n\n" % (dev, diag))
-    assert dev < 1e-6, diag
+    assert dev < 1e-9, diag
 
 
 @pytest.mark.parametrize("name", ["sphere", "combined", "simplex", "soc_direct", "lp_doc", "psd_projection",
